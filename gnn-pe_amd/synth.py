@@ -1,0 +1,130 @@
+"""Deterministic synthetic inputs for the offline path (SURVEY.md 8(d) "Synthetic inputs").
+
+The reference ships one sample graph (Test/) and no generator; BASELINE.json's configs 2-5 are
+synthetic.  This module is the build's own generator plus the prep-step file layout the
+reference's `gnnpe.py` produces (mkdirs `gnnpe.py:60-64`, degree sort + `membership.txt`
+`gnnpe.py:71-76`).  METIS is not available, so the partition column is contiguous id blocks.
+
+Everything here is host-side numpy; nothing touches the GPU.
+"""
+import os
+
+import numpy as np
+
+SEED = 2022  # the reference's own seed (gnnpe.py:14)
+
+
+def _csr_from_edges(n, eu, ev):
+    """Undirected simple edge list (u<v) -> CSR with ascending neighbour lists
+    (what graph.cpp:211-233 builds from `e u v` lines)."""
+    src = np.concatenate([eu, ev])
+    dst = np.concatenate([ev, eu])
+    order = np.lexsort((dst, src))
+    src = src[order]
+    dst = dst[order]
+    deg = np.bincount(src, minlength=n).astype(np.uint32)
+    offs = np.zeros(n + 1, np.uint32)
+    np.cumsum(deg, out=offs[1:])
+    return offs, dst.astype(np.uint32)
+
+
+def gnm_graph(n, m, n_labels=64, seed=SEED):
+    """G(n,m): exactly m distinct undirected edges without self-loops, uniform labels.
+
+    Returns dict(n, m, offsets u32[n+1], nbrs u32[2m], labels u32[n], eu, ev (u<v, sorted))."""
+    rng = np.random.default_rng(seed)
+    keys = np.zeros(0, np.int64)
+    need = m
+    while True:
+        k = int(need * 1.05) + 1024
+        u = rng.integers(0, n, size=k, dtype=np.int64)
+        v = rng.integers(0, n, size=k, dtype=np.int64)
+        ok = u != v
+        lo = np.minimum(u, v)[ok]
+        hi = np.maximum(u, v)[ok]
+        cand = np.concatenate([keys, lo * n + hi])
+        uniq, first = np.unique(cand, return_index=True)
+        # keep draw order so that the first m distinct edges are the ones selected
+        keys = cand[np.sort(first)]
+        if len(keys) >= m:
+            keys = keys[:m]
+            break
+        need = m - len(keys)
+    keys = np.sort(keys)
+    eu = (keys // n).astype(np.uint32)
+    ev = (keys % n).astype(np.uint32)
+    labels = rng.integers(0, n_labels, size=n, dtype=np.int64).astype(np.uint32)
+    offs, nbrs = _csr_from_edges(n, eu.astype(np.int64), ev.astype(np.int64))
+    return dict(n=n, m=m, offsets=offs, nbrs=nbrs, labels=labels, eu=eu, ev=ev)
+
+
+def powerlaw_graph(n, m, exponent=2.1, max_degree=2000, n_labels=64, seed=SEED):
+    """Chung-Lu style power-law graph with a degree cap (config 5 stress input).
+
+    Endpoints are drawn proportionally to weights w_i ~ i^(-1/(exponent-1)) truncated so the
+    expected degree stays <= max_degree; duplicates/self-loops are dropped, so the final edge
+    count is <= m (returned in the dict)."""
+    rng = np.random.default_rng(seed)
+    w = (np.arange(1, n + 1, dtype=np.float64)) ** (-1.0 / (exponent - 1.0))
+    w *= (2.0 * m) / w.sum()
+    w = np.minimum(w, max_degree)
+    p = w / w.sum()
+    cdf = np.cumsum(p)
+    cdf[-1] = 1.0
+    k = int(m * 1.02)
+    u = np.searchsorted(cdf, rng.random(k)).astype(np.int64)
+    v = np.searchsorted(cdf, rng.random(k)).astype(np.int64)
+    perm = rng.permutation(n).astype(np.int64)  # decouple id from weight rank
+    u = perm[u]
+    v = perm[v]
+    ok = u != v
+    lo = np.minimum(u, v)[ok]
+    hi = np.maximum(u, v)[ok]
+    keys = np.unique(lo * n + hi)[:m]
+    eu = (keys // n).astype(np.uint32)
+    ev = (keys % n).astype(np.uint32)
+    labels = rng.integers(0, n_labels, size=n, dtype=np.int64).astype(np.uint32)
+    offs, nbrs = _csr_from_edges(n, eu.astype(np.int64), ev.astype(np.int64))
+    return dict(n=n, m=len(keys), offsets=offs, nbrs=nbrs, labels=labels, eu=eu, ev=ev)
+
+
+def degree_order(offsets):
+    """Processing order of `gnnpe.py:71-72`: ascending degree, ties by id (stable)."""
+    deg = np.diff(offsets.astype(np.int64))
+    return np.argsort(deg, kind="stable").astype(np.uint32)
+
+
+def block_membership(n, p):
+    """Partition column used when METIS is unavailable: contiguous id blocks floor(id*p/n)."""
+    return (np.arange(n, dtype=np.int64) * p // max(n, 1)).astype(np.uint32)
+
+
+def expected_paths_l2(offsets):
+    """P for l=2 on a simple graph: sum_v C(deg v, 2)."""
+    deg = np.diff(offsets.astype(np.int64))
+    return int((deg * (deg - 1) // 2).sum())
+
+
+def write_graph_file(path, g):
+    """Text `.graph` in the format graph.cpp:172-219 parses: `t n m`, `v id label degree`
+    (ascending id, true degree), `e u v` (u<v, sorted)."""
+    n, m = g["n"], g["m"]
+    deg = np.diff(g["offsets"].astype(np.int64))
+    with open(path, "w") as f:
+        f.write(f"t {n} {m}\n")
+        vl = np.column_stack([np.arange(n), g["labels"], deg])
+        np.savetxt(f, vl, fmt="v %d %d %d")
+        np.savetxt(f, np.column_stack([g["eu"], g["ev"]]), fmt="e %d %d")
+
+
+def write_membership(path, sorted_nodes, membership):
+    """`membership.txt` as `gnnpe.py:74-76` writes it: line i = "<vertex> <partition>"."""
+    sn = np.asarray(sorted_nodes, np.int64)
+    np.savetxt(path, np.column_stack([sn, np.asarray(membership, np.int64)[sn]]), fmt="%d %d")
+
+
+def make_dataset_dir(root, p):
+    """Directory layout of `gnnpe.py:60-64`: <root>/gnn-pe/partitions/partition-i/."""
+    for i in range(p):
+        os.makedirs(os.path.join(root, "gnn-pe", "partitions", f"partition-{i}"), exist_ok=True)
+    return os.path.join(root, "gnn-pe")

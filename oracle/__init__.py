@@ -1,0 +1,6 @@
+"""CPU parity oracle for the GNN-PE offline path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this package; the product (``gnn-pe_amd/``) never does.  See ``gnnpe_oracle.h``.
+"""
+from .binding import Oracle, build_oracle, ref_main_path, ref_dump_path  # noqa: F401

@@ -1,0 +1,207 @@
+"""ctypes binding of liboracle.so (gnnpe_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+numpy in, numpy out.  Every method names the reference lines its C function restates
+(see gnnpe_oracle.h).  The product never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+
+
+def build_oracle(force=False):
+    """Compile liboracle.so (and, where /root/reference exists, oracle/_ref)."""
+    src = os.path.join(_HERE, "gnnpe_oracle.c")
+    stale = (not os.path.exists(_LIB)) or os.path.getmtime(_LIB) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/GNN-PE/src/main.cpp") and not os.path.exists(ref_main_path()):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+def ref_main_path():
+    """The unmodified reference `main`, compiled by oracle/Makefile (may be absent)."""
+    return os.path.join(_HERE, "_ref", "ref_main")
+
+
+def ref_dump_path():
+    return os.path.join(_HERE, "_ref", "ref_dump")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Oracle:
+    def __init__(self):
+        build_oracle()
+        L = C.CDLL(_LIB)
+        L.orc_load_graph.restype = C.c_int
+        L.orc_load_graph.argtypes = [C.c_char_p, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
+                                     C.POINTER(_u32p), _u32p, _u32p, _u32p]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_read_membership.restype = C.c_int
+        L.orc_read_membership.argtypes = [C.c_char_p, C.c_uint32, _u32p, _u32p]
+        for name in ("orc_enumerate_dfs_hash", "orc_enumerate_closed"):
+            fn = getattr(L, name)
+            fn.restype = C.c_uint64
+            fn.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _u32p, C.c_uint64]
+        L.orc_count_per_start.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _u64p]
+        L.orc_gen_vde_x.argtypes = [C.c_uint32, C.c_uint32, _f64p]
+        L.orc_gen_vde.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _f64p, _f64p, _f64p]
+        L.orc_gen_pde.argtypes = [C.c_uint64, C.c_uint32, _u32p, C.c_uint32, _u32p, _u32p, _f64p, _f64p,
+                                  _f64p, _f64p, _u32p, _u32p]
+        L.orc_write_all_paths.restype = C.c_int
+        L.orc_write_all_paths.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, _u32p]
+        L.orc_write_partition_paths.restype = C.c_int
+        L.orc_write_partition_paths.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, _u32p, _u32p, C.c_uint32]
+        L.orc_format_all_paths.restype = C.c_uint64
+        L.orc_format_all_paths.argtypes = [C.c_uint64, C.c_uint32, _u32p, C.c_char_p]
+        L.orc_index_validate.restype = C.c_int
+        L.orc_index_validate.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         _f64p, C.c_uint64, C.POINTER(C.c_int32)]
+        self.L = L
+
+    # R0 graph.cpp:163-242
+    def load_graph(self, path):
+        n, m = C.c_uint32(), C.c_uint32()
+        lc, md, mlf = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        po, pn, pl = _u32p(), _u32p(), _u32p()
+        rc = self.L.orc_load_graph(path.encode(), C.byref(n), C.byref(m), C.byref(po), C.byref(pn),
+                                   C.byref(pl), C.byref(lc), C.byref(md), C.byref(mlf))
+        if rc != 0:
+            raise OSError(f"orc_load_graph({path}) -> {rc}")
+        offs = np.ctypeslib.as_array(po, shape=(n.value + 1,)).copy()
+        nbrs = np.ctypeslib.as_array(pn, shape=(max(2 * m.value, 1),)).copy()[: 2 * m.value]
+        labels = np.ctypeslib.as_array(pl, shape=(max(n.value, 1),)).copy()[: n.value]
+        for p in (po, pn, pl):
+            self.L.orc_free(p)
+        meta = dict(n=n.value, m=m.value, labels_count=lc.value, max_degree=md.value, max_label_freq=mlf.value)
+        return offs, nbrs, labels, meta
+
+    # R1 main.cpp:77-85
+    def read_membership(self, path, n):
+        s = np.zeros(n, np.uint32)
+        mem = np.zeros(n, np.uint32)
+        rc = self.L.orc_read_membership(path.encode(), n, _p(s, _u32p), _p(mem, _u32p))
+        if rc != 0:
+            raise OSError(f"orc_read_membership({path}) -> {rc}")
+        return s, mem
+
+    def _enum(self, fn, offs, nbrs, sorted_nodes, L):
+        n = len(offs) - 1
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        sn = np.ascontiguousarray(sorted_nodes, np.uint32)
+        P = fn(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), L, None, 0)
+        out = np.zeros((P, L), np.uint32)
+        if P:
+            P2 = fn(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), L, _p(out, _u32p), P)
+            assert P2 == P
+        return out
+
+    # R2 custom.h:52-92 (faithful hash-set DFS)
+    def enumerate_dfs_hash(self, offs, nbrs, sorted_nodes, L=3):
+        return self._enum(self.L.orc_enumerate_dfs_hash, offs, nbrs, sorted_nodes, L)
+
+    # R2 closed form
+    def enumerate_closed(self, offs, nbrs, sorted_nodes, L=3):
+        return self._enum(self.L.orc_enumerate_closed, offs, nbrs, sorted_nodes, L)
+
+    def count_per_start(self, offs, nbrs, sorted_nodes, L=3):
+        n = len(offs) - 1
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        sn = np.ascontiguousarray(sorted_nodes, np.uint32)
+        c = np.zeros(n, np.uint64)
+        self.L.orc_count_per_start(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), L, _p(c, _u64p))
+        return c
+
+    # R3 custom.h:492-511
+    def gen_vde_x(self, label, e):
+        x = np.zeros(e, np.float64)
+        self.L.orc_gen_vde_x(int(label), e, _p(x, _f64p))
+        return x
+
+    def label_table(self, n_labels, e):
+        return np.stack([self.gen_vde_x(l, e) for l in range(n_labels)]) if n_labels else np.zeros((0, e))
+
+    # R4 custom.h:513-544
+    def gen_vde(self, offs, nbrs, labels, e):
+        n = len(offs) - 1
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        labels = np.ascontiguousarray(labels, np.uint32)
+        x = np.zeros((n, e))
+        nx = np.zeros((n, e))
+        vde = np.zeros((n, e))
+        self.L.orc_gen_vde(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(labels, _u32p), e,
+                           _p(x, _f64p), _p(nx, _f64p), _p(vde, _f64p))
+        return x, nx, vde
+
+    # R5 custom.h:546-572
+    def gen_pde(self, paths, e, offs, labels, x, vde):
+        P, L = paths.shape
+        paths = np.ascontiguousarray(paths, np.uint32)
+        offs = np.ascontiguousarray(offs, np.uint32)
+        labels = np.ascontiguousarray(labels, np.uint32)
+        x = np.ascontiguousarray(x, np.float64)
+        vde = np.ascontiguousarray(vde, np.float64)
+        pde = np.zeros((P, e * L))
+        pdl = np.zeros((P, e * L))
+        pl = np.zeros((P, L), np.uint32)
+        pd = np.zeros((P, L), np.uint32)
+        self.L.orc_gen_pde(P, L, _p(paths, _u32p), e, _p(offs, _u32p), _p(labels, _u32p), _p(x, _f64p),
+                           _p(vde, _f64p), _p(pde, _f64p), _p(pdl, _f64p), _p(pl, _u32p), _p(pd, _u32p))
+        return pde, pdl, pl, pd
+
+    # R7 main.cpp:98-119
+    def write_all_paths(self, path, paths):
+        paths = np.ascontiguousarray(paths, np.uint32)
+        rc = self.L.orc_write_all_paths(path.encode(), paths.shape[0], paths.shape[1], _p(paths, _u32p))
+        if rc:
+            raise OSError(path)
+
+    def write_partition_paths(self, path, paths, membership, pid):
+        paths = np.ascontiguousarray(paths, np.uint32)
+        mem = np.ascontiguousarray(membership, np.uint32)
+        rc = self.L.orc_write_partition_paths(path.encode(), paths.shape[0], paths.shape[1],
+                                              _p(paths, _u32p), _p(mem, _u32p), pid)
+        if rc:
+            raise OSError(path)
+
+    def format_all_paths(self, paths):
+        paths = np.ascontiguousarray(paths, np.uint32)
+        P, L = paths.shape
+        nbytes = self.L.orc_format_all_paths(P, L, _p(paths, _u32p), None)
+        buf = C.create_string_buffer(nbytes)
+        self.L.orc_format_all_paths(P, L, _p(paths, _u32p), buf)
+        return buf.raw
+
+    # R6 decoder/validator
+    def index_validate(self, img):
+        """img: bytes of an index.dat.  Returns dict(hdr..., leaf_son, leaf_pt, height) or raises."""
+        hdr = (C.c_int32 * 8)()
+        rc = self.L.orc_index_validate(img, len(img), hdr, None, None, 0, None)
+        if rc != 0:
+            raise ValueError(f"index.dat invalid: code {rc}, header {list(hdr)}")
+        nd, dim = hdr[3], hdr[2]
+        son = np.zeros(nd, np.int32)
+        pt = np.zeros((nd, dim))
+        h = C.c_int32()
+        rc = self.L.orc_index_validate(img, len(img), hdr, _p(son, C.POINTER(C.c_int32)), _p(pt, _f64p), nd,
+                                       C.byref(h))
+        assert rc == 0
+        keys = ["blocklength", "n_blocks", "dim", "num_data", "dnodes", "inodes", "root_is_data", "root"]
+        out = dict(zip(keys, list(hdr)))
+        out.update(leaf_son=son, leaf_pt=pt, height=h.value)
+        return out

@@ -1,0 +1,564 @@
+/*
+ * gnnpe_oracle.c -- CPU restatement of the GNN-PE offline path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * See gnnpe_oracle.h.  Each function cites the reference lines it follows (paths relative to
+ * /root/reference/).  Pinned against the compiled reference (oracle/_ref) by
+ * tests/test_oracle_vs_reference.py (runs where /root/reference exists) and against the golden
+ * fixtures in tests/golden/ (generated from the reference binaries by tests/golden/make_golden.py).
+ * The product (gnn-pe_amd/) never links this file.
+ */
+#include "gnnpe_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------
+ * R0  Static_Graph::loadGraphFromFile   GNN-PE/libsrc/graph/graph.cpp:163-242
+ *   :172  "t n m" header              :185-206 'v id label degree' (offsets trust `degree`, :192)
+ *   :207-219 'e u v' fills both endpoints at a running per-vertex cursor
+ *   :223  labels_count = max(#distinct labels, max_label+1)    :231-233 sort each list ascending
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_u32(const void *a, const void *b)
+{
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+int orc_load_graph(const char *path, uint32_t *n_out, uint32_t *m_out,
+                   uint32_t **offsets, uint32_t **neighbors, uint32_t **labels,
+                   uint32_t *labels_count, uint32_t *max_degree, uint32_t *max_label_freq)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    char type;
+    uint32_t n = 0, m = 0;
+    if (fscanf(f, " %c %u %u", &type, &n, &m) != 3) { fclose(f); return -2; }
+    uint32_t *offs = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    uint32_t *nbr = (uint32_t *)calloc((size_t)m * 2 + 1, sizeof(uint32_t));
+    uint32_t *lab = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    uint32_t *cursor = (uint32_t *)calloc((size_t)n + 1, sizeof(uint32_t));
+    uint32_t maxdeg = 0, maxlabel = 0;
+    /* label frequency: labels are arbitrary uint32 in the reference (unordered_map); the
+     * oracle grows a dense table on demand. */
+    size_t freq_cap = 1024;
+    uint32_t *freq = (uint32_t *)calloc(freq_cap, sizeof(uint32_t));
+    uint32_t distinct = 0;
+    while (fscanf(f, " %c", &type) == 1) {
+        if (type == 'v') {
+            uint32_t id, label, degree;
+            if (fscanf(f, "%u %u %u", &id, &label, &degree) != 3) break;
+            lab[id] = label;
+            offs[id + 1] = offs[id] + degree; /* graph.cpp:192 */
+            if (degree > maxdeg) maxdeg = degree;
+            if ((size_t)label >= freq_cap) {
+                size_t nc = freq_cap;
+                while (nc <= (size_t)label) nc *= 2;
+                freq = (uint32_t *)realloc(freq, nc * sizeof(uint32_t));
+                memset(freq + freq_cap, 0, (nc - freq_cap) * sizeof(uint32_t));
+                freq_cap = nc;
+            }
+            if (freq[label] == 0) {
+                distinct++;
+                if (label > maxlabel) maxlabel = label;
+            }
+            freq[label]++;
+        } else if (type == 'e') {
+            uint32_t b, e;
+            if (fscanf(f, "%u %u", &b, &e) != 2) break;
+            nbr[offs[b] + cursor[b]++] = e; /* graph.cpp:211-218 */
+            nbr[offs[e] + cursor[e]++] = b;
+        }
+    }
+    fclose(f);
+    uint32_t mlf = 0;
+    for (size_t i = 0; i < freq_cap; i++)
+        if (freq[i] > mlf) mlf = freq[i];
+    for (uint32_t i = 0; i < n; i++)
+        qsort(nbr + offs[i], offs[i + 1] - offs[i], sizeof(uint32_t), cmp_u32); /* :231-233 */
+    free(cursor);
+    free(freq);
+    *n_out = n;
+    *m_out = m;
+    *offsets = offs;
+    *neighbors = nbr;
+    *labels = lab;
+    if (labels_count) *labels_count = distinct > maxlabel + 1 ? distinct : maxlabel + 1; /* :223 */
+    if (max_degree) *max_degree = maxdeg;
+    if (max_label_freq) *max_label_freq = mlf;
+    return 0;
+}
+
+/* R1  GNN-PE/src/main.cpp:77-85: line i = "<vertex> <partition>"; line order = processing order */
+int orc_read_membership(const char *path, uint32_t n, uint32_t *sorted_nodes, uint32_t *membership)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v, p;
+        if (fscanf(f, "%u %u", &v, &p) != 2) { fclose(f); return -2; }
+        sorted_nodes[i] = v;
+        membership[v] = p;
+    }
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R2  dfs + VectorHash   GNN-PE/include/custom.h:52-92, driver loop main.cpp:87-96
+ * Faithful form: recursion over ascending neighbours (custom.h:81-91), simple-path test by
+ * linear search of the current path (:85), at full depth keep iff neither the path (:68) nor
+ * its reverse (:70-72) is in the set; then append (:74-76).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t L;
+    uint32_t *paths; /* growable P x L */
+    uint64_t P, cap;
+    uint64_t *table; /* open addressing: 0 = empty, else path index + 1 */
+    uint64_t tmask, tused;
+    const uint32_t *offs, *nbr;
+} dfs_state;
+
+static uint64_t hash_tuple(const uint32_t *p, uint32_t L)
+{
+    /* same mixing as VectorHash (custom.h:52-64); only set semantics matter for parity */
+    uint64_t h = 0;
+    for (uint32_t i = 0; i < L; i++) h ^= (uint64_t)p[i] + 0x9e3779b9ull + (h << 6) + (h >> 2);
+    return h * 0x9E3779B97F4A7C15ull;
+}
+
+static int set_contains(const dfs_state *st, const uint32_t *p)
+{
+    uint64_t i = hash_tuple(p, st->L) & st->tmask;
+    while (st->table[i]) {
+        const uint32_t *q = st->paths + (st->table[i] - 1) * st->L;
+        if (memcmp(q, p, st->L * sizeof(uint32_t)) == 0) return 1;
+        i = (i + 1) & st->tmask;
+    }
+    return 0;
+}
+
+static void set_insert_index(dfs_state *st, uint64_t idx)
+{
+    const uint32_t *p = st->paths + idx * st->L;
+    uint64_t i = hash_tuple(p, st->L) & st->tmask;
+    while (st->table[i]) i = (i + 1) & st->tmask;
+    st->table[i] = idx + 1;
+    st->tused++;
+}
+
+static void set_grow(dfs_state *st)
+{
+    uint64_t ncap = (st->tmask + 1) * 2;
+    free(st->table);
+    st->table = (uint64_t *)calloc(ncap, sizeof(uint64_t));
+    st->tmask = ncap - 1;
+    st->tused = 0;
+    for (uint64_t k = 0; k < st->P; k++) set_insert_index(st, k);
+}
+
+static void dfs_rec(dfs_state *st, uint32_t node, uint32_t depth, uint32_t *path)
+{
+    uint32_t L = st->L;
+    if (depth == L) {
+        if (set_contains(st, path)) return;
+        uint32_t rev[16];
+        for (uint32_t i = 0; i < L; i++) rev[i] = path[L - 1 - i];
+        if (set_contains(st, rev)) return;
+        if (st->P == st->cap) {
+            st->cap = st->cap ? st->cap * 2 : 1024;
+            st->paths = (uint32_t *)realloc(st->paths, st->cap * L * sizeof(uint32_t));
+        }
+        memcpy(st->paths + st->P * L, path, L * sizeof(uint32_t));
+        st->P++;
+        if ((st->tused + 1) * 2 > st->tmask + 1) set_grow(st);
+        else set_insert_index(st, st->P - 1);
+        return;
+    }
+    for (uint32_t j = st->offs[node]; j < st->offs[node + 1]; j++) {
+        uint32_t c = st->nbr[j];
+        int seen = 0;
+        for (uint32_t k = 0; k < depth; k++)
+            if (path[k] == c) { seen = 1; break; }
+        if (seen) continue;
+        path[depth] = c;
+        dfs_rec(st, c, depth + 1, path);
+    }
+}
+
+uint64_t orc_enumerate_dfs_hash(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                                const uint32_t *sorted_nodes, uint32_t L,
+                                uint32_t *paths, uint64_t capacity)
+{
+    dfs_state st;
+    memset(&st, 0, sizeof(st));
+    st.L = L;
+    st.offs = offsets;
+    st.nbr = neighbors;
+    st.tmask = (1u << 16) - 1;
+    st.table = (uint64_t *)calloc(st.tmask + 1, sizeof(uint64_t));
+    uint32_t path[16];
+    for (uint32_t i = 0; i < n; i++) { /* main.cpp:92-96 */
+        path[0] = sorted_nodes[i];
+        dfs_rec(&st, sorted_nodes[i], 1, path);
+    }
+    uint64_t P = st.P;
+    if (paths && capacity >= P) memcpy(paths, st.paths, P * L * sizeof(uint32_t));
+    free(st.paths);
+    free(st.table);
+    return P;
+}
+
+/* Closed form of the same enumeration: the reverse of (v0..vL-1) is emitted
+ * from start vL-1, which is processed earlier iff rank[vL-1] < rank[v0]; so a simple path is
+ * kept iff rank[last] > rank[first].  Requires a simple graph (no duplicate edges). */
+typedef struct {
+    uint32_t L;
+    const uint32_t *offs, *nbr, *rank;
+    uint32_t *out;
+    uint64_t P, cap;
+} cf_state;
+
+static void cf_rec(cf_state *st, uint32_t node, uint32_t depth, uint32_t *path)
+{
+    uint32_t L = st->L;
+    for (uint32_t j = st->offs[node]; j < st->offs[node + 1]; j++) {
+        uint32_t c = st->nbr[j];
+        int seen = 0;
+        for (uint32_t k = 0; k < depth; k++)
+            if (path[k] == c) { seen = 1; break; }
+        if (seen) continue;
+        if (depth + 1 == L) {
+            if (st->rank[c] > st->rank[path[0]]) {
+                if (st->out && st->P < st->cap) {
+                    memcpy(st->out + st->P * L, path, depth * sizeof(uint32_t));
+                    st->out[st->P * L + depth] = c;
+                }
+                st->P++;
+            }
+        } else {
+            path[depth] = c;
+            cf_rec(st, c, depth + 1, path);
+        }
+    }
+}
+
+static uint32_t *make_rank(uint32_t n, const uint32_t *sorted_nodes)
+{
+    uint32_t *rank = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) rank[sorted_nodes[i]] = i;
+    return rank;
+}
+
+uint64_t orc_enumerate_closed(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *sorted_nodes, uint32_t L,
+                              uint32_t *paths, uint64_t capacity)
+{
+    cf_state st = {L, offsets, neighbors, make_rank(n, sorted_nodes), paths, 0, capacity};
+    uint32_t path[16];
+    for (uint32_t i = 0; i < n; i++) {
+        path[0] = sorted_nodes[i];
+        cf_rec(&st, sorted_nodes[i], 1, path);
+    }
+    free((void *)st.rank);
+    return st.P;
+}
+
+void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                         const uint32_t *sorted_nodes, uint32_t L, uint64_t *counts)
+{
+    cf_state st = {L, offsets, neighbors, make_rank(n, sorted_nodes), NULL, 0, 0};
+    uint32_t path[16];
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t before = st.P;
+        path[0] = sorted_nodes[i];
+        cf_rec(&st, sorted_nodes[i], 1, path);
+        counts[i] = st.P - before;
+    }
+    free((void *)st.rank);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R3  gen_vde_x   custom.h:492-511
+ *   std::mt19937(seed = label) (:495); e draws of uniform_real_distribution<double>(0,1) (:496-502);
+ *   std::accumulate from 0.0 (:504); divide (:505-508).
+ * libstdc++ semantics (what the reference is built with): the distribution calls
+ * generate_canonical<double,53>, which for a 32-bit engine takes k=2 outputs r0,r1 and returns
+ * (double(r0) + double(r1)*2^32) / 2^64, clamped below 1.  mt19937 is the published MT19937
+ * (Matsumoto & Nishimura) with init_genrand(seed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { uint32_t mt[624]; int idx; } mt_state;
+
+static void mt_seed(mt_state *s, uint32_t seed)
+{
+    s->mt[0] = seed;
+    for (int i = 1; i < 624; i++)
+        s->mt[i] = 1812433253u * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->idx = 624;
+}
+
+static uint32_t mt_next(mt_state *s)
+{
+    if (s->idx >= 624) {
+        for (int k = 0; k < 624; k++) {
+            uint32_t y = (s->mt[k] & 0x80000000u) | (s->mt[(k + 1) % 624] & 0x7fffffffu);
+            s->mt[k] = s->mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        s->idx = 0;
+    }
+    uint32_t y = s->mt[s->idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+void orc_gen_vde_x(uint32_t label, uint32_t e, double *x_out)
+{
+    mt_state s;
+    mt_seed(&s, label);
+    for (uint32_t i = 0; i < e; i++) {
+        double sum = 0.0, tmp = 1.0;
+        sum += (double)mt_next(&s) * tmp;
+        tmp *= 4294967296.0;
+        sum += (double)mt_next(&s) * tmp;
+        tmp *= 4294967296.0;
+        double r = sum / tmp;
+        if (r >= 1.0) r = nextafter(1.0, 0.0);
+        x_out[i] = r * (1.0 - 0.0) + 0.0;
+    }
+    double acc = 0.0;
+    for (uint32_t i = 0; i < e; i++) acc += x_out[i];
+    for (uint32_t i = 0; i < e; i++) x_out[i] = x_out[i] / acc;
+}
+
+/* R4  gen_vde   custom.h:513-544: x = table[label]; nx accumulated over neighbours in CSR
+ * (ascending id) order from 0.0 (:527-534); vde = x + nx (:536-540). */
+void orc_gen_vde(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                 const uint32_t *labels, uint32_t e, double *x, double *nx, double *vde)
+{
+    for (uint32_t i = 0; i < n; i++) orc_gen_vde_x(labels[i], e, x + (size_t)i * e);
+    for (uint32_t i = 0; i < n; i++) {
+        for (uint32_t k = 0; k < e; k++) nx[(size_t)i * e + k] = 0.0;
+        for (uint32_t j = offsets[i]; j < offsets[i + 1]; j++)
+            for (uint32_t k = 0; k < e; k++) nx[(size_t)i * e + k] += x[(size_t)neighbors[j] * e + k];
+        for (uint32_t k = 0; k < e; k++)
+            vde[(size_t)i * e + k] = x[(size_t)i * e + k] + nx[(size_t)i * e + k];
+    }
+}
+
+/* R5  gen_pde   custom.h:546-572: per path, per vertex k: vid, label, degree; pde = concat vde,
+ * pde_label = concat x. */
+void orc_gen_pde(uint64_t P, uint32_t L, const uint32_t *paths, uint32_t e,
+                 const uint32_t *offsets, const uint32_t *labels,
+                 const double *x, const double *vde,
+                 double *pde, double *pde_label, uint32_t *plabels, uint32_t *pdegrees)
+{
+    for (uint64_t i = 0; i < P; i++)
+        for (uint32_t j = 0; j < L; j++) {
+            uint32_t v = paths[i * L + j];
+            if (plabels) plabels[i * L + j] = labels[v];
+            if (pdegrees) pdegrees[i * L + j] = offsets[v + 1] - offsets[v];
+            for (uint32_t k = 0; k < e; k++) {
+                if (pde) pde[(i * L + j) * e + k] = vde[(size_t)v * e + k];
+                if (pde_label) pde_label[(i * L + j) * e + k] = x[(size_t)v * e + k];
+            }
+        }
+}
+
+/* R7  writers   main.cpp:98-119.  all_paths.txt: "<P>\n" then per path every id followed by one
+ * space (including the last) then "\n" (:114-118).  partition_paths.txt: "<count>\n" then one
+ * global path id per line (:102-106). */
+static uint32_t fmt_u64(char *dst, uint64_t v)
+{
+    char tmp[24];
+    uint32_t k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    for (uint32_t i = 0; i < k; i++) dst[i] = tmp[k - 1 - i];
+    return k;
+}
+
+uint64_t orc_format_all_paths(uint64_t P, uint32_t L, const uint32_t *paths, char *buf)
+{
+    char tmp[32];
+    uint64_t pos = 0;
+    uint32_t k = fmt_u64(tmp, P);
+    if (buf) memcpy(buf + pos, tmp, k);
+    pos += k;
+    if (buf) buf[pos] = '\n';
+    pos++;
+    for (uint64_t i = 0; i < P; i++) {
+        for (uint32_t j = 0; j < L; j++) {
+            k = fmt_u64(tmp, paths[i * L + j]);
+            if (buf) { memcpy(buf + pos, tmp, k); buf[pos + k] = ' '; }
+            pos += k + 1;
+        }
+        if (buf) buf[pos] = '\n';
+        pos++;
+    }
+    return pos;
+}
+
+int orc_write_all_paths(const char *path, uint64_t P, uint32_t L, const uint32_t *paths)
+{
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    fprintf(f, "%llu\n", (unsigned long long)P);
+    for (uint64_t i = 0; i < P; i++) {
+        for (uint32_t j = 0; j < L; j++) fprintf(f, "%u ", paths[i * L + j]);
+        fputc('\n', f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int orc_write_partition_paths(const char *path, uint64_t P, uint32_t L, const uint32_t *paths,
+                              const uint32_t *membership, uint32_t pid)
+{
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    uint64_t cnt = 0;
+    for (uint64_t i = 0; i < P; i++)
+        if (membership[paths[i * L]] == pid) cnt++;
+    fprintf(f, "%llu\n", (unsigned long long)cnt);
+    for (uint64_t i = 0; i < P; i++)
+        if (membership[paths[i * L]] == pid) fprintf(f, "%llu\n", (unsigned long long)i);
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * R6  index.dat decoder + consumer-constraint checker.
+ * File layout (little endian, packed):
+ *   block 0: int32 blocklength, int32 number_of_node_blocks      blk_file.cpp:38-39,51-52
+ *            at byte 8: int32 dimension, num_of_data, num_of_dnodes, num_of_inodes,
+ *            bool root_is_data (1 B), int32 root                 rtree.cpp:341-362
+ *   node block k at offset (k+1)*blocklength                     blk_file.cpp:108-125
+ *   node: char level, int32 num_entries, entries                 rtnode.cpp:1099-1117
+ *   entry: 2*dim doubles (lo0,hi0,lo1,hi1,...), int32 son        entry.cpp:127-136
+ *   capacity = (blocklength - 5) / (16*dim + 4)                  rtnode.cpp:27-28
+ * Consumer constraints (custom.h:258-266, 366-380): block ids dense 0..N-1 = exactly the nodes
+ * reachable from root; root internal; child level = parent level - 1; internal MBR encloses child.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint8_t *img;
+    int32_t bl, nblocks, dim, cap;
+    uint8_t *visited;
+    int64_t leaves, inodes, data;
+    int32_t *leaf_son;
+    double *leaf_pt;
+    uint64_t leaf_cap;
+    int err;
+} idx_state;
+
+static void node_mbr(const idx_state *st, int32_t blk, double *mbr /* 2*dim */, int *level, int32_t *ne)
+{
+    const uint8_t *b = st->img + (uint64_t)(blk + 1) * st->bl;
+    *level = (int)(signed char)b[0];
+    memcpy(ne, b + 1, 4);
+    size_t es = (size_t)16 * st->dim + 4;
+    for (int d = 0; d < st->dim; d++) { mbr[2 * d] = INFINITY; mbr[2 * d + 1] = -INFINITY; }
+    for (int32_t i = 0; i < *ne && i < st->cap; i++) {
+        double e[64];
+        memcpy(e, b + 5 + i * es, (size_t)16 * st->dim);
+        for (int d = 0; d < st->dim; d++) {
+            if (e[2 * d] < mbr[2 * d]) mbr[2 * d] = e[2 * d];
+            if (e[2 * d + 1] > mbr[2 * d + 1]) mbr[2 * d + 1] = e[2 * d + 1];
+        }
+    }
+}
+
+static void idx_walk(idx_state *st, int32_t blk, int expect_level)
+{
+    if (st->err) return;
+    if (blk < 0 || blk >= st->nblocks) { st->err = -10; return; }
+    if (st->visited[blk]) { st->err = -11; return; }
+    st->visited[blk] = 1;
+    const uint8_t *b = st->img + (uint64_t)(blk + 1) * st->bl;
+    int level = (int)(signed char)b[0];
+    int32_t ne;
+    memcpy(&ne, b + 1, 4);
+    if (expect_level >= 0 && level != expect_level) { st->err = -12; return; }
+    if (ne < 1 || ne > st->cap) { st->err = -13; return; }
+    size_t es = (size_t)16 * st->dim + 4;
+    if (level == 0) {
+        st->leaves++;
+        for (int32_t i = 0; i < ne; i++) {
+            double e[64];
+            int32_t son;
+            memcpy(e, b + 5 + i * es, (size_t)16 * st->dim);
+            memcpy(&son, b + 5 + i * es + (size_t)16 * st->dim, 4);
+            for (int d = 0; d < st->dim; d++)
+                if (e[2 * d] != e[2 * d + 1]) { st->err = -14; return; } /* points: custom.h:244-248 */
+            if ((uint64_t)st->data < st->leaf_cap) {
+                if (st->leaf_son) st->leaf_son[st->data] = son;
+                if (st->leaf_pt)
+                    for (int d = 0; d < st->dim; d++) st->leaf_pt[st->data * st->dim + d] = e[2 * d];
+            }
+            st->data++;
+        }
+    } else {
+        st->inodes++;
+        for (int32_t i = 0; i < ne; i++) {
+            double e[64], cm[64];
+            int32_t son;
+            memcpy(e, b + 5 + i * es, (size_t)16 * st->dim);
+            memcpy(&son, b + 5 + i * es + (size_t)16 * st->dim, 4);
+            if (son < 0 || son >= st->nblocks) { st->err = -10; return; }
+            int cl;
+            int32_t cne;
+            node_mbr(st, son, cm, &cl, &cne);
+            for (int d = 0; d < st->dim; d++)
+                if (e[2 * d] > cm[2 * d] || e[2 * d + 1] < cm[2 * d + 1]) { st->err = -15; return; }
+            idx_walk(st, son, level - 1);
+            if (st->err) return;
+        }
+    }
+}
+
+int orc_index_validate(const uint8_t *img, uint64_t nbytes, int32_t hdr[8],
+                       int32_t *leaf_son, double *leaf_pt, uint64_t leaf_capacity,
+                       int32_t *height_out)
+{
+    if (nbytes < 29) return -1;
+    int32_t bl, nb, dim, nd, dn, in, root;
+    memcpy(&bl, img, 4);
+    memcpy(&nb, img + 4, 4);
+    memcpy(&dim, img + 8, 4);
+    memcpy(&nd, img + 12, 4);
+    memcpy(&dn, img + 16, 4);
+    memcpy(&in, img + 20, 4);
+    uint8_t rid = img[24];
+    memcpy(&root, img + 25, 4);
+    hdr[0] = bl; hdr[1] = nb; hdr[2] = dim; hdr[3] = nd; hdr[4] = dn; hdr[5] = in; hdr[6] = rid; hdr[7] = root;
+    if (bl != 4096) return -2;
+    if (nb < 1 || (uint64_t)(nb + 1) * (uint64_t)bl != nbytes) return -3;
+    if (dim < 1 || dim > 32) return -4;
+    if (rid != 0) return -5;              /* root must be internal: custom.h:375 seeds level=1 */
+    if (root < 0 || root >= nb) return -6;
+    idx_state st;
+    memset(&st, 0, sizeof(st));
+    st.img = img; st.bl = bl; st.nblocks = nb; st.dim = dim;
+    st.cap = (bl - 5) / (16 * dim + 4);
+    st.visited = (uint8_t *)calloc((size_t)nb, 1);
+    st.leaf_son = leaf_son; st.leaf_pt = leaf_pt; st.leaf_cap = leaf_capacity;
+    int rl = (int)(signed char)img[(uint64_t)(root + 1) * bl];
+    if (rl < 1) { free(st.visited); return -5; }
+    idx_walk(&st, root, rl);
+    int err = st.err;
+    if (!err) {
+        for (int32_t k = 0; k < nb; k++)
+            if (!st.visited[k]) { err = -20; break; }   /* dense ids: custom.h:261,264,379 */
+    }
+    free(st.visited);
+    if (err) return err;
+    if (st.data != nd) return -21;
+    if (st.leaves != dn) return -22;
+    if (st.inodes != in) return -23;
+    if (height_out) *height_out = rl + 1;
+    return 0;
+}

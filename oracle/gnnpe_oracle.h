@@ -1,0 +1,92 @@
+/*
+ * gnnpe_oracle.h -- CPU restatement of the GNN-PE offline path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for the MI355X engine in gnn-pe_amd/.  It restates, in plain C,
+ * the algorithm of the reference (JamesWhiteSnow/GNN-PE) for the hot path named in
+ * BASELINE.json / SURVEY.md section 8.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product never links or calls it.
+ *
+ * Pinning: every function below is checked against the *compiled reference itself*
+ * (oracle/_ref/ref_main, oracle/_ref/ref_dump; see oracle/Makefile) and against the golden
+ * fixtures in tests/golden/ that were generated from those binaries
+ * (tests/golden/make_golden.py).  Citations are relative to /root/reference/.
+ */
+#ifndef GNNPE_ORACLE_H
+#define GNNPE_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- R0: graph loader (GNN-PE/libsrc/graph/graph.cpp:163-242) ------------------------- */
+/* Returns 0 on success, -1 if the file cannot be opened (reference: exit(-1), graph.cpp:166-169).
+ * offsets/neighbors/labels are malloc'ed; free with orc_free(). */
+int orc_load_graph(const char *path, uint32_t *n_out, uint32_t *m_out,
+                   uint32_t **offsets, uint32_t **neighbors, uint32_t **labels,
+                   uint32_t *labels_count, uint32_t *max_degree, uint32_t *max_label_freq);
+void orc_free(void *p);
+
+/* ---- R1: membership reader (GNN-PE/src/main.cpp:77-85) -------------------------------- */
+int orc_read_membership(const char *path, uint32_t n, uint32_t *sorted_nodes, uint32_t *membership);
+
+/* ---- R2: path enumeration (GNN-PE/include/custom.h:52-92, main.cpp:87-96) -------------- */
+/* Reference-faithful recursive DFS with a hash set keyed on the vertex tuple; keeps a path iff
+ * neither it nor its reverse is already in the set.  L = number of vertices per path
+ * (reference: always 3).  Two-phase: call with paths == NULL to get the count.
+ * paths: P x L uint32 (row major) in emission order.  start_of: optional P uint32 giving the
+ * start vertex' processing index.  Returns P. */
+uint64_t orc_enumerate_dfs_hash(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                                const uint32_t *sorted_nodes, uint32_t L,
+                                uint32_t *paths, uint64_t capacity);
+
+/* Closed form: for s in processing order, DFS over ascending neighbours,
+ * simple paths only, keep iff rank[last] > rank[first].  Valid for simple graphs. */
+uint64_t orc_enumerate_closed(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *sorted_nodes, uint32_t L,
+                              uint32_t *paths, uint64_t capacity);
+
+/* per start vertex (indexed by processing position i) path counts, closed form */
+void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                         const uint32_t *sorted_nodes, uint32_t L, uint64_t *counts);
+
+/* ---- R3: label feature (custom.h:492-511), libstdc++ mt19937 + generate_canonical ------- */
+void orc_gen_vde_x(uint32_t label, uint32_t e, double *x_out);
+
+/* ---- R4: vertex embedding (custom.h:513-544) ------------------------------------------ */
+/* x, nx, vde: n x e doubles each (row major). */
+void orc_gen_vde(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                 const uint32_t *labels, uint32_t e, double *x, double *nx, double *vde);
+
+/* ---- R5: path embedding (custom.h:546-572) -------------------------------------------- */
+/* pde, pde_label: P x (e*L) doubles; plabels, pdegrees: P x L uint32 (any may be NULL). */
+void orc_gen_pde(uint64_t P, uint32_t L, const uint32_t *paths, uint32_t e,
+                 const uint32_t *offsets, const uint32_t *labels,
+                 const double *x, const double *vde,
+                 double *pde, double *pde_label, uint32_t *plabels, uint32_t *pdegrees);
+
+/* ---- R7: writers (main.cpp:98-119) ----------------------------------------------------- */
+int orc_write_all_paths(const char *path, uint64_t P, uint32_t L, const uint32_t *paths);
+/* partition_paths.txt for partition pid: ids of paths whose start vertex is in pid, ascending */
+int orc_write_partition_paths(const char *path, uint64_t P, uint32_t L, const uint32_t *paths,
+                              const uint32_t *membership, uint32_t pid);
+/* in-memory variants: returns byte length; buf may be NULL to size */
+uint64_t orc_format_all_paths(uint64_t P, uint32_t L, const uint32_t *paths, char *buf);
+
+/* ---- R6: index.dat reader / structural validator --------------------------------------- */
+/* (rtree.cpp:318-362, rtnode.cpp:789-807,1099-1117, entry.cpp:127-136, blk_file.cpp:22-63,108-168)
+ * Decodes the file image and checks every consumer constraint of SURVEY 8(a) R6.
+ * On success returns 0 and fills hdr[8] = {blocklength, n_blocks, dim, num_data, dnodes,
+ * inodes, root_is_data, root}; leaf_son (num_data int32) and leaf_pt (num_data x dim doubles,
+ * the lo bounds) receive the leaf entries in DFS order when non-NULL.
+ * Negative return = which constraint failed (see gnnpe_oracle.c). */
+int orc_index_validate(const uint8_t *img, uint64_t nbytes, int32_t hdr[8],
+                       int32_t *leaf_son, double *leaf_pt, uint64_t leaf_capacity,
+                       int32_t *height_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
