@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- offline path-embedding build throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one full pass of the hot path over the synthetic 1M-vertex / 10M-edge labelled graph
+(BASELINE.json configs[2]; l=2, e=2): [N>1: halo exchange + vde all-gather] -> vde -> count + scan
+-> fill (path ids + fp64 path embeddings written to HBM).  Inputs (this rank's CSR rows, order,
+label table) are resident in HBM before the timed region.  N>1 partitions the SAME graph across the
+ranks (configs[3]), so scaling is "strong".  value = paths of all ranks / max-over-ranks step time.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (k_fill_tiled): algorithmic bytes (92 B/path at l=2,e=2,
+                  SURVEY 8(d)) / its launch duration, timed live with events on the launch stream;
+  cpu_baseline -- the UNMODIFIED reference `main -m offline` (oracle/_ref/ref_main), single thread,
+                  on a bounded sample of the same generator (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import gnnpe_amd  # noqa: E402,F401
+from gnnpe_amd import binding, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def bytes_per_path(L, e):
+    """B_path = 4L (ids) + 8eL (pde) + 16 (two candidate reads: id + rank) + 8e (vde[c])."""
+    return 4 * L + 8 * e * L + 16 + 8 * e
+
+
+def cpu_baseline(sample_n, sample_m, seed):
+    """Time the reference's own offline step on a bounded sample.  Only this leg (and tests /
+    smoke) may touch oracle/."""
+    from oracle import Oracle, ref_main_path
+    g = synth.gnm_graph(sample_n, sample_m, seed=seed)
+    sn = synth.degree_order(g["offsets"])
+    P = synth.expected_paths_l2(g["offsets"])
+    sample = f"G(n={sample_n}, m={sample_m}) same generator/seed family, l=2, p=1: {P} paths"
+    if os.path.exists(ref_main_path()):
+        with tempfile.TemporaryDirectory() as wd:
+            gp = os.path.join(wd, "g.graph")
+            synth.write_graph_file(gp, g)
+            synth.make_dataset_dir(wd, 1)
+            synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), sn, np.zeros(sample_n, np.uint32))
+            t0 = time.perf_counter()
+            subprocess.check_call([ref_main_path(), "-f", wd + "/", "-d", gp, "-m", "offline", "-p", "1"],
+                                  stdout=subprocess.DEVNULL)
+            dt = time.perf_counter() - t0
+            hdr = int(open(os.path.join(wd, "gnn-pe", "all_paths.txt")).readline())
+            assert hdr == P, (hdr, P)
+        kind = "reference"
+        sample += "; whole `main -m offline` wall-clock (load + DFS/hash-set + both text files)"
+    else:
+        orc = Oracle()
+        t0 = time.perf_counter()
+        paths = orc.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 3)
+        orc.format_all_paths(paths)
+        dt = time.perf_counter() - t0
+        assert len(paths) == P
+        kind = "port"
+        sample += "; oracle hash-set DFS + text formatting"
+    return dict(value=P / dt, unit="paths/s", cores=1, kind=kind, sample=sample, seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--m", type=int, default=10_000_000)
+    ap.add_argument("--e", type=int, default=2)
+    ap.add_argument("--labels", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=synth.SEED)
+    ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
+    ap.add_argument("--fill-variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="15000,150000")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    L, e = 3, args.e
+    g = synth.gnm_graph(args.n, args.m, n_labels=args.labels, seed=args.seed)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(args.n, max(world, 1))
+
+    from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs
+    eng = binding.Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    bounds = plan_slabs(g["offsets"], sn, world)
+    if world == 1:
+        eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    else:
+        rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
+        eng.load_rows(args.n, g["labels"], rows, roff, rnbr, nbr_capacity=2 * args.m + int(roff[-1]))
+    eng.set_order(sn, mem, max(world, 1))
+    eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
+    eng.set_label_table(binding.host_label_table(args.labels, e))
+    eng.set_fill_variant(args.fill_variant)
+    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=2 * args.m)
+
+    # first pass sizes the outputs (and every internal buffer); not timed
+    total, base = sb.step()
+    out_ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
+    out_pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
+
+    fill_ms = []
+
+    def one_step(timed):
+        if world > 1:
+            sb.exchange_halo()
+            sb.exchange_vde()
+            t = sb.count()
+        else:
+            eng.vde(want=False)
+            t = sb._count_single()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        eng.fill_paths_device(0, t, out_ids, out_pde, None)
+        ev1.record()
+        if timed:
+            fill_ms.append((ev0, ev1))
+        return t
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = one_step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    global_total = sb.global_total
+    ms_per_step = dt * 1e3 / args.steps
+    value = global_total / (ms_per_step / 1e3)
+
+    fill_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ms])) if fill_ms else float("nan")
+    bpp = (4 * L + 16) if args.ids_only else bytes_per_path(L, e)
+    achieved = total * bpp / (fill_avg_ms / 1e3) / 1e9
+    roofline = dict(bound="hbm", kernel=binding.load().gnnpe_fill_kernel_name().decode() if args.fill_variant == 0
+                    else "k_fill_edge_wave", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_path=bpp, paths_per_launch=total,
+                    launch_ms=fill_avg_ms)
+
+    out = dict(metric="offline paths-embedded/sec + index-build wallclock, 1M-V/10M-E l=2",
+               value_is="paths-embedded/sec of one device-resident pass (halo+vde+count+scan+fill)",
+               value=value, unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="u32 ids + f64 embeddings", data="synthetic",
+               config=dict(workload=f"G(n={args.n}, m={args.m}) seed {args.seed}, {args.labels} labels, l=2, e={e}, "
+                                    f"degree-sorted order; {'ids only' if args.ids_only else 'ids + pde'}",
+                           paths=global_total, parallelism=f"slab{world}", fill_variant=args.fill_variant),
+               roofline=roofline)
+    if world > 1:
+        out["halo"] = sb.stats
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))
+            out["cpu_baseline"] = cpu_baseline(sn_, sm_, args.seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

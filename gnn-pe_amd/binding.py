@@ -1,0 +1,256 @@
+"""ctypes view of the C-ABI in include/gnnpe_hip.h (libgnnpe_hip.so).
+
+This is plumbing for bench.py and the tests: numpy arrays / raw device pointers go in, nothing
+torch-typed crosses the boundary.  `load()` raises if the HIP library is missing or cannot be
+loaded -- there is deliberately no CPU fallback (the oracle lives in oracle/ and is never
+imported from here).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnnpe_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnpe_hip.h")
+
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): one row per declaration in include/gnnpe_hip.h
+SIGNATURES = {
+    "gnnpe_abi_version": (C.c_int, []),
+    "gnnpe_last_error": (C.c_char_p, []),
+    "gnnpe_create": (_vp, [C.c_int]),
+    "gnnpe_destroy": (None, [_vp]),
+    "gnnpe_set_stream": (C.c_int, [_vp, _vp]),
+    "gnnpe_sync": (C.c_int, [_vp]),
+    "gnnpe_load_csr": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p]),
+    "gnnpe_load_rows": (C.c_int, [_vp, C.c_uint32, _u32p, C.c_uint32, _u32p, _u64p, _u32p, C.c_uint64]),
+    "gnnpe_set_order": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32]),
+    "gnnpe_set_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "gnnpe_set_label_table": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f64p]),
+    "gnnpe_host_label_table": (C.c_int, [C.c_uint32, C.c_uint32, _f64p]),
+    "gnnpe_halo_need": (C.c_int, [_vp, C.c_uint32, _u32p, _vp, C.c_uint64, _u64p]),
+    "gnnpe_rows_degree": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
+    "gnnpe_rows_pack": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
+    "gnnpe_rows_append": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64]),
+    "gnnpe_rows_drop_halo": (C.c_int, [_vp]),
+    "gnnpe_vde": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
+    "gnnpe_vde_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gnnpe_vde_pack_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "gnnpe_vde_unpack_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "gnnpe_count_paths": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
+    "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
+    "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    "gnnpe_path_partitions_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "gnnpe_fill_kernel_name": (C.c_char_p, []),
+    "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+class GnnpeError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libgnnpe_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [HEADER_PATH]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "libgnnpe_hip.so"])
+    return LIB_PATH
+
+
+def load():
+    """dlopen libgnnpe_hip.so and bind every symbol the header declares.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GnnpeError(f"{LIB_PATH} is missing: build it with `make -C gnn-pe_amd` "
+                         "(there is no CPU fallback for the HIP engine)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnnpe_abi_version() != 1:
+        raise GnnpeError(f"ABI version {lib.gnnpe_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def _np(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype)
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _dev(t):
+    """Raw device pointer of a torch tensor / int / None."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def host_label_table(n_labels, e):
+    """R3: gen_vde_x (custom.h:492-511) for labels 0..n_labels-1 -- host arithmetic inside the library."""
+    out = np.zeros((n_labels, e))
+    rc = load().gnnpe_host_label_table(n_labels, e, _ptr(out, _f64p))
+    if rc:
+        raise GnnpeError(load().gnnpe_last_error().decode())
+    return out
+
+
+class Engine:
+    """One context = one GPU.  Method names follow the reference functions they replace."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        self.ctx = self.lib.gnnpe_create(int(device))
+        if not self.ctx:
+            raise GnnpeError("gnnpe_create: " + self.lib.gnnpe_last_error().decode())
+        self.n = 0
+        self.e = 0
+        self.slab = (0, 0)
+        self.total = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self.ctx:
+            self.lib.gnnpe_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise GnnpeError(f"[{rc}] " + self.lib.gnnpe_last_error().decode())
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t as int (torch.cuda.current_stream().cuda_stream), or None."""
+        self._ck(self.lib.gnnpe_set_stream(self.ctx, C.c_void_p(stream) if stream else None))
+
+    def sync(self):
+        self._ck(self.lib.gnnpe_sync(self.ctx))
+
+    # R0: Static_Graph::loadGraphFromFile output (graph.cpp:163-242)
+    def load_csr(self, offsets, nbrs, labels):
+        offsets, nbrs, labels = _np(offsets, np.uint32), _np(nbrs, np.uint32), _np(labels, np.uint32)
+        n = len(offsets) - 1
+        assert len(labels) == n and len(nbrs) == offsets[-1]
+        self._ck(self.lib.gnnpe_load_csr(self.ctx, n, _ptr(offsets, _u32p), _ptr(nbrs, _u32p), _ptr(labels, _u32p)))
+        self.n = n
+        self.slab = (0, n)
+
+    def load_rows(self, n, labels, rows, row_offsets, row_nbrs, nbr_capacity=0):
+        labels, rows = _np(labels, np.uint32), _np(rows, np.uint32)
+        row_offsets, row_nbrs = _np(row_offsets, np.uint64), _np(row_nbrs, np.uint32)
+        self._ck(self.lib.gnnpe_load_rows(self.ctx, n, _ptr(labels, _u32p), len(rows), _ptr(rows, _u32p),
+                                          _ptr(row_offsets, _u64p), _ptr(row_nbrs, _u32p), int(nbr_capacity)))
+        self.n = n
+        self.slab = (0, n)
+
+    # R1: main.cpp:77-85
+    def set_order(self, sorted_nodes, membership, p):
+        sn, mem = _np(sorted_nodes, np.uint32), _np(membership, np.uint32)
+        assert len(sn) == self.n and len(mem) == self.n
+        self._ck(self.lib.gnnpe_set_order(self.ctx, _ptr(sn, _u32p), _ptr(mem, _u32p), int(p)))
+
+    def set_slab(self, begin, end):
+        self._ck(self.lib.gnnpe_set_slab(self.ctx, int(begin), int(end)))
+        self.slab = (int(begin), int(end))
+
+    # R3: gen_vde_x table (custom.h:492-511)
+    def set_label_table(self, table):
+        t = _np(table, np.float64)
+        assert t.ndim == 2
+        self._ck(self.lib.gnnpe_set_label_table(self.ctx, t.shape[0], t.shape[1], _ptr(t, _f64p)))
+        self.e = t.shape[1]
+
+    # R4: gen_vde (custom.h:513-544)
+    def vde(self, want=True):
+        if not want:
+            self._ck(self.lib.gnnpe_vde(self.ctx, None, None, None))
+            return None
+        x = np.zeros((self.n, self.e))
+        nx = np.zeros((self.n, self.e))
+        v = np.zeros((self.n, self.e))
+        self._ck(self.lib.gnnpe_vde(self.ctx, _ptr(x, _f64p), _ptr(nx, _f64p), _ptr(v, _f64p)))
+        return x, nx, v
+
+    def vde_device_ptr(self):
+        a, b = _vp(), _vp()
+        self._ck(self.lib.gnnpe_vde_device_ptr(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def vde_pack_slab(self, begin, end, dev_buf):
+        self._ck(self.lib.gnnpe_vde_pack_slab(self.ctx, begin, end, _dev(dev_buf)))
+
+    def vde_unpack_slab(self, begin, end, dev_buf):
+        self._ck(self.lib.gnnpe_vde_unpack_slab(self.ctx, begin, end, _dev(dev_buf)))
+
+    # R2: dfs + VectorHash (custom.h:52-92), count half
+    def count_paths(self, l=2, per_start=False):
+        tot = C.c_uint64()
+        ps = np.zeros(self.slab[1] - self.slab[0], np.uint64) if per_start else None
+        self._ck(self.lib.gnnpe_count_paths(self.ctx, l, _ptr(ps, _u64p), C.byref(tot)))
+        self.total = tot.value
+        return (tot.value, ps) if per_start else tot.value
+
+    # R2 + R5: emit half (gen_pde, custom.h:546-572)
+    def fill_paths(self, begin=0, end=None, ids=True, pde=True, pde_label=False, L=3):
+        end = self.total if end is None else end
+        cnt = end - begin
+        D = self.e * L
+        v = np.zeros((cnt, L), np.uint32) if ids else None
+        p = np.zeros((cnt, D)) if pde else None
+        q = np.zeros((cnt, D)) if pde_label else None
+        self._ck(self.lib.gnnpe_fill_paths(self.ctx, begin, end, _ptr(v, _u32p), _ptr(p, _f64p), _ptr(q, _f64p)))
+        return v, p, q
+
+    def fill_paths_device(self, begin, end, dev_vids=None, dev_pde=None, dev_pde_label=None):
+        self._ck(self.lib.gnnpe_fill_paths_device(self.ctx, begin, end, _dev(dev_vids), _dev(dev_pde),
+                                                  _dev(dev_pde_label)))
+
+    def path_partitions_device(self, begin, end, dev_part):
+        self._ck(self.lib.gnnpe_path_partitions_device(self.ctx, begin, end, _dev(dev_part)))
+
+    def set_fill_variant(self, v):
+        self._ck(self.lib.gnnpe_set_fill_variant(self.ctx, int(v)))
+
+    # halo exchange helpers
+    def halo_need(self, slab_bounds, dev_ids, cap):
+        b = _np(slab_bounds, np.uint32)
+        counts = np.zeros(len(b) - 1, np.uint64)
+        self._ck(self.lib.gnnpe_halo_need(self.ctx, len(b) - 1, _ptr(b, _u32p), _dev(dev_ids), int(cap),
+                                          _ptr(counts, _u64p)))
+        return counts
+
+    def rows_degree(self, n_req, dev_ids, dev_deg):
+        self._ck(self.lib.gnnpe_rows_degree(self.ctx, int(n_req), _dev(dev_ids), _dev(dev_deg)))
+
+    def rows_pack(self, n_req, dev_ids, dev_out, cap):
+        self._ck(self.lib.gnnpe_rows_pack(self.ctx, int(n_req), _dev(dev_ids), _dev(dev_out), int(cap)))
+
+    def rows_append(self, n_rows, dev_ids, dev_deg, dev_nbrs, n_nbrs):
+        self._ck(self.lib.gnnpe_rows_append(self.ctx, int(n_rows), _dev(dev_ids), _dev(dev_deg), _dev(dev_nbrs),
+                                            int(n_nbrs)))
+
+    def rows_drop_halo(self):
+        self._ck(self.lib.gnnpe_rows_drop_halo(self.ctx))

@@ -1,0 +1,114 @@
+// gnnpe_common.h -- internal helpers shared by the HIP translation units of libgnnpe_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/gnnpe_hip.h"
+
+namespace gnnpe {
+
+void set_error(const char *fmt, ...);
+
+#define GNNPE_HIP_TRY(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            gnnpe::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                             __LINE__);                                                           \
+            return GNNPE_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+#define GNNPE_REQUIRE(cond, code, ...)                                                            \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            gnnpe::set_error(__VA_ARGS__);                                                        \
+            return (code);                                                                        \
+        }                                                                                         \
+    } while (0)
+
+// Grow-only device buffer: allocations are made outside the steady-state step (first call sizes
+// them), so repeated steps enqueue kernels only.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need)
+    {
+        if (need <= bytes) return GNNPE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return GNNPE_ERR_HIP;
+        }
+        bytes = want;
+        return GNNPE_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+constexpr int kBlock = 256;            // 4 wave64 per workgroup
+constexpr int kMaxGrid = 256 * 8 * 4;  // grid-stride cap: 256 CUs x 8 blocks (guide G11) x 4
+
+inline int grid_for(uint64_t items, int per_block = kBlock)
+{
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+}  // namespace gnnpe
+
+struct gnnpe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+
+    // ---- graph (R0) ----
+    uint32_t n = 0;
+    bool have_graph = false;
+    bool rows_identity = true;  // rows == 0..n-1 (full CSR) vs. an owned-row list
+    uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
+    uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
+    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows;
+
+    // ---- order (R1) ----
+    bool have_order = false;
+    uint32_t p = 1;
+    uint32_t slab_begin = 0, slab_end = 0;
+    bool slab_set = false;
+    gnnpe::DevBuf sorted, rank, member;
+
+    // ---- label table (R3) / vertex embeddings (R4) ----
+    uint32_t n_labels = 0, e = 0;
+    bool have_table = false, have_vde = false;
+    gnnpe::DevBuf xtab, x, nx, vde;
+
+    // ---- enumeration state (R2) ----
+    bool counted = false;
+    uint32_t l = 0;
+    uint64_t n_edges = 0;  // directed (start, middle) pairs of the slab
+    uint64_t total_paths = 0;
+    gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, tile_edge, cub_tmp, scratch, mark, small;
+    uint32_t tile_T = 0;  // tile size tile_edge was built for (0 = stale)
+    int fill_variant = 0;
+
+    // pinned host words for small read-backs
+    uint64_t *h_pinned = nullptr;
+};

@@ -1,0 +1,752 @@
+// gnnpe_engine.hip -- C-ABI (include/gnnpe_hip.h) over the gfx950 kernels in gnnpe_kernels.hip.h.
+//
+// Host-side orchestration only: buffer ownership, launch configuration, the rocPRIM/hipCUB scans
+// and selections that glue the hand-written kernels together.  No CPU fallback exists: if HIP is
+// not usable every entry point returns an error.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <random>
+#include <vector>
+
+#include "gnnpe_common.h"
+#include "gnnpe_kernels.hip.h"
+
+namespace gnnpe {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct CastU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+struct CastU8 {
+    __host__ __device__ uint32_t operator()(uint8_t v) const { return (uint32_t)v; }
+};
+
+// exclusive sum of cnt uint32 -> uint64 (n items) on the context stream
+static int scan_u32_to_u64(gnnpe_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n)
+{
+    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t *> it(in, CastU64());
+    size_t tb = 0;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, out, (int64_t)n, c->stream));
+    int rc = c->cub_tmp.reserve(tb);
+    if (rc) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, out, (int64_t)n, c->stream));
+    return GNNPE_OK;
+}
+
+static int scan_u32(gnnpe_ctx *c, const uint32_t *in, uint32_t *out, uint64_t n)
+{
+    size_t tb = 0;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int64_t)n, c->stream));
+    int rc = c->cub_tmp.reserve(tb);
+    if (rc) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, in, out, (int64_t)n, c->stream));
+    return GNNPE_OK;
+}
+
+static int read_back_u64(gnnpe_ctx *c, const void *dev, size_t bytes, uint64_t *host_word)
+{
+    *c->h_pinned = 0;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    *host_word = *c->h_pinned;
+    return GNNPE_OK;
+}
+
+static int ensure_rank_arrays(gnnpe_ctx *c)
+{
+    GNNPE_REQUIRE(c->have_graph, GNNPE_ERR_ARG, "no graph loaded (gnnpe_load_csr / gnnpe_load_rows first)");
+    GNNPE_REQUIRE(c->have_order, GNNPE_ERR_ARG, "no processing order (gnnpe_set_order first)");
+    return GNNPE_OK;
+}
+
+template <int E, int T, bool PDL> static void launch_tiled(const FillParams &P, uint32_t ntiles, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_fill_tiled<E, T, PDL>), dim3(ntiles), dim3(256), 0, s, P);
+}
+
+// tile size per (e, pde_label?) -- keeps the staged tile near 30-50 KiB of LDS
+static uint32_t tile_size_for(uint32_t e, bool pdl)
+{
+    switch (e) {
+    case 1: return 512;
+    case 2: return pdl ? 256 : 512;
+    case 3: return pdl ? 128 : 256;
+    case 4: return pdl ? 128 : 256;
+    case 8: return pdl ? 64 : 128;
+    default: return 0;  // no tiled instantiation: edge-per-wave variant
+    }
+}
+
+static bool launch_tiled_dispatch(uint32_t e, bool pdl, const FillParams &P, uint32_t ntiles, hipStream_t s)
+{
+    switch (e) {
+    case 1: pdl ? launch_tiled<1, 512, true>(P, ntiles, s) : launch_tiled<1, 512, false>(P, ntiles, s); return true;
+    case 2: pdl ? launch_tiled<2, 256, true>(P, ntiles, s) : launch_tiled<2, 512, false>(P, ntiles, s); return true;
+    case 3: pdl ? launch_tiled<3, 128, true>(P, ntiles, s) : launch_tiled<3, 256, false>(P, ntiles, s); return true;
+    case 4: pdl ? launch_tiled<4, 128, true>(P, ntiles, s) : launch_tiled<4, 256, false>(P, ntiles, s); return true;
+    case 8: pdl ? launch_tiled<8, 64, true>(P, ntiles, s) : launch_tiled<8, 128, false>(P, ntiles, s); return true;
+    default: return false;
+    }
+}
+
+}  // namespace gnnpe
+
+using namespace gnnpe;
+
+extern "C" {
+
+int gnnpe_abi_version(void) { return GNNPE_ABI_VERSION; }
+const char *gnnpe_last_error(void) { return g_err; }
+const char *gnnpe_fill_kernel_name(void) { return "k_fill_tiled"; }
+
+gnnpe_ctx *gnnpe_create(int device_id)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (%s); this engine has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        set_error("device %d out of range (have %d)", device_id, ndev);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) {
+        set_error("hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+        return nullptr;
+    }
+    gnnpe_ctx *c = new gnnpe_ctx();
+    c->device = device_id;
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(uint64_t))) != hipSuccess) {
+        set_error("context setup: %s", hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void gnnpe_destroy(gnnpe_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
+                      &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small};
+    for (DevBuf *b : bufs) b->release();
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int gnnpe_set_stream(gnnpe_ctx *c, void *hip_stream)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GNNPE_OK;
+}
+
+int gnnpe_sync(gnnpe_ctx *c)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+static int alloc_vertex_arrays(gnnpe_ctx *c, uint32_t n)
+{
+    int rc;
+    if ((rc = c->adj_start.reserve((size_t)(n + 1) * 4))) return rc;
+    if ((rc = c->adj_deg.reserve((size_t)(n + 1) * 4))) return rc;
+    if ((rc = c->present.reserve((size_t)n + 1))) return rc;
+    if ((rc = c->labels.reserve((size_t)(n + 1) * 4))) return rc;
+    GNNPE_HIP_TRY(hipMemsetAsync(c->adj_start.p, 0, (size_t)(n + 1) * 4, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->adj_deg.p, 0, (size_t)(n + 1) * 4, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->present.p, 0, (size_t)n + 1, c->stream));
+    return GNNPE_OK;
+}
+
+static void invalidate_derived(gnnpe_ctx *c)
+{
+    c->have_vde = false;
+    c->counted = false;
+    c->tile_T = 0;
+}
+
+int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_t *nbrs, const uint32_t *labels)
+{
+    GNNPE_REQUIRE(c && offs && labels && (nbrs || offs[n] == 0), GNNPE_ERR_ARG, "gnnpe_load_csr: null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint64_t m2 = offs[n];
+    for (uint32_t i = 0; i < n; i++)
+        GNNPE_REQUIRE(offs[i] <= offs[i + 1], GNNPE_ERR_ARG, "offsets not monotone at %u", i);
+    int rc;
+    if ((rc = alloc_vertex_arrays(c, n))) return rc;
+    if ((rc = c->nbrs.reserve((m2 + 1) * 4))) return rc;
+    if ((rc = c->scratch.reserve((size_t)(n + 1) * 4))) return rc;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->scratch.p, offs, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (m2) GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.p, nbrs, m2 * 4, hipMemcpyHostToDevice, c->stream));
+    if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->labels.p, labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (n)
+        hipLaunchKernelGGL(k_offsets_to_start_deg, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n,
+                           c->scratch.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                           c->present.as<uint8_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = n;
+    c->have_graph = true;
+    c->rows_identity = true;
+    c->n_rows = n;
+    c->nbr_used = c->nbr_owned = m2;
+    c->nbr_cap = c->nbrs.bytes / 4;
+    if (!c->slab_set) {
+        c->slab_begin = 0;
+        c->slab_end = n;
+    }
+    invalidate_derived(c);
+    return GNNPE_OK;
+}
+
+int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n_rows, const uint32_t *rows,
+                    const uint64_t *row_offsets, const uint32_t *row_nbrs, uint64_t nbr_capacity)
+{
+    GNNPE_REQUIRE(c && labels && (n_rows == 0 || (rows && row_offsets)), GNNPE_ERR_ARG,
+                  "gnnpe_load_rows: null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint64_t used = n_rows ? row_offsets[n_rows] : 0;
+    GNNPE_REQUIRE(used == 0 || row_nbrs, GNNPE_ERR_ARG, "gnnpe_load_rows: null neighbour buffer");
+    for (uint32_t k = 0; k < n_rows; k++)
+        GNNPE_REQUIRE(rows[k] < n && row_offsets[k] <= row_offsets[k + 1], GNNPE_ERR_ARG, "bad row %u", k);
+    const uint64_t cap = std::max<uint64_t>(nbr_capacity, used) + 1;
+    GNNPE_REQUIRE(cap < (1ull << 32), GNNPE_ERR_RANGE, "neighbour buffer of %llu entries exceeds 32-bit addressing",
+                  (unsigned long long)cap);
+    int rc;
+    if ((rc = alloc_vertex_arrays(c, n))) return rc;
+    if ((rc = c->nbrs.reserve(cap * 4))) return rc;
+    if ((rc = c->rows.reserve((size_t)(n_rows + 1) * 4))) return rc;
+    if ((rc = c->scratch.reserve((size_t)(n_rows + 1) * 8))) return rc;
+    if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->labels.p, labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_rows) {
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->rows.p, rows, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->scratch.p, row_offsets, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice,
+                                     c->stream));
+        if (used) GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.p, row_nbrs, used * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_install_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, (uint64_t)n_rows,
+                           c->rows.as<uint32_t>(), c->scratch.as<uint64_t>(), (uint64_t)0,
+                           c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = c->owned.reserve((size_t)n + 1))) return rc;
+    if (n) GNNPE_HIP_TRY(hipMemcpy(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice));
+    c->n = n;
+    c->have_graph = true;
+    c->rows_identity = false;
+    c->n_rows = n_rows;
+    c->nbr_used = c->nbr_owned = used;
+    c->nbr_cap = c->nbrs.bytes / 4;
+    if (!c->slab_set) {
+        c->slab_begin = 0;
+        c->slab_end = n;
+    }
+    invalidate_derived(c);
+    return GNNPE_OK;
+}
+
+int gnnpe_set_order(gnnpe_ctx *c, const uint32_t *sorted_nodes, const uint32_t *membership, uint32_t p)
+{
+    GNNPE_REQUIRE(c && sorted_nodes && membership, GNNPE_ERR_ARG, "gnnpe_set_order: null argument");
+    GNNPE_REQUIRE(c->have_graph, GNNPE_ERR_ARG, "gnnpe_set_order: load the graph first");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    // membership.txt must list every vertex exactly once (main.cpp:80-85 never checks; we do)
+    {
+        std::vector<uint8_t> seen(n, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            GNNPE_REQUIRE(sorted_nodes[i] < n && !seen[sorted_nodes[i]], GNNPE_ERR_ARG,
+                          "processing order is not a permutation (entry %u = %u)", i, sorted_nodes[i]);
+            seen[sorted_nodes[i]] = 1;
+            GNNPE_REQUIRE(membership[i] < p, GNNPE_ERR_ARG, "membership[%u] = %u >= p = %u", i, membership[i], p);
+        }
+    }
+    int rc;
+    if ((rc = c->sorted.reserve((size_t)(n + 1) * 4))) return rc;
+    if ((rc = c->rank.reserve((size_t)(n + 1) * 4))) return rc;
+    if ((rc = c->member.reserve((size_t)(n + 1) * 4))) return rc;
+    if (n) {
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->sorted.p, sorted_nodes, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->member.p, membership, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_invert_order, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, c->sorted.as<uint32_t>(),
+                           c->rank.as<uint32_t>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->p = p;
+    c->have_order = true;
+    c->counted = false;
+    c->tile_T = 0;
+    return GNNPE_OK;
+}
+
+int gnnpe_set_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_set_slab: load the graph first");
+    GNNPE_REQUIRE(begin <= end && end <= c->n, GNNPE_ERR_ARG, "slab [%u,%u) outside [0,%u]", begin, end, c->n);
+    c->slab_begin = begin;
+    c->slab_end = end;
+    c->slab_set = true;
+    c->counted = false;
+    c->tile_T = 0;
+    return GNNPE_OK;
+}
+
+int gnnpe_set_label_table(gnnpe_ctx *c, uint32_t n_labels, uint32_t e, const double *x_table)
+{
+    GNNPE_REQUIRE(c && x_table && n_labels > 0, GNNPE_ERR_ARG, "gnnpe_set_label_table: null/empty table");
+    GNNPE_REQUIRE(e >= 1 && e <= 32, GNNPE_ERR_UNSUPPORTED, "embedding dimension e=%u outside [1,32]", e);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->xtab.reserve((size_t)n_labels * e * 8))) return rc;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->xtab.p, x_table, (size_t)n_labels * e * 8, hipMemcpyHostToDevice, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_labels = n_labels;
+    c->e = e;
+    c->have_table = true;
+    c->have_vde = false;
+    return GNNPE_OK;
+}
+
+// R3: gen_vde_x (custom.h:492-511) with the same libstdc++ engine/distribution classes the reference
+// is compiled against; depends only on the label, so it is tabulated once on the host.
+int gnnpe_host_label_table(uint32_t n_labels, uint32_t e, double *out)
+{
+    GNNPE_REQUIRE(out && e >= 1, GNNPE_ERR_ARG, "gnnpe_host_label_table: null output / e=0");
+    for (uint32_t label = 0; label < n_labels; label++) {
+        std::mt19937 gen(label);
+        std::uniform_real_distribution<double> dis(0.0, 1.0);
+        double *row = out + (size_t)label * e;
+        for (uint32_t k = 0; k < e; k++) row[k] = dis(gen);
+        double sum = 0.0;
+        for (uint32_t k = 0; k < e; k++) sum += row[k];
+        for (uint32_t k = 0; k < e; k++) row[k] = row[k] / sum;
+    }
+    return GNNPE_OK;
+}
+
+// ---- R4 ---------------------------------------------------------------------------------------
+static int run_vde(gnnpe_ctx *c)
+{
+    GNNPE_REQUIRE(c->have_graph && c->have_table, GNNPE_ERR_ARG, "gnnpe_vde: need graph and label table");
+    const uint32_t n = c->n, e = c->e;
+    int rc;
+    const size_t bytes = (size_t)n * e * 8 + 16;
+    if ((rc = c->x.reserve(bytes)) || (rc = c->nx.reserve(bytes)) || (rc = c->vde.reserve(bytes))) return rc;
+    if (n == 0) {
+        c->have_vde = true;
+        return GNNPE_OK;
+    }
+    // every label must index the table (its size is the loader's labels_count, graph.cpp:223)
+    {
+        size_t tb = 0;
+        if ((rc = c->small.reserve(256))) return rc;
+        uint32_t *d_max = c->small.as<uint32_t>();
+        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->labels.as<uint32_t>(), d_max, (int)n, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(c->cub_tmp.p, tb, c->labels.as<uint32_t>(), d_max, (int)n, c->stream));
+        uint64_t mx = 0;
+        if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
+        GNNPE_REQUIRE((uint32_t)mx < c->n_labels, GNNPE_ERR_ARG, "label %u has no row in the %u-row label table",
+                      (uint32_t)mx, c->n_labels);
+    }
+    GNNPE_HIP_TRY(hipMemsetAsync(c->nx.p, 0, bytes, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->vde.p, 0, bytes, c->stream));
+    hipLaunchKernelGGL(k_x_from_labels, dim3(grid_for((uint64_t)n * e)), dim3(kBlock), 0, c->stream, n, e,
+                       c->labels.as<uint32_t>(), c->xtab.as<double>(), c->x.as<double>());
+    const uint32_t nr = c->n_rows;
+    if (nr) {
+        const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
+        dim3 grid((nr + 255) / 256), block(256);
+#define GNNPE_VDE_ARGS                                                                                   \
+    nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),           \
+        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>()
+        switch (e) {
+        case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        case 2: hipLaunchKernelGGL((k_vde<2>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        case 3: hipLaunchKernelGGL((k_vde<3>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        case 4: hipLaunchKernelGGL((k_vde<4>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        case 8: hipLaunchKernelGGL((k_vde<8>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        default: hipLaunchKernelGGL((k_vde<0>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        }
+#undef GNNPE_VDE_ARGS
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->have_vde = true;
+    return GNNPE_OK;
+}
+
+int gnnpe_vde(gnnpe_ctx *c, double *hx, double *hnx, double *hvde)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc = run_vde(c);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->n * c->e * 8;
+    if (bytes) {
+        if (hx) GNNPE_HIP_TRY(hipMemcpyAsync(hx, c->x.p, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (hnx) GNNPE_HIP_TRY(hipMemcpyAsync(hnx, c->nx.p, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (hvde) GNNPE_HIP_TRY(hipMemcpyAsync(hvde, c->vde.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (hx || hnx || hvde) GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+int gnnpe_vde_device_ptr(gnnpe_ctx *c, void **dev_vde, void **dev_x)
+{
+    GNNPE_REQUIRE(c && c->have_vde, GNNPE_ERR_ARG, "gnnpe_vde_device_ptr: call gnnpe_vde first");
+    if (dev_vde) *dev_vde = c->vde.p;
+    if (dev_x) *dev_x = c->x.p;
+    return GNNPE_OK;
+}
+
+int gnnpe_vde_pack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, void *dev_buf)
+{
+    GNNPE_REQUIRE(c && c->have_vde && c->have_order && dev_buf, GNNPE_ERR_ARG, "gnnpe_vde_pack_slab: bad state");
+    GNNPE_REQUIRE(begin <= end && end <= c->n, GNNPE_ERR_ARG, "bad slab");
+    if (end > begin)
+        hipLaunchKernelGGL(k_vde_pack, dim3(grid_for((uint64_t)(end - begin) * c->e)), dim3(kBlock), 0, c->stream, begin,
+                           end, c->e, c->sorted.as<uint32_t>(), c->vde.as<double>(), (double *)dev_buf);
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void *dev_buf)
+{
+    GNNPE_REQUIRE(c && c->have_vde && c->have_order && dev_buf, GNNPE_ERR_ARG, "gnnpe_vde_unpack_slab: bad state");
+    GNNPE_REQUIRE(begin <= end && end <= c->n, GNNPE_ERR_ARG, "bad slab");
+    if (end > begin)
+        hipLaunchKernelGGL(k_vde_unpack, dim3(grid_for((uint64_t)(end - begin) * c->e)), dim3(kBlock), 0, c->stream,
+                           begin, end, c->e, c->sorted.as<uint32_t>(), (const double *)dev_buf, c->vde.as<double>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+// ---- R2 count -----------------------------------------------------------------------------------
+int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_rank_arrays(c);
+    if (rc) return rc;
+    // The reference enumerates 3-vertex paths whatever -l says; l=2 is the parity path.
+    GNNPE_REQUIRE(l == 2, GNNPE_ERR_UNSUPPORTED, "path length l=%u: only l=2 (3-vertex paths) is implemented", l);
+    const uint32_t sb = c->slab_begin, se = c->slab_end, len = se - sb;
+    c->counted = false;
+    c->tile_T = 0;
+
+    // 1. slab rows -> directed (s, b) pairs in emission order
+    if ((rc = c->poffs.reserve((size_t)(len + 2) * 4)) || (rc = c->scratch.reserve((size_t)(len + 2) * 8))) return rc;
+    uint32_t *pdeg = c->scratch.as<uint32_t>();
+    hipLaunchKernelGGL(k_slab_degrees, dim3(grid_for(len + 1)), dim3(kBlock), 0, c->stream, len, sb,
+                       c->sorted.as<uint32_t>(), c->adj_deg.as<uint32_t>(), pdeg);
+    if ((rc = scan_u32(c, pdeg, c->poffs.as<uint32_t>(), (uint64_t)len + 1))) return rc;
+    uint64_t w = 0;
+    if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
+    const uint64_t ne = (uint32_t)w;
+    c->n_edges = ne;
+    if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4)) ||
+        (rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->eoff.reserve((ne + 2) * 8)) ||
+        (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4)))
+        return rc;
+    if (len)
+        hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
+                           c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                           c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
+    // 2. rank of every held neighbour entry (turns the rank test into a coalesced stream)
+    if (c->nbr_used)
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
+                           c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
+    // 3. per-pair counts and their exclusive scan (global slot of every pair's first path)
+    hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
+                       c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                       c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
+    if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
+    c->total_paths = w;
+    c->l = l;
+    c->counted = true;
+    if (host_total) *host_total = w;
+    if (host_per_start && len) {
+        if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
+        hipLaunchKernelGGL(k_per_start_counts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len,
+                           c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->scratch.as<uint64_t>());
+        GNNPE_HIP_TRY(hipMemcpyAsync(host_per_start, c->scratch.p, (size_t)len * 8, hipMemcpyDeviceToHost, c->stream));
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return GNNPE_OK;
+}
+
+static int ensure_tiles(gnnpe_ctx *c, uint32_t T)
+{
+    if (c->tile_T == T) return GNNPE_OK;
+    const uint64_t ntiles = (c->total_paths + T - 1) / T;
+    int rc;
+    if ((rc = c->tile_edge.reserve((ntiles + 2) * 4))) return rc;
+    if (c->n_edges)
+        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for(c->n_edges)), dim3(kBlock), 0, c->stream, c->n_edges, T,
+                           c->eoff.as<uint64_t>(), c->tile_edge.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->tile_T = T;
+    return GNNPE_OK;
+}
+
+static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids, void *d_pde, void *d_pdl,
+                       void *d_part)
+{
+    GNNPE_REQUIRE(c && c->counted, GNNPE_ERR_ARG, "gnnpe_fill_paths: call gnnpe_count_paths first");
+    GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "path range [%llu,%llu) outside [0,%llu]",
+                  (unsigned long long)begin, (unsigned long long)end, (unsigned long long)c->total_paths);
+    GNNPE_REQUIRE((!d_pde && !d_pdl) || c->have_vde, GNNPE_ERR_ARG, "gnnpe_fill_paths: embeddings requested before gnnpe_vde");
+    if (begin == end) return GNNPE_OK;
+    FillParams P;
+    P.erow = c->erow.as<uint32_t>();
+    P.pnbr = c->pnbr.as<uint32_t>();
+    P.adj_start = c->adj_start.as<uint32_t>();
+    P.adj_deg = c->adj_deg.as<uint32_t>();
+    P.nbrs = c->nbrs.as<uint32_t>();
+    P.nbr_rank = c->nbr_rank.as<uint32_t>();
+    P.sorted = c->sorted.as<uint32_t>();
+    P.member = c->member.as<uint32_t>();
+    P.eoff = c->eoff.as<uint64_t>();
+    P.vde = c->vde.as<double>();
+    P.x = c->x.as<double>();
+    P.n_edges = c->n_edges;
+    P.begin = begin;
+    P.end = end;
+    P.slab_begin = c->slab_begin;
+    P.e = c->have_table ? c->e : 1;
+    P.out_ids = (uint32_t *)d_vids;
+    P.out_pde = (double *)d_pde;
+    P.out_pdl = (double *)d_pdl;
+    P.out_part = (uint32_t *)d_part;
+    P.tile_edge = nullptr;
+    P.tile0 = 0;
+    const bool pdl = d_pdl != nullptr;
+    const uint32_t T = (c->fill_variant == 0) ? tile_size_for(P.e, pdl) : 0;
+    if (T) {
+        int rc = ensure_tiles(c, T);
+        if (rc) return rc;
+        const uint64_t t0 = begin / T, t1 = (end - 1) / T;
+        GNNPE_REQUIRE(t1 - t0 + 1 < (1ull << 31), GNNPE_ERR_RANGE, "too many tiles in one call; chunk the range");
+        P.tile_edge = c->tile_edge.as<uint32_t>();
+        P.tile0 = (uint32_t)t0;
+        GNNPE_REQUIRE(t0 < (1ull << 32), GNNPE_ERR_RANGE, "tile index overflow");
+        launch_tiled_dispatch(P.e, pdl, P, (uint32_t)(t1 - t0 + 1), c->stream);
+    } else {
+        hipLaunchKernelGGL(k_fill_edge_wave, dim3(grid_for(c->n_edges * 64)), dim3(kBlock), 0, c->stream, P);
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+int gnnpe_fill_paths_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *dev_vids, void *dev_pde,
+                            void *dev_pde_label)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    return fill_device(c, begin, end, dev_vids, dev_pde, dev_pde_label, nullptr);
+}
+
+int gnnpe_path_partitions_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *dev_part)
+{
+    GNNPE_REQUIRE(c && dev_part, GNNPE_ERR_ARG, "null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    return fill_device(c, begin, end, nullptr, nullptr, nullptr, dev_part);
+}
+
+int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, double *hpde, double *hpdl)
+{
+    GNNPE_REQUIRE(c && c->counted, GNNPE_ERR_ARG, "gnnpe_fill_paths: call gnnpe_count_paths first");
+    GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "bad path range");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint64_t cnt = end - begin;
+    if (!cnt) return GNNPE_OK;
+    const uint32_t e = c->have_table ? c->e : 1, D = 3 * e;
+    DevBuf bv, bp, bl;
+    int rc = GNNPE_OK;
+    if (hv) rc = bv.reserve(cnt * 3 * 4);
+    if (!rc && hpde) rc = bp.reserve(cnt * D * 8);
+    if (!rc && hpdl) rc = bl.reserve(cnt * D * 8);
+    if (!rc) rc = fill_device(c, begin, end, hv ? bv.p : nullptr, hpde ? bp.p : nullptr, hpdl ? bl.p : nullptr, nullptr);
+    hipError_t he = hipSuccess;
+    if (!rc && hv) he = hipMemcpyAsync(hv, bv.p, cnt * 3 * 4, hipMemcpyDeviceToHost, c->stream);
+    if (!rc && he == hipSuccess && hpde) he = hipMemcpyAsync(hpde, bp.p, cnt * D * 8, hipMemcpyDeviceToHost, c->stream);
+    if (!rc && he == hipSuccess && hpdl) he = hipMemcpyAsync(hpdl, bl.p, cnt * D * 8, hipMemcpyDeviceToHost, c->stream);
+    if (!rc && he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (!rc && he != hipSuccess) {
+        set_error("gnnpe_fill_paths copy-back: %s", hipGetErrorString(he));
+        rc = GNNPE_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    bv.release();
+    bp.release();
+    bl.release();
+    return rc;
+}
+
+int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
+{
+    GNNPE_REQUIRE(c && (variant == 0 || variant == 1), GNNPE_ERR_ARG, "fill variant must be 0 or 1");
+    c->fill_variant = variant;
+    return GNNPE_OK;
+}
+
+// ---- halo helpers -------------------------------------------------------------------------------
+int gnnpe_halo_need(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds, void *dev_ids, uint64_t cap,
+                    uint64_t *host_counts)
+{
+    GNNPE_REQUIRE(c && bounds && host_counts && n_ranks >= 1, GNNPE_ERR_ARG, "gnnpe_halo_need: null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_rank_arrays(c);
+    if (rc) return rc;
+    const uint32_t n = c->n;
+    if ((rc = c->mark.reserve((size_t)2 * n + 16))) return rc;
+    uint8_t *mark = c->mark.as<uint8_t>(), *flag = mark + n;
+    GNNPE_HIP_TRY(hipMemsetAsync(mark, 0, n, c->stream));
+    if (c->nbr_owned)
+        hipLaunchKernelGGL(k_mark_needed, dim3(grid_for(c->nbr_owned)), dim3(kBlock), 0, c->stream, c->nbr_owned,
+                           c->nbrs.as<uint32_t>(), mark);
+    uint64_t used = 0;
+    if ((rc = c->small.reserve(256))) return rc;
+    uint32_t *d_num = c->small.as<uint32_t>() + 8;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        hipLaunchKernelGGL(k_flag_owner, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, mark,
+                           c->present.as<uint8_t>(), c->rank.as<uint32_t>(), bounds[r], bounds[r + 1], flag);
+        hipcub::CountingInputIterator<uint32_t> ids(0);
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb, ids, flag, (uint32_t *)nullptr, d_num, (int)n, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        if ((rc = c->scratch.reserve((size_t)(n + 1) * 4))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceSelect::Flagged(c->cub_tmp.p, tb, ids, flag, c->scratch.as<uint32_t>(), d_num, (int)n,
+                                                    c->stream));
+        uint64_t k = 0;
+        if ((rc = read_back_u64(c, d_num, 4, &k))) return rc;
+        k = (uint32_t)k;
+        host_counts[r] = k;
+        if (k) {
+            GNNPE_REQUIRE(dev_ids && used + k <= cap, GNNPE_ERR_ARG, "gnnpe_halo_need: id buffer too small (%llu needed)",
+                          (unsigned long long)(used + k));
+            GNNPE_HIP_TRY(hipMemcpyAsync((uint32_t *)dev_ids + used, c->scratch.p, k * 4, hipMemcpyDeviceToDevice,
+                                         c->stream));
+        }
+        used += k;
+    }
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+int gnnpe_rows_drop_halo(gnnpe_ctx *c)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_drop_halo: no graph");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (c->rows_identity || c->nbr_used == c->nbr_owned) return GNNPE_OK;
+    hipLaunchKernelGGL(k_drop_halo, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->owned.as<uint8_t>(),
+                       c->present.as<uint8_t>(), c->adj_deg.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->nbr_used = c->nbr_owned;
+    c->counted = false;
+    c->tile_T = 0;
+    return GNNPE_OK;
+}
+
+int gnnpe_rows_degree(gnnpe_ctx *c, uint64_t n_req, const void *dev_ids, void *dev_deg)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_degree: no graph");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (!n_req) return GNNPE_OK;
+    GNNPE_REQUIRE(dev_ids && dev_deg, GNNPE_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n_req)), dim3(kBlock), 0, c->stream, n_req, (const uint32_t *)dev_ids,
+                       c->adj_deg.as<uint32_t>(), (uint32_t *)dev_deg);
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+int gnnpe_rows_pack(gnnpe_ctx *c, uint64_t n_req, const void *dev_ids, void *dev_out, uint64_t cap)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_pack: no graph");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (!n_req) return GNNPE_OK;
+    GNNPE_REQUIRE(dev_ids && dev_out, GNNPE_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = c->scratch.reserve((n_req + 1) * 12 + 64))) return rc;
+    uint64_t *roff = c->scratch.as<uint64_t>();
+    uint32_t *deg = reinterpret_cast<uint32_t *>(roff + n_req + 1);
+    hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n_req)), dim3(kBlock), 0, c->stream, n_req, (const uint32_t *)dev_ids,
+                       c->adj_deg.as<uint32_t>(), deg);
+    GNNPE_HIP_TRY(hipMemsetAsync(deg + n_req, 0, 4, c->stream));
+    if ((rc = scan_u32_to_u64(c, deg, roff, n_req + 1))) return rc;
+    uint64_t tot = 0;
+    if ((rc = read_back_u64(c, roff + n_req, 8, &tot))) return rc;
+    GNNPE_REQUIRE(tot <= cap, GNNPE_ERR_ARG, "gnnpe_rows_pack: output holds %llu entries, need %llu",
+                  (unsigned long long)cap, (unsigned long long)tot);
+    hipLaunchKernelGGL(k_rows_pack, dim3(grid_for(n_req * 16)), dim3(kBlock), 0, c->stream, n_req,
+                       (const uint32_t *)dev_ids, roff, c->adj_start.as<uint32_t>(), c->nbrs.as<uint32_t>(),
+                       (uint32_t *)dev_out);
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const void *dev_deg, const void *dev_nbrs,
+                      uint64_t n_nbrs)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_append: no graph");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (!n_rows) return GNNPE_OK;
+    GNNPE_REQUIRE(dev_ids && dev_deg && (dev_nbrs || !n_nbrs), GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->nbr_used + n_nbrs <= c->nbr_cap, GNNPE_ERR_ARG,
+                  "gnnpe_rows_append: neighbour buffer full (%llu + %llu > %llu); reserve more in gnnpe_load_rows",
+                  (unsigned long long)c->nbr_used, (unsigned long long)n_nbrs, (unsigned long long)c->nbr_cap);
+    int rc;
+    if ((rc = c->scratch.reserve((n_rows + 1) * 12 + 64))) return rc;
+    uint64_t *roff = c->scratch.as<uint64_t>();
+    uint32_t *deg = reinterpret_cast<uint32_t *>(roff + n_rows + 1);
+    GNNPE_HIP_TRY(hipMemcpyAsync(deg, dev_deg, n_rows * 4, hipMemcpyDeviceToDevice, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(deg + n_rows, 0, 4, c->stream));
+    if ((rc = scan_u32_to_u64(c, deg, roff, n_rows + 1))) return rc;
+    uint64_t tot = 0;
+    if ((rc = read_back_u64(c, roff + n_rows, 8, &tot))) return rc;
+    GNNPE_REQUIRE(tot == n_nbrs, GNNPE_ERR_ARG, "gnnpe_rows_append: degrees sum to %llu but %llu entries given",
+                  (unsigned long long)tot, (unsigned long long)n_nbrs);
+    if (n_nbrs)
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.as<uint32_t>() + c->nbr_used, dev_nbrs, n_nbrs * 4, hipMemcpyDeviceToDevice,
+                                     c->stream));
+    hipLaunchKernelGGL(k_install_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, n_rows,
+                       (const uint32_t *)dev_ids, roff, c->nbr_used, c->adj_start.as<uint32_t>(),
+                       c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->nbr_used += n_nbrs;
+    c->counted = false;
+    c->tile_T = 0;
+    return GNNPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,517 @@
+// gnnpe_kernels.hip.h -- hand-written gfx950 kernels of the offline path (included by gnnpe_engine.hip).
+//
+// All kernels are HBM/L2-bound integer + fp64 gather/scatter work (the reference has no
+// dense contraction, so there is nothing for MFMA).  Wave = 64 lanes; blocks are 256 threads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gnnpe {
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ unsigned wave_id() { return threadIdx.x >> 6; }
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_invert_order(uint32_t n, const uint32_t *__restrict__ sorted, uint32_t *__restrict__ rank)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        rank[sorted[i]] = (uint32_t)i;
+}
+
+__global__ void k_offsets_to_start_deg(uint32_t n, const uint32_t *__restrict__ offs, uint32_t *__restrict__ start,
+                                       uint32_t *__restrict__ deg, uint8_t *__restrict__ present)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t a = offs[i], b = offs[i + 1];
+        start[i] = a;
+        deg[i] = b - a;
+        present[i] = 1;
+    }
+}
+
+// rows loaded through gnnpe_load_rows / gnnpe_rows_append: row k (vertex ids[k]) occupies
+// [base + roff[k], base + roff[k+1]) of the neighbour buffer.
+__global__ void k_install_rows(uint64_t n_rows, const uint32_t *__restrict__ ids, const uint64_t *__restrict__ roff,
+                               uint64_t base, uint32_t *__restrict__ start, uint32_t *__restrict__ deg,
+                               uint8_t *__restrict__ present)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_rows; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = ids[k];
+        start[v] = (uint32_t)(base + roff[k]);
+        deg[v] = (uint32_t)(roff[k + 1] - roff[k]);
+        present[v] = 1;
+    }
+}
+
+__global__ void k_gather_u32(uint64_t cnt, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ table,
+                             uint32_t *__restrict__ out)
+{
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < cnt; q += (uint64_t)gridDim.x * blockDim.x)
+        out[q] = table[idx[q]];
+}
+
+// slab row degrees: pdeg[i] = deg(sorted[slab_begin + i]); pdeg[len] = 0 (scan sentinel)
+__global__ void k_slab_degrees(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
+                               const uint32_t *__restrict__ deg, uint32_t *__restrict__ pdeg)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= len; i += (uint64_t)gridDim.x * blockDim.x)
+        pdeg[i] = i < len ? deg[sorted[slab_begin + i]] : 0u;
+}
+
+// Directed (start, middle) pairs of the slab in emission order: 16 lanes per start vertex.
+__global__ void k_perm_edges(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
+                             const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ poffs,
+                             const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ erow, uint32_t *__restrict__ pnbr)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < len; g += ng) {
+        uint32_t s = sorted[slab_begin + g];
+        uint32_t a = adj_start[s];
+        uint32_t o = poffs[g], d = poffs[g + 1] - o;
+        for (uint32_t j = sub; j < d; j += 16) {
+            erow[o + j] = (uint32_t)g;
+            pnbr[o + j] = nbrs[a + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R4 gen_vde (custom.h:513-544).  One thread per held row; the block's adjacency range is contiguous
+// in the neighbour buffer, so it is streamed once with coalesced loads, turned into neighbour LABELS
+// in LDS, and every thread then adds its own row's features in ascending-neighbour order -- the same
+// operation order as the reference loop (:527-534), hence bit-identical fp64 results.
+// The label table (|Sigma| x e doubles) also sits in LDS when it fits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kVdeStage = 6144;        // neighbour labels staged per pass (24 KiB)
+constexpr int kVdeTabMax = 4096;       // table doubles kept in LDS (32 KiB)
+
+template <int E>
+__global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__restrict__ rows,
+                                             const uint32_t *__restrict__ adj_start,
+                                             const uint32_t *__restrict__ adj_deg,
+                                             const uint32_t *__restrict__ nbrs,
+                                             const uint32_t *__restrict__ labels,
+                                             const double *__restrict__ xtab, uint32_t n_labels, uint32_t e_rt,
+                                             double *__restrict__ nx, double *__restrict__ vde)
+{
+    const int e = E ? E : (int)e_rt;
+    __shared__ uint32_t s_lab[kVdeStage];
+    __shared__ double s_tab[kVdeTabMax];
+    const bool tab_in_lds = (uint64_t)n_labels * e <= (uint64_t)kVdeTabMax;
+    if (tab_in_lds)
+        for (uint32_t i = threadIdx.x; i < n_labels * e; i += blockDim.x) s_tab[i] = xtab[i];
+
+    const uint32_t r0 = blockIdx.x * blockDim.x;
+    const uint32_t r = r0 + threadIdx.x;
+    const uint32_t rlast = min(r0 + blockDim.x, n_rows) - 1;
+    const uint32_t v0 = rows ? rows[r0] : r0;
+    const uint32_t vl = rows ? rows[rlast] : rlast;
+    const uint32_t q_begin = adj_start[v0];
+    const uint32_t q_end = adj_start[vl] + adj_deg[vl];
+
+    uint32_t v = 0, my_b = 0, my_e = 0;
+    if (r < n_rows) {
+        v = rows ? rows[r] : r;
+        my_b = adj_start[v];
+        my_e = my_b + adj_deg[v];
+    }
+    double acc[E ? E : 32];
+#pragma unroll
+    for (int k = 0; k < (E ? E : 32); k++) acc[k] = 0.0;
+
+    __syncthreads();
+    for (uint32_t c0 = q_begin; c0 < q_end; c0 += kVdeStage) {
+        const uint32_t c1 = min(c0 + (uint32_t)kVdeStage, q_end);
+        for (uint32_t q = c0 + threadIdx.x; q < c1; q += blockDim.x) s_lab[q - c0] = labels[nbrs[q]];
+        __syncthreads();
+        const uint32_t lo = max(my_b, c0), hi = min(my_e, c1);
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint32_t lb = s_lab[q - c0];
+            if (E) {
+#pragma unroll
+                for (int k = 0; k < E; k++) acc[k] += tab_in_lds ? s_tab[lb * E + k] : xtab[(uint64_t)lb * E + k];
+            } else {
+                for (int k = 0; k < e; k++) acc[k] += tab_in_lds ? s_tab[lb * e + k] : xtab[(uint64_t)lb * e + k];
+            }
+        }
+        __syncthreads();
+    }
+    if (r < n_rows) {
+        const uint32_t lv = labels[v];
+        for (int k = 0; k < e; k++) {
+            const double xv = tab_in_lds ? s_tab[lv * e + k] : xtab[(uint64_t)lv * e + k];
+            nx[(uint64_t)v * e + k] = acc[k];
+            vde[(uint64_t)v * e + k] = xv + acc[k];
+        }
+    }
+}
+
+// x[v] = table[label[v]] for every vertex (labels are replicated on every rank)
+__global__ void k_x_from_labels(uint32_t n, uint32_t e, const uint32_t *__restrict__ labels,
+                                const double *__restrict__ xtab, double *__restrict__ x)
+{
+    const uint64_t tot = (uint64_t)n * e;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = (uint32_t)(i / e), k = (uint32_t)(i % e);
+        x[i] = xtab[(uint64_t)labels[v] * e + k];
+    }
+}
+
+__global__ void k_vde_pack(uint32_t begin, uint32_t end, uint32_t e, const uint32_t *__restrict__ sorted,
+                           const double *__restrict__ vde, double *__restrict__ buf)
+{
+    const uint64_t tot = (uint64_t)(end - begin) * e;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t row = (uint32_t)(i / e), k = (uint32_t)(i % e);
+        buf[i] = vde[(uint64_t)sorted[begin + row] * e + k];
+    }
+}
+
+__global__ void k_vde_unpack(uint32_t begin, uint32_t end, uint32_t e, const uint32_t *__restrict__ sorted,
+                             const double *__restrict__ buf, double *__restrict__ vde)
+{
+    const uint64_t tot = (uint64_t)(end - begin) * e;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t row = (uint32_t)(i / e), k = (uint32_t)(i % e);
+        vde[(uint64_t)sorted[begin + row] * e + k] = buf[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2 count (closed form of dfs + VectorHash, custom.h:52-92): for the directed pair e = (s, b),
+// cnt[e] = |{ c in N(b) : rank[c] > rank[s] }|  (c != s is implied).  16 lanes per pair; the
+// neighbour RANKS of b are a contiguous 4-byte stream.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_edges(uint64_t n_edges, uint32_t slab_begin,
+                                                     const uint32_t *__restrict__ erow,
+                                                     const uint32_t *__restrict__ pnbr,
+                                                     const uint32_t *__restrict__ adj_start,
+                                                     const uint32_t *__restrict__ adj_deg,
+                                                     const uint32_t *__restrict__ nbr_rank,
+                                                     uint32_t *__restrict__ ecnt)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    // all 16 lanes of a group iterate together; groups past the end still take part in shuffles
+    const uint64_t g_end = (n_edges + 3) & ~(uint64_t)3;  // whole waves (4 groups per wave)
+    for (; g < g_end; g += ng) {
+        uint32_t cnt = 0;
+        if (g < n_edges) {
+            const uint32_t thr = slab_begin + erow[g];
+            const uint32_t b = pnbr[g];
+            const uint32_t st = adj_start[b], d = adj_deg[b];
+            for (uint32_t j = sub; j < d; j += 16) cnt += nbr_rank[st + j] > thr ? 1u : 0u;
+        }
+        cnt += __shfl_xor(cnt, 8);
+        cnt += __shfl_xor(cnt, 4);
+        cnt += __shfl_xor(cnt, 2);
+        cnt += __shfl_xor(cnt, 1);
+        if (sub == 0 && g < n_edges) ecnt[g] = cnt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ecnt[n_edges] = 0;
+}
+
+__global__ void k_per_start_counts(uint32_t len, const uint32_t *__restrict__ poffs,
+                                   const uint64_t *__restrict__ eoff, uint64_t *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = eoff[poffs[i + 1]] - eoff[poffs[i]];
+}
+
+// tile k starts inside pair e iff eoff[e] <= k*T < eoff[e+1]
+__global__ void k_tile_edges(uint64_t n_edges, uint32_t T, const uint64_t *__restrict__ eoff,
+                             uint32_t *__restrict__ tile_edge)
+{
+    for (uint64_t e = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; e < n_edges; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = eoff[e], b = eoff[e + 1];
+        if (b > a) {
+            for (uint64_t k = (a + T - 1) / T; k * T < b; k++) tile_edge[k] = (uint32_t)e;
+        }
+    }
+}
+
+struct FillParams {
+    const uint32_t *erow, *pnbr, *adj_start, *adj_deg, *nbrs, *nbr_rank, *sorted, *tile_edge, *member;
+    const uint64_t *eoff;
+    const double *vde, *x;
+    uint64_t n_edges, begin, end;
+    uint32_t slab_begin, e, tile0;
+    uint32_t *out_ids;
+    double *out_pde, *out_pdl;
+    uint32_t *out_part;
+};
+
+// ------------------------------------------------------------------------------------------------
+// R2 + R5 fill, variant 1 (first correct version, kept for A/B): one wave per (s, b) pair, kept
+// candidates compacted with ballot/popcount and stored straight to global memory.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill_edge_wave(FillParams P)
+{
+    const unsigned lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t e = P.e, D = 3 * P.e;
+    for (; w < P.n_edges; w += nw) {
+        uint64_t base = P.eoff[w];
+        const uint64_t nxt = P.eoff[w + 1];
+        if (nxt == base || base >= P.end || nxt <= P.begin) continue;
+        const uint32_t i = P.erow[w], b = P.pnbr[w];
+        const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+        const uint32_t st = P.adj_start[b], d = P.adj_deg[b];
+        for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            uint32_t c = 0, r = 0;
+            if (j < d) {
+                c = P.nbrs[st + j];
+                r = P.nbr_rank[st + j];
+            }
+            const bool keep = j < d && r > thr;
+            const uint64_t mask = __ballot(keep);
+            const uint64_t pos = base + __popcll(mask & lt);
+            base += __popcll(mask);
+            if (keep && pos >= P.begin && pos < P.end) {
+                const uint64_t o = pos - P.begin;
+                if (P.out_ids) {
+                    P.out_ids[o * 3 + 0] = s;
+                    P.out_ids[o * 3 + 1] = b;
+                    P.out_ids[o * 3 + 2] = c;
+                }
+                if (P.out_pde)
+                    for (uint32_t k = 0; k < e; k++) {
+                        P.out_pde[o * D + k] = P.vde[(uint64_t)s * e + k];
+                        P.out_pde[o * D + e + k] = P.vde[(uint64_t)b * e + k];
+                        P.out_pde[o * D + 2 * e + k] = P.vde[(uint64_t)c * e + k];
+                    }
+                if (P.out_pdl)
+                    for (uint32_t k = 0; k < e; k++) {
+                        P.out_pdl[o * D + k] = P.x[(uint64_t)s * e + k];
+                        P.out_pdl[o * D + e + k] = P.x[(uint64_t)b * e + k];
+                        P.out_pdl[o * D + 2 * e + k] = P.x[(uint64_t)c * e + k];
+                    }
+                if (P.out_part) P.out_part[o] = P.member[s];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2 + R5 fill, variant 0 (default): OUTPUT-TILED.  Block k owns paths [k*T, (k+1)*T): it walks the
+// (s, b) pairs that cover that range, flattens their candidate lists across all 256 lanes (full
+// lane use whatever the degrees are), keeps candidates with rank[c] > rank[s], turns the keep
+// flags into output slots with a block-wide prefix count (the scanned pair offsets make slots
+// contiguous across pairs), stages ids + embeddings in LDS, and finally streams the whole tile to
+// HBM with 16-byte-per-lane stores -- every output byte is written exactly once, in full lines.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFillChunk = 256;  // (s, b) pairs whose metadata is staged per pass
+
+template <int E, int T, bool PDL>
+__global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
+{
+    constexpr int D = 3 * E;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ids[T * 3];
+    __shared__ __attribute__((aligned(16))) double s_pde[T * D];
+    __shared__ __attribute__((aligned(16))) double s_pdl[PDL ? T * D : 1];
+    __shared__ uint32_t s_thr[kFillChunk], s_s[kFillChunk], s_b[kFillChunk], s_st[kFillChunk];
+    __shared__ uint32_t s_cstart[kFillChunk + 1];
+    __shared__ uint32_t s_wsum[2][4];
+
+    const unsigned tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t k = (uint64_t)P.tile0 + blockIdx.x;
+    const uint64_t tlo = k * T;
+    const uint64_t lo = max(tlo, P.begin), hi = min(tlo + T, P.end);
+    if (lo >= hi) return;
+    const int64_t olo = (int64_t)(lo - tlo), ohi = (int64_t)(hi - tlo);
+
+    uint64_t e0 = P.tile_edge[k];
+    // slot (relative to the tile) of the first kept candidate of pair e0; <= 0
+    int64_t pos_base = (int64_t)P.eoff[e0] - (int64_t)tlo;
+    int64_t running = 0;
+    int parity = 0;
+    bool done = false;
+
+    while (!done && e0 < P.n_edges) {
+        __syncthreads();  // previous chunk's rounds are done reading the metadata arrays
+        // ---- stage metadata of up to kFillChunk pairs, scan their degrees ----
+        const uint64_t ee = e0 + tid;
+        uint32_t d = 0;
+        if (ee < P.n_edges) {
+            const uint32_t i = P.erow[ee], b = P.pnbr[ee];
+            s_thr[tid] = P.slab_begin + i;
+            s_s[tid] = P.sorted[P.slab_begin + i];
+            s_b[tid] = b;
+            s_st[tid] = P.adj_start[b];
+            d = P.adj_deg[b];
+        }
+        // inclusive wave scan of d
+        uint32_t incl = d;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= (unsigned)off) incl += t;
+        }
+        if (lane == 63) s_wsum[parity][wv] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; w2++)
+            if ((unsigned)w2 < wv) wbase += s_wsum[parity][w2];
+        const uint32_t C = s_wsum[parity][0] + s_wsum[parity][1] + s_wsum[parity][2] + s_wsum[parity][3];
+        s_cstart[tid] = wbase + incl - d;
+        if (tid == 0) s_cstart[kFillChunk] = C;
+        parity ^= 1;
+        __syncthreads();
+
+        // ---- flattened candidates of this chunk, 256 per round ----
+        for (uint32_t q0 = 0; q0 < C; q0 += 256) {
+            const uint32_t q = q0 + tid;
+            bool keep = false;
+            uint32_t j = 0, c = 0;
+            if (q < C) {
+                // largest j with cstart[j] <= q
+                uint32_t a = 0, bnd = kFillChunk;
+                while (bnd - a > 1) {
+                    const uint32_t mid = (a + bnd) >> 1;
+                    if (s_cstart[mid] <= q) a = mid; else bnd = mid;
+                }
+                j = a;
+                const uint32_t idx = s_st[j] + (q - s_cstart[j]);
+                c = P.nbrs[idx];
+                keep = P.nbr_rank[idx] > s_thr[j];
+            }
+            const uint64_t mask = __ballot(keep);
+            if (lane == 0) s_wsum[parity][wv] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; w2++) {
+                const uint32_t t = s_wsum[parity][w2];
+                if ((unsigned)w2 < wv) before += t;
+                tot += t;
+            }
+            parity ^= 1;
+            const int64_t slot = pos_base + running + before + (int64_t)__popcll(mask & lt);
+            if (keep && slot >= olo && slot < ohi) {
+                const uint32_t s = s_s[j], b = s_b[j];
+                s_ids[slot * 3 + 0] = s;
+                s_ids[slot * 3 + 1] = b;
+                s_ids[slot * 3 + 2] = c;
+                if (P.out_pde) {
+#pragma unroll
+                    for (int kk = 0; kk < E; kk++) {
+                        s_pde[slot * D + kk] = P.vde[(uint64_t)s * E + kk];
+                        s_pde[slot * D + E + kk] = P.vde[(uint64_t)b * E + kk];
+                        s_pde[slot * D + 2 * E + kk] = P.vde[(uint64_t)c * E + kk];
+                    }
+                }
+                if (PDL && P.out_pdl) {
+#pragma unroll
+                    for (int kk = 0; kk < E; kk++) {
+                        s_pdl[slot * D + kk] = P.x[(uint64_t)s * E + kk];
+                        s_pdl[slot * D + E + kk] = P.x[(uint64_t)b * E + kk];
+                        s_pdl[slot * D + 2 * E + kk] = P.x[(uint64_t)c * E + kk];
+                    }
+                }
+            }
+            running += tot;
+            if (pos_base + running >= ohi) {  // block-uniform: the tile is complete
+                done = true;
+                break;
+            }
+        }
+        e0 += kFillChunk;
+    }
+    __syncthreads();
+
+    // ---- stream the staged tile to HBM ----
+    const uint64_t obase = lo - P.begin;  // first output row of this block
+    const uint32_t nout = (uint32_t)(hi - lo);
+    const bool full = (nout == (uint32_t)T) && (olo == 0) && ((obase & 3ull) == 0);
+    if (P.out_ids) {
+        uint32_t *dst = P.out_ids + obase * 3;
+        if (full && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(s_ids);
+            uint4 *dst4 = reinterpret_cast<uint4 *>(dst);
+            for (uint32_t i = tid; i < (uint32_t)(T * 3 / 4); i += 256) dst4[i] = src4[i];
+        } else {
+            for (uint32_t i = tid; i < nout * 3; i += 256) dst[i] = s_ids[olo * 3 + i];
+        }
+    }
+    if (P.out_pde) {
+        double *dst = P.out_pde + obase * D;
+        if (full && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            const double2 *src2 = reinterpret_cast<const double2 *>(s_pde);
+            double2 *dst2 = reinterpret_cast<double2 *>(dst);
+            for (uint32_t i = tid; i < (uint32_t)(T * D / 2); i += 256) dst2[i] = src2[i];
+        } else {
+            for (uint32_t i = tid; i < nout * D; i += 256) dst[i] = s_pde[olo * D + i];
+        }
+    }
+    if (PDL && P.out_pdl) {
+        double *dst = P.out_pdl + obase * D;
+        if (full && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+            const double2 *src2 = reinterpret_cast<const double2 *>(s_pdl);
+            double2 *dst2 = reinterpret_cast<double2 *>(dst);
+            for (uint32_t i = tid; i < (uint32_t)(T * D / 2); i += 256) dst2[i] = src2[i];
+        } else {
+            for (uint32_t i = tid; i < nout * D; i += 256) dst[i] = s_pdl[olo * D + i];
+        }
+    }
+    if (P.out_part) {
+        for (uint32_t i = tid; i < nout; i += 256) P.out_part[obase + i] = P.member[s_ids[(olo + i) * 3]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// halo helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_needed(uint64_t cnt, const uint32_t *__restrict__ nbrs, uint8_t *__restrict__ mark)
+{
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < cnt; q += (uint64_t)gridDim.x * blockDim.x)
+        mark[nbrs[q]] = 1;
+}
+
+// flag[v] = 1 iff v is needed, not held, and owned by rank r (slab bounds over the processing order)
+__global__ void k_flag_owner(uint32_t n, const uint8_t *__restrict__ mark, const uint8_t *__restrict__ present,
+                             const uint32_t *__restrict__ rank, uint32_t lo, uint32_t hi, uint8_t *__restrict__ flag)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t rk = rank[v];
+        flag[v] = (mark[v] && !present[v] && rk >= lo && rk < hi) ? 1 : 0;
+    }
+}
+
+// back to owned rows only: present := owned, halo degrees := 0
+__global__ void k_drop_halo(uint32_t n, const uint8_t *__restrict__ owned, uint8_t *__restrict__ present,
+                            uint32_t *__restrict__ deg)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        if (!owned[v]) deg[v] = 0;
+        present[v] = owned[v];
+    }
+}
+
+__global__ void k_rows_pack(uint64_t n_req, const uint32_t *__restrict__ ids, const uint64_t *__restrict__ roff,
+                            const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ nbrs,
+                            uint32_t *__restrict__ out)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < n_req; g += ng) {
+        const uint32_t a = adj_start[ids[g]];
+        const uint64_t o = roff[g];
+        const uint32_t d = (uint32_t)(roff[g + 1] - o);
+        for (uint32_t j = sub; j < d; j += 16) out[o + j] = nbrs[a + j];
+    }
+}
+
+}  // namespace gnnpe

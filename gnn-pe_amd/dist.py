@@ -1,0 +1,166 @@
+"""One-process-per-GPU driver of the offline path.
+
+The processing order (membership.txt line order, main.cpp:77-85) is cut into R contiguous SLABS,
+one per rank.  Because every path is owned by its start vertex and start vertices are emitted in
+processing order, rank r's paths are one contiguous range of global path ids: all_paths.txt is
+the rank-order concatenation of the slabs' rows and partition_paths.txt the rank-order
+concatenation of per-slab id lists, for any R (SURVEY 8(e) "Invariant").
+
+Each rank holds the adjacency rows of its own start vertices only.  One step is:
+  1. halo exchange  -- all-to-all-v of the adjacency lists of the 1-hop middle vertices
+                       (requests, degrees, neighbour lists: three all-to-all-v over RCCL/xGMI),
+  2. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
+  3. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
+  4. fill           -- local, into caller-provided device buffers.
+There is no reduction across ranks anywhere.
+
+torch.distributed supplies the collectives (backend "nccl" = RCCL on GPUs, "gloo" in the CPU
+tests); the engine behind `eng` is the C-ABI library (`binding.Engine`).  Tests substitute an
+engine with the same methods to exercise this exchange logic on CPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def plan_slabs(offsets, sorted_nodes, n_ranks):
+    """Cut the processing order into n_ranks contiguous slabs of roughly equal fill work.
+
+    Host-side prep (the analogue of the reference's partitioning script): the work of start s is
+    about (sum of its neighbours' degrees) x (fraction of vertices ranked after s), a cheap proxy
+    for count(s) = sum_b |{c in N(b): rank[c] > rank[s]}|.  Returns uint32 bounds[n_ranks+1]."""
+    n = len(sorted_nodes)
+    offs = offsets.astype(np.int64)
+    deg = np.diff(offs)
+    # sum of neighbour degrees per vertex needs the adjacency; approximate by deg * mean degree
+    mean_deg = max(float(deg.mean()) if n else 0.0, 1.0)
+    w = deg[sorted_nodes.astype(np.int64)].astype(np.float64) * mean_deg
+    w *= 1.0 - (np.arange(n, dtype=np.float64) + 0.5) / max(n, 1)
+    w += 1e-3  # vertices without work still need a home
+    cw = np.cumsum(w)
+    targets = cw[-1] * np.arange(1, n_ranks) / n_ranks if n else np.zeros(0)
+    cuts = np.searchsorted(cw, targets).astype(np.int64)
+    bounds = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
+    return np.maximum.accumulate(bounds)
+
+
+def owned_rows(g, sorted_nodes, bounds, r):
+    """Adjacency rows (in slab order) of rank r's start vertices: rows, row_offsets u64, row_nbrs."""
+    rows = np.ascontiguousarray(sorted_nodes[int(bounds[r]):int(bounds[r + 1])], np.uint32)
+    offs = g["offsets"].astype(np.int64)
+    deg = offs[rows.astype(np.int64) + 1] - offs[rows.astype(np.int64)]
+    roff = np.zeros(len(rows) + 1, np.uint64)
+    np.cumsum(deg, out=roff[1:])
+    tot = int(roff[-1])
+    # gather the ragged rows without a Python loop
+    idx = np.repeat(offs[rows.astype(np.int64)] - roff[:-1].astype(np.int64), deg) + np.arange(tot, dtype=np.int64)
+    rnbr = np.ascontiguousarray(g["nbrs"][idx], np.uint32) if tot else np.zeros(0, np.uint32)
+    return rows, roff, rnbr
+
+
+class SlabBuild:
+    """Per-rank state of the distributed offline build.  `eng` already holds this rank's rows
+    (load_rows), the replicated order (set_order), slab (set_slab) and label table."""
+
+    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, group=None):
+        self.eng, self.n, self.e = eng, int(n), int(e)
+        self.bounds = np.ascontiguousarray(bounds, np.uint32)
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+        i32 = dict(dtype=torch.int32, device=device)
+        self.need = torch.zeros(max(self.n, 1), **i32)
+        self.req = torch.zeros(max(self.n, 1), **i32)
+        self.deg_out = torch.zeros(max(self.n, 1), **i32)
+        self.deg_in = torch.zeros(max(self.n, 1), **i32)
+        self.cap = int(max(nbr_capacity, 1))
+        self.pack = torch.zeros(self.cap, **i32)
+        self.nbr_in = torch.zeros(self.cap, **i32)
+        lens = (self.bounds[1:].astype(np.int64) - self.bounds[:-1].astype(np.int64))
+        self.maxlen = int(lens.max()) if len(lens) else 0
+        self.vde_send = torch.zeros((max(self.maxlen, 1), self.e), dtype=torch.float64, device=device)
+        self.vde_all = torch.zeros((world, max(self.maxlen, 1), self.e), dtype=torch.float64, device=device)
+        self.tot_all = torch.zeros(world, dtype=torch.int64, device=device)
+        self.stats = {}
+
+    def _a2a(self, out, inp, out_splits, in_splits):
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
+    def exchange_halo(self):
+        eng, R = self.eng, self.world
+        eng.rows_drop_halo()
+        need_counts = [int(x) for x in eng.halo_need(self.bounds, self.need, self.n)]
+        n_need = sum(need_counts)
+        # 1. how many rows does every peer want from me
+        sc = torch.tensor(need_counts, dtype=torch.int64, device=self.device)
+        rc = torch.zeros(R, dtype=torch.int64, device=self.device)
+        self._a2a(rc, sc, [1] * R, [1] * R)
+        req_counts = [int(x) for x in rc.tolist()]
+        n_req = sum(req_counts)
+        # 2. the requested vertex ids
+        req = self.req[:n_req]
+        self._a2a(req, self.need[:n_need], req_counts, need_counts)
+        # 3. their degrees, back to the requester
+        deg_out = self.deg_out[:n_req]
+        eng.rows_degree(n_req, req, deg_out)
+        deg_in = self.deg_in[:n_need]
+        self._a2a(deg_in, deg_out, need_counts, req_counts)
+        # 4. the adjacency lists themselves
+        send_sizes = self._segment_sums(deg_out, req_counts)
+        recv_sizes = self._segment_sums(deg_in, need_counts)
+        n_send, n_recv = sum(send_sizes), sum(recv_sizes)
+        if n_send > self.cap or n_recv > self.cap:
+            raise RuntimeError(f"halo buffers too small: send {n_send}, recv {n_recv}, capacity {self.cap}")
+        eng.rows_pack(n_req, req, self.pack, self.cap)
+        self._a2a(self.nbr_in[:n_recv], self.pack[:n_send], recv_sizes, send_sizes)
+        eng.rows_append(n_need, self.need[:n_need], deg_in, self.nbr_in[:n_recv], n_recv)
+        self.stats.update(halo_rows=n_need, halo_entries=n_recv, served_rows=n_req, served_entries=n_send)
+
+    @staticmethod
+    def _segment_sums(t, counts):
+        if t.numel() == 0:
+            return [0] * len(counts)
+        cs = torch.cumsum(t.to(torch.int64), 0)
+        ends = np.cumsum(counts)
+        out, prev = [], 0
+        vals = cs[torch.as_tensor(np.maximum(ends - 1, 0), device=t.device)].tolist()
+        for k, c in enumerate(counts):
+            cur = vals[k] if c > 0 else prev
+            out.append(int(cur - prev))
+            prev = cur
+        return out
+
+    def exchange_vde(self):
+        eng, R = self.eng, self.world
+        b = self.bounds
+        eng.vde(want=False)
+        eng.vde_pack_slab(int(b[self.rank]), int(b[self.rank + 1]), self.vde_send)
+        dist.all_gather_into_tensor(self.vde_all.view(-1), self.vde_send.view(-1), group=self.group)
+        for r in range(R):
+            if r != self.rank and b[r + 1] > b[r]:
+                eng.vde_unpack_slab(int(b[r]), int(b[r + 1]), self.vde_all[r])
+
+    def count(self):
+        total = self.eng.count_paths(2)
+        mine = torch.tensor([total], dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(self.tot_all, mine, group=self.group)
+        tots = [int(x) for x in self.tot_all.tolist()]
+        self.local_total = total
+        self.base = sum(tots[:self.rank])
+        self.global_total = sum(tots)
+        return total
+
+    def step(self, out_ids=None, out_pde=None, out_pde_label=None):
+        """One full pass of the hot path for this rank's slab; returns (local paths, global id base)."""
+        if self.world > 1:
+            self.exchange_halo()
+            self.exchange_vde()
+        else:
+            self.eng.vde(want=False)
+        total = self.count() if self.world > 1 else self._count_single()
+        if out_ids is not None or out_pde is not None or out_pde_label is not None:
+            self.eng.fill_paths_device(0, total, out_ids, out_pde, out_pde_label)
+        return total, self.base
+
+    def _count_single(self):
+        self.local_total = self.global_total = self.eng.count_paths(2)
+        self.base = 0
+        return self.local_total

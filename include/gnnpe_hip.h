@@ -1,0 +1,151 @@
+/*
+ * gnnpe_hip.h -- C-ABI of the MI355X offline path-embedding engine (libgnnpe_hip.so).
+ *
+ * The reference (JamesWhiteSnow/GNN-PE) has no plugin / FFI seam: `custom.h` is a header of free
+ * functions included by one translation unit.  This header is therefore the seam a
+ * maintainer would add: every entry point names the reference function (file:line under
+ * /root/reference/) whose work it takes over.  INTEGRATION.md shows the call sites in
+ * GNN-PE/src/main.cpp.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, <0 on error; gnnpe_last_error() gives the message
+ *     (thread local).  Unlike the reference, nothing calls exit() (functions.cpp:24-29).
+ *   - "host" pointers are ordinary CPU memory owned by the caller; "dev" pointers are HIP device
+ *     memory on the context's device (e.g. a torch tensor's data_ptr()).  The library owns every
+ *     other device allocation behind the opaque context.
+ *   - one context per GPU, driven from one host thread; work is enqueued on the context's stream
+ *     (gnnpe_set_stream) and host-returning calls synchronise that stream.
+ *   - ids are uint32 like the reference (`ui`, include/configuration/types.h:13-17); path counts and
+ *     path ids are uint64 so inputs beyond the reference's 2^32 limit can be counted and streamed.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef GNNPE_HIP_H
+#define GNNPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNPE_ABI_VERSION 1
+
+#define GNNPE_OK 0
+#define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
+#define GNNPE_ERR_HIP (-2)     /* a HIP runtime call failed (message has the HIP error string) */
+#define GNNPE_ERR_UNSUPPORTED (-3)
+#define GNNPE_ERR_IO (-4)
+#define GNNPE_ERR_RANGE (-5)   /* output does not fit the reference's 32-bit limits */
+
+typedef struct gnnpe_ctx gnnpe_ctx;
+
+int gnnpe_abi_version(void);
+const char *gnnpe_last_error(void);
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* Binds to HIP device `device_id`.  Returns NULL (and sets last_error) when no device is usable. */
+gnnpe_ctx *gnnpe_create(int device_id);
+void gnnpe_destroy(gnnpe_ctx *ctx);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own. */
+int gnnpe_set_stream(gnnpe_ctx *ctx, void *hip_stream);
+int gnnpe_sync(gnnpe_ctx *ctx);
+
+/* ---- inputs ---------------------------------------------------------------------------------- */
+/* R0: the CSR that Static_Graph::loadGraphFromFile builds (graph.cpp:163-242; accessors
+ * graph.h:154-176): offsets[n+1], neighbours sorted ascending per vertex, labels[n].  Host -> HBM. */
+int gnnpe_load_csr(gnnpe_ctx *ctx, uint32_t n, const uint32_t *host_offsets, const uint32_t *host_nbrs,
+                   const uint32_t *host_labels);
+
+/* Vertex-partitioned variant (multi-GPU): this context holds the adjacency rows of
+ * `rows[0..n_rows)` only (global vertex ids, any order; the rank's owned start vertices in
+ * processing order), row k occupying row_nbrs[row_offsets[k] .. row_offsets[k+1]).  labels[n] is
+ * replicated.  `nbr_capacity` reserves room (in neighbour entries) for halo rows appended later. */
+int gnnpe_load_rows(gnnpe_ctx *ctx, uint32_t n, const uint32_t *host_labels, uint32_t n_rows,
+                    const uint32_t *host_rows, const uint64_t *host_row_offsets, const uint32_t *host_row_nbrs,
+                    uint64_t nbr_capacity);
+
+/* R1: processing order and partition of every vertex, as main.cpp:77-85 reads them from
+ * membership.txt (line i = "<sorted_nodes[i]> <membership[sorted_nodes[i]]>").  p = partition_num. */
+int gnnpe_set_order(gnnpe_ctx *ctx, const uint32_t *host_sorted_nodes, const uint32_t *host_membership,
+                    uint32_t p);
+
+/* Slab of the processing order this context enumerates: start vertices sorted_nodes[begin..end).
+ * Default (never called) = [0, n).  Multi-GPU: rank r owns one contiguous slab, so its paths are one
+ * contiguous range of global path ids. */
+int gnnpe_set_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end);
+
+/* R3: x_table[label][k] = gen_vde_x(label)[k] (custom.h:492-511), n_labels x e doubles.  The table
+ * is host arithmetic (std::mt19937 re-seeded per label); host/label_table.cpp computes it. */
+int gnnpe_set_label_table(gnnpe_ctx *ctx, uint32_t n_labels, uint32_t e, const double *host_x_table);
+
+/* R3 itself: host arithmetic, exactly the reference's gen_vde_x (custom.h:492-511) for labels
+ * 0..n_labels-1: std::mt19937(label), e draws of std::uniform_real_distribution<double>(0,1),
+ * divided by their left-to-right sum.  out: n_labels x e doubles.  Needs no GPU. */
+int gnnpe_host_label_table(uint32_t n_labels, uint32_t e, double *out);
+
+/* ---- halo exchange helpers (device side of the RCCL all-to-all-v) ----------------- */
+/* List the vertices whose adjacency rows this context needs (neighbours of its slab's start
+ * vertices) but does not hold, grouped by owning rank: owner r holds the slab
+ * [slab_bounds[r], slab_bounds[r+1]) of the processing order.  dev_ids receives the ids (capacity
+ * cap entries), host_counts[r] the number per owner.  Ids are ascending inside each group. */
+int gnnpe_halo_need(gnnpe_ctx *ctx, uint32_t n_ranks, const uint32_t *host_slab_bounds, void *dev_ids,
+                    uint64_t cap, uint64_t *host_counts);
+/* Degrees of requested rows (rows this context holds): dev_deg[k] = deg(dev_ids[k]). */
+int gnnpe_rows_degree(gnnpe_ctx *ctx, uint64_t n_req, const void *dev_ids, void *dev_deg);
+/* Pack the adjacency lists of the requested rows back to back into dev_out (sum of degrees entries). */
+int gnnpe_rows_pack(gnnpe_ctx *ctx, uint64_t n_req, const void *dev_ids, void *dev_out, uint64_t cap);
+/* Install received halo rows: ids, their degrees, and the packed adjacency (all device memory). */
+int gnnpe_rows_append(gnnpe_ctx *ctx, uint64_t n_rows, const void *dev_ids, const void *dev_deg,
+                      const void *dev_nbrs, uint64_t n_nbrs);
+
+/* Forget every appended halo row (back to the state right after gnnpe_load_rows), so the exchange
+ * can be repeated. */
+int gnnpe_rows_drop_halo(gnnpe_ctx *ctx);
+
+/* ---- R4: vertex embedding (gen_vde, custom.h:513-544) ------------------------------------------ */
+/* x = table[label], nx = sum of neighbours' x in ascending-neighbour order from 0.0 (bit-identical
+ * to the reference's loop :527-534), vde = x + nx.  Computed for the rows this context holds
+ * adjacency for (all vertices after gnnpe_load_csr; the slab rows after gnnpe_load_rows).  Any of
+ * the host outputs (n x e doubles each, indexed by vertex id) may be NULL. */
+int gnnpe_vde(gnnpe_ctx *ctx, double *host_x, double *host_nx, double *host_vde);
+/* Device-resident vde table (n x e doubles, vertex-id indexed) for exchange between ranks. */
+int gnnpe_vde_device_ptr(gnnpe_ctx *ctx, void **dev_vde, void **dev_x);
+/* Gather / scatter slab rows of the vde table to/from a packed buffer of (end-begin) x e doubles in
+ * processing order -- the all-gather payload (x needs no exchange: labels are replicated). */
+int gnnpe_vde_pack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, void *dev_buf);
+int gnnpe_vde_unpack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, const void *dev_buf);
+
+/* ---- R2: path enumeration (dfs + VectorHash, custom.h:52-92; driver loop main.cpp:87-96) ------- */
+/* Counts the paths of the context's slab with l edges (l+1 vertices; the reference only works for
+ * l=2).  host_per_start[i] (slab length entries, may be NULL) = number of paths whose
+ * start is sorted_nodes[slab_begin+i]; *host_total = their sum.  Leaves the scanned offsets on the
+ * device for gnnpe_fill_paths*. */
+int gnnpe_count_paths(gnnpe_ctx *ctx, uint32_t l, uint64_t *host_per_start, uint64_t *host_total);
+
+/* ---- R2 + R5: emit paths and their embeddings (gen_pde, custom.h:546-572) ----------------------- */
+/* Emits the slab-local paths [begin, end) in the reference's order (start vertices in processing
+ * order, neighbours ascending, reverse-dedup): vids (end-begin) x (l+1) uint32; pde = concat of
+ * vde rows, pde_label = concat of x rows, (end-begin) x e(l+1) doubles each.  Any output may be
+ * NULL.  The *_device form writes device memory and only enqueues work on the stream. */
+int gnnpe_fill_paths(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, uint32_t *host_vids, double *host_pde,
+                     double *host_pde_label);
+int gnnpe_fill_paths_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *dev_vids, void *dev_pde,
+                            void *dev_pde_label);
+
+/* Per path, the partition of its start vertex (membership[vids[0]]): what main.cpp:98-108 groups
+ * partition_paths.txt by.  dev_part: (end-begin) uint32. */
+int gnnpe_path_partitions_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *dev_part);
+
+/* ---- introspection for bench / tests ------------------------------------------------------------ */
+/* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
+const char *gnnpe_fill_kernel_name(void);
+/* Selects the fill implementation: 0 = output-tiled LDS-staged kernel (default), 1 = edge-per-wave
+ * direct-store kernel (first correct version, kept for A/B). */
+int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,311 @@
+"""GPU parity tests: the HIP engine, called through the C-ABI (include/gnnpe_hip.h), against the CPU
+oracle and the golden vectors from the compiled reference.  Integer/index outputs are compared
+bit-exactly; fp64 embeddings are also compared bit-exactly (the kernels keep the reference's
+operation order), which is far inside the north-star tolerance of 1e-5."""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, small_cases
+
+pytestmark = pytest.mark.gpu
+
+FP_TOL = 0.0  # bit-exact; north_star allows 1e-5, the online filter's epsilon is 1e-6 (custom.h:43)
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from gnnpe_amd import binding as b
+    b.load()
+    return b
+
+
+def _engine(binding, g, sn, mem, p, e):
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    nl = int(g["labels"].max()) + 1 if len(g["labels"]) else 1
+    eng.set_label_table(binding.host_label_table(nl, e))
+    return eng
+
+
+def test_library_reports_its_kernel(binding):
+    assert binding.load().gnnpe_fill_kernel_name().decode() == "k_fill_tiled"
+
+
+@pytest.mark.parametrize("e", [2, 8])
+def test_vde_matches_reference_dump(binding, test_graph, e):
+    z = np.load(os.path.join(GOLDEN, "test_graph", f"vde_e{e}.npz"))
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, e)
+    x, nx, vde = eng.vde()
+    assert np.array_equal(x, z["x"])
+    assert np.array_equal(nx, z["nx"])
+    assert np.array_equal(vde, z["vde"])
+    assert np.abs(vde - z["vde"]).max() <= FP_TOL
+    eng.close()
+
+
+def test_test_graph_paths_and_embeddings(binding, oracle, test_graph):
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, 2)
+    x, nx, vde = eng.vde()
+    total, per_start = eng.count_paths(2, per_start=True)
+    assert total == gold["p1"]["header"] == 415545
+    assert np.array_equal(per_start, oracle.count_per_start(test_graph["offsets"], test_graph["nbrs"],
+                                                            test_graph["sorted_nodes"], 3))
+    ids, pde, pdl = eng.fill_paths(pde_label=True)
+    ref_ids = oracle.enumerate_closed(test_graph["offsets"], test_graph["nbrs"], test_graph["sorted_nodes"], 3)
+    assert np.array_equal(ids, ref_ids)
+    # byte-exact all_paths.txt (formatting by the oracle writer; the ids are the GPU's)
+    txt = oracle.format_all_paths(ids)
+    assert hashlib.md5(txt).hexdigest() == gold["p1"]["all_paths_md5"]
+    assert txt == gzip.open(os.path.join(GOLDEN, "test_graph", "all_paths.txt.gz")).read()
+    ox, onx, ovde = oracle.gen_vde(test_graph["offsets"], test_graph["nbrs"], test_graph["labels"], 2)
+    rpde, rpdl, _, _ = oracle.gen_pde(ref_ids, 2, test_graph["offsets"], test_graph["labels"], ox, ovde)
+    assert np.array_equal(pde, rpde) and np.array_equal(pdl, rpdl)
+    z = np.load(os.path.join(GOLDEN, "test_graph", "pde_sample_e2.npz"))
+    assert np.array_equal(pde[z["index"]], z["pde"]) and np.array_equal(pdl[z["index"]], z["pde_label"])
+    eng.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_subranges_and_variants(binding, oracle, test_graph, variant):
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, 2)
+    eng.vde(want=False)
+    eng.set_fill_variant(variant)
+    total = eng.count_paths(2)
+    ref_ids = oracle.enumerate_closed(test_graph["offsets"], test_graph["nbrs"], test_graph["sorted_nodes"], 3)
+    ox, onx, ovde = oracle.gen_vde(test_graph["offsets"], test_graph["nbrs"], test_graph["labels"], 2)
+    rpde, _, _, _ = oracle.gen_pde(ref_ids, 2, test_graph["offsets"], test_graph["labels"], ox, ovde)
+    for b, e in [(0, 1), (0, 511), (1, 513), (511, 1025), (1000, 1000), (12345, 54321), (total - 7, total),
+                 (4, total), (3, total - 1)]:
+        ids, pde, _ = eng.fill_paths(b, e)
+        assert np.array_equal(ids, ref_ids[b:e]), (b, e)
+        assert np.array_equal(pde, rpde[b:e]), (b, e)
+    ids, _, _ = eng.fill_paths(0, total, pde=False)
+    assert np.array_equal(ids, ref_ids)
+    eng.close()
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_small_graphs_any_order(binding, oracle, ci):
+    c = small_cases()[ci]
+    g = dict(offsets=c["offsets"], nbrs=c["nbrs"], labels=c["labels"])
+    eng = _engine(binding, g, c["sorted_nodes"], c["membership"], 3, 2)
+    x, nx, vde = eng.vde()
+    assert np.array_equal(vde, c["vde"]) and np.array_equal(nx, c["nx"])
+    total = eng.count_paths(2)
+    ids, pde, pdl = eng.fill_paths(pde_label=True)
+    ref = c["paths"].reshape(-1, 3)
+    assert total == len(ref) and np.array_equal(ids, ref)
+    assert hashlib.md5(oracle.format_all_paths(ids)).hexdigest() == bytes(c["all_paths_md5"]).decode()
+    assert np.array_equal(pde, vde[ref].reshape(len(ref), 6))
+    assert np.array_equal(pdl, x[ref].reshape(len(ref), 6))
+    eng.close()
+
+
+@pytest.mark.parametrize("e", [1, 3, 4, 5, 8])
+def test_embedding_dims(binding, oracle, e):
+    from gnnpe_amd import synth
+    g = synth.gnm_graph(300, 1500, n_labels=11, seed=40 + e)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, np.zeros(300, np.uint32), 1, e)
+    x, nx, vde = eng.vde()
+    ox, onx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)
+    assert np.array_equal(x, ox) and np.array_equal(nx, onx) and np.array_equal(vde, ovde)
+    eng.count_paths(2)
+    ids, pde, pdl = eng.fill_paths(pde_label=True)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    rpde, rpdl, _, _ = oracle.gen_pde(ref, e, g["offsets"], g["labels"], ox, ovde)
+    assert np.array_equal(ids, ref) and np.array_equal(pde, rpde) and np.array_equal(pdl, rpdl)
+    eng.close()
+
+
+def test_edge_cases_and_errors(binding, oracle):
+    from gnnpe_amd import synth
+    # isolated vertices only
+    g = dict(offsets=np.zeros(6, np.uint32), nbrs=np.zeros(0, np.uint32), labels=np.arange(5, dtype=np.uint32) % 2)
+    eng = _engine(binding, g, np.arange(5, dtype=np.uint32), np.zeros(5, np.uint32), 1, 2)
+    x, nx, vde = eng.vde()
+    assert np.all(nx == 0) and np.array_equal(vde, x)
+    assert eng.count_paths(2) == 0
+    ids, pde, _ = eng.fill_paths()
+    assert ids.shape == (0, 3) and pde.shape == (0, 6)
+    eng.close()
+    # a single edge, a star (hub with high degree, ragged lists), a triangle
+    for offs, nbrs in [(np.array([0, 1, 2], np.uint32), np.array([1, 0], np.uint32)),
+                       (np.array([0, 2, 4, 6], np.uint32), np.array([1, 2, 0, 2, 0, 1], np.uint32))]:
+        n = len(offs) - 1
+        g = dict(offsets=offs, nbrs=nbrs, labels=np.zeros(n, np.uint32))
+        sn = np.arange(n - 1, -1, -1).astype(np.uint32)
+        eng = _engine(binding, g, sn, np.zeros(n, np.uint32), 1, 2)
+        eng.vde(want=False)
+        eng.count_paths(2)
+        ids, _, _ = eng.fill_paths(pde=False)
+        assert np.array_equal(ids, oracle.enumerate_closed(offs, nbrs, sn, 3))
+        eng.close()
+    hub = 700
+    offs = np.zeros(hub + 2, np.uint32)
+    offs[1] = hub
+    offs[2:] = hub + np.arange(1, hub + 1)
+    nbrs = np.concatenate([np.arange(1, hub + 1), np.zeros(hub)]).astype(np.uint32)
+    g = dict(offsets=offs, nbrs=nbrs, labels=(np.arange(hub + 1) % 3).astype(np.uint32))
+    sn = synth.degree_order(offs)
+    eng = _engine(binding, g, sn, np.zeros(hub + 1, np.uint32), 1, 2)
+    x, nx, vde = eng.vde()
+    ox, onx, ovde = oracle.gen_vde(offs, nbrs, g["labels"], 2)
+    assert np.array_equal(nx, onx)  # 700-term sequential sum, bit-exact
+    assert eng.count_paths(2) == hub * (hub - 1) // 2
+    ids, pde, _ = eng.fill_paths()
+    ref = oracle.enumerate_closed(offs, nbrs, sn, 3)
+    assert np.array_equal(ids, ref) and np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
+    # error behaviour: fail loudly, never exit()
+    with pytest.raises(binding.GnnpeError):
+        eng.count_paths(3)  # l != 2 unsupported (reference is broken there too)
+    with pytest.raises(binding.GnnpeError):
+        eng.set_order(np.zeros(hub + 1, np.uint32), np.zeros(hub + 1, np.uint32), 1)  # not a permutation
+    with pytest.raises(binding.GnnpeError):
+        eng.fill_paths(0, 10 ** 12)
+    eng.set_label_table(binding.host_label_table(2, 2))  # labels go up to 2 -> table too small
+    with pytest.raises(binding.GnnpeError):
+        eng.vde()
+    eng.close()
+
+
+def test_config2_100k_1m_exact(binding, oracle):
+    """BASELINE config 2 (100K vertices / 1M edges): every id bit-exact against the oracle."""
+    from gnnpe_amd import synth
+    g = synth.gnm_graph(100_000, 1_000_000)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, synth.block_membership(g["n"], 4), 4, 2)
+    x, nx, vde = eng.vde()
+    ox, onx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    assert np.array_equal(vde, ovde)
+    total = eng.count_paths(2)
+    assert total == synth.expected_paths_l2(g["offsets"])
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    ids, pde, _ = eng.fill_paths()
+    assert np.array_equal(ids, ref)
+    assert np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
+    eng.close()
+
+
+def test_config3_1m_10m_properties():
+    """BASELINE config 3 (headline, 1M / 10M, ~2e8 paths): size-independent properties on the device.
+    count == sum C(deg,2); rows strictly increasing in (rank[s], b, c) (=> unique, reference order);
+    (s,b) and (b,c) are edges; rank[c] > rank[s]; pde rows are the vde gather.  A set of
+    sum C(deg,2) distinct valid triples is the complete path set, so these imply exactness."""
+    import torch
+    from gnnpe_amd import binding, synth
+    g = synth.gnm_graph(1_000_000, 10_000_000)
+    n = g["n"]
+    sn = synth.degree_order(g["offsets"])
+    eng = binding.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, synth.block_membership(n, 8), 8)
+    eng.set_label_table(binding.host_label_table(64, 2))
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    assert total == synth.expected_paths_l2(g["offsets"])
+    dev = torch.device("cuda:0")
+    ids = torch.empty((total, 3), dtype=torch.int32, device=dev)
+    pde = torch.empty((total, 6), dtype=torch.float64, device=dev)
+    eng.fill_paths_device(0, total, ids, pde, None)
+    torch.cuda.synchronize()
+    rank = np.empty(n, np.int64)
+    rank[sn] = np.arange(n)
+    rank_t = torch.from_numpy(rank).to(dev)
+    s, b, c = ids[:, 0].long(), ids[:, 1].long(), ids[:, 2].long()
+    assert bool((rank_t[c] > rank_t[s]).all())
+    key = (rank_t[s] * n + b) * n + c  # < 1e18, fits int64
+    assert bool((key[1:] > key[:-1]).all())
+    del key
+    ekeys = torch.from_numpy(np.sort(np.concatenate([g["eu"].astype(np.int64) * n + g["ev"],
+                                                     g["ev"].astype(np.int64) * n + g["eu"]]))).to(dev)
+    for u, v in ((s, b), (b, c)):
+        q = u * n + v
+        pos = torch.searchsorted(ekeys, q).clamp_(max=len(ekeys) - 1)
+        assert bool((ekeys[pos] == q).all())
+        del q, pos
+    vde_t = torch.from_numpy(vde).to(dev)
+    for k, col in enumerate((s, b, c)):
+        assert bool((pde[:, 2 * k:2 * k + 2] == vde_t[col]).all())
+    # checksum of checksums against the closed form: every vertex v is a middle C(deg,2) times
+    deg = torch.from_numpy(np.diff(g["offsets"].astype(np.int64))).to(dev)
+    assert int(b.sum()) == int((torch.arange(n, device=dev) * (deg * (deg - 1) // 2)).sum())
+    eng.close()
+
+
+def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle):
+    """The multi-GPU path driven by hand on one device: two contexts own the two halves of the
+    processing order, exchange halo rows and vde through the C-ABI helpers, and their
+    concatenated outputs equal the single-context result."""
+    import torch
+    from gnnpe_amd import synth
+    g = synth.gnm_graph(3000, 20000, n_labels=13, seed=77)
+    n = g["n"]
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(n, 3)
+    table = binding.host_label_table(13, 2)
+    ref_ids = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    ox, onx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    bounds = np.array([0, 1700, n], np.uint32)
+    dev = torch.device("cuda:0")
+    offs = g["offsets"].astype(np.int64)
+    engs = []
+    for r in range(2):
+        rows = sn[bounds[r]:bounds[r + 1]]
+        deg = offs[rows + 1] - offs[rows]
+        roff = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)
+        rn = np.concatenate([g["nbrs"][offs[v]:offs[v + 1]] for v in rows]) if len(rows) else np.zeros(0, np.uint32)
+        eng = binding.Engine(0)
+        eng.load_rows(n, g["labels"], rows, roff, rn, nbr_capacity=2 * len(g["nbrs"]))
+        eng.set_order(sn, mem, 3)
+        eng.set_slab(int(bounds[r]), int(bounds[r + 1]))
+        eng.set_label_table(table)
+        engs.append(eng)
+    for rep in range(2):  # the exchange is repeatable (drop_halo)
+        for r in range(2):
+            engs[r].rows_drop_halo()
+        for r in range(2):
+            o = 1 - r
+            need = torch.zeros(n, dtype=torch.int32, device=dev)
+            counts = engs[r].halo_need(bounds, need, n)
+            assert counts[r] == 0
+            k = int(counts[o])
+            ids = need[:k]
+            degs = torch.zeros(k, dtype=torch.int32, device=dev)
+            engs[o].rows_degree(k, ids, degs)
+            engs[o].sync()
+            tot = int(degs.long().sum())
+            nb = torch.zeros(max(tot, 1), dtype=torch.int32, device=dev)
+            engs[o].rows_pack(k, ids, nb, tot)
+            engs[o].sync()
+            engs[r].rows_append(k, ids, degs, nb, tot)
+        # vde: each computes its slab rows, then exchanges them
+        for r in range(2):
+            engs[r].vde(want=False)
+        bufs = []
+        for r in range(2):
+            buf = torch.zeros((int(bounds[r + 1] - bounds[r]), 2), dtype=torch.float64, device=dev)
+            engs[r].vde_pack_slab(int(bounds[r]), int(bounds[r + 1]), buf)
+            engs[r].sync()
+            bufs.append(buf)
+        for r in range(2):
+            engs[r].vde_unpack_slab(int(bounds[1 - r]), int(bounds[2 - r]), bufs[1 - r])
+        out_ids, out_pde = [], []
+        for r in range(2):
+            total = engs[r].count_paths(2)
+            i, p, _ = engs[r].fill_paths(0, total)
+            out_ids.append(i)
+            out_pde.append(p)
+        ids = np.concatenate(out_ids)
+        pde = np.concatenate(out_pde)
+        assert np.array_equal(ids, ref_ids)
+        assert np.array_equal(pde, ovde[ref_ids].reshape(len(ref_ids), 6))
+    for e in engs:
+        e.close()
