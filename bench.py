@@ -114,18 +114,25 @@ def main():
     mem = synth.block_membership(args.n, max(world, 1))
 
     from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs
-    eng = binding.Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    # a dedicated (non-null) stream shared by torch and the engine, so torch events bracket the
+    # engine's kernels (handle 0 = "context's own stream" in the C-ABI)
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    eng = binding.Engine(local_rank, stream=stream.cuda_stream)
     bounds = plan_slabs(g["offsets"], sn, world)
+    owned_entries = 2 * args.m
     if world == 1:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     else:
         rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
-        eng.load_rows(args.n, g["labels"], rows, roff, rnbr, nbr_capacity=2 * args.m + int(roff[-1]))
+        owned_entries = int(roff[-1])
+        eng.load_rows(args.n, g["labels"], rows, roff, rnbr, nbr_capacity=2 * args.m + owned_entries)
     eng.set_order(sn, mem, max(world, 1))
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(args.labels, e))
     eng.set_fill_variant(args.fill_variant)
-    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=2 * args.m)
+    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=2 * args.m, owned_entries=owned_entries)
 
     # first pass sizes the outputs (and every internal buffer); not timed
     total, base = sb.step()

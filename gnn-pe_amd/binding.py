@@ -75,6 +75,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GnnpeError(f"{LIB_PATH} is missing: build it with `make -C gnn-pe_amd` "
                          "(there is no CPU fallback for the HIP engine)")
+    try:
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): whichever is loaded first
+        # serves the whole process, and torch cannot initialise on the other one.  Load torch's first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol

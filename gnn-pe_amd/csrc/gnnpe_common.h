@@ -98,7 +98,8 @@ struct gnnpe_ctx {
     // ---- label table (R3) / vertex embeddings (R4) ----
     uint32_t n_labels = 0, e = 0;
     bool have_table = false, have_vde = false;
-    gnnpe::DevBuf xtab, x, nx, vde;
+    gnnpe::DevBuf xtab, x, nx, vde, nbr_vde;
+    bool nbr_vde_valid = false;
 
     // ---- enumeration state (R2) ----
     bool counted = false;

@@ -71,9 +71,9 @@ static int ensure_rank_arrays(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-template <int E, int T, bool PDL> static void launch_tiled(const FillParams &P, uint32_t ntiles, hipStream_t s)
+template <int E, int T, int CH, bool PDL> static void launch_tiled(const FillParams &P, uint32_t ntiles, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_fill_tiled<E, T, PDL>), dim3(ntiles), dim3(256), 0, s, P);
+    hipLaunchKernelGGL((k_fill_tiled<E, T, CH, PDL>), dim3(ntiles), dim3(256), 0, s, P);
 }
 
 // tile size per (e, pde_label?) -- keeps the staged tile near 30-50 KiB of LDS
@@ -92,11 +92,11 @@ static uint32_t tile_size_for(uint32_t e, bool pdl)
 static bool launch_tiled_dispatch(uint32_t e, bool pdl, const FillParams &P, uint32_t ntiles, hipStream_t s)
 {
     switch (e) {
-    case 1: pdl ? launch_tiled<1, 512, true>(P, ntiles, s) : launch_tiled<1, 512, false>(P, ntiles, s); return true;
-    case 2: pdl ? launch_tiled<2, 256, true>(P, ntiles, s) : launch_tiled<2, 512, false>(P, ntiles, s); return true;
-    case 3: pdl ? launch_tiled<3, 128, true>(P, ntiles, s) : launch_tiled<3, 256, false>(P, ntiles, s); return true;
-    case 4: pdl ? launch_tiled<4, 128, true>(P, ntiles, s) : launch_tiled<4, 256, false>(P, ntiles, s); return true;
-    case 8: pdl ? launch_tiled<8, 64, true>(P, ntiles, s) : launch_tiled<8, 128, false>(P, ntiles, s); return true;
+    case 1: pdl ? launch_tiled<1, 512, 256, true>(P, ntiles, s) : launch_tiled<1, 512, 256, false>(P, ntiles, s); return true;
+    case 2: pdl ? launch_tiled<2, 256, 256, true>(P, ntiles, s) : launch_tiled<2, 512, 256, false>(P, ntiles, s); return true;
+    case 3: pdl ? launch_tiled<3, 128, 128, true>(P, ntiles, s) : launch_tiled<3, 256, 128, false>(P, ntiles, s); return true;
+    case 4: pdl ? launch_tiled<4, 128, 128, true>(P, ntiles, s) : launch_tiled<4, 256, 128, false>(P, ntiles, s); return true;
+    case 8: pdl ? launch_tiled<8, 64, 64, true>(P, ntiles, s) : launch_tiled<8, 128, 64, false>(P, ntiles, s); return true;
     default: return false;
     }
 }
@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -185,6 +185,7 @@ static int alloc_vertex_arrays(gnnpe_ctx *c, uint32_t n)
 static void invalidate_derived(gnnpe_ctx *c)
 {
     c->have_vde = false;
+    c->nbr_vde_valid = false;
     c->counted = false;
     c->tile_T = 0;
 }
@@ -329,6 +330,7 @@ int gnnpe_set_label_table(gnnpe_ctx *c, uint32_t n_labels, uint32_t e, const dou
     c->e = e;
     c->have_table = true;
     c->have_vde = false;
+    c->nbr_vde_valid = false;
     return GNNPE_OK;
 }
 
@@ -398,6 +400,7 @@ static int run_vde(gnnpe_ctx *c)
     }
     GNNPE_HIP_TRY(hipGetLastError());
     c->have_vde = true;
+    c->nbr_vde_valid = false;
     return GNNPE_OK;
 }
 
@@ -444,8 +447,11 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
         hipLaunchKernelGGL(k_vde_unpack, dim3(grid_for((uint64_t)(end - begin) * c->e)), dim3(kBlock), 0, c->stream,
                            begin, end, c->e, c->sorted.as<uint32_t>(), (const double *)dev_buf, c->vde.as<double>());
     GNNPE_HIP_TRY(hipGetLastError());
+    c->nbr_vde_valid = false;
     return GNNPE_OK;
 }
+
+static int ensure_nbr_vde(gnnpe_ctx *c);
 
 // ---- R2 count -----------------------------------------------------------------------------------
 int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
@@ -492,6 +498,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->total_paths = w;
     c->l = l;
     c->counted = true;
+    if (c->have_vde && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -500,6 +507,21 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         GNNPE_HIP_TRY(hipMemcpyAsync(host_per_start, c->scratch.p, (size_t)len * 8, hipMemcpyDeviceToHost, c->stream));
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return GNNPE_OK;
+}
+
+// nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (needs the complete vde table)
+static int ensure_nbr_vde(gnnpe_ctx *c)
+{
+    if (c->nbr_vde_valid) return GNNPE_OK;
+    GNNPE_REQUIRE(c->have_vde, GNNPE_ERR_ARG, "embeddings requested before gnnpe_vde");
+    int rc;
+    if ((rc = c->nbr_vde.reserve((c->nbr_used + 1) * c->e * 8))) return rc;
+    if (c->nbr_used)
+        hipLaunchKernelGGL(k_gather_rows_f64, dim3(grid_for(c->nbr_used * c->e)), dim3(kBlock), 0, c->stream,
+                           c->nbr_used, c->e, c->nbrs.as<uint32_t>(), c->vde.as<double>(), c->nbr_vde.as<double>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->nbr_vde_valid = true;
     return GNNPE_OK;
 }
 
@@ -535,8 +557,14 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.sorted = c->sorted.as<uint32_t>();
     P.member = c->member.as<uint32_t>();
     P.eoff = c->eoff.as<uint64_t>();
+    if (d_pde) {
+        int rc = ensure_nbr_vde(c);
+        if (rc) return rc;
+    }
     P.vde = c->vde.as<double>();
     P.x = c->x.as<double>();
+    P.nbr_vde = c->nbr_vde.as<double>();
+    P.total = c->total_paths;
     P.n_edges = c->n_edges;
     P.begin = begin;
     P.end = end;
@@ -672,6 +700,7 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
                        c->present.as<uint8_t>(), c->adj_deg.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     c->nbr_used = c->nbr_owned;
+    c->nbr_vde_valid = false;
     c->counted = false;
     c->tile_T = 0;
     return GNNPE_OK;
@@ -744,6 +773,7 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
     GNNPE_HIP_TRY(hipGetLastError());
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->nbr_used += n_nbrs;
+    c->nbr_vde_valid = false;
     c->counted = false;
     c->tile_T = 0;
     return GNNPE_OK;

@@ -240,13 +240,27 @@ __global__ void k_tile_edges(uint64_t n_edges, uint32_t T, const uint64_t *__res
 struct FillParams {
     const uint32_t *erow, *pnbr, *adj_start, *adj_deg, *nbrs, *nbr_rank, *sorted, *tile_edge, *member;
     const uint64_t *eoff;
-    const double *vde, *x;
-    uint64_t n_edges, begin, end;
+    const double *vde, *x, *nbr_vde;  // nbr_vde[q] = vde[nbrs[q]] (e doubles per adjacency entry)
+    uint64_t n_edges, begin, end, total;
     uint32_t slab_begin, e, tile0;
     uint32_t *out_ids;
     double *out_pde, *out_pdl;
     uint32_t *out_part;
 };
+
+// nbr_vde[q][k] = vde[nbrs[q]][k]: one random gather per ADJACENCY ENTRY (2m of them) instead of one
+// per emitted path (sum deg^2 of them): the fill kernels then read the endpoint's embedding from
+// the same contiguous neighbour segment they scan for the rank test.
+__global__ void k_gather_rows_f64(uint64_t cnt, uint32_t e, const uint32_t *__restrict__ idx,
+                                  const double *__restrict__ table, double *__restrict__ out)
+{
+    const uint64_t tot = cnt * e;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = i / e;
+        const uint32_t k = (uint32_t)(i % e);
+        out[i] = table[(uint64_t)idx[q] * e + k];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // R2 + R5 fill, variant 1 (first correct version, kept for A/B): one wave per (s, b) pair, kept
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fill_edge_wave(FillParams P)
                     for (uint32_t k = 0; k < e; k++) {
                         P.out_pde[o * D + k] = P.vde[(uint64_t)s * e + k];
                         P.out_pde[o * D + e + k] = P.vde[(uint64_t)b * e + k];
-                        P.out_pde[o * D + 2 * e + k] = P.vde[(uint64_t)c * e + k];
+                        P.out_pde[o * D + 2 * e + k] = P.nbr_vde[(uint64_t)(st + j) * e + k];
                     }
                 if (P.out_pdl)
                     for (uint32_t k = 0; k < e; k++) {
@@ -304,23 +318,26 @@ __global__ __launch_bounds__(256) void k_fill_edge_wave(FillParams P)
 
 // ------------------------------------------------------------------------------------------------
 // R2 + R5 fill, variant 0 (default): OUTPUT-TILED.  Block k owns paths [k*T, (k+1)*T): it walks the
-// (s, b) pairs that cover that range, flattens their candidate lists across all 256 lanes (full
-// lane use whatever the degrees are), keeps candidates with rank[c] > rank[s], turns the keep
-// flags into output slots with a block-wide prefix count (the scanned pair offsets make slots
-// contiguous across pairs), stages ids + embeddings in LDS, and finally streams the whole tile to
-// HBM with 16-byte-per-lane stores -- every output byte is written exactly once, in full lines.
+// (s, b) pairs that cover that range (tile_edge[k] .. tile_edge[k+1]), flattens their candidate
+// lists across all 256 lanes (full lane use whatever the degrees are), keeps candidates with
+// rank[c] > rank[s], turns the keep flags into output slots with a block-wide prefix count (the
+// scanned pair offsets make slots contiguous across pairs), stages ids + embeddings in LDS, and
+// finally streams the whole tile to HBM with 16-byte-per-lane stores -- every output byte is
+// written exactly once, in full lines.  All reads in the candidate loop are contiguous segments
+// (neighbour ids, their ranks, their embeddings); the start / middle embeddings are fetched once
+// per pair into LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int kFillChunk = 256;  // (s, b) pairs whose metadata is staged per pass
-
-template <int E, int T, bool PDL>
+template <int E, int T, int CH, bool PDL>
 __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
 {
     constexpr int D = 3 * E;
+    static_assert(CH <= 256 && (CH & (CH - 1)) == 0, "chunk must be a power of two <= block size");
     __shared__ __attribute__((aligned(16))) uint32_t s_ids[T * 3];
     __shared__ __attribute__((aligned(16))) double s_pde[T * D];
     __shared__ __attribute__((aligned(16))) double s_pdl[PDL ? T * D : 1];
-    __shared__ uint32_t s_thr[kFillChunk], s_s[kFillChunk], s_b[kFillChunk], s_st[kFillChunk];
-    __shared__ uint32_t s_cstart[kFillChunk + 1];
+    __shared__ __attribute__((aligned(16))) double s_vs[CH * E], s_vb[CH * E];
+    __shared__ uint32_t s_thr[CH], s_s[CH], s_b[CH], s_st[CH];
+    __shared__ uint32_t s_cstart[CH + 1];
     __shared__ uint32_t s_wsum[2][4];
 
     const unsigned tid = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -330,26 +347,37 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
     const uint64_t lo = max(tlo, P.begin), hi = min(tlo + T, P.end);
     if (lo >= hi) return;
     const int64_t olo = (int64_t)(lo - tlo), ohi = (int64_t)(hi - tlo);
+    const bool want_pde = P.out_pde != nullptr;
 
     uint64_t e0 = P.tile_edge[k];
+    // last pair that can contribute to this tile: the one holding the next tile's first path
+    const uint64_t e_last = (tlo + T < P.total) ? (uint64_t)P.tile_edge[k + 1] : P.n_edges - 1;
     // slot (relative to the tile) of the first kept candidate of pair e0; <= 0
-    int64_t pos_base = (int64_t)P.eoff[e0] - (int64_t)tlo;
+    const int64_t pos_base = (int64_t)P.eoff[e0] - (int64_t)tlo;
     int64_t running = 0;
     int parity = 0;
     bool done = false;
 
-    while (!done && e0 < P.n_edges) {
+    while (!done && e0 <= e_last) {
         __syncthreads();  // previous chunk's rounds are done reading the metadata arrays
-        // ---- stage metadata of up to kFillChunk pairs, scan their degrees ----
+        // ---- stage metadata of up to CH pairs, scan their degrees ----
         const uint64_t ee = e0 + tid;
         uint32_t d = 0;
-        if (ee < P.n_edges) {
+        if (tid < (unsigned)CH && ee <= e_last) {
             const uint32_t i = P.erow[ee], b = P.pnbr[ee];
+            const uint32_t s = P.sorted[P.slab_begin + i];
             s_thr[tid] = P.slab_begin + i;
-            s_s[tid] = P.sorted[P.slab_begin + i];
+            s_s[tid] = s;
             s_b[tid] = b;
             s_st[tid] = P.adj_start[b];
             d = P.adj_deg[b];
+            if (want_pde) {
+#pragma unroll
+                for (int kk = 0; kk < E; kk++) {
+                    s_vs[tid * E + kk] = P.vde[(uint64_t)s * E + kk];
+                    s_vb[tid * E + kk] = P.vde[(uint64_t)b * E + kk];
+                }
+            }
         }
         // inclusive wave scan of d
         uint32_t incl = d;
@@ -365,8 +393,8 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
         for (int w2 = 0; w2 < 4; w2++)
             if ((unsigned)w2 < wv) wbase += s_wsum[parity][w2];
         const uint32_t C = s_wsum[parity][0] + s_wsum[parity][1] + s_wsum[parity][2] + s_wsum[parity][3];
-        s_cstart[tid] = wbase + incl - d;
-        if (tid == 0) s_cstart[kFillChunk] = C;
+        if (tid < (unsigned)CH) s_cstart[tid] = wbase + incl - d;
+        if (tid == 0) s_cstart[CH] = C;
         parity ^= 1;
         __syncthreads();
 
@@ -374,16 +402,16 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
         for (uint32_t q0 = 0; q0 < C; q0 += 256) {
             const uint32_t q = q0 + tid;
             bool keep = false;
-            uint32_t j = 0, c = 0;
+            uint32_t j = 0, c = 0, idx = 0;
             if (q < C) {
                 // largest j with cstart[j] <= q
-                uint32_t a = 0, bnd = kFillChunk;
+                uint32_t a = 0, bnd = CH;
                 while (bnd - a > 1) {
                     const uint32_t mid = (a + bnd) >> 1;
                     if (s_cstart[mid] <= q) a = mid; else bnd = mid;
                 }
                 j = a;
-                const uint32_t idx = s_st[j] + (q - s_cstart[j]);
+                idx = s_st[j] + (q - s_cstart[j]);
                 c = P.nbrs[idx];
                 keep = P.nbr_rank[idx] > s_thr[j];
             }
@@ -404,12 +432,12 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
                 s_ids[slot * 3 + 0] = s;
                 s_ids[slot * 3 + 1] = b;
                 s_ids[slot * 3 + 2] = c;
-                if (P.out_pde) {
+                if (want_pde) {
 #pragma unroll
                     for (int kk = 0; kk < E; kk++) {
-                        s_pde[slot * D + kk] = P.vde[(uint64_t)s * E + kk];
-                        s_pde[slot * D + E + kk] = P.vde[(uint64_t)b * E + kk];
-                        s_pde[slot * D + 2 * E + kk] = P.vde[(uint64_t)c * E + kk];
+                        s_pde[slot * D + kk] = s_vs[j * E + kk];
+                        s_pde[slot * D + E + kk] = s_vb[j * E + kk];
+                        s_pde[slot * D + 2 * E + kk] = P.nbr_vde[(uint64_t)idx * E + kk];
                     }
                 }
                 if (PDL && P.out_pdl) {
@@ -427,7 +455,7 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
                 break;
             }
         }
-        e0 += kFillChunk;
+        e0 += CH;
     }
     __syncthreads();
 
@@ -445,7 +473,7 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
             for (uint32_t i = tid; i < nout * 3; i += 256) dst[i] = s_ids[olo * 3 + i];
         }
     }
-    if (P.out_pde) {
+    if (want_pde) {
         double *dst = P.out_pde + obase * D;
         if (full && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
             const double2 *src2 = reinterpret_cast<const double2 *>(s_pde);

@@ -62,7 +62,10 @@ class SlabBuild:
     """Per-rank state of the distributed offline build.  `eng` already holds this rank's rows
     (load_rows), the replicated order (set_order), slab (set_slab) and label table."""
 
-    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, group=None):
+    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None):
+        """nbr_capacity: most neighbour entries this rank can RECEIVE (<= 2m); owned_entries: size
+        of its own rows -- every peer may ask for all of them, so the send buffer holds
+        (world-1) x owned_entries."""
         self.eng, self.n, self.e = eng, int(n), int(e)
         self.bounds = np.ascontiguousarray(bounds, np.uint32)
         self.rank, self.world, self.device, self.group = rank, world, device, group
@@ -72,7 +75,9 @@ class SlabBuild:
         self.deg_out = torch.zeros(max(self.n, 1), **i32)
         self.deg_in = torch.zeros(max(self.n, 1), **i32)
         self.cap = int(max(nbr_capacity, 1))
-        self.pack = torch.zeros(self.cap, **i32)
+        own = int(nbr_capacity if owned_entries is None else owned_entries)
+        self.send_cap = int(max(own * max(world - 1, 1), 1))
+        self.pack = torch.zeros(self.send_cap, **i32)
         self.nbr_in = torch.zeros(self.cap, **i32)
         lens = (self.bounds[1:].astype(np.int64) - self.bounds[:-1].astype(np.int64))
         self.maxlen = int(lens.max()) if len(lens) else 0
@@ -107,9 +112,9 @@ class SlabBuild:
         send_sizes = self._segment_sums(deg_out, req_counts)
         recv_sizes = self._segment_sums(deg_in, need_counts)
         n_send, n_recv = sum(send_sizes), sum(recv_sizes)
-        if n_send > self.cap or n_recv > self.cap:
-            raise RuntimeError(f"halo buffers too small: send {n_send}, recv {n_recv}, capacity {self.cap}")
-        eng.rows_pack(n_req, req, self.pack, self.cap)
+        if n_send > self.send_cap or n_recv > self.cap:
+            raise RuntimeError(f"halo buffers too small: send {n_send}/{self.send_cap}, recv {n_recv}/{self.cap}")
+        eng.rows_pack(n_req, req, self.pack, self.send_cap)
         self._a2a(self.nbr_in[:n_recv], self.pack[:n_send], recv_sizes, send_sizes)
         eng.rows_append(n_need, self.need[:n_need], deg_in, self.nbr_in[:n_recv], n_recv)
         self.stats.update(halo_rows=n_need, halo_entries=n_recv, served_rows=n_req, served_entries=n_send)

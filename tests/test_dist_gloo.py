@@ -1,0 +1,92 @@
+"""world_size-2/3 gloo tests of the slab-partitioned build (gnn-pe_amd/dist.py): the real driver
+code runs its all-to-all-v halo exchange and all-gathers over gloo on CPU, with the local kernels
+replaced by an oracle-backed engine (tests/fake_engine.py).  The concatenated per-rank outputs must
+equal the single-rank reference output for every world size (SURVEY 8(e) invariant)."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gnnpe_amd import synth
+from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, bounds):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_engine import FakeEngine
+    from oracle import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
+    eng = FakeEngine(Oracle(), g["n"], g["labels"], rows, roff, rnbr, sn, 2)
+    eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
+    sb = SlabBuild(eng, g["n"], 2, bounds, rank, world, torch.device("cpu"), nbr_capacity=2 * g["m"],
+                   owned_entries=int(roff[-1]))
+    res = []
+    for rep in range(2):  # the step is repeatable
+        total, base = sb.step()
+        ids = torch.zeros((max(total, 1), 3), dtype=torch.int32)
+        pde = torch.zeros((max(total, 1), 6), dtype=torch.float64)
+        total2, base2 = sb.step(ids, pde)
+        assert (total2, base2) == (total, base)
+        res.append(dict(total=total, base=base, global_total=sb.global_total, ids=ids[:total].numpy(),
+                        pde=pde[:total].numpy(), stats=dict(sb.stats)))
+    with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
+        pickle.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "planned"), (3, "planned"), (2, "empty_slab")])
+def test_slab_build_equals_single_rank(oracle, tmp_path, world, kind):
+    g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    bounds = plan_slabs(g["offsets"], sn, world)
+    if kind == "empty_slab":
+        bounds = np.array([0, 0, g["n"]], np.uint32)
+    assert bounds[0] == 0 and bounds[-1] == g["n"] and np.all(np.diff(bounds.astype(np.int64)) >= 0)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), bounds), nprocs=world, join=True)
+    ref_ids = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    res = [pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(world)]
+    for rep in range(2):
+        parts = [res[r][rep] for r in range(world)]
+        assert [p["base"] for p in parts] == list(np.cumsum([0] + [p["total"] for p in parts[:-1]]))
+        assert all(p["global_total"] == len(ref_ids) for p in parts)
+        ids = np.concatenate([p["ids"] for p in parts]).astype(np.uint32)
+        pde = np.concatenate([p["pde"] for p in parts])
+        assert np.array_equal(ids, ref_ids)
+        assert np.array_equal(pde, vde[ref_ids].reshape(len(ref_ids), 6))
+    if kind == "planned":  # partitioning must actually move rows between ranks
+        assert all(res[r][0]["stats"]["halo_rows"] > 0 for r in range(world))
+
+
+def test_plan_slabs_balances_and_covers():
+    g = synth.gnm_graph(5000, 40000, seed=5)
+    sn = synth.degree_order(g["offsets"])
+    for R in (1, 2, 4, 8):
+        b = plan_slabs(g["offsets"], sn, R)
+        assert len(b) == R + 1 and b[0] == 0 and b[-1] == g["n"]
+        assert np.all(np.diff(b.astype(np.int64)) >= 0)
+    rows, roff, rnbr = owned_rows(g, sn, plan_slabs(g["offsets"], sn, 4), 2)
+    offs = g["offsets"].astype(np.int64)
+    for k in (0, len(rows) // 2, len(rows) - 1):
+        v = int(rows[k])
+        assert np.array_equal(rnbr[int(roff[k]):int(roff[k + 1])], g["nbrs"][offs[v]:offs[v + 1]])

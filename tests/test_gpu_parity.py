@@ -204,7 +204,9 @@ def test_config3_1m_10m_properties():
     g = synth.gnm_graph(1_000_000, 10_000_000)
     n = g["n"]
     sn = synth.degree_order(g["offsets"])
-    eng = binding.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    eng = binding.Engine(0, stream=stream.cuda_stream)
     eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     eng.set_order(sn, synth.block_membership(n, 8), 8)
     eng.set_label_table(binding.host_label_table(64, 2))
