@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->rev, &c->pair_off};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -214,6 +214,7 @@ int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_
     c->have_graph = true;
     c->rows_identity = true;
     c->n_rows = n;
+    c->n_held = n;
     c->nbr_used = c->nbr_owned = m2;
     c->nbr_cap = c->nbrs.bytes / 4;
     if (!c->slab_set) {
@@ -241,10 +242,12 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
     if ((rc = alloc_vertex_arrays(c, n))) return rc;
     if ((rc = c->nbrs.reserve(cap * 4))) return rc;
     if ((rc = c->rows.reserve((size_t)(n_rows + 1) * 4))) return rc;
+    if ((rc = c->held.reserve((size_t)(n + 1) * 4))) return rc;
     if ((rc = c->scratch.reserve((size_t)(n_rows + 1) * 8))) return rc;
     if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->labels.p, labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (n_rows) {
         GNNPE_HIP_TRY(hipMemcpyAsync(c->rows.p, rows, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->held.p, rows, (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream));
         GNNPE_HIP_TRY(hipMemcpyAsync(c->scratch.p, row_offsets, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice,
                                      c->stream));
         if (used) GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.p, row_nbrs, used * 4, hipMemcpyHostToDevice, c->stream));
@@ -260,6 +263,7 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
     c->have_graph = true;
     c->rows_identity = false;
     c->n_rows = n_rows;
+    c->n_held = n_rows;
     c->nbr_used = c->nbr_owned = used;
     c->nbr_cap = c->nbrs.bytes / 4;
     if (!c->slab_set) {
@@ -489,15 +493,35 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                            c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
     // 3. per-pair counts and their exclusive scan (global slot of every pair's first path)
-    hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
-                       c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
-                       c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
+    const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+    if (c->fill_variant == 2) {
+        // middle-vertex-centric: each row is read once; counts land at the pair's emission index
+        if ((rc = c->rev.reserve((c->nbr_used + 1) * 4)) || (rc = c->pair_off.reserve((c->nbr_used + 1) * 8))) return rc;
+        GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
+        if (c->n_held) {
+            hipLaunchKernelGGL(k_rev_edge, dim3(grid_for((uint64_t)c->n_held * 16)), dim3(kBlock), 0, c->stream,
+                               c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                               c->nbrs.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->rev.as<uint32_t>());
+            hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
+                               c->n_held, held, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                               c->nbr_rank.as<uint32_t>(), c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
+        }
+    } else {
+        hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
+                           c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                           c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
+    }
     GNNPE_HIP_TRY(hipGetLastError());
     if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
+    if (c->fill_variant == 2 && c->nbr_used)
+        hipLaunchKernelGGL(k_pair_off, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
+                           c->rev.as<uint32_t>(), c->eoff.as<uint64_t>(), c->pair_off.as<uint64_t>());
     c->total_paths = w;
     c->l = l;
     c->counted = true;
+    c->counted_variant = c->fill_variant;
     if (c->have_vde && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
@@ -577,6 +601,38 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.tile_edge = nullptr;
     P.tile0 = 0;
     const bool pdl = d_pdl != nullptr;
+    if (c->fill_variant == 2 && (P.e == 1 || P.e == 2 || P.e == 3 || P.e == 4 || P.e == 8)) {
+        GNNPE_REQUIRE(c->counted_variant == 2, GNNPE_ERR_ARG, "fill variant changed after gnnpe_count_paths");
+        FillBParams B;
+        B.held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+        B.adj_start = P.adj_start;
+        B.adj_deg = P.adj_deg;
+        B.nbrs = P.nbrs;
+        B.nbr_rank = P.nbr_rank;
+        B.member = P.member;
+        B.pair_off = c->pair_off.as<uint64_t>();
+        B.vde = P.vde;
+        B.x = P.x;
+        B.nbr_vde = P.nbr_vde;
+        B.n_held = c->n_held;
+        B.e = P.e;
+        B.begin = begin;
+        B.end = end;
+        B.out_ids = P.out_ids;
+        B.out_pde = P.out_pde;
+        B.out_pdl = P.out_pdl;
+        B.out_part = P.out_part;
+        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+        switch (P.e) {
+        case 1: hipLaunchKernelGGL((k_fill_b<1>), grid, block, 0, c->stream, B); break;
+        case 2: hipLaunchKernelGGL((k_fill_b<2>), grid, block, 0, c->stream, B); break;
+        case 3: hipLaunchKernelGGL((k_fill_b<3>), grid, block, 0, c->stream, B); break;
+        case 4: hipLaunchKernelGGL((k_fill_b<4>), grid, block, 0, c->stream, B); break;
+        default: hipLaunchKernelGGL((k_fill_b<8>), grid, block, 0, c->stream, B); break;
+        }
+        GNNPE_HIP_TRY(hipGetLastError());
+        return GNNPE_OK;
+    }
     const uint32_t T = (c->fill_variant == 0) ? tile_size_for(P.e, pdl) : 0;
     if (T) {
         int rc = ensure_tiles(c, T);
@@ -641,7 +697,11 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && (variant == 0 || variant == 1), GNNPE_ERR_ARG, "fill variant must be 0 or 1");
+    GNNPE_REQUIRE(c && variant >= 0 && variant <= 2, GNNPE_ERR_ARG, "fill variant must be 0, 1 or 2");
+    if (variant != c->fill_variant) {
+        c->counted = false;
+        c->tile_T = 0;
+    }
     c->fill_variant = variant;
     return GNNPE_OK;
 }
@@ -700,6 +760,7 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
                        c->present.as<uint8_t>(), c->adj_deg.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     c->nbr_used = c->nbr_owned;
+    c->n_held = c->n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
     c->tile_T = 0;
@@ -767,12 +828,17 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
     if (n_nbrs)
         GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.as<uint32_t>() + c->nbr_used, dev_nbrs, n_nbrs * 4, hipMemcpyDeviceToDevice,
                                      c->stream));
+    GNNPE_REQUIRE(!c->rows_identity && (uint64_t)c->n_held + n_rows <= c->n, GNNPE_ERR_ARG,
+                  "gnnpe_rows_append: more rows than vertices");
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->held.as<uint32_t>() + c->n_held, dev_ids, n_rows * 4, hipMemcpyDeviceToDevice,
+                                 c->stream));
     hipLaunchKernelGGL(k_install_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, n_rows,
                        (const uint32_t *)dev_ids, roff, c->nbr_used, c->adj_start.as<uint32_t>(),
                        c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->nbr_used += n_nbrs;
+    c->n_held += (uint32_t)n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
     c->tile_T = 0;

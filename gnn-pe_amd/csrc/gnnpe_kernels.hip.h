@@ -499,6 +499,218 @@ __global__ __launch_bounds__(256) void k_fill_tiled(FillParams P)
 }
 
 // ------------------------------------------------------------------------------------------------
+// MIDDLE-VERTEX-CENTRIC enumeration (variant 2).
+//
+// Every path (s, b, c) is a pair of neighbours of its middle vertex b, oriented from the lower to
+// the higher rank.  So one pass over the rows is enough: a wave takes row b, keeps N(b) -- ids,
+// ranks, embeddings, and for every neighbour u_i the output offset of the pair (s = u_i, b) -- in
+// registers, and for each i emits the neighbours c with rank[c] > rank[u_i] in ascending-id order
+// at that offset.  The adjacency is read ONCE (2m entries) instead of once per (s, b) pair
+// (sum deg^2 entries), and there is no dependent load inside the emit loop.  The price is that a
+// pair's rows (cnt x 60 B) are written as one short contiguous run per wave iteration.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
+constexpr uint64_t kNoOff = ~0ull;
+
+__device__ __forceinline__ uint32_t rl32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l)
+{
+    return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
+}
+__device__ __forceinline__ double rlf64(double v, int l)
+{
+    return __hiloint2double((int)rl32((uint32_t)__double2hiint(v), l), (int)rl32((uint32_t)__double2loint(v), l));
+}
+
+// rev[q] for adjacency entry q = (b -> u): index of the directed pair (s = u, b) in the slab's
+// emission order (poffs[rank[u] - slab_begin] + position of b in N(u)), or kNoEdge when u is not a
+// start vertex of this slab.  16 lanes per row, one binary search per entry.
+__global__ void k_rev_edge(uint32_t n_held, const uint32_t *__restrict__ held, uint32_t slab_begin, uint32_t slab_end,
+                           const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
+                           const uint32_t *__restrict__ nbrs, const uint32_t *__restrict__ nbr_rank,
+                           const uint32_t *__restrict__ poffs, uint32_t *__restrict__ rev)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < n_held; g += ng) {
+        const uint32_t b = held ? held[g] : (uint32_t)g;
+        const uint32_t st = adj_start[b], d = adj_deg[b];
+        for (uint32_t i = sub; i < d; i += 16) {
+            const uint32_t u = nbrs[st + i], ru = nbr_rank[st + i];
+            uint32_t r = kNoEdge;
+            if (ru >= slab_begin && ru < slab_end) {
+                const uint32_t lo0 = adj_start[u];
+                uint32_t lo = 0, hi = adj_deg[u];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (nbrs[lo0 + mid] < b) lo = mid + 1; else hi = mid;
+                }
+                if (lo < adj_deg[u] && nbrs[lo0 + lo] == b) r = poffs[ru - slab_begin] + lo;
+            }
+            rev[st + i] = r;
+        }
+    }
+}
+
+// cnt(s = u_i, b) = |{ j : rank[u_j] > rank[u_i] }| for every neighbour u_i of b that starts a path here.
+__global__ __launch_bounds__(256) void k_count_b(uint32_t n_held, const uint32_t *__restrict__ held,
+                                                 const uint32_t *__restrict__ adj_start,
+                                                 const uint32_t *__restrict__ adj_deg,
+                                                 const uint32_t *__restrict__ nbr_rank,
+                                                 const uint32_t *__restrict__ rev, uint32_t *__restrict__ ecnt)
+{
+    const unsigned lane = lane_id();
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w < n_held; w += nw) {
+        const uint32_t b = held ? held[w] : (uint32_t)w;
+        const uint32_t st = adj_start[b], d = adj_deg[b];
+        for (uint32_t i0 = 0; i0 < d; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t ri = i < d ? nbr_rank[st + i] : 0xFFFFFFFFu;
+            const uint32_t rv = i < d ? rev[st + i] : kNoEdge;
+            if (__ballot(rv != kNoEdge) == 0) continue;
+            uint32_t cnt = 0;
+            if (d <= 64) {
+                for (uint32_t j = 0; j < d; j++) cnt += rl32(ri, (int)j) > ri ? 1u : 0u;
+            } else {
+                for (uint32_t j = 0; j < d; j++) cnt += nbr_rank[st + j] > ri ? 1u : 0u;
+            }
+            if (rv != kNoEdge) ecnt[rv] = cnt;
+        }
+    }
+}
+
+__global__ void k_pair_off(uint64_t cnt, const uint32_t *__restrict__ rev, const uint64_t *__restrict__ eoff,
+                           uint64_t *__restrict__ pair_off)
+{
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < cnt; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rev[q];
+        pair_off[q] = r == kNoEdge ? kNoOff : eoff[r];
+    }
+}
+
+struct FillBParams {
+    const uint32_t *held, *adj_start, *adj_deg, *nbrs, *nbr_rank, *member;
+    const uint64_t *pair_off;
+    const double *vde, *x, *nbr_vde;
+    uint32_t n_held, e;
+    uint64_t begin, end;
+    uint32_t *out_ids;
+    double *out_pde, *out_pdl;
+    uint32_t *out_part;
+};
+
+struct __attribute__((packed, aligned(4))) Triple {
+    uint32_t s, b, c;
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
+{
+    constexpr int D = 3 * E;
+    const unsigned lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const bool want_pde = P.out_pde != nullptr;
+    for (; w < P.n_held; w += nw) {
+        const uint32_t b = P.held ? P.held[w] : (uint32_t)w;
+        const uint32_t st = P.adj_start[b], d = P.adj_deg[b];
+        if (d < 2) continue;
+        double vb[E];
+        if (want_pde) {
+#pragma unroll
+            for (int k = 0; k < E; k++) vb[k] = P.vde[(uint64_t)b * E + k];
+        }
+        for (uint32_t i0 = 0; i0 < d; i0 += 64) {
+            // this lane's neighbour of the i-chunk: id, rank, pair offset, embedding
+            const uint32_t ii = i0 + lane;
+            const bool iv = ii < d;
+            const uint32_t ui = iv ? P.nbrs[st + ii] : 0u;
+            const uint32_t ri = iv ? P.nbr_rank[st + ii] : 0u;
+            const uint64_t oi = iv ? P.pair_off[st + ii] : kNoOff;
+            double vi[E];
+            if (want_pde) {
+#pragma unroll
+                for (int k = 0; k < E; k++) vi[k] = iv ? P.nbr_vde[(uint64_t)(st + ii) * E + k] : 0.0;
+            }
+            if (__ballot(oi != kNoOff && oi < P.end) == 0) continue;
+            const uint32_t ni = min(64u, d - i0);
+            for (uint32_t i = 0; i < ni; i++) {
+                uint64_t run = rl64(oi, (int)i);
+                if (run == kNoOff || run >= P.end) continue;
+                const uint32_t s = rl32(ui, (int)i), rs = rl32(ri, (int)i);
+                double vs[E];
+                if (want_pde) {
+#pragma unroll
+                    for (int k = 0; k < E; k++) vs[k] = rlf64(vi[k], (int)i);
+                }
+                for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+                    uint32_t c, rc;
+                    bool jv;
+                    double vc[E];
+                    if (j0 == i0) {  // the common case (deg <= 64): the candidates are already in registers
+                        c = ui;
+                        rc = ri;
+                        jv = iv;
+#pragma unroll
+                        for (int k = 0; k < E; k++) vc[k] = want_pde ? vi[k] : 0.0;
+                    } else {
+                        const uint32_t jj = j0 + lane;
+                        jv = jj < d;
+                        c = jv ? P.nbrs[st + jj] : 0u;
+                        rc = jv ? P.nbr_rank[st + jj] : 0u;
+#pragma unroll
+                        for (int k = 0; k < E; k++) vc[k] = (want_pde && jv) ? P.nbr_vde[(uint64_t)(st + jj) * E + k] : 0.0;
+                    }
+                    const bool keep = jv && rc > rs;
+                    const uint64_t mask = __ballot(keep);
+                    const uint64_t pos = run + __popcll(mask & lt);
+                    run += __popcll(mask);
+                    if (keep && pos >= P.begin && pos < P.end) {
+                        const uint64_t o = pos - P.begin;
+                        if (P.out_ids) {
+                            Triple t = {s, b, c};
+                            *reinterpret_cast<Triple *>(P.out_ids + o * 3) = t;
+                        }
+                        if (want_pde) {
+                            double *dst = P.out_pde + o * D;
+                            if ((E & 1) == 0) {
+                                double2 *d2 = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+                                for (int k = 0; k < E / 2; k++) {
+                                    d2[k] = make_double2(vs[2 * k], vs[2 * k + 1]);
+                                    d2[E / 2 + k] = make_double2(vb[2 * k], vb[2 * k + 1]);
+                                    d2[E + k] = make_double2(vc[2 * k], vc[2 * k + 1]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < E; k++) {
+                                    dst[k] = vs[k];
+                                    dst[E + k] = vb[k];
+                                    dst[2 * E + k] = vc[k];
+                                }
+                            }
+                        }
+                        if (P.out_pdl) {
+#pragma unroll
+                            for (int k = 0; k < E; k++) {
+                                P.out_pdl[o * D + k] = P.x[(uint64_t)s * E + k];
+                                P.out_pdl[o * D + E + k] = P.x[(uint64_t)b * E + k];
+                                P.out_pdl[o * D + 2 * E + k] = P.x[(uint64_t)c * E + k];
+                            }
+                        }
+                        if (P.out_part) P.out_part[o] = P.member[s];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // halo helpers
 // ------------------------------------------------------------------------------------------------
 __global__ void k_mark_needed(uint64_t cnt, const uint32_t *__restrict__ nbrs, uint8_t *__restrict__ mark)

@@ -141,8 +141,9 @@ int gnnpe_path_partitions_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, v
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);
-/* Selects the fill implementation: 0 = output-tiled LDS-staged kernel (default), 1 = edge-per-wave
- * direct-store kernel (first correct version, kept for A/B). */
+/* Selects the enumeration implementation (call before gnnpe_count_paths): 0 = output-tiled LDS-staged
+ * fill, 1 = pair-per-wave direct-store fill (first correct version), 2 = middle-vertex-centric count +
+ * fill (each adjacency row read once).  All produce identical outputs; kept selectable for A/B. */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
 
 #ifdef __cplusplus
