@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->rev, &c->pair_off};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->pair_off};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -209,6 +209,15 @@ int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_
                            c->scratch.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                            c->present.as<uint8_t>());
     GNNPE_HIP_TRY(hipGetLastError());
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve((m2 + 1) * 4))) return rc;
+    if (n) {
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
+        // reverse positions: part of building the graph structure (depends on the graph only)
+        hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n * 16)), dim3(kBlock), 0, c->stream, n,
+                           (const uint32_t *)nullptr, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->n = n;
     c->have_graph = true;
@@ -257,8 +266,15 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
         GNNPE_HIP_TRY(hipGetLastError());
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = c->owned.reserve((size_t)n + 1))) return rc;
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes))) return rc;
     if (n) GNNPE_HIP_TRY(hipMemcpy(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice));
+    if (n_rows) {
+        hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows,
+                           c->rows.as<uint32_t>(), c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+        GNNPE_HIP_TRY(hipGetLastError());
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->n = n;
     c->have_graph = true;
     c->rows_identity = false;
@@ -496,17 +512,13 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     if (c->fill_variant == 2) {
         // middle-vertex-centric: each row is read once; counts land at the pair's emission index
-        if ((rc = c->rev.reserve((c->nbr_used + 1) * 4)) || (rc = c->pair_off.reserve((c->nbr_used + 1) * 8))) return rc;
+        if ((rc = c->pair_off.reserve((c->nbr_used + 1) * 8))) return rc;
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (c->n_held) {
-            hipLaunchKernelGGL(k_rev_edge, dim3(grid_for((uint64_t)c->n_held * 16)), dim3(kBlock), 0, c->stream,
-                               c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                               c->nbrs.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                               c->rev.as<uint32_t>());
+        if (c->n_held)
             hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
-                               c->n_held, held, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                               c->nbr_rank.as<uint32_t>(), c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
-        }
+                               c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                               c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->ecnt.as<uint32_t>());
     } else {
         hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
                            c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
@@ -516,13 +528,15 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
     if (c->fill_variant == 2 && c->nbr_used)
-        hipLaunchKernelGGL(k_pair_off, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
-                           c->rev.as<uint32_t>(), c->eoff.as<uint64_t>(), c->pair_off.as<uint64_t>());
+        hipLaunchKernelGGL(k_pair_off, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb, se,
+                           c->revpos.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                           c->eoff.as<uint64_t>(), c->pair_off.as<uint64_t>());
     c->total_paths = w;
     c->l = l;
     c->counted = true;
     c->counted_variant = c->fill_variant;
-    if (c->have_vde && (rc = ensure_nbr_vde(c))) return rc;
+    const bool b_centric = c->fill_variant == 2 && c->have_table && (c->e == 2 || c->e == 4 || c->e == 8);
+    if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -581,7 +595,9 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.sorted = c->sorted.as<uint32_t>();
     P.member = c->member.as<uint32_t>();
     P.eoff = c->eoff.as<uint64_t>();
-    if (d_pde) {
+    const uint32_t e_eff = c->have_table ? c->e : 2;
+    const bool b_centric = c->fill_variant == 2 && (e_eff == 2 || e_eff == 4 || e_eff == 8);
+    if (d_pde && !b_centric) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
     }
@@ -601,7 +617,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.tile_edge = nullptr;
     P.tile0 = 0;
     const bool pdl = d_pdl != nullptr;
-    if (c->fill_variant == 2 && (P.e == 1 || P.e == 2 || P.e == 3 || P.e == 4 || P.e == 8)) {
+    if (b_centric) {
         GNNPE_REQUIRE(c->counted_variant == 2, GNNPE_ERR_ARG, "fill variant changed after gnnpe_count_paths");
         FillBParams B;
         B.held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
@@ -613,9 +629,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         B.pair_off = c->pair_off.as<uint64_t>();
         B.vde = P.vde;
         B.x = P.x;
-        B.nbr_vde = P.nbr_vde;
         B.n_held = c->n_held;
-        B.e = P.e;
+        B.e = e_eff;
         B.begin = begin;
         B.end = end;
         B.out_ids = P.out_ids;
@@ -623,10 +638,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         B.out_pdl = P.out_pdl;
         B.out_part = P.out_part;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-        switch (P.e) {
-        case 1: hipLaunchKernelGGL((k_fill_b<1>), grid, block, 0, c->stream, B); break;
+        switch (e_eff) {
         case 2: hipLaunchKernelGGL((k_fill_b<2>), grid, block, 0, c->stream, B); break;
-        case 3: hipLaunchKernelGGL((k_fill_b<3>), grid, block, 0, c->stream, B); break;
         case 4: hipLaunchKernelGGL((k_fill_b<4>), grid, block, 0, c->stream, B); break;
         default: hipLaunchKernelGGL((k_fill_b<8>), grid, block, 0, c->stream, B); break;
         }
@@ -835,6 +848,9 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
     hipLaunchKernelGGL(k_install_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, n_rows,
                        (const uint32_t *)dev_ids, roff, c->nbr_used, c->adj_start.as<uint32_t>(),
                        c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
+    hipLaunchKernelGGL(k_revpos, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, c->stream, (uint32_t)n_rows,
+                       (const uint32_t *)dev_ids, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->nbr_used += n_nbrs;

@@ -522,43 +522,53 @@ __device__ __forceinline__ double rlf64(double v, int l)
     return __hiloint2double((int)rl32((uint32_t)__double2hiint(v), l), (int)rl32((uint32_t)__double2loint(v), l));
 }
 
-// rev[q] for adjacency entry q = (b -> u): index of the directed pair (s = u, b) in the slab's
-// emission order (poffs[rank[u] - slab_begin] + position of b in N(u)), or kNoEdge when u is not a
-// start vertex of this slab.  16 lanes per row, one binary search per entry.
-__global__ void k_rev_edge(uint32_t n_held, const uint32_t *__restrict__ held, uint32_t slab_begin, uint32_t slab_end,
-                           const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
-                           const uint32_t *__restrict__ nbrs, const uint32_t *__restrict__ nbr_rank,
-                           const uint32_t *__restrict__ poffs, uint32_t *__restrict__ rev)
+// revpos[q] for adjacency entry q = (b -> u): position of b inside N(u), or kNoEdge when row u is not
+// an OWNED row of this device (only owned rows start paths here).  Depends on the graph only -- not on
+// the processing order -- so it is built when rows are loaded / appended, like the loader's sort of
+// the adjacency lists (graph.cpp:231-233).  16 lanes per row, one binary search per entry.
+__global__ void k_revpos(uint32_t n_rows, const uint32_t *__restrict__ rows, const uint8_t *__restrict__ owned,
+                         const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
+                         const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ revpos)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
     const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    for (; g < n_held; g += ng) {
-        const uint32_t b = held ? held[g] : (uint32_t)g;
+    for (; g < n_rows; g += ng) {
+        const uint32_t b = rows ? rows[g] : (uint32_t)g;
         const uint32_t st = adj_start[b], d = adj_deg[b];
         for (uint32_t i = sub; i < d; i += 16) {
-            const uint32_t u = nbrs[st + i], ru = nbr_rank[st + i];
+            const uint32_t u = nbrs[st + i];
             uint32_t r = kNoEdge;
-            if (ru >= slab_begin && ru < slab_end) {
-                const uint32_t lo0 = adj_start[u];
-                uint32_t lo = 0, hi = adj_deg[u];
+            if (owned[u]) {
+                const uint32_t lo0 = adj_start[u], du = adj_deg[u];
+                uint32_t lo = 0, hi = du;
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (nbrs[lo0 + mid] < b) lo = mid + 1; else hi = mid;
                 }
-                if (lo < adj_deg[u] && nbrs[lo0 + lo] == b) r = poffs[ru - slab_begin] + lo;
+                if (lo < du && nbrs[lo0 + lo] == b) r = lo;
             }
-            rev[st + i] = r;
+            revpos[st + i] = r;
         }
     }
 }
 
+// emission index of the directed pair (s = u, b) for adjacency entry q = (b -> u), or kNoEdge
+__device__ __forceinline__ uint32_t pair_index(uint32_t revpos, uint32_t rank_u, uint32_t slab_begin, uint32_t slab_end,
+                                               const uint32_t *__restrict__ poffs)
+{
+    return (revpos != kNoEdge && rank_u >= slab_begin && rank_u < slab_end) ? poffs[rank_u - slab_begin] + revpos
+                                                                            : kNoEdge;
+}
+
 // cnt(s = u_i, b) = |{ j : rank[u_j] > rank[u_i] }| for every neighbour u_i of b that starts a path here.
 __global__ __launch_bounds__(256) void k_count_b(uint32_t n_held, const uint32_t *__restrict__ held,
+                                                 uint32_t slab_begin, uint32_t slab_end,
                                                  const uint32_t *__restrict__ adj_start,
                                                  const uint32_t *__restrict__ adj_deg,
                                                  const uint32_t *__restrict__ nbr_rank,
-                                                 const uint32_t *__restrict__ rev, uint32_t *__restrict__ ecnt)
+                                                 const uint32_t *__restrict__ revpos,
+                                                 const uint32_t *__restrict__ poffs, uint32_t *__restrict__ ecnt)
 {
     const unsigned lane = lane_id();
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(256) void k_count_b(uint32_t n_held, const uint32_t
         for (uint32_t i0 = 0; i0 < d; i0 += 64) {
             const uint32_t i = i0 + lane;
             const uint32_t ri = i < d ? nbr_rank[st + i] : 0xFFFFFFFFu;
-            const uint32_t rv = i < d ? rev[st + i] : kNoEdge;
+            const uint32_t rv = i < d ? pair_index(revpos[st + i], ri, slab_begin, slab_end, poffs) : kNoEdge;
             if (__ballot(rv != kNoEdge) == 0) continue;
             uint32_t cnt = 0;
             if (d <= 64) {
@@ -582,11 +592,13 @@ __global__ __launch_bounds__(256) void k_count_b(uint32_t n_held, const uint32_t
     }
 }
 
-__global__ void k_pair_off(uint64_t cnt, const uint32_t *__restrict__ rev, const uint64_t *__restrict__ eoff,
-                           uint64_t *__restrict__ pair_off)
+// pair_off[q] = first output slot of the pair (s = u, b) of adjacency entry q, or kNoOff
+__global__ void k_pair_off(uint64_t cnt, uint32_t slab_begin, uint32_t slab_end, const uint32_t *__restrict__ revpos,
+                           const uint32_t *__restrict__ nbr_rank, const uint32_t *__restrict__ poffs,
+                           const uint64_t *__restrict__ eoff, uint64_t *__restrict__ pair_off)
 {
     for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < cnt; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = rev[q];
+        const uint32_t r = pair_index(revpos[q], nbr_rank[q], slab_begin, slab_end, poffs);
         pair_off[q] = r == kNoEdge ? kNoOff : eoff[r];
     }
 }
@@ -594,7 +606,7 @@ __global__ void k_pair_off(uint64_t cnt, const uint32_t *__restrict__ rev, const
 struct FillBParams {
     const uint32_t *held, *adj_start, *adj_deg, *nbrs, *nbr_rank, *member;
     const uint64_t *pair_off;
-    const double *vde, *x, *nbr_vde;
+    const double *vde, *x;
     uint32_t n_held, e;
     uint64_t begin, end;
     uint32_t *out_ids;
@@ -602,27 +614,36 @@ struct FillBParams {
     uint32_t *out_part;
 };
 
-struct __attribute__((packed, aligned(4))) Triple {
-    uint32_t s, b, c;
-};
-
+// One wave per middle vertex.  For each start s = u_i the kept neighbours are compacted (ballot +
+// popcount), their ids / embeddings pass through a per-wave LDS strip, and the run of cnt rows is
+// written with CONSECUTIVE lanes on CONSECUTIVE 16-byte (pde) / 4-byte (ids) pieces: one store
+// instruction covers up to 1 KiB of contiguous output however few neighbours were kept.
 template <int E>
 __global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
 {
+    static_assert(E % 2 == 0, "contiguous-store path needs whole 16-byte pieces");
     constexpr int D = 3 * E;
-    const unsigned lane = lane_id();
+    constexpr int H = E / 2;     // 16-byte pieces per vertex embedding
+    constexpr int PPP = 3 * H;   // 16-byte pieces per path row
+    __shared__ __attribute__((aligned(16))) double2 s_vc[4][64 * H];
+    __shared__ uint32_t s_c[4][64];
+
+    const unsigned lane = lane_id(), wv = wave_id();
     const uint64_t lt = (1ull << lane) - 1ull;
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const bool want_pde = P.out_pde != nullptr;
+    double2 *const my_vc = s_vc[wv];
+    uint32_t *const my_c = s_c[wv];
+
     for (; w < P.n_held; w += nw) {
         const uint32_t b = P.held ? P.held[w] : (uint32_t)w;
         const uint32_t st = P.adj_start[b], d = P.adj_deg[b];
         if (d < 2) continue;
-        double vb[E];
+        double2 vb[H];
         if (want_pde) {
 #pragma unroll
-            for (int k = 0; k < E; k++) vb[k] = P.vde[(uint64_t)b * E + k];
+            for (int k = 0; k < H; k++) vb[k] = reinterpret_cast<const double2 *>(P.vde + (uint64_t)b * E)[k];
         }
         for (uint32_t i0 = 0; i0 < d; i0 += 64) {
             // this lane's neighbour of the i-chunk: id, rank, pair offset, embedding
@@ -631,79 +652,110 @@ __global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
             const uint32_t ui = iv ? P.nbrs[st + ii] : 0u;
             const uint32_t ri = iv ? P.nbr_rank[st + ii] : 0u;
             const uint64_t oi = iv ? P.pair_off[st + ii] : kNoOff;
-            double vi[E];
+            if (__ballot(oi != kNoOff && oi < P.end) == 0) continue;
+            double2 vi[H];
             if (want_pde) {
 #pragma unroll
-                for (int k = 0; k < E; k++) vi[k] = iv ? P.nbr_vde[(uint64_t)(st + ii) * E + k] : 0.0;
+                for (int k = 0; k < H; k++)
+                    vi[k] = iv ? reinterpret_cast<const double2 *>(P.vde + (uint64_t)ui * E)[k] : make_double2(0.0, 0.0);
             }
-            if (__ballot(oi != kNoOff && oi < P.end) == 0) continue;
             const uint32_t ni = min(64u, d - i0);
             for (uint32_t i = 0; i < ni; i++) {
-                uint64_t run = rl64(oi, (int)i);
-                if (run == kNoOff || run >= P.end) continue;
+                const uint64_t off = rl64(oi, (int)i);
+                if (off == kNoOff || off >= P.end) continue;
                 const uint32_t s = rl32(ui, (int)i), rs = rl32(ri, (int)i);
-                double vs[E];
+                double2 vs[H];
                 if (want_pde) {
 #pragma unroll
-                    for (int k = 0; k < E; k++) vs[k] = rlf64(vi[k], (int)i);
+                    for (int k = 0; k < H; k++) vs[k] = make_double2(rlf64(vi[k].x, (int)i), rlf64(vi[k].y, (int)i));
                 }
+                uint64_t run = off;
                 for (uint32_t j0 = 0; j0 < d; j0 += 64) {
                     uint32_t c, rc;
                     bool jv;
-                    double vc[E];
+                    double2 vc[H];
                     if (j0 == i0) {  // the common case (deg <= 64): the candidates are already in registers
                         c = ui;
                         rc = ri;
                         jv = iv;
 #pragma unroll
-                        for (int k = 0; k < E; k++) vc[k] = want_pde ? vi[k] : 0.0;
+                        for (int k = 0; k < H; k++) vc[k] = want_pde ? vi[k] : make_double2(0.0, 0.0);
                     } else {
                         const uint32_t jj = j0 + lane;
                         jv = jj < d;
                         c = jv ? P.nbrs[st + jj] : 0u;
                         rc = jv ? P.nbr_rank[st + jj] : 0u;
 #pragma unroll
-                        for (int k = 0; k < E; k++) vc[k] = (want_pde && jv) ? P.nbr_vde[(uint64_t)(st + jj) * E + k] : 0.0;
+                        for (int k = 0; k < H; k++)
+                            vc[k] = (want_pde && jv) ? reinterpret_cast<const double2 *>(P.vde + (uint64_t)c * E)[k]
+                                                     : make_double2(0.0, 0.0);
                     }
                     const bool keep = jv && rc > rs;
                     const uint64_t mask = __ballot(keep);
-                    const uint64_t pos = run + __popcll(mask & lt);
-                    run += __popcll(mask);
-                    if (keep && pos >= P.begin && pos < P.end) {
-                        const uint64_t o = pos - P.begin;
-                        if (P.out_ids) {
-                            Triple t = {s, b, c};
-                            *reinterpret_cast<Triple *>(P.out_ids + o * 3) = t;
-                        }
+                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    if (cnt == 0) continue;
+                    const uint32_t p = (uint32_t)__popcll(mask & lt);  // this lane's slot inside the run
+                    const uint64_t first = run;                        // output slot of the run's first row
+                    run += cnt;
+                    if (first >= P.end || first + cnt <= P.begin) continue;
+                    // kept lanes park their id / embedding at their slot of the wave's LDS strip
+                    if (keep) {
+                        my_c[p] = c;
                         if (want_pde) {
-                            double *dst = P.out_pde + o * D;
-                            if ((E & 1) == 0) {
-                                double2 *d2 = reinterpret_cast<double2 *>(dst);
 #pragma unroll
-                                for (int k = 0; k < E / 2; k++) {
-                                    d2[k] = make_double2(vs[2 * k], vs[2 * k + 1]);
-                                    d2[E / 2 + k] = make_double2(vb[2 * k], vb[2 * k + 1]);
-                                    d2[E + k] = make_double2(vc[2 * k], vc[2 * k + 1]);
-                                }
+                            for (int k = 0; k < H; k++) my_vc[p * H + k] = vc[k];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // ids: 3*cnt dwords, lane g writes dword g of the run
+                    if (P.out_ids) {
+                        for (uint32_t g = lane; g < 3 * cnt; g += 64) {
+                            const uint32_t pp = g / 3, jx = g - 3 * pp;
+                            const uint64_t pos = first + pp;
+                            const uint32_t val = jx == 0 ? s : (jx == 1 ? b : my_c[pp]);
+                            if (pos >= P.begin && pos < P.end) P.out_ids[(pos - P.begin) * 3 + jx] = val;
+                        }
+                    }
+                    if (want_pde) {
+                        for (uint32_t g = lane; g < (uint32_t)PPP * cnt; g += 64) {
+                            const uint32_t pp = g / PPP, jx = g - PPP * pp;
+                            const uint64_t pos = first + pp;
+                            double2 val = make_double2(0.0, 0.0);
+                            if (jx >= 2u * H) {
+                                val = my_vc[pp * H + (jx - 2 * H)];
                             } else {
 #pragma unroll
+                                for (int k = 0; k < H; k++) {  // static register indices only
+                                    if (jx == (uint32_t)k) val = vs[k];
+                                    if (jx == (uint32_t)(H + k)) val = vb[k];
+                                }
+                            }
+                            if (pos >= P.begin && pos < P.end)
+                                reinterpret_cast<double2 *>(P.out_pde + (pos - P.begin) * D)[jx] = val;
+                        }
+                    }
+                    if (P.out_pdl) {
+                        if (keep) {
+                            const uint64_t pos = first + p;
+                            if (pos >= P.begin && pos < P.end) {
+                                const uint64_t o = pos - P.begin;
+#pragma unroll
                                 for (int k = 0; k < E; k++) {
-                                    dst[k] = vs[k];
-                                    dst[E + k] = vb[k];
-                                    dst[2 * E + k] = vc[k];
+                                    P.out_pdl[o * D + k] = P.x[(uint64_t)s * E + k];
+                                    P.out_pdl[o * D + E + k] = P.x[(uint64_t)b * E + k];
+                                    P.out_pdl[o * D + 2 * E + k] = P.x[(uint64_t)c * E + k];
                                 }
                             }
                         }
-                        if (P.out_pdl) {
-#pragma unroll
-                            for (int k = 0; k < E; k++) {
-                                P.out_pdl[o * D + k] = P.x[(uint64_t)s * E + k];
-                                P.out_pdl[o * D + E + k] = P.x[(uint64_t)b * E + k];
-                                P.out_pdl[o * D + 2 * E + k] = P.x[(uint64_t)c * E + k];
-                            }
-                        }
-                        if (P.out_part) P.out_part[o] = P.member[s];
                     }
+                    if (P.out_part) {
+                        const uint32_t part = P.member[s];
+                        for (uint32_t g = lane; g < cnt; g += 64) {
+                            const uint64_t pos = first + g;
+                            if (pos >= P.begin && pos < P.end) P.out_part[pos - P.begin] = part;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // strip is reused by the next run
                 }
             }
         }
