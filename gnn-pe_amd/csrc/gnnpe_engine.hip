@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->pair_off};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -512,13 +512,13 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     if (c->fill_variant == 2) {
         // middle-vertex-centric: each row is read once; counts land at the pair's emission index
-        if ((rc = c->pair_off.reserve((c->nbr_used + 1) * 8))) return rc;
+        if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
         if (c->n_held)
             hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
                                c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                                c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                               c->ecnt.as<uint32_t>());
+                               c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
     } else {
         hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
                            c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
@@ -527,15 +527,11 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     GNNPE_HIP_TRY(hipGetLastError());
     if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
-    if (c->fill_variant == 2 && c->nbr_used)
-        hipLaunchKernelGGL(k_pair_off, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb, se,
-                           c->revpos.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                           c->eoff.as<uint64_t>(), c->pair_off.as<uint64_t>());
     c->total_paths = w;
     c->l = l;
     c->counted = true;
     c->counted_variant = c->fill_variant;
-    const bool b_centric = c->fill_variant == 2 && c->have_table && (c->e == 2 || c->e == 4 || c->e == 8);
+    const bool b_centric = c->fill_variant == 2 && c->have_table && (c->e <= 4 || c->e == 8);
     if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
@@ -596,7 +592,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.member = c->member.as<uint32_t>();
     P.eoff = c->eoff.as<uint64_t>();
     const uint32_t e_eff = c->have_table ? c->e : 2;
-    const bool b_centric = c->fill_variant == 2 && (e_eff == 2 || e_eff == 4 || e_eff == 8);
+    const bool b_centric = c->fill_variant == 2 && (e_eff <= 4 || e_eff == 8);
     if (d_pde && !b_centric) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
@@ -626,7 +622,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         B.nbrs = P.nbrs;
         B.nbr_rank = P.nbr_rank;
         B.member = P.member;
-        B.pair_off = c->pair_off.as<uint64_t>();
+        B.rev = c->rev.as<uint32_t>();
+        B.eoff = c->eoff.as<uint64_t>();
         B.vde = P.vde;
         B.x = P.x;
         B.n_held = c->n_held;
@@ -639,7 +636,9 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         B.out_part = P.out_part;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
         switch (e_eff) {
+        case 1: hipLaunchKernelGGL((k_fill_b<1>), grid, block, 0, c->stream, B); break;
         case 2: hipLaunchKernelGGL((k_fill_b<2>), grid, block, 0, c->stream, B); break;
+        case 3: hipLaunchKernelGGL((k_fill_b<3>), grid, block, 0, c->stream, B); break;
         case 4: hipLaunchKernelGGL((k_fill_b<4>), grid, block, 0, c->stream, B); break;
         default: hipLaunchKernelGGL((k_fill_b<8>), grid, block, 0, c->stream, B); break;
         }

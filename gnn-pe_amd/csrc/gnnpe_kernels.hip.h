@@ -561,51 +561,90 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t revpos, uint32_t rank_u,
                                                                             : kNoEdge;
 }
 
-// cnt(s = u_i, b) = |{ j : rank[u_j] > rank[u_i] }| for every neighbour u_i of b that starts a path here.
+// ---- packed wave layout for a row of degree d <= 64 -----------------------------------------------
+// A wave holds PER = 64 / d complete copies of the row: lane L works on the ordered pair
+// (i = ib + L / d, j = L % d).  The j side (candidate c = u_j) never changes while the row is
+// processed, the i side (start s = u_i) advances by PER per iteration, so a row of degree 20 takes
+// 7 iterations with 60 of 64 lanes busy instead of 20 iterations with 20 lanes.
+struct RowLanes {
+    uint32_t j, iq, per;
+    bool lane_ok;  // lane belongs to a complete copy
+};
+__device__ __forceinline__ RowLanes row_lanes(uint32_t d, unsigned lane)
+{
+    RowLanes r;
+    r.per = 64u / d;
+    r.iq = lane / d;
+    r.j = lane - r.iq * d;
+    r.lane_ok = r.iq < r.per;
+    return r;
+}
+// kept-lane bits of this lane's copy, and the number of kept lanes before it inside the copy
+__device__ __forceinline__ uint64_t copy_bits(uint64_t mask, uint32_t iq, uint32_t d)
+{
+    const uint64_t seg = mask >> (iq * d);  // iq * d <= 63 whenever the lane is valid
+    return d >= 64 ? seg : (seg & ((1ull << d) - 1ull));
+}
+
+// cnt(s = u_i, b) = |{ j : rank[u_j] > rank[u_i] }| for every neighbour u_i of b that starts a path
+// here, stored at the pair's emission index; rev[q] keeps that index for the fill.
 __global__ __launch_bounds__(256) void k_count_b(uint32_t n_held, const uint32_t *__restrict__ held,
                                                  uint32_t slab_begin, uint32_t slab_end,
                                                  const uint32_t *__restrict__ adj_start,
                                                  const uint32_t *__restrict__ adj_deg,
                                                  const uint32_t *__restrict__ nbr_rank,
                                                  const uint32_t *__restrict__ revpos,
-                                                 const uint32_t *__restrict__ poffs, uint32_t *__restrict__ ecnt)
+                                                 const uint32_t *__restrict__ poffs, uint32_t *__restrict__ rev,
+                                                 uint32_t *__restrict__ ecnt)
 {
-    const unsigned lane = lane_id();
+    __shared__ uint32_t s_rank[4][64], s_rev[4][64];
+    const unsigned lane = lane_id(), wv = wave_id();
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (; w < n_held; w += nw) {
         const uint32_t b = held ? held[w] : (uint32_t)w;
         const uint32_t st = adj_start[b], d = adj_deg[b];
-        for (uint32_t i0 = 0; i0 < d; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            const uint32_t ri = i < d ? nbr_rank[st + i] : 0xFFFFFFFFu;
-            const uint32_t rv = i < d ? pair_index(revpos[st + i], ri, slab_begin, slab_end, poffs) : kNoEdge;
-            if (__ballot(rv != kNoEdge) == 0) continue;
-            uint32_t cnt = 0;
-            if (d <= 64) {
-                for (uint32_t j = 0; j < d; j++) cnt += rl32(ri, (int)j) > ri ? 1u : 0u;
-            } else {
-                for (uint32_t j = 0; j < d; j++) cnt += nbr_rank[st + j] > ri ? 1u : 0u;
+        if (d == 0) continue;
+        if (d <= 64) {
+            uint32_t rt = 0xFFFFFFFFu, rv = kNoEdge;
+            if (lane < d) {
+                rt = nbr_rank[st + lane];
+                rv = pair_index(revpos[st + lane], rt, slab_begin, slab_end, poffs);
+                rev[st + lane] = rv;
             }
-            if (rv != kNoEdge) ecnt[rv] = cnt;
+            if (__ballot(rv != kNoEdge) == 0) continue;
+            s_rank[wv][lane] = rt;
+            s_rev[wv][lane] = rv;
+            __builtin_amdgcn_wave_barrier();
+            const RowLanes R = row_lanes(d, lane);
+            const uint32_t rc = s_rank[wv][R.j];
+            for (uint32_t ib = 0; ib < d; ib += R.per) {
+                const uint32_t i = ib + R.iq;
+                const bool act = R.lane_ok && i < d;
+                const uint32_t rs = act ? s_rank[wv][i] : 0xFFFFFFFFu;
+                const uint32_t ri = act ? s_rev[wv][i] : kNoEdge;
+                const uint64_t mask = __ballot(act && ri != kNoEdge && rc > rs);
+                if (act && R.j == 0 && ri != kNoEdge) ecnt[ri] = (uint32_t)__popcll(copy_bits(mask, R.iq, d));
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (uint32_t i0 = 0; i0 < d; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const uint32_t ri = i < d ? nbr_rank[st + i] : 0xFFFFFFFFu;
+                const uint32_t rv = i < d ? pair_index(revpos[st + i], ri, slab_begin, slab_end, poffs) : kNoEdge;
+                if (i < d) rev[st + i] = rv;
+                if (__ballot(rv != kNoEdge) == 0) continue;
+                uint32_t cnt = 0;
+                for (uint32_t j = 0; j < d; j++) cnt += nbr_rank[st + j] > ri ? 1u : 0u;
+                if (rv != kNoEdge) ecnt[rv] = cnt;
+            }
         }
     }
 }
 
-// pair_off[q] = first output slot of the pair (s = u, b) of adjacency entry q, or kNoOff
-__global__ void k_pair_off(uint64_t cnt, uint32_t slab_begin, uint32_t slab_end, const uint32_t *__restrict__ revpos,
-                           const uint32_t *__restrict__ nbr_rank, const uint32_t *__restrict__ poffs,
-                           const uint64_t *__restrict__ eoff, uint64_t *__restrict__ pair_off)
-{
-    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < cnt; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = pair_index(revpos[q], nbr_rank[q], slab_begin, slab_end, poffs);
-        pair_off[q] = r == kNoEdge ? kNoOff : eoff[r];
-    }
-}
-
 struct FillBParams {
-    const uint32_t *held, *adj_start, *adj_deg, *nbrs, *nbr_rank, *member;
-    const uint64_t *pair_off;
+    const uint32_t *held, *adj_start, *adj_deg, *nbrs, *nbr_rank, *rev, *member;
+    const uint64_t *eoff;
     const double *vde, *x;
     uint32_t n_held, e;
     uint64_t begin, end;
@@ -614,148 +653,146 @@ struct FillBParams {
     uint32_t *out_part;
 };
 
-// One wave per middle vertex.  For each start s = u_i the kept neighbours are compacted (ballot +
-// popcount), their ids / embeddings pass through a per-wave LDS strip, and the run of cnt rows is
-// written with CONSECUTIVE lanes on CONSECUTIVE 16-byte (pde) / 4-byte (ids) pieces: one store
-// instruction covers up to 1 KiB of contiguous output however few neighbours were kept.
+struct __attribute__((packed, aligned(4))) Triple {
+    uint32_t s, b, c;
+};
+
+template <int E>
+__device__ __forceinline__ void emit_path(const FillBParams &P, uint64_t pos, uint32_t s, uint32_t b, uint32_t c,
+                                          const double *vs, const double *vb, const double *vc)
+{
+    constexpr int D = 3 * E;
+    const uint64_t o = pos - P.begin;
+    if (P.out_ids) {
+        Triple t = {s, b, c};
+        *reinterpret_cast<Triple *>(P.out_ids + o * 3) = t;
+    }
+    if (P.out_pde) {
+        double *dst = P.out_pde + o * D;
+        if ((E & 1) == 0) {
+            double2 *d2 = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+            for (int k = 0; k < E / 2; k++) {
+                d2[k] = make_double2(vs[2 * k], vs[2 * k + 1]);
+                d2[E / 2 + k] = make_double2(vb[2 * k], vb[2 * k + 1]);
+                d2[E + k] = make_double2(vc[2 * k], vc[2 * k + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                dst[k] = vs[k];
+                dst[E + k] = vb[k];
+                dst[2 * E + k] = vc[k];
+            }
+        }
+    }
+    if (P.out_pdl) {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            P.out_pdl[o * D + k] = P.x[(uint64_t)s * E + k];
+            P.out_pdl[o * D + E + k] = P.x[(uint64_t)b * E + k];
+            P.out_pdl[o * D + 2 * E + k] = P.x[(uint64_t)c * E + k];
+        }
+    }
+    if (P.out_part) P.out_part[o] = P.member[s];
+}
+
+// One wave per middle vertex b.  Rows of degree <= 64 use the packed layout above: the row's ids,
+// ranks, first-slot offsets and embeddings are fetched once (one lane per neighbour) into a
+// per-wave LDS strip; every iteration compares PER starts against all candidates, compacts the kept
+// ones per copy (ballot + popcount), and each kept lane stores its own 12-byte id triple and
+// 24e-byte embedding row -- consecutive kept lanes hit consecutive rows of the pair's output run.
 template <int E>
 __global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
 {
-    static_assert(E % 2 == 0, "contiguous-store path needs whole 16-byte pieces");
-    constexpr int D = 3 * E;
-    constexpr int H = E / 2;     // 16-byte pieces per vertex embedding
-    constexpr int PPP = 3 * H;   // 16-byte pieces per path row
-    __shared__ __attribute__((aligned(16))) double2 s_vc[4][64 * H];
-    __shared__ uint32_t s_c[4][64];
+    __shared__ uint32_t s_u[4][64], s_r[4][64];
+    __shared__ uint64_t s_off[4][64];
+    __shared__ __attribute__((aligned(16))) double s_v[4][64 * E];
 
     const unsigned lane = lane_id(), wv = wave_id();
     const uint64_t lt = (1ull << lane) - 1ull;
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const bool want_pde = P.out_pde != nullptr;
-    double2 *const my_vc = s_vc[wv];
-    uint32_t *const my_c = s_c[wv];
 
     for (; w < P.n_held; w += nw) {
         const uint32_t b = P.held ? P.held[w] : (uint32_t)w;
         const uint32_t st = P.adj_start[b], d = P.adj_deg[b];
         if (d < 2) continue;
-        double2 vb[H];
-        if (want_pde) {
+        double vb[E];
 #pragma unroll
-            for (int k = 0; k < H; k++) vb[k] = reinterpret_cast<const double2 *>(P.vde + (uint64_t)b * E)[k];
-        }
-        for (uint32_t i0 = 0; i0 < d; i0 += 64) {
-            // this lane's neighbour of the i-chunk: id, rank, pair offset, embedding
-            const uint32_t ii = i0 + lane;
-            const bool iv = ii < d;
-            const uint32_t ui = iv ? P.nbrs[st + ii] : 0u;
-            const uint32_t ri = iv ? P.nbr_rank[st + ii] : 0u;
-            const uint64_t oi = iv ? P.pair_off[st + ii] : kNoOff;
-            if (__ballot(oi != kNoOff && oi < P.end) == 0) continue;
-            double2 vi[H];
-            if (want_pde) {
-#pragma unroll
-                for (int k = 0; k < H; k++)
-                    vi[k] = iv ? reinterpret_cast<const double2 *>(P.vde + (uint64_t)ui * E)[k] : make_double2(0.0, 0.0);
+        for (int k = 0; k < E; k++) vb[k] = want_pde ? P.vde[(uint64_t)b * E + k] : 0.0;
+
+        if (d <= 64) {
+            // ---- one lane per neighbour: fetch, park in the wave's strip ----
+            uint32_t ut = 0, rt = 0;
+            uint64_t ot = kNoOff;
+            if (lane < d) {
+                ut = P.nbrs[st + lane];
+                rt = P.nbr_rank[st + lane];
+                const uint32_t rv = P.rev[st + lane];
+                if (rv != kNoEdge) ot = P.eoff[rv];
             }
-            const uint32_t ni = min(64u, d - i0);
-            for (uint32_t i = 0; i < ni; i++) {
-                const uint64_t off = rl64(oi, (int)i);
-                if (off == kNoOff || off >= P.end) continue;
-                const uint32_t s = rl32(ui, (int)i), rs = rl32(ri, (int)i);
-                double2 vs[H];
-                if (want_pde) {
+            if (__ballot(ot != kNoOff && ot < P.end) == 0) continue;
+            s_u[wv][lane] = ut;
+            s_r[wv][lane] = rt;
+            s_off[wv][lane] = ot;
+            if (want_pde && lane < d) {
 #pragma unroll
-                    for (int k = 0; k < H; k++) vs[k] = make_double2(rlf64(vi[k].x, (int)i), rlf64(vi[k].y, (int)i));
-                }
-                uint64_t run = off;
-                for (uint32_t j0 = 0; j0 < d; j0 += 64) {
-                    uint32_t c, rc;
-                    bool jv;
-                    double2 vc[H];
-                    if (j0 == i0) {  // the common case (deg <= 64): the candidates are already in registers
-                        c = ui;
-                        rc = ri;
-                        jv = iv;
+                for (int k = 0; k < E; k++) s_v[wv][lane * E + k] = P.vde[(uint64_t)ut * E + k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const RowLanes R = row_lanes(d, lane);
+            const uint32_t c = s_u[wv][R.j], rc = s_r[wv][R.j];
+            double vc[E];
 #pragma unroll
-                        for (int k = 0; k < H; k++) vc[k] = want_pde ? vi[k] : make_double2(0.0, 0.0);
-                    } else {
-                        const uint32_t jj = j0 + lane;
-                        jv = jj < d;
-                        c = jv ? P.nbrs[st + jj] : 0u;
-                        rc = jv ? P.nbr_rank[st + jj] : 0u;
+            for (int k = 0; k < E; k++) vc[k] = want_pde ? s_v[wv][R.j * E + k] : 0.0;
+            const uint64_t jbits = (1ull << R.j) - 1ull;
+            for (uint32_t ib = 0; ib < d; ib += R.per) {
+                const uint32_t i = ib + R.iq;
+                const bool act = R.lane_ok && i < d;
+                const uint64_t off = act ? s_off[wv][i] : kNoOff;
+                const uint32_t rs = act ? s_r[wv][i] : 0xFFFFFFFFu;
+                const bool keep = act && off != kNoOff && rc > rs;
+                const uint64_t mask = __ballot(keep);
+                if (mask == 0) continue;
+                if (keep) {
+                    const uint64_t pos = off + (uint64_t)__popcll(copy_bits(mask, R.iq, d) & jbits);
+                    if (pos >= P.begin && pos < P.end) {
+                        double vs[E];
 #pragma unroll
-                        for (int k = 0; k < H; k++)
-                            vc[k] = (want_pde && jv) ? reinterpret_cast<const double2 *>(P.vde + (uint64_t)c * E)[k]
-                                                     : make_double2(0.0, 0.0);
+                        for (int k = 0; k < E; k++) vs[k] = want_pde ? s_v[wv][i * E + k] : 0.0;
+                        emit_path<E>(P, pos, s_u[wv][i], b, c, vs, vb, vc);
                     }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the strip is reused by the wave's next row
+        } else {
+            // ---- long rows: one start per iteration, candidates in 64-lane chunks ----
+            for (uint32_t i = 0; i < d; i++) {
+                const uint32_t rv = P.rev[st + i];
+                if (rv == kNoEdge) continue;
+                uint64_t run = P.eoff[rv];
+                if (run >= P.end) continue;
+                const uint32_t s = P.nbrs[st + i], rs = P.nbr_rank[st + i];
+                double vs[E];
+#pragma unroll
+                for (int k = 0; k < E; k++) vs[k] = want_pde ? P.vde[(uint64_t)s * E + k] : 0.0;
+                for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+                    const uint32_t jj = j0 + lane;
+                    const bool jv = jj < d;
+                    const uint32_t c = jv ? P.nbrs[st + jj] : 0u;
+                    const uint32_t rc = jv ? P.nbr_rank[st + jj] : 0u;
                     const bool keep = jv && rc > rs;
                     const uint64_t mask = __ballot(keep);
-                    const uint32_t cnt = (uint32_t)__popcll(mask);
-                    if (cnt == 0) continue;
-                    const uint32_t p = (uint32_t)__popcll(mask & lt);  // this lane's slot inside the run
-                    const uint64_t first = run;                        // output slot of the run's first row
-                    run += cnt;
-                    if (first >= P.end || first + cnt <= P.begin) continue;
-                    // kept lanes park their id / embedding at their slot of the wave's LDS strip
-                    if (keep) {
-                        my_c[p] = c;
-                        if (want_pde) {
+                    const uint64_t pos = run + (uint64_t)__popcll(mask & lt);
+                    run += (uint64_t)__popcll(mask);
+                    if (keep && pos >= P.begin && pos < P.end) {
+                        double vc[E];
 #pragma unroll
-                            for (int k = 0; k < H; k++) my_vc[p * H + k] = vc[k];
-                        }
+                        for (int k = 0; k < E; k++) vc[k] = want_pde ? P.vde[(uint64_t)c * E + k] : 0.0;
+                        emit_path<E>(P, pos, s, b, c, vs, vb, vc);
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    // ids: 3*cnt dwords, lane g writes dword g of the run
-                    if (P.out_ids) {
-                        for (uint32_t g = lane; g < 3 * cnt; g += 64) {
-                            const uint32_t pp = g / 3, jx = g - 3 * pp;
-                            const uint64_t pos = first + pp;
-                            const uint32_t val = jx == 0 ? s : (jx == 1 ? b : my_c[pp]);
-                            if (pos >= P.begin && pos < P.end) P.out_ids[(pos - P.begin) * 3 + jx] = val;
-                        }
-                    }
-                    if (want_pde) {
-                        for (uint32_t g = lane; g < (uint32_t)PPP * cnt; g += 64) {
-                            const uint32_t pp = g / PPP, jx = g - PPP * pp;
-                            const uint64_t pos = first + pp;
-                            double2 val = make_double2(0.0, 0.0);
-                            if (jx >= 2u * H) {
-                                val = my_vc[pp * H + (jx - 2 * H)];
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < H; k++) {  // static register indices only
-                                    if (jx == (uint32_t)k) val = vs[k];
-                                    if (jx == (uint32_t)(H + k)) val = vb[k];
-                                }
-                            }
-                            if (pos >= P.begin && pos < P.end)
-                                reinterpret_cast<double2 *>(P.out_pde + (pos - P.begin) * D)[jx] = val;
-                        }
-                    }
-                    if (P.out_pdl) {
-                        if (keep) {
-                            const uint64_t pos = first + p;
-                            if (pos >= P.begin && pos < P.end) {
-                                const uint64_t o = pos - P.begin;
-#pragma unroll
-                                for (int k = 0; k < E; k++) {
-                                    P.out_pdl[o * D + k] = P.x[(uint64_t)s * E + k];
-                                    P.out_pdl[o * D + E + k] = P.x[(uint64_t)b * E + k];
-                                    P.out_pdl[o * D + 2 * E + k] = P.x[(uint64_t)c * E + k];
-                                }
-                            }
-                        }
-                    }
-                    if (P.out_part) {
-                        const uint32_t part = P.member[s];
-                        for (uint32_t g = lane; g < cnt; g += 64) {
-                            const uint64_t pos = first + g;
-                            if (pos >= P.begin && pos < P.end) P.out_part[pos - P.begin] = part;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();  // strip is reused by the next run
                 }
             }
         }
