@@ -510,7 +510,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
                            c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
     // 3. per-pair counts and their exclusive scan (global slot of every pair's first path)
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
-    if (c->fill_variant == 2) {
+    if (c->fill_variant >= 2) {
         // middle-vertex-centric: each row is read once; counts land at the pair's emission index
         if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
@@ -531,7 +531,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->l = l;
     c->counted = true;
     c->counted_variant = c->fill_variant;
-    const bool b_centric = c->fill_variant == 2 && c->have_table && (c->e <= 4 || c->e == 8);
+    const bool b_centric = c->fill_variant >= 2 && c->have_table && (c->e <= 4 || c->e == 8);
     if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
@@ -593,7 +593,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.eoff = c->eoff.as<uint64_t>();
     const uint32_t e_eff = c->have_table ? c->e : 2;
     const bool b_centric = c->fill_variant == 2 && (e_eff <= 4 || e_eff == 8);
-    if (d_pde && !b_centric) {
+    const bool s_wave = c->fill_variant == 3 && (e_eff <= 4 || e_eff == 8);
+    if (d_pde && !b_centric && !s_wave) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
     }
@@ -641,6 +642,21 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         case 3: hipLaunchKernelGGL((k_fill_b<3>), grid, block, 0, c->stream, B); break;
         case 4: hipLaunchKernelGGL((k_fill_b<4>), grid, block, 0, c->stream, B); break;
         default: hipLaunchKernelGGL((k_fill_b<8>), grid, block, 0, c->stream, B); break;
+        }
+        GNNPE_HIP_TRY(hipGetLastError());
+        return GNNPE_OK;
+    }
+    if (c->fill_variant == 3 && (e_eff <= 4 || e_eff == 8)) {
+        P.e = e_eff;
+        const uint32_t len = c->slab_end - c->slab_begin;
+        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        const uint32_t *poffs = c->poffs.as<uint32_t>();
+        switch (e_eff) {
+        case 1: hipLaunchKernelGGL((k_fill_s<1, 4>), grid, block, 0, c->stream, P, poffs, len); break;
+        case 2: hipLaunchKernelGGL((k_fill_s<2, 4>), grid, block, 0, c->stream, P, poffs, len); break;
+        case 3: hipLaunchKernelGGL((k_fill_s<3, 4>), grid, block, 0, c->stream, P, poffs, len); break;
+        case 4: hipLaunchKernelGGL((k_fill_s<4, 2>), grid, block, 0, c->stream, P, poffs, len); break;
+        default: hipLaunchKernelGGL((k_fill_s<8, 2>), grid, block, 0, c->stream, P, poffs, len); break;
         }
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
@@ -709,7 +725,7 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= 0 && variant <= 2, GNNPE_ERR_ARG, "fill variant must be 0, 1 or 2");
+    GNNPE_REQUIRE(c && variant >= 0 && variant <= 3, GNNPE_ERR_ARG, "fill variant must be 0..3");
     if (variant != c->fill_variant) {
         c->counted = false;
         c->tile_T = 0;

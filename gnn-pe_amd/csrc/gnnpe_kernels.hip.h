@@ -657,8 +657,8 @@ struct __attribute__((packed, aligned(4))) Triple {
     uint32_t s, b, c;
 };
 
-template <int E>
-__device__ __forceinline__ void emit_path(const FillBParams &P, uint64_t pos, uint32_t s, uint32_t b, uint32_t c,
+template <int E, class PT>
+__device__ __forceinline__ void emit_path(const PT &P, uint64_t pos, uint32_t s, uint32_t b, uint32_t c,
                                           const double *vs, const double *vb, const double *vc)
 {
     constexpr int D = 3 * E;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
                         double vs[E];
 #pragma unroll
                         for (int k = 0; k < E; k++) vs[k] = want_pde ? s_v[wv][i * E + k] : 0.0;
-                        emit_path<E>(P, pos, s_u[wv][i], b, c, vs, vb, vc);
+                        emit_path<E, FillBParams>(P, pos, s_u[wv][i], b, c, vs, vb, vc);
                     }
                 }
             }
@@ -791,10 +791,122 @@ __global__ __launch_bounds__(256) void k_fill_b(FillBParams P)
                         double vc[E];
 #pragma unroll
                         for (int k = 0; k < E; k++) vc[k] = want_pde ? P.vde[(uint64_t)c * E + k] : 0.0;
-                        emit_path<E>(P, pos, s, b, c, vs, vb, vc);
+                        emit_path<E, FillBParams>(P, pos, s, b, c, vs, vb, vc);
                     }
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2 + R5 fill, variant 3: START-VERTEX-CENTRIC, one wave per start vertex s.
+//
+// All paths of s occupy ONE contiguous run of the output (count(s) rows starting at the scanned
+// offset of its first pair), so a wave that emits them in order writes its region front to back:
+// sequential in memory (DRAM-page and TLB friendly), every byte written once.  The candidates of s
+// (the neighbour lists of its neighbours b_k) are flattened over the 64 lanes; a batch of R rounds
+// first issues every id / rank load, then compacts (ballot + popcount against rank[s]), gathers the
+// kept endpoints' embeddings from the n x e table (cache resident) and stores the rows.  No block
+// barrier, no dependent load inside a batch beyond the endpoint gather.
+// ------------------------------------------------------------------------------------------------
+template <int E, int R>
+__global__ __launch_bounds__(256) void k_fill_s(FillParams P, const uint32_t *__restrict__ poffs, uint32_t slab_len)
+{
+    __shared__ uint32_t s_cs[4][65], s_st[4][64], s_b[4][64];
+    __shared__ __attribute__((aligned(16))) double s_vb[4][64 * E];
+    const unsigned lane = lane_id(), wv = wave_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const bool want_pde = P.out_pde != nullptr;
+
+    for (; w < slab_len; w += nw) {
+        const uint32_t e0 = poffs[w], ds = poffs[w + 1] - e0;
+        if (ds == 0) continue;
+        uint64_t run = P.eoff[e0];
+        const uint64_t run_end = P.eoff[e0 + ds];
+        if (run_end == run || run >= P.end || run_end <= P.begin) continue;
+        const uint32_t thr = P.slab_begin + (uint32_t)w;
+        const uint32_t s = P.sorted[thr];
+        double vs[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) vs[k] = want_pde ? P.vde[(uint64_t)s * E + k] : 0.0;
+
+        for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
+            // ---- up to 64 middle vertices: where their neighbour lists start, how long they are ----
+            const uint32_t k = k0 + lane;
+            uint32_t b = 0, st = 0, dg = 0;
+            if (k < ds) {
+                b = P.pnbr[e0 + k];
+                st = P.adj_start[b];
+                dg = P.adj_deg[b];
+            }
+            uint32_t incl = dg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if (lane >= (unsigned)off) incl += t;
+            }
+            const uint32_t C = rl32(incl, 63);
+            s_cs[wv][lane] = incl - dg;
+            s_st[wv][lane] = st;
+            s_b[wv][lane] = b;
+            if (lane == 0) s_cs[wv][64] = C;
+            if (want_pde && k < ds) {
+#pragma unroll
+                for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = P.vde[(uint64_t)b * E + kk];
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            for (uint32_t q0 = 0; q0 < C; q0 += 64 * R) {
+                uint32_t cc[R], rc[R], kk[R];
+                // ---- phase A: every id / rank load of the batch ----
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t q = q0 + r * 64 + lane;
+                    cc[r] = 0;
+                    rc[r] = 0;
+                    kk[r] = 0;
+                    if (q < C) {
+                        uint32_t a = 0, bnd = 64;  // largest a with cs[a] <= q
+#pragma unroll
+                        for (int it = 0; it < 6; it++) {
+                            const uint32_t mid = (a + bnd) >> 1;
+                            if (s_cs[wv][mid] <= q) a = mid; else bnd = mid;
+                        }
+                        const uint32_t idx = s_st[wv][a] + (q - s_cs[wv][a]);
+                        kk[r] = a;
+                        cc[r] = P.nbrs[idx];
+                        rc[r] = P.nbr_rank[idx];
+                    }
+                }
+                // ---- phase B: compact, gather the endpoint embedding, store ----
+                uint64_t pos[R];
+                bool kp[R];
+                double vc[R][E];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t q = q0 + r * 64 + lane;
+                    const bool keep = q < C && rc[r] > thr;
+                    const uint64_t mask = __ballot(keep);
+                    pos[r] = run + (uint64_t)__popcll(mask & lt);
+                    run += (uint64_t)__popcll(mask);
+                    kp[r] = keep && pos[r] >= P.begin && pos[r] < P.end;
+#pragma unroll
+                    for (int k2 = 0; k2 < E; k2++) vc[r][k2] = (want_pde && kp[r]) ? P.vde[(uint64_t)cc[r] * E + k2] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (kp[r]) {
+                        double vb[E];
+#pragma unroll
+                        for (int k2 = 0; k2 < E; k2++) vb[k2] = want_pde ? s_vb[wv][kk[r] * E + k2] : 0.0;
+                        emit_path<E, FillParams>(P, pos[r], s, s_b[wv][kk[r]], cc[r], vs, vb, vc[r]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // strip reused by the next chunk / start vertex
         }
     }
 }

@@ -24,7 +24,7 @@ def binding():
     return b
 
 
-VARIANTS = [0, 1, 2]  # output-tiled, pair-per-wave, middle-vertex-centric: identical outputs required
+VARIANTS = [0, 1, 2, 3]  # output-tiled, pair-per-wave, middle-vertex-centric: identical outputs required
 
 
 def _engine(binding, g, sn, mem, p, e, variant=None):
@@ -77,7 +77,7 @@ def test_test_graph_paths_and_embeddings(binding, oracle, test_graph):
     eng.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_subranges_and_variants(binding, oracle, test_graph, variant):
     eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, 2)
     eng.vde(want=False)
