@@ -531,7 +531,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->l = l;
     c->counted = true;
     c->counted_variant = c->fill_variant;
-    const bool b_centric = c->fill_variant >= 2 && c->have_table && (c->e <= 4 || c->e == 8);
+    const bool b_centric = c->fill_variant >= 2 && c->fill_variant != 5 && c->have_table && (c->e <= 4 || c->e == 8);
     if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
@@ -593,7 +593,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.eoff = c->eoff.as<uint64_t>();
     const uint32_t e_eff = c->have_table ? c->e : 2;
     const bool b_centric = c->fill_variant == 2 && (e_eff <= 4 || e_eff == 8);
-    const bool s_wave = c->fill_variant == 3 && (e_eff <= 4 || e_eff == 8);
+    const bool s_wave = (c->fill_variant == 3 || c->fill_variant == 4) && (e_eff <= 4 || e_eff == 8);
     if (d_pde && !b_centric && !s_wave) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
@@ -661,6 +661,28 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
+    if (c->fill_variant >= 4 && (e_eff <= 4 || e_eff == 8)) {
+        P.e = e_eff;
+        const bool nv = c->fill_variant == 5;
+        const uint32_t len = c->slab_end - c->slab_begin;
+        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        const uint32_t *poffs = c->poffs.as<uint32_t>();
+#define GNNPE_FS(EE, RR)                                                                                          \
+    do {                                                                                                          \
+        if (nv) hipLaunchKernelGGL((k_fill_s_staged<EE, RR, true>), grid, block, 0, c->stream, P, poffs, len);    \
+        else hipLaunchKernelGGL((k_fill_s_staged<EE, RR, false>), grid, block, 0, c->stream, P, poffs, len);      \
+    } while (0)
+        switch (e_eff) {
+        case 1: GNNPE_FS(1, 4); break;
+        case 2: GNNPE_FS(2, 4); break;
+        case 3: GNNPE_FS(3, 4); break;
+        case 4: GNNPE_FS(4, 2); break;
+        default: GNNPE_FS(8, 2); break;
+        }
+#undef GNNPE_FS
+        GNNPE_HIP_TRY(hipGetLastError());
+        return GNNPE_OK;
+    }
     const uint32_t T = (c->fill_variant == 0) ? tile_size_for(P.e, pdl) : 0;
     if (T) {
         int rc = ensure_tiles(c, T);
@@ -725,7 +747,7 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= 0 && variant <= 3, GNNPE_ERR_ARG, "fill variant must be 0..3");
+    GNNPE_REQUIRE(c && variant >= 0 && variant <= 5, GNNPE_ERR_ARG, "fill variant must be 0..5");
     if (variant != c->fill_variant) {
         c->counted = false;
         c->tile_T = 0;
