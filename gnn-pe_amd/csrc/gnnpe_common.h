@@ -86,7 +86,7 @@ struct gnnpe_ctx {
     bool rows_identity = true;  // rows == 0..n-1 (full CSR) vs. an owned-row list
     uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
-    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev;
+    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec;
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
 
     // ---- order (R1) ----

@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -527,11 +527,23 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     GNNPE_HIP_TRY(hipGetLastError());
     if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
+    if (c->fill_variant >= 6 && len) {
+        if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec))) || (rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))))
+            return rc;
+        hipLaunchKernelGGL(k_pair_recs, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
+                           c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                           c->poffs.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->prec.as<PairRec>());
+        hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
+                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                           c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
     c->total_paths = w;
     c->l = l;
     c->counted = true;
     c->counted_variant = c->fill_variant;
-    const bool b_centric = c->fill_variant >= 2 && c->fill_variant != 5 && c->have_table && (c->e <= 4 || c->e == 8);
+    const bool b_centric = c->fill_variant >= 2 && c->fill_variant != 5 && c->fill_variant != 7 && c->fill_variant != 9 &&
+                           c->have_table && (c->e <= 4 || c->e == 8);
     if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
@@ -593,7 +605,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.eoff = c->eoff.as<uint64_t>();
     const uint32_t e_eff = c->have_table ? c->e : 2;
     const bool b_centric = c->fill_variant == 2 && (e_eff <= 4 || e_eff == 8);
-    const bool s_wave = (c->fill_variant == 3 || c->fill_variant == 4) && (e_eff <= 4 || e_eff == 8);
+    const bool s_wave = (c->fill_variant == 3 || c->fill_variant == 4 || c->fill_variant == 6 || c->fill_variant == 8) &&
+                        (e_eff <= 4 || e_eff == 8);
     if (d_pde && !b_centric && !s_wave) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
@@ -658,6 +671,31 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         case 4: hipLaunchKernelGGL((k_fill_s<4, 2>), grid, block, 0, c->stream, P, poffs, len); break;
         default: hipLaunchKernelGGL((k_fill_s<8, 2>), grid, block, 0, c->stream, P, poffs, len); break;
         }
+        GNNPE_HIP_TRY(hipGetLastError());
+        return GNNPE_OK;
+    }
+    if (c->fill_variant >= 6 && (e_eff <= 4 || e_eff == 8)) {
+        P.e = e_eff;
+        const int fv = c->fill_variant;
+        const bool nv = (fv == 7 || fv == 9);
+        const bool r2 = (fv >= 8);
+        const uint32_t len = c->slab_end - c->slab_begin;
+        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        const StartRec *sr = c->srec.as<StartRec>();
+        const PairRec *pr = c->prec.as<PairRec>();
+#define GNNPE_FR(EE, RR)                                                                                       \
+    do {                                                                                                       \
+        if (nv) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
+        else hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false>), grid, block, 0, c->stream, P, sr, pr, len);     \
+    } while (0)
+        switch (e_eff) {
+        case 1: GNNPE_FR(1, 4); break;
+        case 2: if (r2) GNNPE_FR(2, 2); else GNNPE_FR(2, 4); break;
+        case 3: GNNPE_FR(3, 2); break;
+        case 4: GNNPE_FR(4, 2); break;
+        default: GNNPE_FR(8, 1); break;
+        }
+#undef GNNPE_FR
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
@@ -747,7 +785,7 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= 0 && variant <= 5, GNNPE_ERR_ARG, "fill variant must be 0..5");
+    GNNPE_REQUIRE(c && variant >= 0 && variant <= 9, GNNPE_ERR_ARG, "fill variant must be 0..9");
     if (variant != c->fill_variant) {
         c->counted = false;
         c->tile_T = 0;
