@@ -678,19 +678,21 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         P.e = e_eff;
         const int fv = c->fill_variant;
         const bool nv = (fv == 7 || fv == 9);
-        const bool r2 = (fv >= 8);
+        const bool r2 = (fv >= 8);  // variants 8/9: non-temporal output stores
         const uint32_t len = c->slab_end - c->slab_begin;
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const StartRec *sr = c->srec.as<StartRec>();
         const PairRec *pr = c->prec.as<PairRec>();
-#define GNNPE_FR(EE, RR)                                                                                       \
-    do {                                                                                                       \
-        if (nv) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
-        else hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false>), grid, block, 0, c->stream, P, sr, pr, len);     \
+#define GNNPE_FR(EE, RR)                                                                                              \
+    do {                                                                                                              \
+        if (nv && r2) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
+        else if (nv) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true, false>), grid, block, 0, c->stream, P, sr, pr, len);   \
+        else if (r2) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
+        else hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false, false>), grid, block, 0, c->stream, P, sr, pr, len);          \
     } while (0)
         switch (e_eff) {
         case 1: GNNPE_FR(1, 4); break;
-        case 2: if (r2) GNNPE_FR(2, 2); else GNNPE_FR(2, 4); break;
+        case 2: GNNPE_FR(2, 4); break;
         case 3: GNNPE_FR(3, 2); break;
         case 4: GNNPE_FR(4, 2); break;
         default: GNNPE_FR(8, 1); break;

@@ -1132,7 +1132,7 @@ __global__ void k_start_recs(uint32_t len, uint32_t slab_begin, const uint32_t *
     }
 }
 
-template <int E, int R, bool NV>
+template <int E, int R, bool NV, bool NT>
 __global__ __launch_bounds__(256) void k_fill_s_rec(FillParams P, const StartRec *__restrict__ srec,
                                                     const PairRec *__restrict__ prec, uint32_t slab_len)
 {
@@ -1166,13 +1166,21 @@ __global__ __launch_bounds__(256) void k_fill_s_rec(FillParams P, const StartRec
             if (hi > lo) {
                 const uint32_t r0 = (uint32_t)(lo - fbase), nr = (uint32_t)(hi - lo);
                 const uint64_t o = lo - P.begin;
-                if (P.out_ids)
-                    for (uint32_t g = lane; g < nr * 3; g += 64) P.out_ids[o * 3 + g] = my_ids[r0 * 3 + g];
+                if (P.out_ids) {
+                    for (uint32_t g = lane; g < nr * 3; g += 64) {
+                        if (NT) __builtin_nontemporal_store(my_ids[r0 * 3 + g], &P.out_ids[o * 3 + g]);
+                        else P.out_ids[o * 3 + g] = my_ids[r0 * 3 + g];
+                    }
+                }
                 if (want_pde) {
                     if ((D & 1) == 0) {
-                        const double2 *src = reinterpret_cast<const double2 *>(my_pde + (size_t)r0 * D);
-                        double2 *dst = reinterpret_cast<double2 *>(P.out_pde + o * D);
-                        for (uint32_t g = lane; g < nr * (D / 2); g += 64) dst[g] = src[g];
+                        typedef double dbl2 __attribute__((ext_vector_type(2)));
+                        const dbl2 *src = reinterpret_cast<const dbl2 *>(my_pde + (size_t)r0 * D);
+                        dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o * D);
+                        for (uint32_t g = lane; g < nr * (D / 2); g += 64) {
+                            if (NT) __builtin_nontemporal_store(src[g], &dst[g]);
+                            else dst[g] = src[g];
+                        }
                     } else {
                         for (uint32_t g = lane; g < nr * D; g += 64) P.out_pde[o * D + g] = my_pde[(size_t)r0 * D + g];
                     }
