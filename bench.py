@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--labels", type=int, default=64)
     ap.add_argument("--seed", type=int, default=synth.SEED)
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
-    ap.add_argument("--fill-variant", type=int, default=0)
+    ap.add_argument("--fill-variant", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="15000,150000")
     args = ap.parse_args()
@@ -183,8 +183,9 @@ def main():
     fill_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ms])) if fill_ms else float("nan")
     bpp = (4 * L + 16) if args.ids_only else bytes_per_path(L, e)
     achieved = total * bpp / (fill_avg_ms / 1e3) / 1e9
-    roofline = dict(bound="hbm", kernel=binding.load().gnnpe_fill_kernel_name().decode() if args.fill_variant == 0
-                    else "k_fill_edge_wave", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+    kname = {0: "k_fill_tiled", 1: "k_fill_edge_wave", 2: "k_fill_b", 3: "k_fill_s", 4: "k_fill_s_staged",
+             5: "k_fill_s_staged"}.get(args.fill_variant, binding.load().gnnpe_fill_kernel_name().decode())
+    roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_path=bpp, paths_per_launch=total,
                     launch_ms=fill_avg_ms)
 

@@ -86,7 +86,7 @@ struct gnnpe_ctx {
     bool rows_identity = true;  // rows == 0..n-1 (full CSR) vs. an owned-row list
     uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
-    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec;
+    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec, nbr_row;
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
 
     // ---- order (R1) ----
@@ -109,7 +109,7 @@ struct gnnpe_ctx {
     uint64_t total_paths = 0;
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, tile_edge, cub_tmp, scratch, mark, small;
     uint32_t tile_T = 0;  // tile size tile_edge was built for (0 = stale)
-    int fill_variant = 0, counted_variant = 0;
+    int fill_variant = 9, counted_variant = 9;  // 9 = record-driven wave-per-start fill (default)
 
     // pinned host words for small read-backs
     uint64_t *h_pinned = nullptr;

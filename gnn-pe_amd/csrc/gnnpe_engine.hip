@@ -109,7 +109,7 @@ extern "C" {
 
 int gnnpe_abi_version(void) { return GNNPE_ABI_VERSION; }
 const char *gnnpe_last_error(void) { return g_err; }
-const char *gnnpe_fill_kernel_name(void) { return "k_fill_tiled"; }
+const char *gnnpe_fill_kernel_name(void) { return "k_fill_s_rec"; }
 
 gnnpe_ctx *gnnpe_create(int device_id)
 {
@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -209,13 +209,13 @@ int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_
                            c->scratch.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                            c->present.as<uint8_t>());
     GNNPE_HIP_TRY(hipGetLastError());
-    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve((m2 + 1) * 4))) return rc;
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve((m2 + 1) * 4)) || (rc = c->nbr_row.reserve((m2 + 1) * 4))) return rc;
     if (n) {
         GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
         // reverse positions: part of building the graph structure (depends on the graph only)
         hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n * 16)), dim3(kBlock), 0, c->stream, n,
                            (const uint32_t *)nullptr, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
         GNNPE_HIP_TRY(hipGetLastError());
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -266,12 +266,12 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
         GNNPE_HIP_TRY(hipGetLastError());
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes))) return rc;
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes)) || (rc = c->nbr_row.reserve(c->nbrs.bytes))) return rc;
     if (n) GNNPE_HIP_TRY(hipMemcpy(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice));
     if (n_rows) {
         hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows,
                            c->rows.as<uint32_t>(), c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
         GNNPE_HIP_TRY(hipGetLastError());
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -500,7 +500,8 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         (rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->eoff.reserve((ne + 2) * 8)) ||
         (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4)))
         return rc;
-    if (len)
+    const bool need_perm = c->fill_variant < 6;  // erow / pnbr feed the pair-indexed kernels only
+    if (len && need_perm)
         hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
                            c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
                            c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
@@ -514,7 +515,13 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         // middle-vertex-centric: each row is read once; counts land at the pair's emission index
         if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (c->n_held)
+        if (c->fill_variant >= 6) {
+            if (c->nbr_used)
+                hipLaunchKernelGGL(k_count_flat, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb,
+                                   se, c->nbr_row.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                                   c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(),
+                                   c->poffs.as<uint32_t>(), (uint32_t *)nullptr, c->ecnt.as<uint32_t>());
+        } else if (c->n_held)
             hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
                                c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                                c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
@@ -927,7 +934,7 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
                        c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
     hipLaunchKernelGGL(k_revpos, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, c->stream, (uint32_t)n_rows,
                        (const uint32_t *)dev_ids, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->nbr_used += n_nbrs;

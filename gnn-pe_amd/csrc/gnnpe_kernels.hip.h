@@ -528,7 +528,8 @@ __device__ __forceinline__ double rlf64(double v, int l)
 // the adjacency lists (graph.cpp:231-233).  16 lanes per row, one binary search per entry.
 __global__ void k_revpos(uint32_t n_rows, const uint32_t *__restrict__ rows, const uint8_t *__restrict__ owned,
                          const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
-                         const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ revpos)
+                         const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ revpos,
+                         uint32_t *__restrict__ nbr_row)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
@@ -549,6 +550,7 @@ __global__ void k_revpos(uint32_t n_rows, const uint32_t *__restrict__ rows, con
                 if (lo < du && nbrs[lo0 + lo] == b) r = lo;
             }
             revpos[st + i] = r;
+            nbr_row[st + i] = b;  // row of every adjacency entry (lets kernels run one thread per entry)
         }
     }
 }
@@ -559,6 +561,31 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t revpos, uint32_t rank_u,
 {
     return (revpos != kNoEdge && rank_u >= slab_begin && rank_u < slab_end) ? poffs[rank_u - slab_begin] + revpos
                                                                             : kNoEdge;
+}
+
+// cnt(s = u, b) for the adjacency entry q = (b -> u): one THREAD per entry, looping over the row's
+// rank stream (lanes of the same row read the same addresses, so the loads are broadcasts).  Work per
+// row is deg^2 / 64 wave-iterations whatever the degree, so hubs spread over many waves.
+__global__ __launch_bounds__(256) void k_count_flat(uint64_t n_entries, uint32_t slab_begin, uint32_t slab_end,
+                                                    const uint32_t *__restrict__ nbr_row,
+                                                    const uint32_t *__restrict__ adj_start,
+                                                    const uint32_t *__restrict__ adj_deg,
+                                                    const uint32_t *__restrict__ nbr_rank,
+                                                    const uint32_t *__restrict__ revpos,
+                                                    const uint32_t *__restrict__ poffs, uint32_t *__restrict__ rev,
+                                                    uint32_t *__restrict__ ecnt)
+{
+    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n_entries; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ri = nbr_rank[q];
+        const uint32_t rv = pair_index(revpos[q], ri, slab_begin, slab_end, poffs);
+        if (rev) rev[q] = rv;
+        if (rv == kNoEdge) continue;
+        const uint32_t b = nbr_row[q];
+        const uint32_t st = adj_start[b], d = adj_deg[b];
+        uint32_t cnt = 0;
+        for (uint32_t j = 0; j < d; j++) cnt += nbr_rank[st + j] > ri ? 1u : 0u;
+        ecnt[rv] = cnt;
+    }
 }
 
 // ---- packed wave layout for a row of degree d <= 64 -----------------------------------------------

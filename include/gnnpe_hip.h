@@ -141,9 +141,13 @@ int gnnpe_path_partitions_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, v
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);
-/* Selects the enumeration implementation (call before gnnpe_count_paths): 0 = output-tiled LDS-staged
- * fill, 1 = pair-per-wave direct-store fill (first correct version), 2 = middle-vertex-centric count +
- * fill (each adjacency row read once).  All produce identical outputs; kept selectable for A/B. */
+/* Selects the enumeration implementation (call before gnnpe_count_paths).  All variants produce
+ * identical outputs and stay selectable for A/B measurements (DESIGN.md "fill kernel history"):
+ *   0 output-tiled block kernel (LDS-staged tile)      1 pair-per-wave direct stores (first version)
+ *   2 middle-vertex-centric count + fill               3 wave per start vertex, direct stores
+ *   4/5 wave per start vertex + LDS strip (5: embeddings streamed from the per-adjacency array)
+ *   6/7 as 4/5 driven by per-start / per-pair records  8/9 as 6/7 with non-temporal output stores
+ * Default: 9. */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
 
 #ifdef __cplusplus

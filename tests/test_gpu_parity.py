@@ -39,7 +39,7 @@ def _engine(binding, g, sn, mem, p, e, variant=None):
 
 
 def test_library_reports_its_kernel(binding):
-    assert binding.load().gnnpe_fill_kernel_name().decode() == "k_fill_tiled"
+    assert binding.load().gnnpe_fill_kernel_name().decode() == "k_fill_s_rec"
 
 
 @pytest.mark.parametrize("e", [2, 8])
