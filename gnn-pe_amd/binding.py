@@ -28,6 +28,10 @@ SIGNATURES = {
     "gnnpe_destroy": (None, [_vp]),
     "gnnpe_set_stream": (C.c_int, [_vp, _vp]),
     "gnnpe_sync": (C.c_int, [_vp]),
+    "gnnpe_dev_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "gnnpe_dev_free": (C.c_int, [_vp, _vp]),
+    "gnnpe_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "gnnpe_device_count": (C.c_int, []),
     "gnnpe_load_csr": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p]),
     "gnnpe_load_rows": (C.c_int, [_vp, C.c_uint32, _u32p, C.c_uint32, _u32p, _u64p, _u32p, C.c_uint64]),
     "gnnpe_set_order": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32]),
@@ -47,6 +51,9 @@ SIGNATURES = {
     "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
     "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
     "gnnpe_path_partitions_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "gnnpe_text_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_uint64, _u64p]),
+    "gnnpe_text_ids": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p]),
+    "gnnpe_select_partition": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, C.c_uint64, _vp, _u64p]),
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -260,3 +267,21 @@ class Engine:
 
     def rows_drop_halo(self):
         self._ck(self.lib.gnnpe_rows_drop_halo(self.ctx))
+
+    # R7: text rendering (main.cpp:98-119)
+    def text_paths(self, n_rows, L, dev_vids, dev_text=None, cap=0):
+        nb = C.c_uint64()
+        self._ck(self.lib.gnnpe_text_paths(self.ctx, int(n_rows), int(L), _dev(dev_vids), _dev(dev_text), int(cap),
+                                           C.byref(nb)))
+        return nb.value
+
+    def text_ids(self, n, dev_ids, dev_text=None, cap=0):
+        nb = C.c_uint64()
+        self._ck(self.lib.gnnpe_text_ids(self.ctx, int(n), _dev(dev_ids), _dev(dev_text), int(cap), C.byref(nb)))
+        return nb.value
+
+    def select_partition(self, n, dev_part, pid, id_base, dev_ids):
+        cnt = C.c_uint64()
+        self._ck(self.lib.gnnpe_select_partition(self.ctx, int(n), _dev(dev_part), int(pid), int(id_base),
+                                                 _dev(dev_ids), C.byref(cnt)))
+        return cnt.value

@@ -87,6 +87,7 @@ struct gnnpe_ctx {
     uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
     gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec, nbr_row;
+    gnnpe::DevBuf text_len, text_off;  // R7 scratch
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
 
     // ---- order (R1) ----

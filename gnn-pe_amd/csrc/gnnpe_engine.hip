@@ -147,7 +147,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -165,6 +165,37 @@ int gnnpe_set_stream(gnnpe_ctx *c, void *hip_stream)
 int gnnpe_sync(gnnpe_ctx *c)
 {
     GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+int gnnpe_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int gnnpe_dev_alloc(gnnpe_ctx *c, uint64_t bytes, void **dev_ptr)
+{
+    GNNPE_REQUIRE(c && dev_ptr, GNNPE_ERR_ARG, "null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    GNNPE_HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return GNNPE_OK;
+}
+
+int gnnpe_dev_free(gnnpe_ctx *c, void *dev_ptr)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (dev_ptr) GNNPE_HIP_TRY(hipFree(dev_ptr));
+    return GNNPE_OK;
+}
+
+int gnnpe_copy_to_host(gnnpe_ctx *c, void *host_dst, const void *dev_src, uint64_t bytes)
+{
+    GNNPE_REQUIRE(c && (bytes == 0 || (host_dst && dev_src)), GNNPE_ERR_ARG, "null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (bytes) GNNPE_HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     return GNNPE_OK;
 }

@@ -583,7 +583,13 @@ __global__ __launch_bounds__(256) void k_count_flat(uint64_t n_entries, uint32_t
         const uint32_t b = nbr_row[q];
         const uint32_t st = adj_start[b], d = adj_deg[b];
         uint32_t cnt = 0;
-        for (uint32_t j = 0; j < d; j++) cnt += nbr_rank[st + j] > ri ? 1u : 0u;
+        for (uint32_t j0 = 0; j0 < d; j0 += 8) {  // 8 independent loads in flight per lane
+            uint32_t r[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) r[t] = (j0 + t < d) ? nbr_rank[st + j0 + t] : 0u;
+#pragma unroll
+            for (int t = 0; t < 8; t++) cnt += r[t] > ri ? 1u : 0u;
+        }
         ecnt[rv] = cnt;
     }
 }

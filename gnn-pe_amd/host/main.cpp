@@ -1,0 +1,394 @@
+// main.cpp -- `gnnpe_main`: drop-in for the reference's `main -m offline` (GNN-PE/src/main.cpp:38-120).
+//
+// Same flags, same defaults, same input files and the same output files:
+//   <f>gnn-pe/membership.txt                       (read;  main.cpp:77-85)
+//   <f>gnn-pe/partitions/partition-i/partition_paths.txt   (written; main.cpp:98-108)
+//   <f>/gnn-pe/all_paths.txt                       (written; main.cpp:110-119)
+// The enumeration, embeddings and text rendering run on MI355X GPUs through the C-ABI in
+// include/gnnpe_hip.h; this file is host orchestration and file I/O only.  `-m online` stays the
+// reference's own binary: it consumes the files written here unchanged.
+//
+// Deliberate differences from the reference (all fail-loud instead of silent):
+//   - missing membership.txt / partition directories are errors (the reference reads zeros /
+//     writes nothing: main.cpp:80,101,110 never check their streams);
+//   - `-l` other than 2 is refused: the reference enumerates 3-vertex paths whatever -l says and
+//     then prints garbage or truncated rows;
+//   - path counts beyond 2^32-1 are refused unless --allow-large (the reference's `ui` overflows).
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gnnpe_hip.h"
+#include "graph_loader.h"
+
+using gnnpe_host::StaticGraph;
+using Clock = std::chrono::steady_clock;
+
+namespace {
+
+struct Options {
+    // the reference's flags and defaults (main.cpp:40-56, custom.h:45-50)
+    std::string dataset_path = "../Test/";
+    std::string data_graph = "../Test/data_graph.graph";
+    std::string query_graph = "../Test/query_graph.graph";
+    std::string mode = "offline";
+    std::string answers = "MAX";
+    uint32_t partition_num = 5, path_length = 2, vde_dim = 2;
+    // extensions
+    int gpus = 1;
+    uint64_t chunk_paths = 32ull << 20;
+    bool allow_large = false, timing = false, sidecars = false, write_index = false;
+};
+
+double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+[[noreturn]] void die(const std::string &msg, int code = 1)
+{
+    fprintf(stderr, "gnnpe_main: %s\n", msg.c_str());
+    exit(code);
+}
+
+void check(int rc, const char *what)
+{
+    if (rc != 0) die(std::string(what) + ": " + gnnpe_last_error());
+}
+
+bool parse_u32(const std::string &s, uint32_t *v)
+{
+    if (s.empty()) return false;
+    char *end = nullptr;
+    unsigned long long x = strtoull(s.c_str(), &end, 10);
+    if (*end || x > 0xFFFFFFFFull) return false;
+    *v = (uint32_t)x;
+    return true;
+}
+
+// CLI11-style parsing of `-x v`, `-xv`, `--long v`, `--long=v`
+Options parse_args(int argc, char **argv)
+{
+    Options o;
+    struct Opt { char s; const char *l; } opts[] = {{'f', "file"}, {'d', "data"}, {'q', "query"}, {'m', "mode"},
+                                                     {'p', "partition"}, {'l', "length"}, {'e', "embedding"}, {'n', "answers"}};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], val;
+        char key = 0;
+        if (a == "-h" || a == "--help") {
+            printf("gnnpe_main -f <dataset dir/> -d <data.graph> -m offline -p <partitions> [-l 2] [-e 2]\n"
+                   "           [--gpus N] [--chunk PATHS] [--index] [--sidecars] [--timing] [--allow-large]\n");
+            exit(0);
+        }
+        if (a == "--gpus" || a == "--chunk") {
+            if (i + 1 >= argc) die(a + " needs a value");
+            uint64_t v = strtoull(argv[++i], nullptr, 10);
+            if (a == "--gpus") o.gpus = (int)v; else o.chunk_paths = v;
+            continue;
+        }
+        if (a == "--allow-large") { o.allow_large = true; continue; }
+        if (a == "--timing") { o.timing = true; continue; }
+        if (a == "--sidecars") { o.sidecars = true; continue; }
+        if (a == "--index") { o.write_index = true; continue; }
+        if (a.rfind("--", 0) == 0) {
+            std::string name = a.substr(2);
+            size_t eq = name.find('=');
+            bool has_val = eq != std::string::npos;
+            if (has_val) { val = name.substr(eq + 1); name = name.substr(0, eq); }
+            for (auto &op : opts) if (name == op.l) key = op.s;
+            if (!key) die("unknown option " + a);
+            if (!has_val) { if (i + 1 >= argc) die(a + " needs a value"); val = argv[++i]; }
+        } else if (a.size() >= 2 && a[0] == '-') {
+            for (auto &op : opts) if (a[1] == op.s) key = op.s;
+            if (!key) die("unknown option " + a);
+            if (a.size() > 2) val = a.substr(2);
+            else { if (i + 1 >= argc) die(a + " needs a value"); val = argv[++i]; }
+        } else {
+            die("unexpected argument " + a);
+        }
+        bool ok = true;
+        switch (key) {
+        case 'f': o.dataset_path = val; break;
+        case 'd': o.data_graph = val; break;
+        case 'q': o.query_graph = val; break;
+        case 'm': o.mode = val; break;
+        case 'n': o.answers = val; break;
+        case 'p': ok = parse_u32(val, &o.partition_num); break;
+        case 'l': ok = parse_u32(val, &o.path_length); break;
+        case 'e': ok = parse_u32(val, &o.vde_dim); break;
+        }
+        if (!ok) die("bad value for -" + std::string(1, key) + ": " + val);
+    }
+    return o;
+}
+
+bool is_dir(const std::string &p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+// Background writer: the GPU renders chunk k+1 while chunk k goes to the file.
+class FileSink {
+public:
+    explicit FileSink(const std::string &path) : path_(path)
+    {
+        f_ = fopen(path.c_str(), "wb");
+        if (!f_) die("cannot open " + path + " for writing");
+        setvbuf(f_, nullptr, _IOFBF, 8 << 20);
+        th_ = std::thread([this] { run(); });
+    }
+    std::vector<char> *acquire()
+    {  // a free buffer (two in flight)
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return pending_ < 2; });
+        return &bufs_[next_++ & 1];
+    }
+    void submit(std::vector<char> *b, size_t n)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        queue_.push_back({b, n});
+        pending_++;
+        cv_.notify_all();
+    }
+    void write_now(const std::string &s) { submit_copy(s); }
+    uint64_t close()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_ = true;
+            cv_.notify_all();
+        }
+        th_.join();
+        if (fclose(f_) != 0 || failed_) die("write error on " + path_);
+        return bytes_;
+    }
+
+private:
+    void submit_copy(const std::string &s)
+    {
+        std::vector<char> *b = acquire();
+        b->assign(s.begin(), s.end());
+        submit(b, s.size());
+    }
+    void run()
+    {
+        for (;;) {
+            std::pair<std::vector<char> *, size_t> item;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return !queue_.empty() || done_; });
+                if (queue_.empty()) return;
+                item = queue_.front();
+                queue_.erase(queue_.begin());
+            }
+            if (item.second && fwrite(item.first->data(), 1, item.second, f_) != item.second) failed_ = true;
+            bytes_ += item.second;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                pending_--;
+                cv_.notify_all();
+            }
+        }
+    }
+    std::string path_;
+    FILE *f_ = nullptr;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::pair<std::vector<char> *, size_t>> queue_;
+    std::vector<char> bufs_[2];
+    int pending_ = 0, next_ = 0;
+    bool done_ = false, failed_ = false;
+    uint64_t bytes_ = 0;
+};
+
+struct Device {
+    gnnpe_ctx *ctx = nullptr;
+    uint32_t slab_begin = 0, slab_end = 0;
+    uint64_t total = 0, base = 0;
+};
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options o = parse_args(argc, argv);
+    const auto t_start = Clock::now();
+
+    // main.cpp:58-59: path_length += 1; pde_dim = vde_dim * path_length
+    if (o.path_length != 2)
+        die("-l " + std::to_string(o.path_length) + ": only -l 2 is supported (the reference always enumerates 3-vertex "
+            "paths and mis-prints them for any other -l)");
+    const uint32_t L = o.path_length + 1;
+    if (o.answers != "MAX") {  // main.cpp:62-69 (MAX_LIMIT is an online-only knob)
+        uint32_t lim;
+        if (!parse_u32(o.answers, &lim)) die("-n must be MAX or an integer");
+    }
+    if (o.partition_num == 0) die("-p must be >= 1");
+    if (o.mode == "online")
+        die("-m online is the reference's own binary: run it on the files this tool wrote (INTEGRATION.md)", 2);
+    if (o.mode != "offline") return 0;  // the reference does nothing for other modes
+
+    StaticGraph g;
+    std::string err;
+    int rc = g.load(o.data_graph, &err);
+    if (rc == -1) {  // graph.cpp:166-169
+        printf("%s\n", err.c_str());
+        exit(-1);
+    }
+    if (rc != 0) die(o.data_graph + ": " + err);
+    fputs(g.metadata_text().c_str(), stdout);  // printGraphMetaData, main.cpp:73
+    const auto t_loaded = Clock::now();
+
+    std::vector<uint32_t> sorted_nodes, membership;
+    if (gnnpe_host::read_membership(o.dataset_path + "gnn-pe/membership.txt", g.n, o.partition_num, &sorted_nodes,
+                                    &membership, &err) != 0)
+        die(err);
+    const std::string partitions_path = o.dataset_path + "gnn-pe/partitions/";
+    for (uint32_t i = 0; i < o.partition_num; i++)
+        if (!is_dir(partitions_path + "partition-" + std::to_string(i)))
+            die("missing directory " + partitions_path + "partition-" + std::to_string(i) + "/ (the prep step creates it)");
+
+    // ---- device setup: one context per GPU, each holding the graph and a slab of the order ----
+    const int ndev = gnnpe_device_count();
+    if (ndev <= 0) die("no HIP device: this tool has no CPU fallback");
+    if (o.gpus < 1 || o.gpus > ndev) die("--gpus " + std::to_string(o.gpus) + " but " + std::to_string(ndev) + " device(s) present");
+    std::vector<double> table((size_t)std::max<uint32_t>(g.labels_count, 1) * o.vde_dim);
+    check(gnnpe_host_label_table(std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "label table");
+    std::vector<Device> devs(o.gpus);
+    for (int d = 0; d < o.gpus; d++) {
+        devs[d].ctx = gnnpe_create(d);
+        if (!devs[d].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
+        check(gnnpe_load_csr(devs[d].ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
+        check(gnnpe_set_order(devs[d].ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
+        check(gnnpe_set_label_table(devs[d].ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()),
+              "set_label_table");
+    }
+    const auto t_setup = Clock::now();
+
+    // ---- R4 + R2 count on device 0 over the whole order: per-start counts size everything ----
+    std::vector<double> hx, hnx, hvde;
+    if (o.sidecars) {
+        hx.resize((size_t)g.n * o.vde_dim);
+        hnx.resize(hx.size());
+        hvde.resize(hx.size());
+    }
+    for (int d = 0; d < o.gpus; d++)
+        check(gnnpe_vde(devs[d].ctx, d == 0 && o.sidecars ? hx.data() : nullptr, d == 0 && o.sidecars ? hnx.data() : nullptr,
+                        d == 0 && o.sidecars ? hvde.data() : nullptr), "vde");
+    std::vector<uint64_t> per_start(g.n);
+    uint64_t P = 0;
+    check(gnnpe_count_paths(devs[0].ctx, o.path_length, per_start.data(), &P), "count_paths");
+    if (P > 0xFFFFFFFFull && !o.allow_large)
+        die(std::to_string(P) + " paths exceed the reference's 32-bit path ids (use --allow-large to write anyway)");
+    // slabs with equal path counts
+    {
+        uint64_t acc = 0;
+        uint32_t i = 0;
+        for (int d = 0; d < o.gpus; d++) {
+            devs[d].slab_begin = i;
+            devs[d].base = acc;
+            const uint64_t target = P * (uint64_t)(d + 1) / (uint64_t)o.gpus;
+            while (i < g.n && (acc < target || d == o.gpus - 1)) acc += per_start[i++];
+            devs[d].slab_end = i;
+            devs[d].total = acc - devs[d].base;
+        }
+    }
+    std::vector<uint64_t> part_count(o.partition_num, 0);  // main.cpp:102: header of partition_paths.txt
+    for (uint32_t i = 0; i < g.n; i++) part_count[membership[sorted_nodes[i]]] += per_start[i];
+    for (int d = 0; d < o.gpus; d++) {
+        if (o.gpus > 1) {
+            check(gnnpe_set_slab(devs[d].ctx, devs[d].slab_begin, devs[d].slab_end), "set_slab");
+            uint64_t t = 0;
+            check(gnnpe_count_paths(devs[d].ctx, o.path_length, nullptr, &t), "count_paths(slab)");
+            if (t != devs[d].total) die("slab count mismatch");
+        }
+    }
+    const auto t_counted = Clock::now();
+
+    // ---- emit + render + write, chunk by chunk, slab by slab (rank order = file order) ----
+    FileSink all_paths(o.dataset_path + "/gnn-pe/all_paths.txt");  // main.cpp:110 (sic: extra slash)
+    all_paths.write_now(std::to_string(P) + "\n");
+    std::vector<FileSink *> part_files;
+    for (uint32_t i = 0; i < o.partition_num; i++) {
+        part_files.push_back(new FileSink(partitions_path + "partition-" + std::to_string(i) + "/partition_paths.txt"));
+        part_files[i]->write_now(std::to_string(part_count[i]) + "\n");
+    }
+    double t_gpu = 0.0;
+    for (int d = 0; d < o.gpus; d++) {
+        gnnpe_ctx *ctx = devs[d].ctx;
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(o.chunk_paths, devs[d].total));
+        void *d_ids = nullptr, *d_part = nullptr, *d_sel = nullptr, *d_text = nullptr;
+        const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
+        check(gnnpe_dev_alloc(ctx, chunk * L * 4, &d_ids), "alloc ids");
+        check(gnnpe_dev_alloc(ctx, chunk * 4, &d_part), "alloc part");
+        check(gnnpe_dev_alloc(ctx, chunk * 8, &d_sel), "alloc sel");
+        check(gnnpe_dev_alloc(ctx, text_cap, &d_text), "alloc text");
+        for (uint64_t b = 0; b < devs[d].total; b += chunk) {
+            const uint64_t e = std::min(devs[d].total, b + chunk), cnt = e - b;
+            const auto g0 = Clock::now();
+            check(gnnpe_fill_paths_device(ctx, b, e, d_ids, nullptr, nullptr), "fill_paths");
+            check(gnnpe_path_partitions_device(ctx, b, e, d_part), "path_partitions");
+            uint64_t nb = 0;
+            check(gnnpe_text_paths(ctx, cnt, L, d_ids, d_text, text_cap, &nb), "text_paths");
+            std::vector<char> *buf = all_paths.acquire();
+            buf->resize(nb);
+            check(gnnpe_copy_to_host(ctx, buf->data(), d_text, nb), "copy text");
+            t_gpu += secs(g0, Clock::now());
+            all_paths.submit(buf, nb);
+            for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+                const auto g1 = Clock::now();
+                uint64_t k = 0, pb = 0;
+                check(gnnpe_select_partition(ctx, cnt, d_part, pid, devs[d].base + b, d_sel, &k), "select_partition");
+                check(gnnpe_text_ids(ctx, k, d_sel, d_text, text_cap, &pb), "text_ids");
+                std::vector<char> *pbuf = part_files[pid]->acquire();
+                pbuf->resize(pb);
+                check(gnnpe_copy_to_host(ctx, pbuf->data(), d_text, pb), "copy ids text");
+                t_gpu += secs(g1, Clock::now());
+                part_files[pid]->submit(pbuf, pb);
+            }
+        }
+        gnnpe_dev_free(ctx, d_ids);
+        gnnpe_dev_free(ctx, d_part);
+        gnnpe_dev_free(ctx, d_sel);
+        gnnpe_dev_free(ctx, d_text);
+    }
+    uint64_t bytes_all = all_paths.close(), bytes_part = 0;
+    for (auto *f : part_files) {
+        bytes_part += f->close();
+        delete f;
+    }
+    const auto t_written = Clock::now();
+
+    if (o.sidecars) {  // ignored by the reference; carrier for the embedding parity check
+        FILE *f = fopen((o.dataset_path + "gnn-pe/vde.bin").c_str(), "wb");
+        if (!f) die("cannot write vde.bin");
+        uint32_t hdr[2] = {g.n, o.vde_dim};
+        fwrite(hdr, 4, 2, f);
+        fwrite(hx.data(), 8, hx.size(), f);
+        fwrite(hnx.data(), 8, hnx.size(), f);
+        fwrite(hvde.data(), 8, hvde.size(), f);
+        fclose(f);
+    }
+    if (o.write_index) die("--index: the R*-tree bulk loader is not part of this build yet");
+    for (auto &d : devs) gnnpe_destroy(d.ctx);
+
+    if (o.timing) {
+        fprintf(stderr,
+                "{\"paths\": %llu, \"gpus\": %d, \"load_s\": %.3f, \"setup_s\": %.3f, \"vde_count_s\": %.3f, "
+                "\"emit_render_copy_s\": %.3f, \"write_total_s\": %.3f, \"end_to_end_s\": %.3f, "
+                "\"all_paths_bytes\": %llu, \"partition_bytes\": %llu}\n",
+                (unsigned long long)P, o.gpus, secs(t_start, t_loaded), secs(t_loaded, t_setup), secs(t_setup, t_counted),
+                t_gpu, secs(t_counted, t_written), secs(t_start, t_written), (unsigned long long)bytes_all,
+                (unsigned long long)bytes_part);
+    }
+    return 0;
+}

@@ -52,6 +52,13 @@ void gnnpe_destroy(gnnpe_ctx *ctx);
 int gnnpe_set_stream(gnnpe_ctx *ctx, void *hip_stream);
 int gnnpe_sync(gnnpe_ctx *ctx);
 
+/* Device buffers for callers without a HIP runtime of their own (the C++ host CLI); Python callers
+ * pass torch tensors instead.  gnnpe_copy_to_host synchronises the context's stream. */
+int gnnpe_dev_alloc(gnnpe_ctx *ctx, uint64_t bytes, void **dev_ptr);
+int gnnpe_dev_free(gnnpe_ctx *ctx, void *dev_ptr);
+int gnnpe_copy_to_host(gnnpe_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+int gnnpe_device_count(void);
+
 /* ---- inputs ---------------------------------------------------------------------------------- */
 /* R0: the CSR that Static_Graph::loadGraphFromFile builds (graph.cpp:163-242; accessors
  * graph.h:154-176): offsets[n+1], neighbours sorted ascending per vertex, labels[n].  Host -> HBM. */
@@ -137,6 +144,18 @@ int gnnpe_fill_paths_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *
 /* Per path, the partition of its start vertex (membership[vids[0]]): what main.cpp:98-108 groups
  * partition_paths.txt by.  dev_part: (end-begin) uint32. */
 int gnnpe_path_partitions_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *dev_part);
+
+/* ---- R7: text rendering of the offline outputs (writers, main.cpp:98-119) ------------------------ */
+/* all_paths.txt body: each row "<v0> <v1> <v2> \n" -- every id followed by one space, then '\n'
+ * (main.cpp:114-118).  dev_vids: n_rows x L uint32.  dev_text == NULL only sizes (*nbytes). */
+int gnnpe_text_paths(gnnpe_ctx *ctx, uint64_t n_rows, uint32_t L, const void *dev_vids, void *dev_text, uint64_t cap,
+                     uint64_t *nbytes);
+/* partition_paths.txt body: one uint64 id per line (main.cpp:102-106). */
+int gnnpe_text_ids(gnnpe_ctx *ctx, uint64_t n, const void *dev_ids, void *dev_text, uint64_t cap, uint64_t *nbytes);
+/* Global ids (id_base + i, ascending) of the rows i < n whose partition dev_part[i] == pid: the list
+ * main.cpp:98-108 writes for partition pid.  dev_ids: room for n uint64. */
+int gnnpe_select_partition(gnnpe_ctx *ctx, uint64_t n, const void *dev_part, uint32_t pid, uint64_t id_base,
+                           void *dev_ids, uint64_t *count);
 
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */

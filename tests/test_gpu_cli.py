@@ -1,0 +1,126 @@
+"""GPU tests of the drop-in boundary at process level: `gnnpe_main -m offline` must write the same
+bytes as the reference's `main -m offline`, and the UNTOUCHED reference `main -m online`
+(oracle/_ref/ref_main) must consume them and print the known answer count."""
+import gzip
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gnnpe_amd import synth
+from oracle import ref_main_path
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+
+
+def _md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def _test_graph_dataset(tmp, p, mem_fn):
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    sn = np.argsort(deg, kind="stable").astype(np.uint32)
+    synth.make_dataset_dir(tmp, p)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), sn, mem_fn(len(deg)))
+    return graph
+
+
+@pytest.mark.parametrize("p", [1, 2])
+def test_test_graph_files_byte_exact_and_online_answer(tmp_path, p):
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))[f"p{p}"]
+    tmp = str(tmp_path)
+    graph = _test_graph_dataset(tmp, p, (lambda n: np.zeros(n, np.uint32)) if p == 1 else
+                                (lambda n: (np.arange(n) % 2).astype(np.uint32)))
+    r = subprocess.run([CLI, "-f", tmp + "/", "-d", graph, "-m", "offline", "-p", str(p), "--timing", "--chunk", "100000"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "|V|: 3112, |E|: 12519, |Σ|: 71\nMax Degree: 168, Max Label Frequency: 622\n"
+    assert _md5(os.path.join(tmp, "gnn-pe", "all_paths.txt")) == gold["all_paths_md5"]
+    for i in range(p):
+        assert _md5(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "partition_paths.txt")) == \
+            gold["partition_paths_md5"][i]
+    if p == 1:
+        assert open(os.path.join(tmp, "gnn-pe", "all_paths.txt"), "rb").read() == \
+            gzip.open(os.path.join(GOLDEN, "test_graph", "all_paths.txt.gz")).read()
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built: online consumer check skipped")
+    # the untouched reference consumes our files (it builds its own index.dat on first run)
+    out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q",
+                                   os.path.join(GOLDEN, "test_graph", "query_graph.graph"), "-m", "online", "-p", str(p)],
+                                  text=True)
+    assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
+
+
+def test_random_graph_random_order_equals_reference_binary(tmp_path):
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    g = synth.gnm_graph(2000, 14000, n_labels=9, seed=91)
+    rng = np.random.default_rng(91)
+    sn = rng.permutation(2000).astype(np.uint32)
+    mem = rng.integers(0, 5, size=2000).astype(np.uint32)
+    ours, ref = str(tmp_path / "ours"), str(tmp_path / "ref")
+    for d in (ours, ref):
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 5)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    subprocess.check_call([ref_main_path(), "-f", ref + "/", "-d", gp, "-m", "offline", "-p", "5"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([CLI, "-f", ours + "/", "-d", gp, "-p", "5", "--chunk", "7777", "--sidecars"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rel = ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(5)]
+    for f in rel:
+        assert open(os.path.join(ours, f), "rb").read() == open(os.path.join(ref, f), "rb").read(), f
+    # sidecar: vde.bin = n, e, x, nx, vde (bit-exact vs the oracle)
+    from oracle import Oracle
+    b = open(os.path.join(ours, "gnn-pe", "vde.bin"), "rb").read()
+    n, e = np.frombuffer(b, np.uint32, 2)
+    arr = np.frombuffer(b, np.float64, 3 * n * e, 8).reshape(3, n, e)
+    x, nx, vde = Oracle().gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    assert np.array_equal(arr[0], x) and np.array_equal(arr[1], nx) and np.array_equal(arr[2], vde)
+
+
+def test_text_rendering_edge_values(oracle):
+    import torch
+    from gnnpe_amd import binding
+    eng = binding.Engine(0)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    edge = np.array([0, 9, 10, 99, 100, 999, 1000, 99999, 100000, 9999999, 10000000, 999999999, 1000000000,
+                     4294967295], np.uint32)
+    for nrows in (1, 3, 511, 512, 513, 5000):
+        ids = rng.choice(edge, size=(nrows, 3)).astype(np.uint32)
+        ids[rng.integers(0, nrows)] = rng.integers(0, 2 ** 32, size=3, dtype=np.uint64).astype(np.uint32)
+        t = torch.from_numpy(ids.view(np.int32)).to(dev)
+        nb = eng.text_paths(nrows, 3, t)
+        ref = oracle.format_all_paths(ids)
+        ref = ref[ref.index(b"\n") + 1:]  # body without the "<P>\n" header
+        assert nb == len(ref)
+        out = torch.zeros(nb + 8, dtype=torch.uint8, device=dev)
+        assert eng.text_paths(nrows, 3, t, out, nb + 8) == nb
+        eng.sync()
+        assert bytes(out[:nb].cpu().numpy()) == ref
+    # uint64 id lines and partition selection
+    part = rng.integers(0, 3, size=10000).astype(np.uint32)
+    tp = torch.from_numpy(part.view(np.int32)).to(dev)
+    sel = torch.zeros(10000, dtype=torch.int64, device=dev)
+    base = (1 << 33) + 12345  # ids beyond 32 bits
+    for pid in range(3):
+        k = eng.select_partition(10000, tp, pid, base, sel)
+        want = np.nonzero(part == pid)[0].astype(np.uint64) + np.uint64(base)
+        eng.sync()
+        assert k == len(want) and np.array_equal(sel[:k].cpu().numpy().view(np.uint64), want)
+        nb = eng.text_ids(k, sel)
+        out = torch.zeros(nb + 8, dtype=torch.uint8, device=dev)
+        eng.text_ids(k, sel, out, nb + 8)
+        eng.sync()
+        assert bytes(out[:nb].cpu().numpy()) == "".join(f"{v}\n" for v in want).encode()
+    eng.close()

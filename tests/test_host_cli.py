@@ -1,0 +1,105 @@
+"""CPU-only tests of the C++ host side (gnn-pe_amd/host): loader semantics, membership checks and
+error behaviour of `gnnpe_main`, up to the point where it needs a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gnnpe_amd import synth
+
+CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gnn-pe_amd"), "gnnpe_main"], stdout=subprocess.DEVNULL)
+
+
+def _run(*args):
+    return subprocess.run([CLI, *args], capture_output=True, text=True)
+
+
+def _dataset(tmp_path, g, sn, mem, p):
+    root = str(tmp_path)
+    gp = os.path.join(root, "g.graph")
+    synth.write_graph_file(gp, g)
+    synth.make_dataset_dir(root, p)
+    synth.write_membership(os.path.join(root, "gnn-pe", "membership.txt"), sn, mem)
+    return root + "/", gp
+
+
+def test_missing_graph_matches_reference_behaviour():
+    r = _run("-d", "/nonexistent.graph", "-f", "/tmp/")
+    assert r.returncode == 255  # exit(-1), graph.cpp:166-169
+    assert r.stdout.strip() == "Can not open the graph file /nonexistent.graph ."
+
+
+def test_metadata_lines_and_no_cpu_fallback(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    g = dict(n=3112)
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    sn = np.argsort(deg, kind="stable").astype(np.uint32)
+    root = str(tmp_path)
+    synth.make_dataset_dir(root, 1)
+    synth.write_membership(os.path.join(root, "gnn-pe", "membership.txt"), sn, np.zeros(len(deg), np.uint32))
+    r = _run("-f", root + "/", "-d", graph, "-m", "offline", "-p", "1")
+    # printGraphMetaData of the reference on Test/ (graph.cpp:245-246)
+    assert r.stdout == "|V|: 3112, |E|: 12519, |Σ|: 71\nMax Degree: 168, Max Label Frequency: 622\n"
+    assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_input_validation_fails_loudly(tmp_path):
+    g = synth.gnm_graph(50, 120, n_labels=3, seed=1)
+    sn = synth.degree_order(g["offsets"])
+    root, gp = _dataset(tmp_path, g, sn, np.zeros(50, np.uint32), 2)
+    # -l other than 2
+    r = _run("-f", root, "-d", gp, "-l", "3", "-p", "2")
+    assert r.returncode == 1 and "only -l 2" in r.stderr
+    # online mode belongs to the reference binary
+    r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2")
+    assert r.returncode == 2
+    # membership.txt missing / short / duplicate vertex / partition out of range
+    os.rename(os.path.join(root, "gnn-pe", "membership.txt"), os.path.join(root, "gnn-pe", "m.bak"))
+    r = _run("-f", root, "-d", gp, "-p", "2")
+    assert r.returncode == 1 and "membership.txt" in r.stderr
+    lines = open(os.path.join(root, "gnn-pe", "m.bak")).read().splitlines()
+    for bad, msg in ((lines[:-1], "missing"), ([lines[0]] + lines[:-1], "listed twice"),
+                     (["0 7"] + lines[1:], "partition")):
+        open(os.path.join(root, "gnn-pe", "membership.txt"), "w").write("\n".join(bad) + "\n")
+        r = _run("-f", root, "-d", gp, "-p", "2")
+        assert r.returncode == 1 and msg in r.stderr, (msg, r.stderr)
+    open(os.path.join(root, "gnn-pe", "membership.txt"), "w").write("\n".join(lines) + "\n")
+    # partition directory missing (the reference silently writes nothing)
+    r = _run("-f", root, "-d", gp, "-p", "3")
+    assert r.returncode == 1 and ("partition-2" in r.stderr or "partition 1" in r.stderr or "partition" in r.stderr)
+    # duplicate edge -> not a simple graph
+    txt = open(gp).read().splitlines()
+    e = [l for l in txt if l.startswith("e")][0]
+    u, v = e.split()[1:]
+    bad = [l for l in txt]
+    # bump the two degrees and append the duplicate so the counts stay consistent
+    out = []
+    for l in bad:
+        f = l.split()
+        if f[0] == "t":
+            l = f"t {f[1]} {int(f[2]) + 1}"
+        if f[0] == "v" and f[1] in (u, v):
+            l = f"v {f[1]} {f[2]} {int(f[3]) + 1}"
+        out.append(l)
+    out.append(e)
+    open(gp, "w").write("\n".join(out) + "\n")
+    r = _run("-f", root, "-d", gp, "-p", "2")
+    assert r.returncode == 1 and "duplicate edge" in r.stderr
+
+
+def test_cli_flag_forms(tmp_path):
+    # CLI11-style spellings the reference accepts: -x v, -xv, --long v, --long=v
+    for args in (["--data=/nonexistent.graph"], ["--data", "/nonexistent.graph"], ["-d/nonexistent.graph"]):
+        r = _run(*args)
+        assert r.returncode == 255 and "Can not open the graph file" in r.stdout
+    assert _run("--bogus").returncode == 1
