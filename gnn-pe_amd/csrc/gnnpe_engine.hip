@@ -298,7 +298,8 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes)) || (rc = c->nbr_row.reserve(c->nbrs.bytes))) return rc;
-    if (n) GNNPE_HIP_TRY(hipMemcpy(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice));
+    // same stream as the kernels that read it: a null-stream copy would not order against c->stream
+    if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
     if (n_rows) {
         hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows,
                            c->rows.as<uint32_t>(), c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
