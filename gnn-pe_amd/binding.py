@@ -54,6 +54,9 @@ SIGNATURES = {
     "gnnpe_text_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_text_ids": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_select_partition": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, C.c_uint64, _vp, _u64p]),
+    "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
+                                           C.POINTER(C.c_int32)]),
+    "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -285,3 +288,19 @@ class Engine:
         self._ck(self.lib.gnnpe_select_partition(self.ctx, int(n), _dev(dev_part), int(pid), int(id_base),
                                                  _dev(dev_ids), C.byref(cnt)))
         return cnt.value
+
+    # R6: index.dat (custom.h:235-257)
+    def build_index_device(self, cnt, L, dev_vids):
+        img, nb = _vp(), C.c_uint64()
+        hdr = (C.c_int32 * 8)()
+        self._ck(self.lib.gnnpe_build_index_device(self.ctx, int(cnt), int(L), _dev(dev_vids), C.byref(img),
+                                                   C.byref(nb), hdr))
+        return img.value, nb.value, list(hdr)
+
+    def build_index(self, pid, path):
+        self._ck(self.lib.gnnpe_build_index(self.ctx, int(pid), path.encode()))
+
+    def copy_to_host(self, dev_ptr, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        self._ck(self.lib.gnnpe_copy_to_host(self.ctx, out.ctypes.data_as(_vp), C.c_void_p(dev_ptr), int(nbytes)))
+        return out

@@ -88,6 +88,7 @@ struct gnnpe_ctx {
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
     gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec, nbr_row;
     gnnpe::DevBuf text_len, text_off;  // R7 scratch
+    gnnpe::DevBuf index_image, idx_keys, idx_vals, idx_mbr;  // R6 scratch + the assembled index.dat image
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
 
     // ---- order (R1) ----

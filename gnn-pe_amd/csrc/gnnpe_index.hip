@@ -1,0 +1,384 @@
+// gnnpe_index.hip -- R6: bulk-loaded R-tree over a partition's path embeddings, emitted directly in
+// the reference's on-disk format (index.dat).
+//
+// The reference builds the tree with one RTree::insert per path (custom.h:235-257 ->
+// libsrc/rtree/rtree.cpp:198-284): ~96 us per insert, each walking root->leaf through 4 KiB block
+// reads.  The online consumer (custom.h:258-266, 366-489) only needs a VALID tree
+// in the same file format: dense node block ids, an internal root, child MBRs enclosed by their
+// parent entries, leaf `son` = the path's index inside the partition.  Tree SHAPE is free, so here it
+// is bulk-loaded: Z-order key of the (quantised) embedding -> one device radix sort -> leaves packed
+// from consecutive runs -> upper levels packed from consecutive children, every node block
+// assembled in LDS and written as one aligned 4 KiB store.
+//
+// File layout (little endian, packed) restated from the reference:
+//   block 0 : int32 blocklength, int32 n_node_blocks                      blk_file.cpp:38-39,51-52
+//             @8: int32 dim, n_data, n_dnodes, n_inodes, bool root_is_data, int32 root   rtree.cpp:341-362
+//   block k+1 = node k: char level, int32 n_entries, entries               rtnode.cpp:1099-1117
+//   entry   : 2*dim doubles (lo0,hi0,lo1,hi1,...), int32 son              entry.cpp:127-136
+//   capacity = (4096 - 5) / (16*dim + 4)                                   rtnode.cpp:27-28
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "gnnpe_common.h"
+
+namespace gnnpe {
+
+constexpr int kBlockLen = 4096;
+
+// ---- keys ---------------------------------------------------------------------------------------
+// per-dimension min / max of the partition's points (point p, dim k = vde[vids[p][k / e]][k % e])
+__global__ void k_point_minmax(uint64_t cnt, uint32_t L, uint32_t e, const uint32_t *__restrict__ vids,
+                               const double *__restrict__ vde, double *__restrict__ mn, double *__restrict__ mx)
+{
+    // one block per dimension-slice of the input; partial results combined with atomics on the
+    // ordered-integer image of the doubles (all embeddings are positive finite numbers)
+    const uint32_t D = L * e;
+    __shared__ double s_mn[256], s_mx[256];
+    for (uint32_t k = 0; k < D; k++) {
+        double a = 1e300, b = -1e300;
+        for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
+            const double v = vde[(uint64_t)vids[p * L + k / e] * e + k % e];
+            a = fmin(a, v);
+            b = fmax(b, v);
+        }
+        s_mn[threadIdx.x] = a;
+        s_mx[threadIdx.x] = b;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_mn[threadIdx.x] = fmin(s_mn[threadIdx.x], s_mn[threadIdx.x + s]);
+                s_mx[threadIdx.x] = fmax(s_mx[threadIdx.x], s_mx[threadIdx.x + s]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            // positive doubles order like their bit patterns
+            atomicMin(reinterpret_cast<unsigned long long *>(mn) + k, (unsigned long long)__double_as_longlong(s_mn[0]));
+            atomicMax(reinterpret_cast<unsigned long long *>(mx) + k, (unsigned long long)__double_as_longlong(s_mx[0]));
+        }
+        __syncthreads();
+    }
+}
+
+// Z-order key: `bits` bits per dimension, most significant bit plane first; within a plane dimension 0
+// is the most significant.  Bit t of dimension k lands at position t*D + (D-1-k).
+__global__ void k_zorder_keys(uint64_t cnt, uint32_t L, uint32_t e, uint32_t bits, const uint32_t *__restrict__ vids,
+                              const double *__restrict__ vde, const double *__restrict__ mn,
+                              const double *__restrict__ mx, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint32_t D = L * e;
+    const uint32_t qmax = (1u << bits) - 1u;
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t key = 0;
+        for (uint32_t k = 0; k < D; k++) {
+            const double v = vde[(uint64_t)vids[p * L + k / e] * e + k % e];
+            const double span = mx[k] - mn[k];
+            const uint32_t q = span > 0.0 ? (uint32_t)fmin((v - mn[k]) / span * (double)qmax, (double)qmax) : 0u;
+            for (uint32_t t = 0; t < bits; t++) key |= (uint64_t)((q >> t) & 1u) << (t * D + (D - 1 - k));
+        }
+        keys[p] = key;
+        vals[p] = (uint32_t)p;
+    }
+}
+
+// ---- node assembly --------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_put(char *dst, const void *src, int n)
+{
+    const char *s = reinterpret_cast<const char *>(src);
+    for (int i = 0; i < n; i++) dst[i] = s[i];
+}
+
+// leaf j holds sorted points [j*F, min((j+1)*F, cnt)); block id = j.  One workgroup per leaf.
+__global__ __launch_bounds__(64) void k_pack_leaves(uint64_t cnt, uint32_t F, uint32_t L, uint32_t e,
+                                                    const uint32_t *__restrict__ order,
+                                                    const uint32_t *__restrict__ vids, const double *__restrict__ vde,
+                                                    char *__restrict__ image, double *__restrict__ node_mbr)
+{
+    __shared__ __attribute__((aligned(16))) char s_blk[kBlockLen];
+    __shared__ double s_lo[64], s_hi[64];
+    const uint32_t D = L * e, esz = 16 * D + 4;
+    const uint64_t j = blockIdx.x;
+    const uint64_t p0 = j * F;
+    const uint32_t ne = (uint32_t)min((uint64_t)F, cnt - p0);
+    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_blk)[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_blk[0] = 0;  // level 0 = leaf
+        const int32_t n32 = (int32_t)ne;
+        lds_put(s_blk + 1, &n32, 4);
+    }
+    if (threadIdx.x < ne) {
+        const uint32_t son = order[p0 + threadIdx.x];  // the path's index inside the partition (custom.h:243)
+        char *ent = s_blk + 5 + threadIdx.x * esz;
+        for (uint32_t k = 0; k < D; k++) {
+            const double v = vde[(uint64_t)vids[(uint64_t)son * L + k / e] * e + k % e];
+            lds_put(ent + 16 * k, &v, 8);      // lo (custom.h:246)
+            lds_put(ent + 16 * k + 8, &v, 8);  // hi (custom.h:247)
+        }
+        const int32_t s32 = (int32_t)son;
+        lds_put(ent + 16 * D, &s32, 4);
+    }
+    // node MBR for the parent level
+    for (uint32_t k = 0; k < D; k++) {
+        double v = 0.0;
+        if (threadIdx.x < ne) {
+            const uint32_t son = order[p0 + threadIdx.x];
+            v = vde[(uint64_t)vids[(uint64_t)son * L + k / e] * e + k % e];
+        }
+        s_lo[threadIdx.x] = threadIdx.x < ne ? v : 1e300;
+        s_hi[threadIdx.x] = threadIdx.x < ne ? v : -1e300;
+        __syncthreads();
+        for (int s = 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_lo[threadIdx.x] = fmin(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
+                s_hi[threadIdx.x] = fmax(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            node_mbr[(j * D + k) * 2] = s_lo[0];
+            node_mbr[(j * D + k) * 2 + 1] = s_hi[0];
+        }
+        __syncthreads();
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
+    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) dst[i] = reinterpret_cast<uint32_t *>(s_blk)[i];
+}
+
+// internal node j of a level: children = nodes [child0 + j*F, child0 + min((j+1)*F, n_child)) of the
+// level below; block id = node0 + j.
+__global__ __launch_bounds__(64) void k_pack_inner(uint64_t n_child, uint64_t child0, uint64_t node0, uint32_t F,
+                                                   uint32_t D, int level, const double *__restrict__ child_mbr,
+                                                   char *__restrict__ image, double *__restrict__ node_mbr)
+{
+    __shared__ __attribute__((aligned(16))) char s_blk[kBlockLen];
+    __shared__ double s_lo[64], s_hi[64];
+    const uint32_t esz = 16 * D + 4;
+    const uint64_t j = blockIdx.x;
+    const uint64_t c0 = j * F;
+    const uint32_t ne = (uint32_t)min((uint64_t)F, n_child - c0);
+    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_blk)[i] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_blk[0] = (char)level;
+        const int32_t n32 = (int32_t)ne;
+        lds_put(s_blk + 1, &n32, 4);
+    }
+    if (threadIdx.x < ne) {
+        char *ent = s_blk + 5 + threadIdx.x * esz;
+        const double *m = child_mbr + (c0 + threadIdx.x) * 2 * D;
+        lds_put(ent, m, 16 * D);  // (lo, hi) pairs already interleaved
+        const int32_t s32 = (int32_t)(child0 + c0 + threadIdx.x);  // son = child's block id
+        lds_put(ent + 16 * D, &s32, 4);
+    }
+    for (uint32_t k = 0; k < D; k++) {
+        s_lo[threadIdx.x] = threadIdx.x < ne ? child_mbr[((c0 + threadIdx.x) * D + k) * 2] : 1e300;
+        s_hi[threadIdx.x] = threadIdx.x < ne ? child_mbr[((c0 + threadIdx.x) * D + k) * 2 + 1] : -1e300;
+        __syncthreads();
+        for (int s = 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_lo[threadIdx.x] = fmin(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
+                s_hi[threadIdx.x] = fmax(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            node_mbr[(j * D + k) * 2] = s_lo[0];
+            node_mbr[(j * D + k) * 2 + 1] = s_hi[0];
+        }
+        __syncthreads();
+    }
+    uint32_t *dst = reinterpret_cast<uint32_t *>(image + (node0 + j + 1) * (uint64_t)kBlockLen);
+    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) dst[i] = reinterpret_cast<uint32_t *>(s_blk)[i];
+}
+
+// rows of `src` (n x L uint32) selected by idx -> dst
+__global__ void k_gather_rows_u32(uint64_t n, uint32_t L, const uint64_t *__restrict__ idx, uint64_t idx_base,
+                                  const uint32_t *__restrict__ src, uint32_t *__restrict__ dst)
+{
+    const uint64_t tot = n * L;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / L;
+        dst[i] = src[(idx[r] - idx_base) * L + i % L];
+    }
+}
+
+}  // namespace gnnpe
+
+using namespace gnnpe;
+
+extern "C" {
+
+int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void *dev_vids, void **dev_image,
+                             uint64_t *nbytes, int32_t hdr_out[8])
+{
+    GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->have_vde, GNNPE_ERR_ARG, "gnnpe_build_index: call gnnpe_vde first");
+    GNNPE_REQUIRE(L >= 1 && cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu points exceeds the format's int32 counts",
+                  (unsigned long long)cnt);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint32_t e = c->e, D = L * e;
+    const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);  // rtnode.cpp:27-28
+    GNNPE_REQUIRE(cap >= 3 && cap <= 64, GNNPE_ERR_UNSUPPORTED, "entry size for dim %u gives node capacity %u", D, cap);
+    // the reference splits a node on reaching capacity-1 (rtnode.cpp:528,576): keep <= capacity-2
+    const uint32_t F = cap - 2;
+    int rc;
+
+    // level sizes: leaves, then parents until a single node remains; root must be internal
+    std::vector<uint64_t> level_n;
+    if (cnt == 0) {
+        level_n.push_back(1);  // the reference's empty tree: one empty leaf that is the root (rtree.cpp:11-32)
+    } else {
+        level_n.push_back((cnt + F - 1) / F);
+        do level_n.push_back((level_n.back() + F - 1) / F); while (level_n.back() > 1);
+    }
+    uint64_t n_nodes = 0;
+    for (uint64_t v : level_n) n_nodes += v;
+    GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
+    const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
+    if ((rc = c->index_image.reserve(image_bytes))) return rc;
+    char *image = c->index_image.as<char>();
+    GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
+
+    int32_t hdr[8] = {kBlockLen, (int32_t)n_nodes, (int32_t)D, (int32_t)cnt, (int32_t)level_n[0],
+                      (int32_t)(n_nodes - level_n[0]), cnt == 0 ? 1 : 0, (int32_t)(n_nodes - 1)};
+    if (cnt == 0) {
+        GNNPE_HIP_TRY(hipMemsetAsync(image + kBlockLen, 0, kBlockLen, c->stream));  // level 0, 0 entries
+    } else {
+        GNNPE_REQUIRE(dev_vids, GNNPE_ERR_ARG, "null path ids");
+        const uint32_t *vids = (const uint32_t *)dev_vids;
+        // 1. keys
+        if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
+        double *mn = reinterpret_cast<double *>(c->small.as<char>() + 256), *mx = mn + 64;
+        GNNPE_REQUIRE(D <= 64, GNNPE_ERR_UNSUPPORTED, "dimension %u > 64", D);
+        std::vector<double> init(128);
+        for (int k = 0; k < 64; k++) {
+            init[k] = 1e300;
+            init[64 + k] = 0.0;
+        }
+        GNNPE_HIP_TRY(hipMemcpyAsync(mn, init.data(), 128 * 8, hipMemcpyHostToDevice, c->stream));
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // init[] is a stack/heap temporary
+        hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt, L,
+                           e, vids, c->vde.as<double>(), mn, mx);
+        const uint32_t bits = std::max(1u, std::min(16u, 64u / D));
+        if ((rc = c->idx_keys.reserve(cnt * 8 * 2)) || (rc = c->idx_vals.reserve(cnt * 4 * 2))) return rc;
+        uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
+        uint32_t *v_in = c->idx_vals.as<uint32_t>(), *v_out = v_in + cnt;
+        hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, L, e, bits, vids,
+                           c->vde.as<double>(), mn, mx, k_in, v_in);
+        GNNPE_HIP_TRY(hipGetLastError());
+        // 2. one radix sort over the used key bits
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)(bits * D),
+                                                        c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
+                                                        (int)(bits * D), c->stream));
+        // 3. leaves, then one launch per upper level
+        uint64_t max_level = 0;
+        for (uint64_t v : level_n) max_level = std::max(max_level, v);
+        if ((rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8))) return rc;
+        double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
+        hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, L, e, v_out, vids,
+                           c->vde.as<double>(), image, mbr_a);
+        uint64_t child0 = 0, node0 = level_n[0];
+        for (size_t lv = 1; lv < level_n.size(); lv++) {
+            hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,
+                               node0, F, D, (int)lv, mbr_a, image, mbr_b);
+            std::swap(mbr_a, mbr_b);
+            child0 = node0;
+            node0 += level_n[lv];
+        }
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    // header block (blk_file.cpp:38-39 + rtree.cpp:341-362): root_is_data is ONE byte, root follows at byte 25
+    char h[64];
+    memset(h, 0, sizeof(h));
+    memcpy(h, &hdr[0], 4);
+    memcpy(h + 4, &hdr[1], 4);
+    memcpy(h + 8, &hdr[2], 4);
+    memcpy(h + 12, &hdr[3], 4);
+    memcpy(h + 16, &hdr[4], 4);
+    memcpy(h + 20, &hdr[5], 4);
+    h[24] = (char)hdr[6];
+    memcpy(h + 25, &hdr[7], 4);
+    GNNPE_HIP_TRY(hipMemcpyAsync(image, h, 64, hipMemcpyHostToDevice, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    *dev_image = image;
+    *nbytes = image_bytes;
+    if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
+    return GNNPE_OK;
+}
+
+int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
+{
+    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
+                  "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
+    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    const uint32_t L = c->l + 1;
+    const uint64_t total = c->total_paths;
+    // collect the partition's paths (vertex triples in path-id order): two passes over the slab in chunks
+    const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(total, 1), 64ull << 20);
+    DevBuf ids, part, sel, mine;
+    int rc;
+    if ((rc = ids.reserve(chunk * L * 4)) || (rc = part.reserve(chunk * 4)) || (rc = sel.reserve(chunk * 8))) return rc;
+    uint64_t cnt = 0;
+    for (int pass = 0; pass < 2 && !rc; pass++) {
+        uint64_t at = 0;
+        for (uint64_t b = 0; b < total && !rc; b += chunk) {
+            const uint64_t e = std::min(total, b + chunk);
+            uint64_t k = 0;
+            if ((rc = gnnpe_path_partitions_device(c, b, e, part.p))) break;
+            if ((rc = gnnpe_select_partition(c, e - b, part.p, pid, 0, sel.p, &k))) break;
+            if (pass == 0) {
+                cnt += k;
+            } else if (k) {
+                if ((rc = gnnpe_fill_paths_device(c, b, e, ids.p, nullptr, nullptr))) break;
+                hipLaunchKernelGGL(k_gather_rows_u32, dim3(grid_for(k * L)), dim3(kBlock), 0, c->stream, k, L,
+                                   sel.as<uint64_t>(), (uint64_t)0, ids.as<uint32_t>(), mine.as<uint32_t>() + at * L);
+                at += k;
+            }
+        }
+        if (pass == 0 && !rc) rc = mine.reserve(std::max<uint64_t>(cnt, 1) * L * 4);
+    }
+    void *image = nullptr;
+    uint64_t nbytes = 0;
+    if (!rc) rc = gnnpe_build_index_device(c, cnt, L, mine.p, &image, &nbytes, nullptr);
+    if (!rc) {
+        FILE *f = fopen(path, "wb");
+        if (!f) {
+            set_error("cannot open %s for writing", path);
+            rc = GNNPE_ERR_IO;
+        } else {
+            std::vector<char> host(std::min<uint64_t>(nbytes, 256ull << 20));
+            for (uint64_t o = 0; o < nbytes && !rc; o += host.size()) {
+                const uint64_t nb = std::min<uint64_t>(host.size(), nbytes - o);
+                hipError_t he = hipMemcpyAsync(host.data(), (char *)image + o, nb, hipMemcpyDeviceToHost, c->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+                if (he != hipSuccess) {
+                    set_error("index copy-back: %s", hipGetErrorString(he));
+                    rc = GNNPE_ERR_HIP;
+                } else if (fwrite(host.data(), 1, nb, f) != nb) {
+                    set_error("short write on %s", path);
+                    rc = GNNPE_ERR_IO;
+                }
+            }
+            if (fclose(f) != 0 && !rc) {
+                set_error("close failed on %s", path);
+                rc = GNNPE_ERR_IO;
+            }
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    ids.release();
+    part.release();
+    sel.release();
+    mine.release();
+    return rc;
+}
+
+}  // extern "C"

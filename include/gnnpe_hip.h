@@ -157,6 +157,21 @@ int gnnpe_text_ids(gnnpe_ctx *ctx, uint64_t n, const void *dev_ids, void *dev_te
 int gnnpe_select_partition(gnnpe_ctx *ctx, uint64_t n, const void *dev_part, uint32_t pid, uint64_t id_base,
                            void *dev_ids, uint64_t *count);
 
+/* ---- R6: index.dat (Partition ctor build loop custom.h:235-257 -> RTree::insert rtree.cpp:198-284) -- */
+/* Bulk-loads the R-tree over `cnt` paths given as vertex tuples (cnt x L uint32, device memory, in the
+ * partition's path order: leaf `son` = row index, custom.h:243) with point MBRs lo = hi = pde row
+ * (custom.h:244-248), and assembles the complete file image in the reference's block format in device
+ * memory owned by the context (valid until the next call).  hdr_out = {blocklength, node blocks, dim,
+ * num_data, leaf nodes, internal nodes, root_is_data, root}.  Tree shape differs from the reference's
+ * insertion-built tree (it is not reproducible even by the reference); every consumer
+ * constraint of the online code holds (dense block ids, internal root, enclosing MBRs). */
+int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const void *dev_vids, void **dev_image,
+                             uint64_t *nbytes, int32_t hdr_out[8]);
+/* Whole job for partition `pid` of the context's slab: collect its paths, build, write `path`
+ * (<f>gnn-pe/partitions/partition-<pid>/index.dat).  The reference online run then skips its insert
+ * loop (custom.h:222-235 only tests that the file exists). */
+int gnnpe_build_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

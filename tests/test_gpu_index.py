@@ -1,0 +1,104 @@
+"""GPU tests of R6: the bulk-loaded index.dat must satisfy every constraint of the reference's online
+consumer (oracle validator restating rtree.cpp / rtnode.cpp / entry.cpp / blk_file.cpp), hold exactly
+the partition's points, and make the UNTOUCHED reference `main -m online` print the known answer."""
+import json
+import os
+import re
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gnnpe_amd import synth
+from oracle import ref_main_path
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+
+
+def _engine(binding, g, sn, mem, p, e):
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1, e))
+    return eng
+
+
+@pytest.mark.parametrize("e", [2, 8])
+def test_index_image_structure_and_contents(oracle, test_graph, e):
+    import torch
+    from gnnpe_amd import binding
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(ids.view(np.int32)).to(dev)
+    img_ptr, nbytes, hdr = eng.build_index_device(total, 3, t)
+    img = eng.copy_to_host(img_ptr, nbytes).tobytes()
+    d = oracle.index_validate(img)  # raises on any violated consumer constraint
+    D = 3 * e
+    cap = (4096 - 5) // (16 * D + 4)
+    assert d["dim"] == D and d["num_data"] == total and d["root_is_data"] == 0
+    assert d["n_blocks"] == d["dnodes"] + d["inodes"] == hdr[1] and len(img) == (hdr[1] + 1) * 4096
+    assert d["dnodes"] == -(-total // (cap - 2))
+    order = np.argsort(d["leaf_son"], kind="stable")
+    assert np.array_equal(d["leaf_son"][order], np.arange(total))  # every path exactly once
+    assert np.array_equal(d["leaf_pt"][order], vde[ids].reshape(total, D))  # lo = hi = pde row, bit exact
+    eng.close()
+
+
+def test_index_small_and_empty_partitions(oracle):
+    import torch
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(200, 700, n_labels=4, seed=8)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, np.zeros(200, np.uint32), 1, 2)
+    x, nx, vde = eng.vde()
+    eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    dev = torch.device("cuda:0")
+    for cnt in (1, 2, 37, 38, 39, 76, 77, 1445):
+        sub = np.ascontiguousarray(ids[:cnt])
+        t = torch.from_numpy(sub.view(np.int32)).to(dev)
+        p, nb, hdr = eng.build_index_device(cnt, 3, t)
+        d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+        assert d["num_data"] == cnt and d["root_is_data"] == 0 and d["inodes"] >= 1
+        o = np.argsort(d["leaf_son"])
+        assert np.array_equal(d["leaf_pt"][o], vde[sub].reshape(cnt, 6))
+    # empty partition: the reference's own empty tree (one empty leaf that is the root)
+    p, nb, hdr = eng.build_index_device(0, 3, None)
+    img = eng.copy_to_host(p, nb).tobytes()
+    assert nb == 2 * 4096 and hdr == [4096, 1, 6, 0, 1, 0, 1, 0]
+    assert img[24] == 1 and img[4096] == 0 and img[4097:4101] == b"\0\0\0\0"
+    eng.close()
+
+
+@pytest.mark.parametrize("p", [1, 2])
+def test_reference_online_consumes_prebuilt_index(tmp_path, oracle, p):
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))[f"p{p}"]
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    sn = np.argsort(deg, kind="stable").astype(np.uint32)
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, p)
+    mem = np.zeros(len(deg), np.uint32) if p == 1 else (np.arange(len(deg)) % 2).astype(np.uint32)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), sn, mem)
+    r = subprocess.run([CLI, "-f", tmp + "/", "-d", graph, "-p", str(p), "--index", "--timing"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for i in range(p):
+        img = open(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "index.dat"), "rb").read()
+        d = oracle.index_validate(img)
+        assert d["num_data"] == (gold["index"][i]["num_data"])
+    t0 = time.time()
+    out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q",
+                                   os.path.join(GOLDEN, "test_graph", "query_graph.graph"), "-m", "online", "-p", str(p)],
+                                  text=True)
+    dt = time.time() - t0
+    assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
+    # the reference skipped its ~40 s insert loop because index.dat already existed (custom.h:222-235)
+    assert dt < 25, dt
