@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
     ap.add_argument("--fill-variant", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-index", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="15000,150000")
     args = ap.parse_args()
 
@@ -201,6 +202,21 @@ def main():
     if world > 1:
         out["halo"] = sb.stats
 
+    # index-build wallclock (second half of BASELINE.json's metric): R*-tree file image of every path of
+    # partition 0 (p = 1 at N = 1), bulk-loaded on the device; measured outside the timed steps
+    if world == 1 and not args.no_index and not args.ids_only:
+        ib = []
+        for _ in range(2):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            img, nbytes, hdr = eng.build_index_device(total, L, out_ids)
+            ev1.record()
+            torch.cuda.synchronize()
+            ib.append(ev0.elapsed_time(ev1))
+        out["index_build"] = dict(wallclock_ms=min(ib), first_call_ms=ib[0], points=total, file_bytes=nbytes,
+                                  node_blocks=hdr[1], leaves=hdr[4], where="device image of index.dat (not written to disk)",
+                                  reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))

@@ -48,6 +48,7 @@ struct Options {
     int gpus = 1;
     uint64_t chunk_paths = 32ull << 20;
     bool allow_large = false, timing = false, sidecars = false, write_index = false;
+    bool same_device = false;  // testing aid: all --gpus contexts on device 0
 };
 
 double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -97,6 +98,7 @@ Options parse_args(int argc, char **argv)
         if (a == "--timing") { o.timing = true; continue; }
         if (a == "--sidecars") { o.sidecars = true; continue; }
         if (a == "--index") { o.write_index = true; continue; }
+        if (a == "--same-device") { o.same_device = true; continue; }
         if (a.rfind("--", 0) == 0) {
             std::string name = a.substr(2);
             size_t eq = name.find('=');
@@ -260,12 +262,12 @@ int main(int argc, char **argv)
     // ---- device setup: one context per GPU, each holding the graph and a slab of the order ----
     const int ndev = gnnpe_device_count();
     if (ndev <= 0) die("no HIP device: this tool has no CPU fallback");
-    if (o.gpus < 1 || o.gpus > ndev) die("--gpus " + std::to_string(o.gpus) + " but " + std::to_string(ndev) + " device(s) present");
+    if (o.gpus < 1 || (o.gpus > ndev && !o.same_device)) die("--gpus " + std::to_string(o.gpus) + " but " + std::to_string(ndev) + " device(s) present");
     std::vector<double> table((size_t)std::max<uint32_t>(g.labels_count, 1) * o.vde_dim);
     check(gnnpe_host_label_table(std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "label table");
     std::vector<Device> devs(o.gpus);
     for (int d = 0; d < o.gpus; d++) {
-        devs[d].ctx = gnnpe_create(d);
+        devs[d].ctx = gnnpe_create(o.same_device ? 0 : d);
         if (!devs[d].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
         check(gnnpe_load_csr(devs[d].ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
         check(gnnpe_set_order(devs[d].ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");

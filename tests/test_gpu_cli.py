@@ -124,3 +124,27 @@ def test_text_rendering_edge_values(oracle):
         eng.sync()
         assert bytes(out[:nb].cpu().numpy()) == "".join(f"{v}\n" for v in want).encode()
     eng.close()
+
+
+@pytest.mark.parametrize("gpus", [2, 3, 8])
+def test_slab_split_writes_identical_files(tmp_path, gpus):
+    """SURVEY 8(e) invariant at process level: the files do not depend on the number of slabs.  The box
+    has one GPU, so the contexts share device 0 (--same-device); each still enumerates only its slab."""
+    g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(3000, 4)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    outs = []
+    for n in (1, gpus):
+        d = str(tmp_path / f"n{n}")
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 4)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "4", "--gpus", str(n), "--same-device", "--chunk", "50000"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(d)
+    rel = ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(4)]
+    for f in rel:
+        assert open(os.path.join(outs[0], f), "rb").read() == open(os.path.join(outs[1], f), "rb").read(), f
