@@ -184,11 +184,21 @@ def main():
     fill_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ms])) if fill_ms else float("nan")
     bpp = (4 * L + 16) if args.ids_only else bytes_per_path(L, e)
     achieved = total * bpp / (fill_avg_ms / 1e3) / 1e9
+    # HBM traffic of the fill launch from the committed PMC passes (profiles/, same command and config);
+    # FETCH_SIZE carries the gfx950 x2 correction for wide streams, so this is an upper bound
+    traffic, traffic_note = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fill.json")
+    if (os.path.exists(pmc) and world == 1 and args.fill_variant == 9 and not args.ids_only
+            and (args.n, args.m, e) == (1_000_000, 10_000_000, 2)):
+        d = json.load(open(pmc))["derived"]
+        traffic = d["traffic_bytes_high"] / 1e9
+        traffic_note = (f"GB per launch from profiles/r01_pmc_fill.json: WRITE_SIZE {d['write_bytes'] / 1e9:.1f} + "
+                        f"2 x FETCH_SIZE {d['fetch_bytes_raw'] / 1e9:.1f} (raw sum {d['traffic_bytes_low'] / 1e9:.1f})")
     kname = {0: "k_fill_tiled", 1: "k_fill_edge_wave", 2: "k_fill_b", 3: "k_fill_s", 4: "k_fill_s_staged",
              5: "k_fill_s_staged"}.get(args.fill_variant, binding.load().gnnpe_fill_kernel_name().decode())
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_path=bpp, paths_per_launch=total,
-                    launch_ms=fill_avg_ms)
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, bytes_per_path=bpp,
+                    paths_per_launch=total, launch_ms=fill_avg_ms)
 
     out = dict(metric="offline paths-embedded/sec + index-build wallclock, 1M-V/10M-E l=2",
                value_is="paths-embedded/sec of one device-resident pass (halo+vde+count+scan+fill)",
