@@ -103,11 +103,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    # debugging aid for boxes with one GPU: GNNPE_BENCH_SAME_DEVICE=1 puts every rank on device 0 and
+    # carries the collectives over gloo (RCCL refuses two ranks on one device).  Never used by the driver.
+    same_device = os.environ.get("GNNPE_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     L, e = 3, args.e
     g = synth.gnm_graph(args.n, args.m, n_labels=args.labels, seed=args.seed)
@@ -174,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if same_device else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     global_total = sb.global_total

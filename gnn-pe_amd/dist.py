@@ -86,8 +86,28 @@ class SlabBuild:
         self.tot_all = torch.zeros(world, dtype=torch.int64, device=device)
         self.stats = {}
 
+    # Collectives.  With backend "nccl" (RCCL) device tensors go straight to the collective.  A gloo
+    # group with device tensors (single-GPU debugging of the N>1 flow: several ranks sharing one
+    # device, where RCCL refuses duplicate GPUs) stages through host memory.
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def _a2a(self, out, inp, out_splits, in_splits):
+        if self._staged(out):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                   group=self.group)
+            out.copy_(o)
+            return
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+
+    def _allgather(self, out_flat, inp_flat):
+        if self._staged(out_flat):
+            o = torch.empty(out_flat.shape, dtype=out_flat.dtype)
+            dist.all_gather_into_tensor(o, inp_flat.cpu(), group=self.group)
+            out_flat.copy_(o)
+            return
+        dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
 
     def exchange_halo(self):
         eng, R = self.eng, self.world
@@ -138,7 +158,7 @@ class SlabBuild:
         b = self.bounds
         eng.vde(want=False)
         eng.vde_pack_slab(int(b[self.rank]), int(b[self.rank + 1]), self.vde_send)
-        dist.all_gather_into_tensor(self.vde_all.view(-1), self.vde_send.view(-1), group=self.group)
+        self._allgather(self.vde_all.view(-1), self.vde_send.view(-1))
         for r in range(R):
             if r != self.rank and b[r + 1] > b[r]:
                 eng.vde_unpack_slab(int(b[r]), int(b[r + 1]), self.vde_all[r])
@@ -146,7 +166,7 @@ class SlabBuild:
     def count(self):
         total = self.eng.count_paths(2)
         mine = torch.tensor([total], dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(self.tot_all, mine, group=self.group)
+        self._allgather(self.tot_all, mine)
         tots = [int(x) for x in self.tot_all.tolist()]
         self.local_total = total
         self.base = sum(tots[:self.rank])
