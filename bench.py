@@ -79,9 +79,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--m", type=int, default=10_000_000)
-    ap.add_argument("--e", type=int, default=2)
+    ap.add_argument("--vertices", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--edges", dest="m", type=int, default=10_000_000)
+    ap.add_argument("--embedding", dest="e", type=int, default=2)
     ap.add_argument("--labels", type=int, default=64)
     ap.add_argument("--seed", type=int, default=synth.SEED)
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
