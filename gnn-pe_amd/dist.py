@@ -70,10 +70,12 @@ class SlabBuild:
         self.bounds = np.ascontiguousarray(bounds, np.uint32)
         self.rank, self.world, self.device, self.group = rank, world, device, group
         i32 = dict(dtype=torch.int32, device=device)
+        # rows I may need: < n.  rows peers may request from me: every peer can ask for all of mine.
+        mine = int(self.bounds[rank + 1]) - int(self.bounds[rank])
         self.need = torch.zeros(max(self.n, 1), **i32)
-        self.req = torch.zeros(max(self.n, 1), **i32)
-        self.deg_out = torch.zeros(max(self.n, 1), **i32)
         self.deg_in = torch.zeros(max(self.n, 1), **i32)
+        self.req = torch.zeros(max(mine * max(world - 1, 1), 1), **i32)
+        self.deg_out = torch.zeros(max(mine * max(world - 1, 1), 1), **i32)
         self.cap = int(max(nbr_capacity, 1))
         own = int(nbr_capacity if owned_entries is None else owned_entries)
         self.send_cap = int(max(own * max(world - 1, 1), 1))
@@ -120,6 +122,7 @@ class SlabBuild:
         self._a2a(rc, sc, [1] * R, [1] * R)
         req_counts = [int(x) for x in rc.tolist()]
         n_req = sum(req_counts)
+        assert n_need <= self.need.numel() and n_req <= self.req.numel(), (n_need, n_req)
         # 2. the requested vertex ids
         req = self.req[:n_req]
         self._a2a(req, self.need[:n_need], req_counts, need_counts)
