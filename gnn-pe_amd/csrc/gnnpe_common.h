@@ -111,7 +111,10 @@ struct gnnpe_ctx {
     uint64_t total_paths = 0;
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, tile_edge, cub_tmp, scratch, mark, small;
     uint32_t tile_T = 0;  // tile size tile_edge was built for (0 = stale)
-    int fill_variant = 9, counted_variant = 9;  // 9 = record-driven wave-per-start fill (default)
+    int fill_variant = 10, counted_variant = 10;  // 10 = rank-sorted neighbour records (default; rows <= 64)
+    bool ranked_active = false;     // the last count built the variant-10 structures
+    bool ranked_vde_valid = false;  // ... with the current vde table inside the records
+    gnnpe::DevBuf rpairs, rrecs;
 
     // pinned host words for small read-backs
     uint64_t *h_pinned = nullptr;

@@ -11,6 +11,7 @@
 
 #include "gnnpe_common.h"
 #include "gnnpe_kernels.hip.h"
+#include "gnnpe_fill_ranked.hip.h"
 
 namespace gnnpe {
 
@@ -109,7 +110,7 @@ extern "C" {
 
 int gnnpe_abi_version(void) { return GNNPE_ABI_VERSION; }
 const char *gnnpe_last_error(void) { return g_err; }
-const char *gnnpe_fill_kernel_name(void) { return "k_fill_s_rec"; }
+const char *gnnpe_fill_kernel_name(void) { return "k_fill_ranked"; }
 
 gnnpe_ctx *gnnpe_create(int device_id)
 {
@@ -147,7 +148,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -453,6 +454,7 @@ static int run_vde(gnnpe_ctx *c)
     GNNPE_HIP_TRY(hipGetLastError());
     c->have_vde = true;
     c->nbr_vde_valid = false;
+    c->ranked_vde_valid = false;
     return GNNPE_OK;
 }
 
@@ -500,10 +502,45 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
                            begin, end, c->e, c->sorted.as<uint32_t>(), (const double *)dev_buf, c->vde.as<double>());
     GNNPE_HIP_TRY(hipGetLastError());
     c->nbr_vde_valid = false;
+    c->ranked_vde_valid = false;
     return GNNPE_OK;
 }
 
 static int ensure_nbr_vde(gnnpe_ctx *c);
+
+static bool ranked_supported_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
+
+// variant 10: rank-sorted neighbour records + per-pair {suffix start, count, G} (gnnpe_fill_ranked.hip.h)
+static int build_ranked(gnnpe_ctx *c, uint64_t ne)
+{
+    const uint32_t e = c->have_table ? c->e : 2;
+    const size_t rec_bytes = 8 + 8 * (size_t)e;
+    int rc;
+    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * rec_bytes)))
+        return rc;
+    GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
+    if (c->n_held) {
+        const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+        const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
+        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+#define GNNPE_RR(EE)                                                                                              \
+    hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin, c->slab_end,  \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),             \
+                       c->rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(), vde,             \
+                       c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>())
+        switch (e) {
+        case 1: GNNPE_RR(1); break;
+        case 2: GNNPE_RR(2); break;
+        case 3: GNNPE_RR(3); break;
+        case 4: GNNPE_RR(4); break;
+        default: GNNPE_RR(8); break;
+        }
+#undef GNNPE_RR
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    c->ranked_vde_valid = c->have_vde;
+    return GNNPE_OK;
+}
 
 // ---- R2 count -----------------------------------------------------------------------------------
 int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
@@ -532,22 +569,40 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         (rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->eoff.reserve((ne + 2) * 8)) ||
         (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4)))
         return rc;
-    const bool need_perm = c->fill_variant < 6;  // erow / pnbr feed the pair-indexed kernels only
+    c->ranked_active = false;
+    if (c->fill_variant == 10 && ranked_supported_e(c->have_table ? c->e : 2)) {
+        // rows longer than 64 cannot carry a one-word id-position set: fall back to variant 9
+        if ((rc = c->small.reserve(256))) return rc;
+        uint32_t *d_max = c->small.as<uint32_t>() + 4;
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(c->cub_tmp.p, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
+        uint64_t mx = 0;
+        if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
+        c->ranked_active = (uint32_t)mx <= 64;
+    }
+    const int eff_variant = (c->fill_variant == 10 && !c->ranked_active) ? 9 : c->fill_variant;
+    const bool need_perm = eff_variant < 6;  // erow / pnbr feed the pair-indexed kernels only
     if (len && need_perm)
         hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
                            c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
                            c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
-    // 2. rank of every held neighbour entry (turns the rank test into a coalesced stream)
-    if (c->nbr_used)
+    // 2. rank of every held neighbour entry (turns the rank test into a coalesced stream); the ranked
+    //    variant gathers ranks inside its row kernel instead
+    if (c->nbr_used && !c->ranked_active)
         hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                            c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
     // 3. per-pair counts and their exclusive scan (global slot of every pair's first path)
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
-    if (c->fill_variant >= 2) {
+    if (c->ranked_active) {
+        if ((rc = build_ranked(c, ne))) return rc;
+    } else if (eff_variant >= 2) {
         // middle-vertex-centric: each row is read once; counts land at the pair's emission index
         if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (c->fill_variant >= 6) {
+        if (eff_variant >= 6) {
             if (c->nbr_used)
                 hipLaunchKernelGGL(k_count_flat, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb,
                                    se, c->nbr_row.as<uint32_t>(), c->adj_start.as<uint32_t>(),
@@ -564,9 +619,24 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
                            c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
     }
     GNNPE_HIP_TRY(hipGetLastError());
-    if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) return rc;
+    if (c->ranked_active) {
+        hipcub::TransformInputIterator<uint64_t, CntOfPair, const RankedPair *> it(c->rpairs.as<RankedPair>(), CntOfPair());
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+    } else if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) {
+        return rc;
+    }
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
-    if (c->fill_variant >= 6 && len) {
+    if (c->ranked_active && len) {
+        if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec)))) return rc;
+        hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
+                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                           c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    } else if (eff_variant >= 6 && len) {
         if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec))) || (rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))))
             return rc;
         hipLaunchKernelGGL(k_pair_recs, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
@@ -580,10 +650,9 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->total_paths = w;
     c->l = l;
     c->counted = true;
-    c->counted_variant = c->fill_variant;
-    const bool b_centric = c->fill_variant >= 2 && c->fill_variant != 5 && c->fill_variant != 7 && c->fill_variant != 9 &&
-                           c->have_table && (c->e <= 4 || c->e == 8);
-    if (c->have_vde && !b_centric && (rc = ensure_nbr_vde(c))) return rc;
+    c->counted_variant = eff_variant;
+    const bool needs_nbr_vde = (eff_variant == 0 || eff_variant == 1 || eff_variant == 5 || eff_variant == 7 || eff_variant == 9);
+    if (c->have_vde && needs_nbr_vde && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -643,10 +712,16 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.member = c->member.as<uint32_t>();
     P.eoff = c->eoff.as<uint64_t>();
     const uint32_t e_eff = c->have_table ? c->e : 2;
-    const bool b_centric = c->fill_variant == 2 && (e_eff <= 4 || e_eff == 8);
-    const bool s_wave = (c->fill_variant == 3 || c->fill_variant == 4 || c->fill_variant == 6 || c->fill_variant == 8) &&
-                        (e_eff <= 4 || e_eff == 8);
-    if (d_pde && !b_centric && !s_wave) {
+    const int fv = c->counted_variant;  // what gnnpe_count_paths prepared (10 may have fallen back to 9)
+    const bool e_ok = ranked_supported_e(e_eff);
+    const bool b_centric = fv == 2 && e_ok;
+    const bool gathers_table = (fv == 3 || fv == 4 || fv == 6 || fv == 8) && e_ok;
+    if (fv == 10) {
+        if (d_pde && !c->ranked_vde_valid) {  // records were built before gnnpe_vde: rebuild them with embeddings
+            int rc = build_ranked(c, c->n_edges);
+            if (rc) return rc;
+        }
+    } else if (d_pde && !b_centric && !gathers_table) {
         int rc = ensure_nbr_vde(c);
         if (rc) return rc;
     }
@@ -666,8 +741,25 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.tile_edge = nullptr;
     P.tile0 = 0;
     const bool pdl = d_pdl != nullptr;
+    if (fv == 10) {
+        P.e = e_eff;
+        const uint32_t len = c->slab_end - c->slab_begin;
+        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        const StartRec *sr = c->srec.as<StartRec>();
+        const RankedPair *rp = c->rpairs.as<RankedPair>();
+#define GNNPE_FK(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, rp, c->rrecs.as<RankedNbr<EE>>(), len)
+        switch (e_eff) {
+        case 1: GNNPE_FK(1); break;
+        case 2: GNNPE_FK(2); break;
+        case 3: GNNPE_FK(3); break;
+        case 4: GNNPE_FK(4); break;
+        default: GNNPE_FK(8); break;
+        }
+#undef GNNPE_FK
+        GNNPE_HIP_TRY(hipGetLastError());
+        return GNNPE_OK;
+    }
     if (b_centric) {
-        GNNPE_REQUIRE(c->counted_variant == 2, GNNPE_ERR_ARG, "fill variant changed after gnnpe_count_paths");
         FillBParams B;
         B.held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         B.adj_start = P.adj_start;
@@ -698,7 +790,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
-    if (c->fill_variant == 3 && (e_eff <= 4 || e_eff == 8)) {
+    if (fv == 3 && e_ok) {
         P.e = e_eff;
         const uint32_t len = c->slab_end - c->slab_begin;
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
@@ -713,9 +805,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
-    if (c->fill_variant >= 6 && (e_eff <= 4 || e_eff == 8)) {
+    if (fv >= 6 && e_ok) {
         P.e = e_eff;
-        const int fv = c->fill_variant;
         const bool nv = (fv == 7 || fv == 9);
         const bool r2 = (fv >= 8);  // variants 8/9: non-temporal output stores
         const uint32_t len = c->slab_end - c->slab_begin;
@@ -740,9 +831,9 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
-    if (c->fill_variant >= 4 && (e_eff <= 4 || e_eff == 8)) {
+    if (fv >= 4 && e_ok) {
         P.e = e_eff;
-        const bool nv = c->fill_variant == 5;
+        const bool nv = fv == 5;
         const uint32_t len = c->slab_end - c->slab_begin;
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const uint32_t *poffs = c->poffs.as<uint32_t>();
@@ -762,7 +853,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipGetLastError());
         return GNNPE_OK;
     }
-    const uint32_t T = (c->fill_variant == 0) ? tile_size_for(P.e, pdl) : 0;
+    const uint32_t T = (fv == 0) ? tile_size_for(P.e, pdl) : 0;
     if (T) {
         int rc = ensure_tiles(c, T);
         if (rc) return rc;
@@ -826,7 +917,7 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= 0 && variant <= 9, GNNPE_ERR_ARG, "fill variant must be 0..9");
+    GNNPE_REQUIRE(c && variant >= 0 && variant <= 10, GNNPE_ERR_ARG, "fill variant must be 0..10");
     if (variant != c->fill_variant) {
         c->counted = false;
         c->tile_T = 0;

@@ -24,7 +24,7 @@ def binding():
     return b
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]  # output-tiled, pair-per-wave, middle-vertex-centric: identical outputs required
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]  # output-tiled, pair-per-wave, middle-vertex-centric: identical outputs required
 
 
 def _engine(binding, g, sn, mem, p, e, variant=None):
@@ -39,7 +39,7 @@ def _engine(binding, g, sn, mem, p, e, variant=None):
 
 
 def test_library_reports_its_kernel(binding):
-    assert binding.load().gnnpe_fill_kernel_name().decode() == "k_fill_s_rec"
+    assert binding.load().gnnpe_fill_kernel_name().decode() == "k_fill_ranked"
 
 
 @pytest.mark.parametrize("e", [2, 8])
