@@ -633,8 +633,8 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     if (c->ranked_active && len) {
         if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec)))) return rc;
         hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                           c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
+                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                           c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
         GNNPE_HIP_TRY(hipGetLastError());
     } else if (eff_variant >= 6 && len) {
         if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec))) || (rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))))
@@ -643,8 +643,8 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
                            c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                            c->poffs.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->prec.as<PairRec>());
         hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                           c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
+                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                           c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
         GNNPE_HIP_TRY(hipGetLastError());
     }
     c->total_paths = w;

@@ -18,11 +18,11 @@
 
 namespace gnnpe {
 
-// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s))
-struct __attribute__((aligned(8))) RankedPair {
-    uint32_t b;       // middle vertex
+// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)).
+// 16 bytes so the scattered store of the row kernel is ONE dwordx4; the middle vertex itself is
+// re-read from N(s) (contiguous) by the fill, the count is popcount(G).
+struct __attribute__((aligned(16))) RankedPair {
     uint32_t sstart;  // first kept record: adj_start[b] + (rank-position of s in N(b)) + 1
-    uint32_t cnt;     // kept records = popcount(G)
     uint32_t pad;
     uint64_t G;       // id-positions of N(b) with rank > rank[s]
 };
@@ -33,14 +33,14 @@ template <int E> struct __attribute__((aligned(8))) RankedNbr {
 };
 
 struct CntOfPair {
-    __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)p.cnt; }
+    __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)__popcll(p.G); }
 };
 
 // One wave per held row b (degree <= 64), one lane per neighbour u_j:
 //   G_j  = { i : rank[u_i] > rank[u_j] }          (d wave-uniform readlanes)
 //   p_j  = d - 1 - |G_j|                            rank-position of u_j inside the row
 //   recs[adj_start + p_j] = { u_j, j, vde[u_j] }    the row, sorted by rank
-//   pairs[index of (s = u_j, b)] = { b, adj_start + p_j + 1, |G_j|, G_j }   when u_j starts paths here
+//   pairs[index of (s = u_j, b)] = { adj_start + p_j + 1, G_j }              when u_j starts paths here
 template <int E>
 __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32_t *__restrict__ held,
                                                    uint32_t slab_begin, uint32_t slab_end,
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             recs[st + p] = rec;
             const uint32_t pi = pair_index(rp, r, slab_begin, slab_end, poffs);
             if (pi != kNoEdge) {
-                RankedPair pr = {b, st + p + 1, cnt, 0u, G};
+                RankedPair pr = {st + p + 1, 0u, G};
                 pairs[pi] = pr;
             }
         }
@@ -120,23 +120,28 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
 
         for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
             const uint32_t k = k0 + lane;
-            RankedPair pr = {0u, 0u, 0u, 0u, 0ull};
-            if (k < ds) pr = pairs[e0 + k];
-            uint32_t incl = pr.cnt;
+            RankedPair pr = {0u, 0u, 0ull};
+            uint32_t bk = 0;
+            if (k < ds) {
+                pr = pairs[e0 + k];
+                bk = P.nbrs[sr.a_s + k];  // the k-th neighbour of s is the pair's middle vertex
+            }
+            const uint32_t pcnt = (uint32_t)__popcll(pr.G);
+            uint32_t incl = pcnt;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t t = __shfl_up(incl, off);
                 if (lane >= (unsigned)off) incl += t;
             }
             const uint32_t C = rl32(incl, 63);
-            s_cs[wv][lane] = incl - pr.cnt;
+            s_cs[wv][lane] = incl - pcnt;
             s_ss[wv][lane] = pr.sstart;
-            s_b[wv][lane] = pr.b;
+            s_b[wv][lane] = bk;
             s_G[wv][lane] = pr.G;
             if (lane == 0) s_cs[wv][64] = C;
             if (want_pde && k < ds) {
 #pragma unroll
-                for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = P.vde[(uint64_t)pr.b * E + kk];
+                for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = P.vde[(uint64_t)bk * E + kk];
             }
             __builtin_amdgcn_wave_barrier();
 

@@ -1131,6 +1131,7 @@ struct __attribute__((aligned(16))) PairRec {
 struct __attribute__((aligned(16))) StartRec {
     uint64_t base, end;  // first / one-past-last output slot of this start vertex
     uint32_t e0, ds, s, part;
+    uint32_t a_s, pad0, pad1, pad2;  // adj_start[s]: N(s) = the middle vertices of its pairs, in pair order
 };
 
 __global__ void k_pair_recs(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
@@ -1154,13 +1155,14 @@ __global__ void k_pair_recs(uint32_t len, uint32_t slab_begin, const uint32_t *_
 }
 
 __global__ void k_start_recs(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
-                             const uint32_t *__restrict__ member, const uint32_t *__restrict__ poffs,
+                             const uint32_t *__restrict__ member, const uint32_t *__restrict__ adj_start,
+                             const uint32_t *__restrict__ poffs,
                              const uint64_t *__restrict__ eoff, StartRec *__restrict__ recs)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t e0 = poffs[i], e1 = poffs[i + 1];
         const uint32_t s = sorted[slab_begin + i];
-        StartRec r = {eoff[e0], eoff[e1], e0, e1 - e0, s, member[s]};
+        StartRec r = {eoff[e0], eoff[e1], e0, e1 - e0, s, member[s], adj_start[s], 0u, 0u, 0u};
         recs[i] = r;
     }
 }
