@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--labels", type=int, default=64)
     ap.add_argument("--seed", type=int, default=synth.SEED)
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
-    ap.add_argument("--fill-variant", type=int, default=10)
+    ap.add_argument("--fill-variant", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="15000,150000")
@@ -196,15 +196,13 @@ def main():
     # FETCH_SIZE carries the gfx950 x2 correction for wide streams, so this is an upper bound
     traffic, traffic_note = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_fill.json")
-    if (os.path.exists(pmc) and world == 1 and args.fill_variant == 10 and not args.ids_only
+    if (os.path.exists(pmc) and world == 1 and args.fill_variant == 4 and not args.ids_only
             and (args.n, args.m, e) == (1_000_000, 10_000_000, 2)):
         d = json.load(open(pmc))["derived"]
         traffic = d["traffic_bytes_high"] / 1e9
         traffic_note = (f"GB per launch from profiles/r01_pmc_fill.json: WRITE_SIZE {d['write_bytes'] / 1e9:.1f} + "
                         f"2 x FETCH_SIZE {d['fetch_bytes_raw'] / 1e9:.1f} (raw sum {d['traffic_bytes_low'] / 1e9:.1f})")
-    kname = {0: "k_fill_tiled", 1: "k_fill_edge_wave", 2: "k_fill_b", 3: "k_fill_s", 4: "k_fill_s_staged",
-             5: "k_fill_s_staged", 6: "k_fill_s_rec", 7: "k_fill_s_rec", 8: "k_fill_s_rec",
-             9: "k_fill_s_rec"}.get(args.fill_variant, binding.load().gnnpe_fill_kernel_name().decode())
+    kname = {1: "k_fill_edge_wave", 2: "k_fill_b", 3: "k_fill_s_rec", 4: "k_fill_ranked"}[args.fill_variant]
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms)

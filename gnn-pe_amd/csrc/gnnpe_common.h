@@ -109,11 +109,9 @@ struct gnnpe_ctx {
     uint32_t l = 0;
     uint64_t n_edges = 0;  // directed (start, middle) pairs of the slab
     uint64_t total_paths = 0;
-    gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, tile_edge, cub_tmp, scratch, mark, small;
-    uint32_t tile_T = 0;  // tile size tile_edge was built for (0 = stale)
-    int fill_variant = 10, counted_variant = 10;  // 10 = rank-sorted neighbour records (default; rows <= 64)
-    bool ranked_active = false;     // the last count built the variant-10 structures
-    bool ranked_vde_valid = false;  // ... with the current vde table inside the records
+    gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
+    int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default; rows <= 64, else 3)
+    bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf rpairs, rrecs;
 
     // pinned host words for small read-backs

@@ -11,6 +11,9 @@
 
 #include "gnnpe_common.h"
 #include "gnnpe_kernels.hip.h"
+#include "gnnpe_fill_pairwave.hip.h"
+#include "gnnpe_fill_middle.hip.h"
+#include "gnnpe_fill_start.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
 
 namespace gnnpe {
@@ -72,36 +75,6 @@ static int ensure_rank_arrays(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-template <int E, int T, int CH, bool PDL> static void launch_tiled(const FillParams &P, uint32_t ntiles, hipStream_t s)
-{
-    hipLaunchKernelGGL((k_fill_tiled<E, T, CH, PDL>), dim3(ntiles), dim3(256), 0, s, P);
-}
-
-// tile size per (e, pde_label?) -- keeps the staged tile near 30-50 KiB of LDS
-static uint32_t tile_size_for(uint32_t e, bool pdl)
-{
-    switch (e) {
-    case 1: return 512;
-    case 2: return pdl ? 256 : 512;
-    case 3: return pdl ? 128 : 256;
-    case 4: return pdl ? 128 : 256;
-    case 8: return pdl ? 64 : 128;
-    default: return 0;  // no tiled instantiation: edge-per-wave variant
-    }
-}
-
-static bool launch_tiled_dispatch(uint32_t e, bool pdl, const FillParams &P, uint32_t ntiles, hipStream_t s)
-{
-    switch (e) {
-    case 1: pdl ? launch_tiled<1, 512, 256, true>(P, ntiles, s) : launch_tiled<1, 512, 256, false>(P, ntiles, s); return true;
-    case 2: pdl ? launch_tiled<2, 256, 256, true>(P, ntiles, s) : launch_tiled<2, 512, 256, false>(P, ntiles, s); return true;
-    case 3: pdl ? launch_tiled<3, 128, 128, true>(P, ntiles, s) : launch_tiled<3, 256, 128, false>(P, ntiles, s); return true;
-    case 4: pdl ? launch_tiled<4, 128, 128, true>(P, ntiles, s) : launch_tiled<4, 256, 128, false>(P, ntiles, s); return true;
-    case 8: pdl ? launch_tiled<8, 64, 64, true>(P, ntiles, s) : launch_tiled<8, 128, 64, false>(P, ntiles, s); return true;
-    default: return false;
-    }
-}
-
 }  // namespace gnnpe
 
 using namespace gnnpe;
@@ -148,7 +121,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->tile_edge, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -219,7 +192,6 @@ static void invalidate_derived(gnnpe_ctx *c)
     c->have_vde = false;
     c->nbr_vde_valid = false;
     c->counted = false;
-    c->tile_T = 0;
 }
 
 int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_t *nbrs, const uint32_t *labels)
@@ -354,7 +326,6 @@ int gnnpe_set_order(gnnpe_ctx *c, const uint32_t *sorted_nodes, const uint32_t *
     c->p = p;
     c->have_order = true;
     c->counted = false;
-    c->tile_T = 0;
     return GNNPE_OK;
 }
 
@@ -366,7 +337,6 @@ int gnnpe_set_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end)
     c->slab_end = end;
     c->slab_set = true;
     c->counted = false;
-    c->tile_T = 0;
     return GNNPE_OK;
 }
 
@@ -506,17 +476,38 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
     return GNNPE_OK;
 }
 
-static int ensure_nbr_vde(gnnpe_ctx *c);
+// ---- R2 / R5: enumeration ---------------------------------------------------------------------------
+// Four implementations with identical outputs:
+//   1 pair-wave   one wave per (s, b) pair, direct stores            (gnnpe_fill_pairwave.hip.h)
+//   2 middle      middle-vertex-centric count + fill                 (gnnpe_fill_middle.hip.h)
+//   3 start       wave per start vertex over id-sorted rows          (gnnpe_fill_start.hip.h)
+//   4 ranked      wave per start vertex over rank-sorted records     (gnnpe_fill_ranked.hip.h)  default
+// Variant 4 needs rows of degree <= 64 and falls back to 3 otherwise.
+enum { kVarPairWave = 1, kVarMiddle = 2, kVarStart = 3, kVarRanked = 4 };
 
-static bool ranked_supported_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
+static bool fast_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
-// variant 10: rank-sorted neighbour records + per-pair {suffix start, count, G} (gnnpe_fill_ranked.hip.h)
+// nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (variants 1 and 3 stream it)
+static int ensure_nbr_vde(gnnpe_ctx *c)
+{
+    if (c->nbr_vde_valid) return GNNPE_OK;
+    GNNPE_REQUIRE(c->have_vde, GNNPE_ERR_ARG, "embeddings requested before gnnpe_vde");
+    int rc;
+    if ((rc = c->nbr_vde.reserve((c->nbr_used + 1) * c->e * 8))) return rc;
+    if (c->nbr_used)
+        hipLaunchKernelGGL(k_gather_rows_f64, dim3(grid_for(c->nbr_used * c->e)), dim3(kBlock), 0, c->stream,
+                           c->nbr_used, c->e, c->nbrs.as<uint32_t>(), c->vde.as<double>(), c->nbr_vde.as<double>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->nbr_vde_valid = true;
+    return GNNPE_OK;
+}
+
+// variant 4: rank-sorted neighbour records + per-pair {suffix start, G}
 static int build_ranked(gnnpe_ctx *c, uint64_t ne)
 {
     const uint32_t e = c->have_table ? c->e : 2;
-    const size_t rec_bytes = 8 + 8 * (size_t)e;
     int rc;
-    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * rec_bytes)))
+    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))))
         return rc;
     GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
     if (c->n_held) {
@@ -542,7 +533,22 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
     return GNNPE_OK;
 }
 
-// ---- R2 count -----------------------------------------------------------------------------------
+static int max_held_degree(gnnpe_ctx *c, uint32_t *out)
+{
+    int rc;
+    if ((rc = c->small.reserve(256))) return rc;
+    uint32_t *d_max = c->small.as<uint32_t>() + 4;
+    size_t tb = 0;
+    GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
+    if ((rc = c->cub_tmp.reserve(tb))) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(c->cub_tmp.p, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
+    uint64_t mx = 0;
+    if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
+    *out = (uint32_t)mx;
+    return GNNPE_OK;
+}
+
 int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
 {
     GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
@@ -552,10 +558,20 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     // The reference enumerates 3-vertex paths whatever -l says; l=2 is the parity path.
     GNNPE_REQUIRE(l == 2, GNNPE_ERR_UNSUPPORTED, "path length l=%u: only l=2 (3-vertex paths) is implemented", l);
     const uint32_t sb = c->slab_begin, se = c->slab_end, len = se - sb;
+    const uint32_t e = c->have_table ? c->e : 2;
     c->counted = false;
-    c->tile_T = 0;
 
-    // 1. slab rows -> directed (s, b) pairs in emission order
+    // which implementation runs: embedding widths without a specialised kernel use the generic pair-wave
+    // kernel; the ranked variant needs every held row to fit one 64-bit id-position set
+    int var = c->fill_variant;
+    if (!fast_e(e)) var = kVarPairWave;
+    if (var == kVarRanked && c->n) {
+        uint32_t mx = 0;
+        if ((rc = max_held_degree(c, &mx))) return rc;
+        if (mx > 64) var = kVarStart;
+    }
+
+    // 1. slab rows -> directed (s, b) pairs in emission order: pair index = poffs[i] + position of b in N(s)
     if ((rc = c->poffs.reserve((size_t)(len + 2) * 4)) || (rc = c->scratch.reserve((size_t)(len + 2) * 8))) return rc;
     uint32_t *pdeg = c->scratch.as<uint32_t>();
     hipLaunchKernelGGL(k_slab_degrees, dim3(grid_for(len + 1)), dim3(kBlock), 0, c->stream, len, sb,
@@ -565,61 +581,47 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
     const uint64_t ne = (uint32_t)w;
     c->n_edges = ne;
-    if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4)) ||
-        (rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->eoff.reserve((ne + 2) * 8)) ||
-        (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4)))
-        return rc;
-    c->ranked_active = false;
-    if (c->fill_variant == 10 && ranked_supported_e(c->have_table ? c->e : 2)) {
-        // rows longer than 64 cannot carry a one-word id-position set: fall back to variant 9
-        if ((rc = c->small.reserve(256))) return rc;
-        uint32_t *d_max = c->small.as<uint32_t>() + 4;
-        size_t tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
-        if ((rc = c->cub_tmp.reserve(tb))) return rc;
-        tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(c->cub_tmp.p, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
-        uint64_t mx = 0;
-        if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
-        c->ranked_active = (uint32_t)mx <= 64;
-    }
-    const int eff_variant = (c->fill_variant == 10 && !c->ranked_active) ? 9 : c->fill_variant;
-    const bool need_perm = eff_variant < 6;  // erow / pnbr feed the pair-indexed kernels only
-    if (len && need_perm)
-        hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                           c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
-    // 2. rank of every held neighbour entry (turns the rank test into a coalesced stream); the ranked
-    //    variant gathers ranks inside its row kernel instead
-    if (c->nbr_used && !c->ranked_active)
-        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
-                           c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
-    // 3. per-pair counts and their exclusive scan (global slot of every pair's first path)
+    if ((rc = c->eoff.reserve((ne + 2) * 8))) return rc;
+
+    // 2. per-pair path counts
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
-    if (c->ranked_active) {
+    if (var == kVarRanked) {
         if ((rc = build_ranked(c, ne))) return rc;
-    } else if (eff_variant >= 2) {
-        // middle-vertex-centric: each row is read once; counts land at the pair's emission index
-        if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
+    } else {
+        if ((rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4))) return rc;
+        // rank of every held neighbour entry: the rank test becomes a contiguous stream
+        if (c->nbr_used)
+            hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
+                               c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (eff_variant >= 6) {
+        if (var == kVarPairWave) {
+            if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4))) return rc;
+            if (len)
+                hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
+                                   c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                                   c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
+            hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
+                               c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
+                               c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
+        } else if (var == kVarMiddle) {
+            if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
+            if (c->n_held)
+                hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
+                                   c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                                   c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                                   c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
+        } else {  // kVarStart
             if (c->nbr_used)
                 hipLaunchKernelGGL(k_count_flat, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb,
                                    se, c->nbr_row.as<uint32_t>(), c->adj_start.as<uint32_t>(),
                                    c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(),
                                    c->poffs.as<uint32_t>(), (uint32_t *)nullptr, c->ecnt.as<uint32_t>());
-        } else if (c->n_held)
-            hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
-                               c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                               c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                               c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
-    } else {
-        hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
-                           c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
+        }
+        GNNPE_HIP_TRY(hipGetLastError());
     }
-    GNNPE_HIP_TRY(hipGetLastError());
-    if (c->ranked_active) {
+
+    // 3. exclusive scan: eoff[pair] = output slot of the pair's first path; eoff[ne] = total
+    if (var == kVarRanked) {
         hipcub::TransformInputIterator<uint64_t, CntOfPair, const RankedPair *> it(c->rpairs.as<RankedPair>(), CntOfPair());
         size_t tb = 0;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
@@ -630,18 +632,16 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         return rc;
     }
     if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
-    if (c->ranked_active && len) {
+
+    // 4. records that shorten the fill's dependent-load chain (variants 3 and 4)
+    if ((var == kVarStart || var == kVarRanked) && len) {
         if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec)))) return rc;
-        hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
-                           c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
-        GNNPE_HIP_TRY(hipGetLastError());
-    } else if (eff_variant >= 6 && len) {
-        if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec))) || (rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))))
-            return rc;
-        hipLaunchKernelGGL(k_pair_recs, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                           c->poffs.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->prec.as<PairRec>());
+        if (var == kVarStart) {
+            if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec)))) return rc;
+            hipLaunchKernelGGL(k_pair_recs, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
+                               c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                               c->poffs.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->prec.as<PairRec>());
+        }
         hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
                            c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
                            c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
@@ -650,9 +650,9 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->total_paths = w;
     c->l = l;
     c->counted = true;
-    c->counted_variant = eff_variant;
-    const bool needs_nbr_vde = (eff_variant == 0 || eff_variant == 1 || eff_variant == 5 || eff_variant == 7 || eff_variant == 9);
-    if (c->have_vde && needs_nbr_vde && (rc = ensure_nbr_vde(c))) return rc;
+    c->counted_variant = var;
+    // embeddings of the adjacency entries, when the vde table is already there (keeps it out of the fill)
+    if (c->have_vde && (var == kVarPairWave || var == kVarStart) && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -664,35 +664,6 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     return GNNPE_OK;
 }
 
-// nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (needs the complete vde table)
-static int ensure_nbr_vde(gnnpe_ctx *c)
-{
-    if (c->nbr_vde_valid) return GNNPE_OK;
-    GNNPE_REQUIRE(c->have_vde, GNNPE_ERR_ARG, "embeddings requested before gnnpe_vde");
-    int rc;
-    if ((rc = c->nbr_vde.reserve((c->nbr_used + 1) * c->e * 8))) return rc;
-    if (c->nbr_used)
-        hipLaunchKernelGGL(k_gather_rows_f64, dim3(grid_for(c->nbr_used * c->e)), dim3(kBlock), 0, c->stream,
-                           c->nbr_used, c->e, c->nbrs.as<uint32_t>(), c->vde.as<double>(), c->nbr_vde.as<double>());
-    GNNPE_HIP_TRY(hipGetLastError());
-    c->nbr_vde_valid = true;
-    return GNNPE_OK;
-}
-
-static int ensure_tiles(gnnpe_ctx *c, uint32_t T)
-{
-    if (c->tile_T == T) return GNNPE_OK;
-    const uint64_t ntiles = (c->total_paths + T - 1) / T;
-    int rc;
-    if ((rc = c->tile_edge.reserve((ntiles + 2) * 4))) return rc;
-    if (c->n_edges)
-        hipLaunchKernelGGL(k_tile_edges, dim3(grid_for(c->n_edges)), dim3(kBlock), 0, c->stream, c->n_edges, T,
-                           c->eoff.as<uint64_t>(), c->tile_edge.as<uint32_t>());
-    GNNPE_HIP_TRY(hipGetLastError());
-    c->tile_T = T;
-    return GNNPE_OK;
-}
-
 static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids, void *d_pde, void *d_pdl,
                        void *d_part)
 {
@@ -701,6 +672,13 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                   (unsigned long long)begin, (unsigned long long)end, (unsigned long long)c->total_paths);
     GNNPE_REQUIRE((!d_pde && !d_pdl) || c->have_vde, GNNPE_ERR_ARG, "gnnpe_fill_paths: embeddings requested before gnnpe_vde");
     if (begin == end) return GNNPE_OK;
+    const int var = c->counted_variant;
+    const uint32_t e = c->have_table ? c->e : 2;
+    const uint32_t len = c->slab_end - c->slab_begin;
+    int rc;
+    if (d_pde && (var == kVarPairWave || var == kVarStart) && (rc = ensure_nbr_vde(c))) return rc;
+    if (d_pde && var == kVarRanked && !c->ranked_vde_valid && (rc = build_ranked(c, c->n_edges))) return rc;
+
     FillParams P;
     P.erow = c->erow.as<uint32_t>();
     P.pnbr = c->pnbr.as<uint32_t>();
@@ -711,68 +689,55 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.sorted = c->sorted.as<uint32_t>();
     P.member = c->member.as<uint32_t>();
     P.eoff = c->eoff.as<uint64_t>();
-    const uint32_t e_eff = c->have_table ? c->e : 2;
-    const int fv = c->counted_variant;  // what gnnpe_count_paths prepared (10 may have fallen back to 9)
-    const bool e_ok = ranked_supported_e(e_eff);
-    const bool b_centric = fv == 2 && e_ok;
-    const bool gathers_table = (fv == 3 || fv == 4 || fv == 6 || fv == 8) && e_ok;
-    if (fv == 10) {
-        if (d_pde && !c->ranked_vde_valid) {  // records were built before gnnpe_vde: rebuild them with embeddings
-            int rc = build_ranked(c, c->n_edges);
-            if (rc) return rc;
-        }
-    } else if (d_pde && !b_centric && !gathers_table) {
-        int rc = ensure_nbr_vde(c);
-        if (rc) return rc;
-    }
     P.vde = c->vde.as<double>();
     P.x = c->x.as<double>();
     P.nbr_vde = c->nbr_vde.as<double>();
-    P.total = c->total_paths;
     P.n_edges = c->n_edges;
     P.begin = begin;
     P.end = end;
     P.slab_begin = c->slab_begin;
-    P.e = c->have_table ? c->e : 1;
+    P.e = e;
     P.out_ids = (uint32_t *)d_vids;
     P.out_pde = (double *)d_pde;
     P.out_pdl = (double *)d_pdl;
     P.out_part = (uint32_t *)d_part;
-    P.tile_edge = nullptr;
-    P.tile0 = 0;
-    const bool pdl = d_pdl != nullptr;
-    if (fv == 10) {
-        P.e = e_eff;
-        const uint32_t len = c->slab_end - c->slab_begin;
+
+#define GNNPE_BY_E(LAUNCH)        \
+    switch (e) {                  \
+    case 1: LAUNCH(1); break;     \
+    case 2: LAUNCH(2); break;     \
+    case 3: LAUNCH(3); break;     \
+    case 4: LAUNCH(4); break;     \
+    default: LAUNCH(8); break;    \
+    }
+    if (var == kVarRanked) {
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const StartRec *sr = c->srec.as<StartRec>();
         const RankedPair *rp = c->rpairs.as<RankedPair>();
-#define GNNPE_FK(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, rp, c->rrecs.as<RankedNbr<EE>>(), len)
-        switch (e_eff) {
-        case 1: GNNPE_FK(1); break;
-        case 2: GNNPE_FK(2); break;
-        case 3: GNNPE_FK(3); break;
-        case 4: GNNPE_FK(4); break;
-        default: GNNPE_FK(8); break;
-        }
-#undef GNNPE_FK
-        GNNPE_HIP_TRY(hipGetLastError());
-        return GNNPE_OK;
-    }
-    if (b_centric) {
+#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, rp, c->rrecs.as<RankedNbr<EE>>(), len)
+        GNNPE_BY_E(GNNPE_L)
+#undef GNNPE_L
+    } else if (var == kVarStart) {
+        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        const StartRec *sr = c->srec.as<StartRec>();
+        const PairRec *pr = c->prec.as<PairRec>();
+#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_s_rec<EE, (EE <= 2 ? 4 : (EE <= 4 ? 2 : 1))>), grid, block, 0, c->stream, P, sr, pr, len)
+        GNNPE_BY_E(GNNPE_L)
+#undef GNNPE_L
+    } else if (var == kVarMiddle) {
         FillBParams B;
         B.held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         B.adj_start = P.adj_start;
         B.adj_deg = P.adj_deg;
         B.nbrs = P.nbrs;
         B.nbr_rank = P.nbr_rank;
-        B.member = P.member;
         B.rev = c->rev.as<uint32_t>();
-        B.eoff = c->eoff.as<uint64_t>();
+        B.member = P.member;
+        B.eoff = P.eoff;
         B.vde = P.vde;
         B.x = P.x;
         B.n_held = c->n_held;
-        B.e = e_eff;
+        B.e = e;
         B.begin = begin;
         B.end = end;
         B.out_ids = P.out_ids;
@@ -780,92 +745,13 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         B.out_pdl = P.out_pdl;
         B.out_part = P.out_part;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-        switch (e_eff) {
-        case 1: hipLaunchKernelGGL((k_fill_b<1>), grid, block, 0, c->stream, B); break;
-        case 2: hipLaunchKernelGGL((k_fill_b<2>), grid, block, 0, c->stream, B); break;
-        case 3: hipLaunchKernelGGL((k_fill_b<3>), grid, block, 0, c->stream, B); break;
-        case 4: hipLaunchKernelGGL((k_fill_b<4>), grid, block, 0, c->stream, B); break;
-        default: hipLaunchKernelGGL((k_fill_b<8>), grid, block, 0, c->stream, B); break;
-        }
-        GNNPE_HIP_TRY(hipGetLastError());
-        return GNNPE_OK;
-    }
-    if (fv == 3 && e_ok) {
-        P.e = e_eff;
-        const uint32_t len = c->slab_end - c->slab_begin;
-        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
-        const uint32_t *poffs = c->poffs.as<uint32_t>();
-        switch (e_eff) {
-        case 1: hipLaunchKernelGGL((k_fill_s<1, 4>), grid, block, 0, c->stream, P, poffs, len); break;
-        case 2: hipLaunchKernelGGL((k_fill_s<2, 4>), grid, block, 0, c->stream, P, poffs, len); break;
-        case 3: hipLaunchKernelGGL((k_fill_s<3, 4>), grid, block, 0, c->stream, P, poffs, len); break;
-        case 4: hipLaunchKernelGGL((k_fill_s<4, 2>), grid, block, 0, c->stream, P, poffs, len); break;
-        default: hipLaunchKernelGGL((k_fill_s<8, 2>), grid, block, 0, c->stream, P, poffs, len); break;
-        }
-        GNNPE_HIP_TRY(hipGetLastError());
-        return GNNPE_OK;
-    }
-    if (fv >= 6 && e_ok) {
-        P.e = e_eff;
-        const bool nv = (fv == 7 || fv == 9);
-        const bool r2 = (fv >= 8);  // variants 8/9: non-temporal output stores
-        const uint32_t len = c->slab_end - c->slab_begin;
-        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
-        const StartRec *sr = c->srec.as<StartRec>();
-        const PairRec *pr = c->prec.as<PairRec>();
-#define GNNPE_FR(EE, RR)                                                                                              \
-    do {                                                                                                              \
-        if (nv && r2) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
-        else if (nv) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, true, false>), grid, block, 0, c->stream, P, sr, pr, len);   \
-        else if (r2) hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false, true>), grid, block, 0, c->stream, P, sr, pr, len);   \
-        else hipLaunchKernelGGL((k_fill_s_rec<EE, RR, false, false>), grid, block, 0, c->stream, P, sr, pr, len);          \
-    } while (0)
-        switch (e_eff) {
-        case 1: GNNPE_FR(1, 4); break;
-        case 2: GNNPE_FR(2, 4); break;
-        case 3: GNNPE_FR(3, 2); break;
-        case 4: GNNPE_FR(4, 2); break;
-        default: GNNPE_FR(8, 1); break;
-        }
-#undef GNNPE_FR
-        GNNPE_HIP_TRY(hipGetLastError());
-        return GNNPE_OK;
-    }
-    if (fv >= 4 && e_ok) {
-        P.e = e_eff;
-        const bool nv = fv == 5;
-        const uint32_t len = c->slab_end - c->slab_begin;
-        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
-        const uint32_t *poffs = c->poffs.as<uint32_t>();
-#define GNNPE_FS(EE, RR)                                                                                          \
-    do {                                                                                                          \
-        if (nv) hipLaunchKernelGGL((k_fill_s_staged<EE, RR, true>), grid, block, 0, c->stream, P, poffs, len);    \
-        else hipLaunchKernelGGL((k_fill_s_staged<EE, RR, false>), grid, block, 0, c->stream, P, poffs, len);      \
-    } while (0)
-        switch (e_eff) {
-        case 1: GNNPE_FS(1, 4); break;
-        case 2: GNNPE_FS(2, 4); break;
-        case 3: GNNPE_FS(3, 4); break;
-        case 4: GNNPE_FS(4, 2); break;
-        default: GNNPE_FS(8, 2); break;
-        }
-#undef GNNPE_FS
-        GNNPE_HIP_TRY(hipGetLastError());
-        return GNNPE_OK;
-    }
-    const uint32_t T = (fv == 0) ? tile_size_for(P.e, pdl) : 0;
-    if (T) {
-        int rc = ensure_tiles(c, T);
-        if (rc) return rc;
-        const uint64_t t0 = begin / T, t1 = (end - 1) / T;
-        GNNPE_REQUIRE(t1 - t0 + 1 < (1ull << 31), GNNPE_ERR_RANGE, "too many tiles in one call; chunk the range");
-        P.tile_edge = c->tile_edge.as<uint32_t>();
-        P.tile0 = (uint32_t)t0;
-        GNNPE_REQUIRE(t0 < (1ull << 32), GNNPE_ERR_RANGE, "tile index overflow");
-        launch_tiled_dispatch(P.e, pdl, P, (uint32_t)(t1 - t0 + 1), c->stream);
-    } else {
+#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_b<EE>), grid, block, 0, c->stream, B)
+        GNNPE_BY_E(GNNPE_L)
+#undef GNNPE_L
+    } else {  // kVarPairWave: runtime embedding width
         hipLaunchKernelGGL(k_fill_edge_wave, dim3(grid_for(c->n_edges * 64)), dim3(kBlock), 0, c->stream, P);
     }
+#undef GNNPE_BY_E
     GNNPE_HIP_TRY(hipGetLastError());
     return GNNPE_OK;
 }
@@ -892,7 +778,7 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     const uint64_t cnt = end - begin;
     if (!cnt) return GNNPE_OK;
-    const uint32_t e = c->have_table ? c->e : 1, D = 3 * e;
+    const uint32_t e = c->have_table ? c->e : 2, D = 3 * e;
     DevBuf bv, bp, bl;
     int rc = GNNPE_OK;
     if (hv) rc = bv.reserve(cnt * 3 * 4);
@@ -917,11 +803,8 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= 0 && variant <= 10, GNNPE_ERR_ARG, "fill variant must be 0..10");
-    if (variant != c->fill_variant) {
-        c->counted = false;
-        c->tile_T = 0;
-    }
+    GNNPE_REQUIRE(c && variant >= kVarPairWave && variant <= kVarRanked, GNNPE_ERR_ARG, "fill variant must be 1..4");
+    if (variant != c->fill_variant) c->counted = false;
     c->fill_variant = variant;
     return GNNPE_OK;
 }
@@ -983,7 +866,6 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
     c->n_held = c->n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
-    c->tile_T = 0;
     return GNNPE_OK;
 }
 
@@ -1064,7 +946,6 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
     c->n_held += (uint32_t)n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
-    c->tile_T = 0;
     return GNNPE_OK;
 }
 

@@ -175,13 +175,13 @@ int gnnpe_build_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);
-/* Selects the enumeration implementation (call before gnnpe_count_paths).  All variants produce
- * identical outputs and stay selectable for A/B measurements (DESIGN.md "fill kernel history"):
- *   0 output-tiled block kernel (LDS-staged tile)      1 pair-per-wave direct stores (first version)
- *   2 middle-vertex-centric count + fill               3 wave per start vertex, direct stores
- *   4/5 wave per start vertex + LDS strip (5: embeddings streamed from the per-adjacency array)
- *   6/7 as 4/5 driven by per-start / per-pair records  8/9 as 6/7 with non-temporal output stores
- * Default: 9. */
+/* Selects the enumeration implementation (call before gnnpe_count_paths).  All produce identical
+ * outputs; they stay selectable for A/B measurements:
+ *   1 one wave per (start, middle) pair, direct stores (first correct version)
+ *   2 middle-vertex-centric count + fill (each adjacency row read once, scattered output runs)
+ *   3 one wave per start vertex over the id-sorted rows (any degree)
+ *   4 one wave per start vertex over rank-sorted neighbour records (default; rows of degree <= 64,
+ *     otherwise 3 is used automatically) */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
 
 #ifdef __cplusplus
