@@ -325,3 +325,50 @@ def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle, variant):
         assert np.array_equal(pde, ovde[ref_ids].reshape(len(ref_ids), 6))
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("hub", [63, 64, 65, 130])
+def test_degree_64_boundary_of_the_ranked_variant(binding, oracle, hub):
+    """The ranked variant keeps one bit per neighbour position: rows up to 64 neighbours use it,
+    longer rows make gnnpe_count_paths fall back to the start-wave variant.  Same outputs either way."""
+    from gnnpe_amd import synth
+    # a hub with `hub` leaves, leaves chained so that ranks are mixed around the hub
+    n = hub + 1
+    eu = np.concatenate([np.zeros(hub, np.int64), np.arange(1, hub, dtype=np.int64)])
+    ev = np.concatenate([np.arange(1, hub + 1, dtype=np.int64), np.arange(2, hub + 1, dtype=np.int64)])
+    offs, nbrs = synth._csr_from_edges(n, eu, ev)
+    g = dict(offsets=offs, nbrs=nbrs, labels=(np.arange(n) % 5).astype(np.uint32))
+    rng = np.random.default_rng(hub)
+    sn = rng.permutation(n).astype(np.uint32)
+    ref = oracle.enumerate_closed(offs, nbrs, sn, 3)
+    ox, onx, ovde = oracle.gen_vde(offs, nbrs, g["labels"], 2)
+    for variant in VARIANTS:
+        eng = _engine(binding, g, sn, np.zeros(n, np.uint32), 1, 2, variant)
+        eng.vde(want=False)
+        assert eng.count_paths(2) == len(ref)
+        ids, pde, _ = eng.fill_paths()
+        assert np.array_equal(ids, ref), (hub, variant)
+        assert np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
+        eng.close()
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_power_law_graph_with_hubs(binding, oracle, variant):
+    """Skewed degrees (Chung-Lu, hubs of several hundred neighbours): the default variant falls back to
+    the any-degree kernel; every id and embedding still matches the oracle."""
+    from gnnpe_amd import synth
+    g = synth.powerlaw_graph(30_000, 180_000, exponent=2.1, max_degree=400, n_labels=32, seed=9)
+    deg = np.diff(g["offsets"].astype(np.int64))
+    assert deg.max() > 64
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, synth.block_membership(g["n"], 3), 3, 2, variant)
+    x, nx, vde = eng.vde()
+    ox, onx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    assert np.array_equal(vde, ovde)
+    total = eng.count_paths(2)
+    assert total == synth.expected_paths_l2(g["offsets"])
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    ids, pde, _ = eng.fill_paths()
+    assert np.array_equal(ids, ref)
+    assert np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
+    eng.close()
