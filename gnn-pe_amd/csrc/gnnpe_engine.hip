@@ -121,7 +121,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -502,30 +502,23 @@ static int ensure_nbr_vde(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-// variant 4: rank-sorted neighbour records + per-pair {suffix start, G, vde[b]}
-static size_t ranked_pair_bytes(uint32_t e) { return 16 + 8 * (size_t)e; }
-
+// variant 4: rank-sorted neighbour records + per-pair {suffix start, G}
 static int build_ranked(gnnpe_ctx *c, uint64_t ne)
 {
     const uint32_t e = c->have_table ? c->e : 2;
     int rc;
-    if ((rc = c->rpairs.reserve((ne + 1) * ranked_pair_bytes(e))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))) ||
-        (rc = c->vinfo.reserve(((size_t)c->n + 1) * (e + 2) * 8)))
+    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))))
         return rc;
-    GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * ranked_pair_bytes(e), c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
     if (c->n_held) {
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-#define GNNPE_RR(EE)                                                                                               \
-    do {                                                                                                           \
-        hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
-                           c->rank.as<uint32_t>(), c->vinfo.as<double>());                                          \
-        hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin,            \
-                           c->slab_end, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),                     \
-                           c->nbrs.as<uint32_t>(), c->vinfo.as<double>(), c->revpos.as<uint32_t>(),                 \
-                           c->poffs.as<uint32_t>(), c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair<EE>>());  \
-    } while (0)
+#define GNNPE_RR(EE)                                                                                              \
+    hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin, c->slab_end,  \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),             \
+                       c->rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(), vde,             \
+                       c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>())
         switch (e) {
         case 1: GNNPE_RR(1); break;
         case 2: GNNPE_RR(2); break;
@@ -629,9 +622,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
 
     // 3. exclusive scan: eoff[pair] = output slot of the pair's first path; eoff[ne] = total
     if (var == kVarRanked) {
-        hipcub::CountingInputIterator<uint64_t> idx(0);
-        hipcub::TransformInputIterator<uint64_t, PairCount, hipcub::CountingInputIterator<uint64_t>> it(
-            idx, PairCount{c->rpairs.as<char>(), ranked_pair_bytes(e)});
+        hipcub::TransformInputIterator<uint64_t, CntOfPair, const RankedPair *> it(c->rpairs.as<RankedPair>(), CntOfPair());
         size_t tb = 0;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
@@ -722,7 +713,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     if (var == kVarRanked) {
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const StartRec *sr = c->srec.as<StartRec>();
-#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, c->rpairs.as<RankedPair<EE>>(), c->rrecs.as<RankedNbr<EE>>(), len)
+        const RankedPair *rp = c->rpairs.as<RankedPair>();
+#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, rp, c->rrecs.as<RankedNbr<EE>>(), len)
         GNNPE_BY_E(GNNPE_L)
 #undef GNNPE_L
     } else if (var == kVarStart) {

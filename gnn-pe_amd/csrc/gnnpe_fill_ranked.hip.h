@@ -18,43 +18,22 @@
 
 namespace gnnpe {
 
-// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)):
-// 16 + 8e bytes written by ONE lane of the row kernel (a scattered partial-line store either way, so
-// the middle vertex' embedding rides along and the fill needs no vde[b] gather).  The middle vertex
-// itself is re-read from N(s) (contiguous) by the fill; the pair's path count is popcount(G).
-template <int E> struct __attribute__((aligned(16))) RankedPair {
+// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)).
+// 16 bytes so the scattered store of the row kernel is ONE dwordx4; the middle vertex itself is
+// re-read from N(s) (contiguous) by the fill, the count is popcount(G).
+struct __attribute__((aligned(16))) RankedPair {
     uint32_t sstart;  // first kept record: adj_start[b] + (rank-position of s in N(b)) + 1
     uint32_t pad;
     uint64_t G;       // id-positions of N(b) with rank > rank[s]
-    double vb[E];     // vde[b]
 };
-
-// one gather per adjacency entry instead of two: {vde[v], rank[v]} side by side (stride E + 2 doubles)
-template <int E>
-__global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const uint32_t *__restrict__ rank,
-                             double *__restrict__ vinfo)
-{
-    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < E; k++) vinfo[v * (E + 2) + k] = vde ? vde[v * E + k] : 0.0;
-        reinterpret_cast<uint64_t *>(vinfo)[v * (E + 2) + E] = rank[v];
-        vinfo[v * (E + 2) + E + 1] = 0.0;
-    }
-}
 
 template <int E> struct __attribute__((aligned(8))) RankedNbr {
     uint32_t id, idpos;
     double vde[E];
 };
 
-// scan input: popcount(G) of pair i, for any record stride
-struct PairCount {
-    const char *base;
-    size_t stride;
-    __host__ __device__ uint64_t operator()(uint64_t i) const
-    {
-        return (uint64_t)__popcll(*reinterpret_cast<const uint64_t *>(base + i * stride + 8));
-    }
+struct CntOfPair {
+    __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)__popcll(p.G); }
 };
 
 // One wave per held row b (degree <= 64), one lane per neighbour u_j:
@@ -67,10 +46,10 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
                                                    uint32_t slab_begin, uint32_t slab_end,
                                                    const uint32_t *__restrict__ adj_start,
                                                    const uint32_t *__restrict__ adj_deg,
-                                                   const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
+                                                   const uint32_t *__restrict__ nbrs, const uint32_t *__restrict__ rank,
                                                    const uint32_t *__restrict__ revpos,
-                                                   const uint32_t *__restrict__ poffs,
-                                                   RankedNbr<E> *__restrict__ recs, RankedPair<E> *__restrict__ pairs)
+                                                   const uint32_t *__restrict__ poffs, const double *__restrict__ vde,
+                                                   RankedNbr<E> *__restrict__ recs, RankedPair *__restrict__ pairs)
 {
     const unsigned lane = lane_id();
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -80,20 +59,11 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
         const uint32_t st = adj_start[b], d = adj_deg[b];
         if (d == 0 || d > 64) continue;  // longer rows: the caller does not select this variant
         uint32_t u = 0, r = 0, rp = kNoEdge;
-        double vu[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) vu[k] = 0.0;
         if (lane < d) {
             u = nbrs[st + lane];
-            const double *vi = vinfo + (uint64_t)u * (E + 2);
-#pragma unroll
-            for (int k = 0; k < E; k++) vu[k] = vi[k];
-            r = (uint32_t) reinterpret_cast<const uint64_t *>(vi)[E];
+            r = rank[u];
             rp = revpos[st + lane];
         }
-        double vb[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) vb[k] = vinfo[(uint64_t)b * (E + 2) + k];
         uint64_t G = 0;
         for (uint32_t i = 0; i < d; i++) G |= (uint64_t)(rl32(r, (int)i) > r ? 1u : 0u) << i;
         if (lane < d) {
@@ -103,16 +73,11 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             rec.id = u;
             rec.idpos = lane;
 #pragma unroll
-            for (int k = 0; k < E; k++) rec.vde[k] = vu[k];
+            for (int k = 0; k < E; k++) rec.vde[k] = vde ? vde[(uint64_t)u * E + k] : 0.0;
             recs[st + p] = rec;
             const uint32_t pi = pair_index(rp, r, slab_begin, slab_end, poffs);
             if (pi != kNoEdge) {
-                RankedPair<E> pr;
-                pr.sstart = st + p + 1;
-                pr.pad = 0u;
-                pr.G = G;
-#pragma unroll
-                for (int k = 0; k < E; k++) pr.vb[k] = vb[k];
+                RankedPair pr = {st + p + 1, 0u, G};
                 pairs[pi] = pr;
             }
         }
@@ -128,7 +93,7 @@ constexpr int kBatch = 128;
 
 template <int E>
 __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
-                                                     const RankedPair<E> *__restrict__ pairs,
+                                                     const RankedPair *__restrict__ pairs,
                                                      const RankedNbr<E> *__restrict__ recs, uint32_t slab_len)
 {
     constexpr int D = 3 * E;
@@ -155,11 +120,7 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
 
         for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
             const uint32_t k = k0 + lane;
-            RankedPair<E> pr;
-            pr.sstart = 0u;
-            pr.G = 0ull;
-#pragma unroll
-            for (int kk = 0; kk < E; kk++) pr.vb[kk] = 0.0;
+            RankedPair pr = {0u, 0u, 0ull};
             uint32_t bk = 0;
             if (k < ds) {
                 pr = pairs[e0 + k];
@@ -178,8 +139,10 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
             s_b[wv][lane] = bk;
             s_G[wv][lane] = pr.G;
             if (lane == 0) s_cs[wv][64] = C;
+            if (want_pde && k < ds) {
 #pragma unroll
-            for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = pr.vb[kk];
+                for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = P.vde[(uint64_t)bk * E + kk];
+            }
             __builtin_amdgcn_wave_barrier();
 
             // batches of whole pairs: [kb, ke) with cs[ke] - cs[kb] <= kBatch (a pair holds <= 63 records)
