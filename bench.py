@@ -181,6 +181,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # sanity of what was just timed (outside the timed region): global path count = sum C(deg, 2) and the
+    # middle-vertex checksum sum_paths(b) = sum_v v * C(deg v, 2), both closed forms of the input graph
+    deg64 = np.diff(g["offsets"].astype(np.int64))
+    want_paths = int((deg64 * (deg64 - 1) // 2).sum())
+    want_mid = int((np.arange(args.n, dtype=np.int64) * (deg64 * (deg64 - 1) // 2)).sum())
+    chk = torch.stack([out_ids[:total, 1].to(torch.int64).sum(), torch.tensor(total, device=device)]).to(torch.int64)
+    if world > 1:
+        chk_h = chk.cpu() if same_device else chk
+        dist.all_reduce(chk_h, op=dist.ReduceOp.SUM)
+        chk = chk_h
+    got_mid, got_paths = (int(x) for x in chk.tolist())
+    if (got_paths, got_mid) != (want_paths, want_mid) or sb.global_total != want_paths:
+        raise SystemExit(f"bench sanity check failed: paths {got_paths} (want {want_paths}), middle checksum {got_mid} "
+                         f"(want {want_mid})")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if same_device else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -215,7 +229,7 @@ def main():
                config=dict(workload=f"G(n={args.n}, m={args.m}) seed {args.seed}, {args.labels} labels, l=2, e={e}, "
                                     f"degree-sorted order; {'ids only' if args.ids_only else 'ids + pde'}",
                            paths=global_total, parallelism=f"slab{world}", fill_variant=args.fill_variant),
-               roofline=roofline)
+               roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms")
     if world > 1:
         out["halo"] = sb.stats
 
