@@ -38,6 +38,10 @@ SIGNATURES = {
     "gnnpe_set_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "gnnpe_set_label_table": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f64p]),
     "gnnpe_host_label_table": (C.c_int, [C.c_uint32, C.c_uint32, _f64p]),
+    "gnnpe_host_load_graph": (C.c_int, [C.c_char_p, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p),
+                                        _u32p]),
+    "gnnpe_host_read_membership": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _u32p, _u32p]),
+    "gnnpe_host_free": (None, [_vp]),
     "gnnpe_halo_need": (C.c_int, [_vp, C.c_uint32, _u32p, _vp, C.c_uint64, _u64p]),
     "gnnpe_rows_degree": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "gnnpe_rows_pack": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
@@ -126,6 +130,37 @@ def host_label_table(n_labels, e):
     if rc:
         raise GnnpeError(load().gnnpe_last_error().decode())
     return out
+
+
+def host_load_graph(path):
+    """R0 through the library's own loader (host/graph_loader.cpp).  Returns a dict like synth graphs."""
+    lib = load()
+    n, m = C.c_uint32(), C.c_uint32()
+    po, pn, pl = _u32p(), _u32p(), _u32p()
+    meta = (C.c_uint32 * 3)()
+    rc = lib.gnnpe_host_load_graph(path.encode(), C.byref(n), C.byref(m), C.byref(po), C.byref(pn), C.byref(pl), meta)
+    if rc == -1:
+        raise FileNotFoundError(lib.gnnpe_last_error().decode())
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    offs = np.ctypeslib.as_array(po, shape=(n.value + 1,)).copy()
+    nbrs = np.ctypeslib.as_array(pn, shape=(max(2 * m.value, 1),)).copy()[: 2 * m.value]
+    labels = np.ctypeslib.as_array(pl, shape=(max(n.value, 1),)).copy()[: n.value]
+    for p in (po, pn, pl):
+        lib.gnnpe_host_free(p)
+    return dict(n=n.value, m=m.value, offsets=offs, nbrs=nbrs, labels=labels, labels_count=meta[0], max_degree=meta[1],
+                max_label_frequency=meta[2])
+
+
+def host_read_membership(path, n, p):
+    """R1 (main.cpp:77-85) through the library's reader."""
+    lib = load()
+    sn = np.zeros(n, np.uint32)
+    mem = np.zeros(n, np.uint32)
+    rc = lib.gnnpe_host_read_membership(path.encode(), n, p, _ptr(sn, _u32p), _ptr(mem, _u32p))
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    return sn, mem
 
 
 class Engine:

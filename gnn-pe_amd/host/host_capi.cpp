@@ -1,0 +1,67 @@
+// host_capi.cpp -- C-ABI wrappers around the host loader (R0 / R1) so that non-C++ callers (the Python
+// multi-GPU driver) use the SAME loader code as gnnpe_main.  Compiled into libgnnpe_hip.so.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gnnpe_hip.h"
+#include "graph_loader.h"
+
+namespace gnnpe {
+void set_error(const char *fmt, ...);
+}
+
+extern "C" {
+
+int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs, uint32_t **labels,
+                          uint32_t meta[3])
+{
+    if (!path || !n || !m || !offsets || !nbrs || !labels) {
+        gnnpe::set_error("gnnpe_host_load_graph: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    gnnpe_host::StaticGraph g;
+    std::string err;
+    const int rc = g.load(path, &err);
+    if (rc != 0) {
+        gnnpe::set_error("%s", err.c_str());
+        return rc;
+    }
+    auto dup = [](const std::vector<uint32_t> &v) {
+        uint32_t *p = (uint32_t *)malloc((v.size() + 1) * sizeof(uint32_t));
+        if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(uint32_t));
+        return p;
+    };
+    *n = g.n;
+    *m = g.m;
+    *offsets = dup(g.offsets);
+    *nbrs = dup(g.neighbors);
+    *labels = dup(g.labels);
+    if (meta) {
+        meta[0] = g.labels_count;
+        meta[1] = g.max_degree;
+        meta[2] = g.max_label_frequency;
+    }
+    return 0;
+}
+
+int gnnpe_host_read_membership(const char *path, uint32_t n, uint32_t p, uint32_t *sorted_nodes, uint32_t *membership)
+{
+    std::vector<uint32_t> sn, mem;
+    std::string err;
+    const int rc = gnnpe_host::read_membership(path ? path : "", n, p, &sn, &mem, &err);
+    if (rc != 0) {
+        gnnpe::set_error("%s", err.c_str());
+        return rc;
+    }
+    if (n) {
+        memcpy(sorted_nodes, sn.data(), (size_t)n * 4);
+        memcpy(membership, mem.data(), (size_t)n * 4);
+    }
+    return 0;
+}
+
+void gnnpe_host_free(void *ptr) { free(ptr); }
+
+}  // extern "C"

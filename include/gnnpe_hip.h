@@ -92,6 +92,17 @@ int gnnpe_set_label_table(gnnpe_ctx *ctx, uint32_t n_labels, uint32_t e, const d
  * divided by their left-to-right sum.  out: n_labels x e doubles.  Needs no GPU. */
 int gnnpe_host_label_table(uint32_t n_labels, uint32_t e, double *out);
 
+/* R0 / R1 on the host, for callers that are not the C++ CLI (same code: host/graph_loader.cpp).
+ * gnnpe_host_load_graph parses a `.graph` file like Static_Graph::loadGraphFromFile
+ * (graph.cpp:163-242); the arrays are malloc'ed by the library, release them with gnnpe_host_free.
+ * meta = {labels_count, max_degree, max_label_frequency} (printGraphMetaData, graph.cpp:244-247).
+ * Returns 0, -1 (cannot open: the reference exits with -1) or -2 (malformed; gnnpe_last_error). */
+int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs,
+                          uint32_t **labels, uint32_t meta[3]);
+/* membership.txt (main.cpp:77-85): sorted_nodes[n], membership[n] caller-allocated; p = partition_num. */
+int gnnpe_host_read_membership(const char *path, uint32_t n, uint32_t p, uint32_t *sorted_nodes, uint32_t *membership);
+void gnnpe_host_free(void *ptr);
+
 /* ---- halo exchange helpers (device side of the RCCL all-to-all-v) ----------------- */
 /* List the vertices whose adjacency rows this context needs (neighbours of its slab's start
  * vertices) but does not hold, grouped by owning rank: owner r holds the slab

@@ -1,0 +1,68 @@
+"""GPU tests of the multi-GPU offline driver (gnn-pe_amd/offline.py): for 1, 2 and 3 ranks the files are
+byte-identical to the reference's (golden md5s), index.dat satisfies the consumer's constraints, and the
+untouched reference `main -m online` prints the known answer.  The box has one GPU, so ranks > 1 share
+device 0 and their collectives run over gloo (GNNPE_BENCH_SAME_DEVICE=1); the slab partition, halo
+exchange, output assembly and index gather are the production code paths."""
+import hashlib
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gnnpe_amd import synth
+from oracle import ref_main_path
+
+pytestmark = pytest.mark.gpu
+DRIVER = os.path.join(ROOT, "gnn-pe_amd", "offline.py")
+
+
+def _md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_driver_files_match_reference_for_any_world_size(tmp_path, oracle, world):
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))["p2"]
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    sn = np.argsort(deg, kind="stable").astype(np.uint32)
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, 2)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), sn, (np.arange(len(deg)) % 2).astype(np.uint32))
+    args = [DRIVER, "-f", tmp + "/", "-d", graph, "-p", "2", "--index", "--chunk", "60000"]
+    env = dict(os.environ)
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "|V|: 3112, |E|: 12519, |Σ|: 71" in r.stdout
+    assert _md5(os.path.join(tmp, "gnn-pe", "all_paths.txt")) == gold["all_paths_md5"]
+    for i in range(2):
+        d = os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}")
+        assert _md5(os.path.join(d, "partition_paths.txt")) == gold["partition_paths_md5"][i]
+        info = oracle.index_validate(open(os.path.join(d, "index.dat"), "rb").read())
+        assert info["num_data"] == gold["partition_sizes"][i]
+        assert np.array_equal(np.sort(info["leaf_son"]), np.arange(gold["partition_sizes"][i]))
+    if world == 3 and os.path.exists(ref_main_path()):
+        out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q",
+                                       os.path.join(GOLDEN, "test_graph", "query_graph.graph"), "-m", "online", "-p", "2"],
+                                      text=True)
+        assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
