@@ -61,6 +61,10 @@ SIGNATURES = {
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                            C.POINTER(C.c_int32)]),
     "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
+    "gnnpe_build_box_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
+                                               C.POINTER(C.c_int32)]),
+    "gnnpe_pge_groups": (C.c_int, [_vp, _f64p, _f64p]),
+    "gnnpe_pge_build_index": (C.c_int, [_vp, C.c_uint64, _u32p, C.c_char_p]),
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
 }
@@ -339,3 +343,14 @@ class Engine:
         out = np.zeros(nbytes, np.uint8)
         self._ck(self.lib.gnnpe_copy_to_host(self.ctx, out.ctypes.data_as(_vp), C.c_void_p(dev_ptr), int(nbytes)))
         return out
+
+    # GNN-PGE offline (GNN-PGE/src/main.cpp:91-195)
+    def pge_groups(self):
+        pg = np.zeros((self.n, 4 * self.e))
+        plg = np.zeros((self.n, 4 * self.e))
+        self._ck(self.lib.gnnpe_pge_groups(self.ctx, _ptr(pg, _f64p), _ptr(plg, _f64p)))
+        return pg, plg
+
+    def pge_build_index(self, vertices, path):
+        v = _np(vertices, np.uint32)
+        self._ck(self.lib.gnnpe_pge_build_index(self.ctx, len(v), _ptr(v, _u32p), path.encode()))

@@ -26,19 +26,39 @@ namespace gnnpe {
 
 constexpr int kBlockLen = 4096;
 
+// Where the leaf rectangles come from: path tuples + the vde table (GNN-PE: point MBRs lo = hi =
+// pde row, custom.h:244-248) or an explicit array of boxes (GNN-PGE: a vertex' path_group,
+// GNN-PGE/include/custom.h:171-177), cnt x 2D doubles laid out (lo0, hi0, lo1, hi1, ...).
+struct LeafSrc {
+    const uint32_t *vids;
+    const double *vde;
+    const double *boxes;
+    uint32_t L, e, D;
+    __device__ __forceinline__ void get(uint64_t p, uint32_t k, double *lo, double *hi) const
+    {
+        if (boxes) {
+            *lo = boxes[(p * D + k) * 2];
+            *hi = boxes[(p * D + k) * 2 + 1];
+        } else {
+            *lo = *hi = vde[(uint64_t)vids[p * L + k / e] * e + k % e];
+        }
+    }
+};
+
 // ---- keys ---------------------------------------------------------------------------------------
 // per-dimension min / max of the partition's points (point p, dim k = vde[vids[p][k / e]][k % e])
-__global__ void k_point_minmax(uint64_t cnt, uint32_t L, uint32_t e, const uint32_t *__restrict__ vids,
-                               const double *__restrict__ vde, double *__restrict__ mn, double *__restrict__ mx)
+__global__ void k_point_minmax(uint64_t cnt, LeafSrc S, double *__restrict__ mn, double *__restrict__ mx)
 {
     // one block per dimension-slice of the input; partial results combined with atomics on the
     // ordered-integer image of the doubles (all embeddings are positive finite numbers)
-    const uint32_t D = L * e;
+    const uint32_t D = S.D;
     __shared__ double s_mn[256], s_mx[256];
     for (uint32_t k = 0; k < D; k++) {
         double a = 1e300, b = -1e300;
         for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
-            const double v = vde[(uint64_t)vids[p * L + k / e] * e + k % e];
+            double lo, hi;
+            S.get(p, k, &lo, &hi);
+            const double v = 0.5 * (lo + hi);  // key on the rectangle's centre
             a = fmin(a, v);
             b = fmax(b, v);
         }
@@ -53,7 +73,7 @@ __global__ void k_point_minmax(uint64_t cnt, uint32_t L, uint32_t e, const uint3
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            // positive doubles order like their bit patterns
+            // non-negative doubles order like their bit patterns
             atomicMin(reinterpret_cast<unsigned long long *>(mn) + k, (unsigned long long)__double_as_longlong(s_mn[0]));
             atomicMax(reinterpret_cast<unsigned long long *>(mx) + k, (unsigned long long)__double_as_longlong(s_mx[0]));
         }
@@ -63,16 +83,17 @@ __global__ void k_point_minmax(uint64_t cnt, uint32_t L, uint32_t e, const uint3
 
 // Z-order key: `bits` bits per dimension, most significant bit plane first; within a plane dimension 0
 // is the most significant.  Bit t of dimension k lands at position t*D + (D-1-k).
-__global__ void k_zorder_keys(uint64_t cnt, uint32_t L, uint32_t e, uint32_t bits, const uint32_t *__restrict__ vids,
-                              const double *__restrict__ vde, const double *__restrict__ mn,
+__global__ void k_zorder_keys(uint64_t cnt, LeafSrc S, uint32_t bits, const double *__restrict__ mn,
                               const double *__restrict__ mx, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const uint32_t D = L * e;
+    const uint32_t D = S.D;
     const uint32_t qmax = (1u << bits) - 1u;
     for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t key = 0;
         for (uint32_t k = 0; k < D; k++) {
-            const double v = vde[(uint64_t)vids[p * L + k / e] * e + k % e];
+            double lo, hi;
+            S.get(p, k, &lo, &hi);
+            const double v = 0.5 * (lo + hi);
             const double span = mx[k] - mn[k];
             const uint32_t q = span > 0.0 ? (uint32_t)fmin((v - mn[k]) / span * (double)qmax, (double)qmax) : 0u;
             for (uint32_t t = 0; t < bits; t++) key |= (uint64_t)((q >> t) & 1u) << (t * D + (D - 1 - k));
@@ -90,14 +111,13 @@ __device__ __forceinline__ void lds_put(char *dst, const void *src, int n)
 }
 
 // leaf j holds sorted points [j*F, min((j+1)*F, cnt)); block id = j.  One workgroup per leaf.
-__global__ __launch_bounds__(64) void k_pack_leaves(uint64_t cnt, uint32_t F, uint32_t L, uint32_t e,
-                                                    const uint32_t *__restrict__ order,
-                                                    const uint32_t *__restrict__ vids, const double *__restrict__ vde,
-                                                    char *__restrict__ image, double *__restrict__ node_mbr)
+__global__ __launch_bounds__(64) void k_pack_leaves(uint64_t cnt, uint32_t F, LeafSrc S,
+                                                    const uint32_t *__restrict__ order, char *__restrict__ image,
+                                                    double *__restrict__ node_mbr)
 {
     __shared__ __attribute__((aligned(16))) char s_blk[kBlockLen];
     __shared__ double s_lo[64], s_hi[64];
-    const uint32_t D = L * e, esz = 16 * D + 4;
+    const uint32_t D = S.D, esz = 16 * D + 4;
     const uint64_t j = blockIdx.x;
     const uint64_t p0 = j * F;
     const uint32_t ne = (uint32_t)min((uint64_t)F, cnt - p0);
@@ -112,22 +132,20 @@ __global__ __launch_bounds__(64) void k_pack_leaves(uint64_t cnt, uint32_t F, ui
         const uint32_t son = order[p0 + threadIdx.x];  // the path's index inside the partition (custom.h:243)
         char *ent = s_blk + 5 + threadIdx.x * esz;
         for (uint32_t k = 0; k < D; k++) {
-            const double v = vde[(uint64_t)vids[(uint64_t)son * L + k / e] * e + k % e];
-            lds_put(ent + 16 * k, &v, 8);      // lo (custom.h:246)
-            lds_put(ent + 16 * k + 8, &v, 8);  // hi (custom.h:247)
+            double lo, hi;
+            S.get(son, k, &lo, &hi);
+            lds_put(ent + 16 * k, &lo, 8);      // bounces[2k]   (custom.h:246)
+            lds_put(ent + 16 * k + 8, &hi, 8);  // bounces[2k+1] (custom.h:247)
         }
         const int32_t s32 = (int32_t)son;
         lds_put(ent + 16 * D, &s32, 4);
     }
     // node MBR for the parent level
     for (uint32_t k = 0; k < D; k++) {
-        double v = 0.0;
-        if (threadIdx.x < ne) {
-            const uint32_t son = order[p0 + threadIdx.x];
-            v = vde[(uint64_t)vids[(uint64_t)son * L + k / e] * e + k % e];
-        }
-        s_lo[threadIdx.x] = threadIdx.x < ne ? v : 1e300;
-        s_hi[threadIdx.x] = threadIdx.x < ne ? v : -1e300;
+        double lo = 1e300, hi = -1e300;
+        if (threadIdx.x < ne) S.get(order[p0 + threadIdx.x], k, &lo, &hi);
+        s_lo[threadIdx.x] = lo;
+        s_hi[threadIdx.x] = hi;
         __syncthreads();
         for (int s = 32; s > 0; s >>= 1) {
             if ((int)threadIdx.x < s) {
@@ -210,15 +228,13 @@ using namespace gnnpe;
 
 extern "C" {
 
-int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void *dev_vids, void **dev_image,
-                             uint64_t *nbytes, int32_t hdr_out[8])
+static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
 {
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
-    GNNPE_REQUIRE(c->have_vde, GNNPE_ERR_ARG, "gnnpe_build_index: call gnnpe_vde first");
-    GNNPE_REQUIRE(L >= 1 && cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu points exceeds the format's int32 counts",
+    GNNPE_REQUIRE(cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu entries exceeds the format's int32 counts",
                   (unsigned long long)cnt);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
-    const uint32_t e = c->e, D = L * e;
+    const uint32_t D = S.D;
     const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);  // rtnode.cpp:27-28
     GNNPE_REQUIRE(cap >= 3 && cap <= 64, GNNPE_ERR_UNSUPPORTED, "entry size for dim %u gives node capacity %u", D, cap);
     // the reference splits a node on reaching capacity-1 (rtnode.cpp:528,576): keep <= capacity-2
@@ -246,8 +262,6 @@ int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void 
     if (cnt == 0) {
         GNNPE_HIP_TRY(hipMemsetAsync(image + kBlockLen, 0, kBlockLen, c->stream));  // level 0, 0 entries
     } else {
-        GNNPE_REQUIRE(dev_vids, GNNPE_ERR_ARG, "null path ids");
-        const uint32_t *vids = (const uint32_t *)dev_vids;
         // 1. keys
         if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
         double *mn = reinterpret_cast<double *>(c->small.as<char>() + 256), *mx = mn + 64;
@@ -259,14 +273,13 @@ int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void 
         }
         GNNPE_HIP_TRY(hipMemcpyAsync(mn, init.data(), 128 * 8, hipMemcpyHostToDevice, c->stream));
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // init[] is a stack/heap temporary
-        hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt, L,
-                           e, vids, c->vde.as<double>(), mn, mx);
+        hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt, S,
+                           mn, mx);
         const uint32_t bits = std::max(1u, std::min(16u, 64u / D));
         if ((rc = c->idx_keys.reserve(cnt * 8 * 2)) || (rc = c->idx_vals.reserve(cnt * 4 * 2))) return rc;
         uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
         uint32_t *v_in = c->idx_vals.as<uint32_t>(), *v_out = v_in + cnt;
-        hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, L, e, bits, vids,
-                           c->vde.as<double>(), mn, mx, k_in, v_in);
+        hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, S, bits, mn, mx, k_in, v_in);
         GNNPE_HIP_TRY(hipGetLastError());
         // 2. one radix sort over the used key bits
         size_t tb = 0;
@@ -281,8 +294,7 @@ int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void 
         for (uint64_t v : level_n) max_level = std::max(max_level, v);
         if ((rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8))) return rc;
         double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
-        hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, L, e, v_out, vids,
-                           c->vde.as<double>(), image, mbr_a);
+        hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, S, v_out, image, mbr_a);
         uint64_t child0 = 0, node0 = level_n[0];
         for (size_t lv = 1; lv < level_n.size(); lv++) {
             hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,
@@ -310,6 +322,23 @@ int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void 
     *nbytes = image_bytes;
     if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
     return GNNPE_OK;
+}
+
+int gnnpe_build_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t L, const void *dev_vids, void **dev_image,
+                             uint64_t *nbytes, int32_t hdr_out[8])
+{
+    GNNPE_REQUIRE(c && c->have_vde, GNNPE_ERR_ARG, "gnnpe_build_index: call gnnpe_vde first");
+    GNNPE_REQUIRE(L >= 1 && (cnt == 0 || dev_vids), GNNPE_ERR_ARG, "null path ids");
+    LeafSrc S = {(const uint32_t *)dev_vids, c->vde.as<double>(), nullptr, L, c->e, L * c->e};
+    return build_image(c, cnt, S, dev_image, nbytes, hdr_out);
+}
+
+int gnnpe_build_box_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t dim, const void *dev_boxes, void **dev_image,
+                                 uint64_t *nbytes, int32_t hdr_out[8])
+{
+    GNNPE_REQUIRE(c && dim >= 1 && (cnt == 0 || dev_boxes), GNNPE_ERR_ARG, "gnnpe_build_box_index_device: bad argument");
+    LeafSrc S = {nullptr, nullptr, (const double *)dev_boxes, 1, dim, dim};
+    return build_image(c, cnt, S, dev_image, nbytes, hdr_out);
 }
 
 int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)

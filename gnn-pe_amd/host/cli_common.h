@@ -1,0 +1,125 @@
+// cli_common.h -- flag parsing and small helpers shared by gnnpe_main (GNN-PE/src/main.cpp mirror) and
+// gnnpge_main (GNN-PGE/src/main.cpp mirror).  Both reference programs take the same eight CLI11 flags.
+#pragma once
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/gnnpe_hip.h"
+
+using Clock = std::chrono::steady_clock;
+
+namespace cli {
+
+struct Options {
+    const char *tool = "gnnpe_main";
+    // the reference's flags and defaults (main.cpp:40-56, custom.h:45-50)
+    std::string dataset_path = "../Test/";
+    std::string data_graph = "../Test/data_graph.graph";
+    std::string query_graph = "../Test/query_graph.graph";
+    std::string mode = "offline";
+    std::string answers = "MAX";
+    uint32_t partition_num = 5, path_length = 2, vde_dim = 2;
+    // extensions
+    int gpus = 1;
+    uint64_t chunk_paths = 32ull << 20;
+    bool allow_large = false, timing = false, sidecars = false, write_index = false;
+    bool same_device = false;  // testing aid: all --gpus contexts on device 0
+};
+
+static const char *g_tool = "gnnpe_main";
+
+inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+[[noreturn]] inline void die(const std::string &msg, int code = 1)
+{
+    fprintf(stderr, "%s: %s\n", g_tool, msg.c_str());
+    exit(code);
+}
+
+inline void check(int rc, const char *what)
+{
+    if (rc != 0) die(std::string(what) + ": " + gnnpe_last_error());
+}
+
+inline bool parse_u32(const std::string &s, uint32_t *v)
+{
+    if (s.empty()) return false;
+    char *end = nullptr;
+    unsigned long long x = strtoull(s.c_str(), &end, 10);
+    if (*end || x > 0xFFFFFFFFull) return false;
+    *v = (uint32_t)x;
+    return true;
+}
+
+// CLI11-style parsing of `-x v`, `-xv`, `--long v`, `--long=v`
+inline Options parse_args(int argc, char **argv, const char *tool = "gnnpe_main")
+{
+    Options o;
+    o.tool = tool;
+    g_tool = tool;
+    struct Opt { char s; const char *l; } opts[] = {{'f', "file"}, {'d', "data"}, {'q', "query"}, {'m', "mode"},
+                                                     {'p', "partition"}, {'l', "length"}, {'e', "embedding"}, {'n', "answers"}};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], val;
+        char key = 0;
+        if (a == "-h" || a == "--help") {
+            printf("%s -f <dataset dir/> -d <data.graph> -m offline -p <partitions> [-l 2] [-e 2]\n"
+                   "           [--gpus N] [--chunk PATHS] [--index] [--sidecars] [--timing] [--allow-large]\n", tool);
+            exit(0);
+        }
+        if (a == "--gpus" || a == "--chunk") {
+            if (i + 1 >= argc) die(a + " needs a value");
+            uint64_t v = strtoull(argv[++i], nullptr, 10);
+            if (a == "--gpus") o.gpus = (int)v; else o.chunk_paths = v;
+            continue;
+        }
+        if (a == "--allow-large") { o.allow_large = true; continue; }
+        if (a == "--timing") { o.timing = true; continue; }
+        if (a == "--sidecars") { o.sidecars = true; continue; }
+        if (a == "--index") { o.write_index = true; continue; }
+        if (a == "--same-device") { o.same_device = true; continue; }
+        if (a.rfind("--", 0) == 0) {
+            std::string name = a.substr(2);
+            size_t eq = name.find('=');
+            bool has_val = eq != std::string::npos;
+            if (has_val) { val = name.substr(eq + 1); name = name.substr(0, eq); }
+            for (auto &op : opts) if (name == op.l) key = op.s;
+            if (!key) die("unknown option " + a);
+            if (!has_val) { if (i + 1 >= argc) die(a + " needs a value"); val = argv[++i]; }
+        } else if (a.size() >= 2 && a[0] == '-') {
+            for (auto &op : opts) if (a[1] == op.s) key = op.s;
+            if (!key) die("unknown option " + a);
+            if (a.size() > 2) val = a.substr(2);
+            else { if (i + 1 >= argc) die(a + " needs a value"); val = argv[++i]; }
+        } else {
+            die("unexpected argument " + a);
+        }
+        bool ok = true;
+        switch (key) {
+        case 'f': o.dataset_path = val; break;
+        case 'd': o.data_graph = val; break;
+        case 'q': o.query_graph = val; break;
+        case 'm': o.mode = val; break;
+        case 'n': o.answers = val; break;
+        case 'p': ok = parse_u32(val, &o.partition_num); break;
+        case 'l': ok = parse_u32(val, &o.path_length); break;
+        case 'e': ok = parse_u32(val, &o.vde_dim); break;
+        }
+        if (!ok) die("bad value for -" + std::string(1, key) + ": " + val);
+    }
+    return o;
+}
+
+inline bool is_dir(const std::string &p)
+{
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+}  // namespace cli

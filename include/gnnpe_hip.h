@@ -183,6 +183,20 @@ int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const voi
  * loop (custom.h:222-235 only tests that the file exists). */
 int gnnpe_build_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
 
+/* Same file format over explicit rectangles: cnt x 2*dim doubles (lo0, hi0, lo1, hi1, ...), son = row. */
+int gnnpe_build_box_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t dim, const void *dev_boxes, void **dev_image,
+                                 uint64_t *nbytes, int32_t hdr_out[8]);
+
+/* ---- GNN-PGE offline (GNN-PGE/src/main.cpp:91-195) ------------------------- */
+/* path_group / path_label_group of every vertex: per-dimension [min, max] over the embeddings
+ * [vde[v], vde[u]] / [x[v], x[u]] of its 1-hop paths (v, u); n x 4e doubles each, laid out
+ * (lo0, hi0, lo1, hi1, ...).  Needs gnnpe_vde.  Host outputs may be NULL. */
+int gnnpe_pge_groups(gnnpe_ctx *ctx, double *host_path_group, double *host_path_label_group);
+/* R-tree of one GNN-PGE partition (GNN-PGE/include/custom.h:141-195): entry i = path_group of
+ * host_vertices[i] (the partition's vertices in membership.txt order), son = i; written to `path`
+ * (<f>gnn-pge/partitions/partition-i/index.dat). */
+int gnnpe_pge_build_index(gnnpe_ctx *ctx, uint64_t n_sel, const uint32_t *host_vertices, const char *path);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

@@ -33,6 +33,11 @@ def ref_main_path():
     return os.path.join(_HERE, "_ref", "ref_main")
 
 
+def ref_main_pge_path():
+    """The unmodified GNN-PGE `main` (next row), compiled by oracle/Makefile (may be absent)."""
+    return os.path.join(_HERE, "_ref", "ref_main_pge")
+
+
 def ref_dump_path():
     return os.path.join(_HERE, "_ref", "ref_dump")
 
@@ -69,6 +74,10 @@ class Oracle:
         L.orc_index_validate.restype = C.c_int
         L.orc_index_validate.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                          _f64p, C.c_uint64, C.POINTER(C.c_int32)]
+        L.orc_pge_groups.argtypes = [C.c_uint32, _u32p, _u32p, C.c_uint32, _f64p, _f64p, _f64p, _f64p]
+        L.orc_pge_write_bin.restype = C.c_int
+        L.orc_pge_write_bin.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u32p, _u32p, _f64p, _f64p, _f64p, _f64p,
+                                        _f64p, C.c_double]
         self.L = L
 
     # R0 graph.cpp:163-242
@@ -205,3 +214,26 @@ class Oracle:
         out = dict(zip(keys, list(hdr)))
         out.update(leaf_son=son, leaf_pt=pt, height=h.value)
         return out
+
+    # GNN-PGE offline (GNN-PGE/src/main.cpp:91-195)
+    def pge_groups(self, offs, nbrs, e, x, vde):
+        n = len(offs) - 1
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        x = np.ascontiguousarray(x, np.float64)
+        vde = np.ascontiguousarray(vde, np.float64)
+        pg = np.zeros((n, 4 * e))
+        plg = np.zeros((n, 4 * e))
+        self.L.orc_pge_groups(n, _p(offs, _u32p), _p(nbrs, _u32p), e, _p(x, _f64p), _p(vde, _f64p), _p(pg, _f64p),
+                              _p(plg, _f64p))
+        return pg, plg
+
+    def pge_write_bin(self, path, e, offs, labels, x, nx, vde, pg, plg, key_fill=0.0):
+        n = len(offs) - 1
+        a = [np.ascontiguousarray(t, np.float64) for t in (x, nx, vde, pg, plg)]
+        offs = np.ascontiguousarray(offs, np.uint32)
+        labels = np.ascontiguousarray(labels, np.uint32)
+        rc = self.L.orc_pge_write_bin(path.encode(), n, e, _p(offs, _u32p), _p(labels, _u32p), *[_p(t, _f64p) for t in a],
+                                      key_fill)
+        if rc:
+            raise OSError(path)

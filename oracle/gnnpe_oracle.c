@@ -562,3 +562,68 @@ int orc_index_validate(const uint8_t *img, uint64_t nbytes, int32_t hdr[8],
     if (height_out) *height_out = rl + 1;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * GNN-PGE offline   GNN-PGE/src/main.cpp:91-195
+ *   :97-102  dfs(node, 1, ...) -> the 2-vertex paths (node, nbr), neighbours ascending
+ *   :104-121 no paths: group = [vde, vde] (+ zeros), label group = [x, x] (+ zeros)
+ *   :123-139 path embedding = concat vde / x of the path's vertices
+ *   :141-176 group initialised from path 0, then per-dimension min / max over the other paths
+ * ------------------------------------------------------------------------------------------ */
+void orc_pge_groups(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, uint32_t e,
+                    const double *x, const double *vde, double *pg, double *plg)
+{
+    const uint32_t D = 2 * e;
+    for (uint32_t v = 0; v < n; v++) {
+        double *g = pg + (size_t)v * 2 * D, *lg = plg + (size_t)v * 2 * D;
+        const uint32_t b = offsets[v], en = offsets[v + 1];
+        if (b == en) {
+            for (uint32_t i = 0; i < e; i++) {
+                g[2 * i] = g[2 * i + 1] = vde[(size_t)v * e + i];
+                lg[2 * i] = lg[2 * i + 1] = x[(size_t)v * e + i];
+            }
+            for (uint32_t i = e; i < D; i++) g[2 * i] = g[2 * i + 1] = lg[2 * i] = lg[2 * i + 1] = 0.0;
+            continue;
+        }
+        for (uint32_t j = b; j < en; j++) {
+            const uint32_t u = neighbors[j];
+            for (uint32_t i = 0; i < D; i++) {
+                const double pe = i < e ? vde[(size_t)v * e + i] : vde[(size_t)u * e + (i - e)];
+                const double le = i < e ? x[(size_t)v * e + i] : x[(size_t)u * e + (i - e)];
+                if (j == b) {
+                    g[2 * i] = g[2 * i + 1] = pe;
+                    lg[2 * i] = lg[2 * i + 1] = le;
+                } else {
+                    if (g[2 * i] > pe) g[2 * i] = pe;
+                    if (g[2 * i + 1] < pe) g[2 * i + 1] = pe;
+                    if (lg[2 * i] > le) lg[2 * i] = le;
+                    if (lg[2 * i + 1] < le) lg[2 * i + 1] = le;
+                }
+            }
+        }
+    }
+}
+
+int orc_pge_write_bin(const char *path, uint32_t n, uint32_t e, const uint32_t *offsets, const uint32_t *labels,
+                      const double *x, const double *nx, const double *vde, const double *pg, const double *plg,
+                      double key_fill)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const uint32_t D = 2 * e;
+    fwrite(&n, 4, 1, f);
+    for (uint32_t v = 0; v < n; v++) {
+        const uint32_t deg = offsets[v + 1] - offsets[v];
+        fwrite(&v, 4, 1, f);
+        fwrite(&labels[v], 4, 1, f);
+        fwrite(&deg, 4, 1, f);
+        fwrite(&key_fill, 8, 1, f);
+        fwrite(x + (size_t)v * e, 8, e, f);
+        fwrite(nx + (size_t)v * e, 8, e, f);
+        fwrite(vde + (size_t)v * e, 8, e, f);
+        fwrite(pg + (size_t)v * 2 * D, 8, 2 * D, f);
+        fwrite(plg + (size_t)v * 2 * D, 8, 2 * D, f);
+    }
+    fclose(f);
+    return 0;
+}

@@ -86,6 +86,21 @@ int orc_index_validate(const uint8_t *img, uint64_t nbytes, int32_t hdr[8],
                        int32_t *leaf_son, double *leaf_pt, uint64_t leaf_capacity,
                        int32_t *height_out);
 
+/* ---- GNN-PGE offline ("next" row): GNN-PGE/src/main.cpp:91-195 ----------------------- */
+/* Per vertex: 1-hop paths (v, nbr) (dfs to depth path_length = 2, GNN-PGE/include/custom.h:52-71); the
+ * path embedding is [vde[v], vde[nbr]] (D = 2e dims); path_group = per-dimension [min, max] over the
+ * vertex' paths, path_label_group the same over [x[v], x[nbr]].  Isolated vertices get
+ * [vde, vde] / [x, x] in the first e dims and zeros after (main.cpp:104-121).
+ * path_group, path_label_group: n x 2D doubles, laid out (lo0, hi0, lo1, hi1, ...). */
+void orc_pge_groups(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, uint32_t e,
+                    const double *x, const double *vde, double *path_group, double *path_label_group);
+/* data_vertices.bin (main.cpp:179-194): u32 count; per vertex u32 vid, label, degree; double key
+ * (uninitialised in the reference for data vertices -- written as `key_fill`); x, nx, vde (e doubles
+ * each); path_group, path_label_group (2D doubles each). */
+int orc_pge_write_bin(const char *path, uint32_t n, uint32_t e, const uint32_t *offsets, const uint32_t *labels,
+                      const double *x, const double *nx, const double *vde, const double *path_group,
+                      const double *path_label_group, double key_fill);
+
 #ifdef __cplusplus
 }
 #endif
