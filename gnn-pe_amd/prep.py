@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Prep step without pymetis: what the reference's gnnpe.py / gnnpge.py leave on
+disk for `main -m offline` -- the partition directories (gnnpe.py:60-64), the processing order
+(ascending degree, ties by id, gnnpe.py:71-72) and `membership.txt` (gnnpe.py:74-76) -- computed from the
+`.graph` text file itself.  The reference partitions with METIS (pymetis.part_graph, gnnpe.py:66-69),
+which is not available here; any partition is valid for the offline/online pipeline (the answer count
+does not depend on it), so this tool offers two simple ones:
+  blocks   contiguous id blocks  floor(id * p / n)
+  bfs      breadth-first growth of p regions of ~n/p vertices each (keeps neighbours together)
+
+    python gnn-pe_amd/prep.py -f <dataset dir>/ -d <graph> -p <partitions> [--variant gnn-pe|gnn-pge] [--method bfs]
+"""
+import argparse
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import gnnpe_amd  # noqa: E402,F401
+from gnnpe_amd import binding, synth  # noqa: E402
+
+
+def bfs_partition(offsets, nbrs, p):
+    """Grow p regions breadth-first from the lowest unassigned id until each holds ~n/p vertices."""
+    n = len(offsets) - 1
+    part = np.full(n, -1, np.int64)
+    target = -(-n // p)
+    cur, filled, nxt = 0, 0, 0
+    from collections import deque
+    q = deque()
+    for _ in range(n):
+        while not q:
+            while nxt < n and part[nxt] >= 0:
+                nxt += 1
+            if nxt >= n:
+                break
+            q.append(nxt)
+            part[nxt] = cur
+            filled += 1
+        if not q:
+            break
+        v = q.popleft()
+        for u in nbrs[offsets[v]:offsets[v + 1]]:
+            if part[u] < 0:
+                if filled >= target and cur < p - 1:
+                    cur, filled = cur + 1, 0
+                    q.clear()
+                    break
+                part[u] = cur
+                filled += 1
+                q.append(u)
+        if filled >= target and cur < p - 1:
+            cur, filled = cur + 1, 0
+            q.clear()
+    part[part < 0] = p - 1
+    return part.astype(np.uint32)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("-f", "--file", dest="dataset", required=True)
+    ap.add_argument("-d", "--data", dest="graph", required=True)
+    ap.add_argument("-p", "--partition", dest="p", type=int, default=5)
+    ap.add_argument("--variant", choices=["gnn-pe", "gnn-pge"], default="gnn-pe")
+    ap.add_argument("--method", choices=["blocks", "bfs"], default="bfs")
+    args = ap.parse_args(argv)
+    g = binding.host_load_graph(args.graph)  # the library's own loader (host/graph_loader.cpp); needs no GPU
+    n = g["n"]
+    base = os.path.join(args.dataset, args.variant)
+    shutil.rmtree(base, ignore_errors=True)  # gnnpe.py:60 deletes the old tree
+    for i in range(args.p):
+        os.makedirs(os.path.join(base, "partitions", f"partition-{i}"))
+    mem = synth.block_membership(n, args.p) if args.method == "blocks" else bfs_partition(g["offsets"], g["nbrs"], args.p)
+    order = synth.degree_order(g["offsets"])
+    synth.write_membership(os.path.join(base, "membership.txt"), order, mem)
+    sizes = np.bincount(mem, minlength=args.p)
+    print(f"{args.variant}: {n} vertices -> {args.p} partitions ({args.method}), sizes {sizes.tolist()}")
+
+
+if __name__ == "__main__":
+    main()

@@ -103,3 +103,24 @@ def test_cli_flag_forms(tmp_path):
         r = _run(*args)
         assert r.returncode == 255 and "Can not open the graph file" in r.stdout
     assert _run("--bogus").returncode == 1
+
+
+def test_prep_tool_writes_the_layout_the_cli_expects(tmp_path):
+    """prep.py replaces gnnpe.py's outputs: directories + degree-sorted membership.txt."""
+    import sys
+    g = synth.gnm_graph(300, 1200, n_labels=4, seed=2)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    for variant, method in (("gnn-pe", "bfs"), ("gnn-pge", "blocks")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "gnn-pe_amd", "prep.py"), "-f", str(tmp_path) + "/", "-d", gp,
+                            "-p", "3", "--variant", variant, "--method", method], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = [l.split() for l in open(tmp_path / variant / "membership.txt")]
+        order = np.array([int(a) for a, _ in lines])
+        part = np.array([int(b) for _, b in lines])
+        assert sorted(order.tolist()) == list(range(300)) and set(part.tolist()) <= {0, 1, 2}
+        deg = np.diff(g["offsets"].astype(np.int64))
+        assert np.all(np.diff(deg[order]) >= 0)  # ascending degree (gnnpe.py:71-72)
+        assert all(os.path.isdir(tmp_path / variant / "partitions" / f"partition-{i}") for i in range(3))
+        sizes = np.bincount(part, minlength=3)
+        assert sizes.min() >= 60  # balanced within reason
