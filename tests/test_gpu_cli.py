@@ -150,31 +150,42 @@ def test_slab_split_writes_identical_files(tmp_path, gpus):
         assert open(os.path.join(outs[0], f), "rb").read() == open(os.path.join(outs[1], f), "rb").read(), f
 
 
-def test_empty_partitions_and_tiny_graph_through_both_binaries(tmp_path):
-    """Edge cases at process level: partitions without any start vertex (empty partition_paths.txt and the
-    reference's own empty tree as index.dat) and a graph with isolated vertices; the untouched reference
-    online run must accept every file."""
+def test_empty_and_small_partitions_through_both_binaries(tmp_path):
+    """Edge cases at process level.  (1) A partition without any start vertex: empty partition_paths.txt
+    ("0\\n") byte-equal to the reference's, and index.dat = the reference's own empty tree.  (The reference's
+    ONLINE run segfaults on its own files when a partition is empty, so only the offline bytes are compared.)
+    (2) Unequal non-empty partitions: the untouched reference online run gives the same answer from the trees
+    it builds itself and from our pre-built index.dat."""
     if not os.path.exists(ref_main_path()):
         pytest.skip("oracle/_ref/ref_main not built")
     g = synth.gnm_graph(400, 1500, n_labels=6, seed=33)
     sn = synth.degree_order(g["offsets"])
-    mem = np.zeros(400, np.uint32)
-    mem[sn[:5]] = 1  # partition 1 owns only the five lowest-degree vertices; partition 2 owns nothing
     gp = str(tmp_path / "g.graph")
     synth.write_graph_file(gp, g)
-    ours, ref = str(tmp_path / "ours"), str(tmp_path / "ref")
-    for d in (ours, ref):
-        os.makedirs(d)
-        synth.make_dataset_dir(d, 3)
-        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
-    subprocess.check_call([ref_main_path(), "-f", ref + "/", "-d", gp, "-m", "offline", "-p", "3"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([CLI, "-f", ours + "/", "-d", gp, "-p", "3", "--index"], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    for f in ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(3)]:
-        assert open(os.path.join(ours, f), "rb").read() == open(os.path.join(ref, f), "rb").read(), f
-    assert open(os.path.join(ours, "gnn-pe/partitions/partition-2/partition_paths.txt")).read() == "0\n"
+    rng = np.random.default_rng(33)
+    mem_empty = np.zeros(400, np.uint32)
+    mem_empty[sn[:5]] = 1          # partition 1: five lowest-degree vertices; partition 2: nothing
+    mem_small = np.zeros(400, np.uint32)
+    mem_small[rng.choice(400, 60, replace=False)] = 1
+    mem_small[rng.choice(400, 120, replace=False)] = 2
     q = os.path.join(GOLDEN, "test_graph", "query_graph.graph")
-    a = subprocess.check_output([ref_main_path(), "-f", ref + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
-    b = subprocess.check_output([ref_main_path(), "-f", ours + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
-    na, nb = (int(re.search(r"Answer Number: (\d+)", t).group(1)) for t in (a, b))
-    assert na == nb  # same answer from the reference-built trees and from our pre-built index.dat
+    for name, mem, online in (("empty", mem_empty, False), ("small", mem_small, True)):
+        ours, ref = str(tmp_path / f"ours_{name}"), str(tmp_path / f"ref_{name}")
+        for d in (ours, ref):
+            os.makedirs(d)
+            synth.make_dataset_dir(d, 3)
+            synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        subprocess.check_call([ref_main_path(), "-f", ref + "/", "-d", gp, "-m", "offline", "-p", "3"], stdout=subprocess.DEVNULL)
+        r = subprocess.run([CLI, "-f", ours + "/", "-d", gp, "-p", "3", "--index"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for f in ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(3)]:
+            assert open(os.path.join(ours, f), "rb").read() == open(os.path.join(ref, f), "rb").read(), (name, f)
+        if not online:
+            assert open(os.path.join(ours, "gnn-pe/partitions/partition-2/partition_paths.txt")).read() == "0\n"
+            img = open(os.path.join(ours, "gnn-pe/partitions/partition-2/index.dat"), "rb").read()
+            assert len(img) == 8192 and img[24] == 1  # one empty leaf that is the root (rtree.cpp:11-32)
+            continue
+        a = subprocess.check_output([ref_main_path(), "-f", ref + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
+        b = subprocess.check_output([ref_main_path(), "-f", ours + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
+        na, nb = (int(re.search(r"Answer Number: (\d+)", t).group(1)) for t in (a, b))
+        assert na == nb
