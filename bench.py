@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--fill-variant", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="15000,150000")
+    ap.add_argument("--cpu-sample", type=str, default="30000,300000")
     args = ap.parse_args()
 
     import torch

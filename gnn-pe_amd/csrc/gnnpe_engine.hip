@@ -353,6 +353,7 @@ int gnnpe_set_label_table(gnnpe_ctx *c, uint32_t n_labels, uint32_t e, const dou
     c->n_labels = n_labels;
     c->e = e;
     c->have_table = true;
+    c->counted = false;  // record layouts of the enumeration depend on e
     c->have_vde = false;
     c->nbr_vde_valid = false;
     return GNNPE_OK;
