@@ -31,9 +31,6 @@ void set_error(const char *fmt, ...)
 struct CastU64 {
     __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
 };
-struct CastU8 {
-    __host__ __device__ uint32_t operator()(uint8_t v) const { return (uint32_t)v; }
-};
 
 // exclusive sum of cnt uint32 -> uint64 (n items) on the context stream
 static int scan_u32_to_u64(gnnpe_ctx *c, const uint32_t *in, uint64_t *out, uint64_t n)

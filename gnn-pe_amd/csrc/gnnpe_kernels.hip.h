@@ -191,14 +191,6 @@ constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
 constexpr uint64_t kNoOff = ~0ull;
 
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-__device__ __forceinline__ uint64_t rl64(uint64_t v, int l)
-{
-    return ((uint64_t)rl32((uint32_t)(v >> 32), l) << 32) | rl32((uint32_t)v, l);
-}
-__device__ __forceinline__ double rlf64(double v, int l)
-{
-    return __hiloint2double((int)rl32((uint32_t)__double2hiint(v), l), (int)rl32((uint32_t)__double2loint(v), l));
-}
 
 // revpos[q] for adjacency entry q = (b -> u): position of b inside N(u), or kNoEdge when row u is not
 // an OWNED row of this device (only owned rows start paths here).  Depends on the graph only -- not on
