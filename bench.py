@@ -129,7 +129,7 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     eng = binding.Engine(local_rank, stream=stream.cuda_stream)
-    bounds = plan_slabs(g["offsets"], sn, world)
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"])
     owned_entries = 2 * args.m
     if world == 1:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])

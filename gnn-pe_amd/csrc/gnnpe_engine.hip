@@ -812,44 +812,47 @@ int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 int gnnpe_halo_need(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds, void *dev_ids, uint64_t cap,
                     uint64_t *host_counts)
 {
-    GNNPE_REQUIRE(c && bounds && host_counts && n_ranks >= 1, GNNPE_ERR_ARG, "gnnpe_halo_need: null argument");
+    GNNPE_REQUIRE(c && bounds && host_counts && n_ranks >= 1 && n_ranks <= 64, GNNPE_ERR_ARG,
+                  "gnnpe_halo_need: null argument / more than 64 ranks");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_rank_arrays(c);
     if (rc) return rc;
     const uint32_t n = c->n;
-    if ((rc = c->mark.reserve((size_t)2 * n + 16))) return rc;
-    uint8_t *mark = c->mark.as<uint8_t>(), *flag = mark + n;
+    for (uint32_t r = 0; r < n_ranks; r++) host_counts[r] = 0;
+    if (n == 0) return GNNPE_OK;
+    // layout of `mark`: mark[n] | key_in[n] | key_out[n] | (aligned) ids_in[n] | ids_out[n]
+    const size_t a4 = ((size_t)3 * n + 15) & ~(size_t)15;
+    if ((rc = c->mark.reserve(a4 + (size_t)8 * n + 64)) || (rc = c->small.reserve(256 + 65 * 4 + 64 * 8))) return rc;
+    uint8_t *mark = c->mark.as<uint8_t>(), *key_in = mark + n, *key_out = mark + 2 * (size_t)n;
+    uint32_t *ids_in = reinterpret_cast<uint32_t *>(mark + a4), *ids_out = ids_in + n;
+    uint32_t *d_bounds = reinterpret_cast<uint32_t *>(c->small.as<char>() + 256);
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(c->small.as<char>() + 256 + 65 * 4 + 4);
     GNNPE_HIP_TRY(hipMemsetAsync(mark, 0, n, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(d_hist, 0, 64 * 8, c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(d_bounds, bounds, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, c->stream));
     if (c->nbr_owned)
         hipLaunchKernelGGL(k_mark_needed, dim3(grid_for(c->nbr_owned)), dim3(kBlock), 0, c->stream, c->nbr_owned,
                            c->nbrs.as<uint32_t>(), mark);
+    hipLaunchKernelGGL(k_need_owner, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, n_ranks, d_bounds, mark,
+                       c->present.as<uint8_t>(), c->rank.as<uint32_t>(), key_in, ids_in, d_hist);
+    GNNPE_HIP_TRY(hipGetLastError());
+    size_t tb = 0;
+    GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_in, key_out, ids_in, ids_out, (int)n, 0, 8, c->stream));
+    if ((rc = c->cub_tmp.reserve(tb))) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, key_in, key_out, ids_in, ids_out, (int)n, 0, 8, c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, d_hist, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // bounds[] (caller memory) and the histogram are done
     uint64_t used = 0;
-    if ((rc = c->small.reserve(256))) return rc;
-    uint32_t *d_num = c->small.as<uint32_t>() + 8;
     for (uint32_t r = 0; r < n_ranks; r++) {
-        hipLaunchKernelGGL(k_flag_owner, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, mark,
-                           c->present.as<uint8_t>(), c->rank.as<uint32_t>(), bounds[r], bounds[r + 1], flag);
-        hipcub::CountingInputIterator<uint32_t> ids(0);
-        size_t tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb, ids, flag, (uint32_t *)nullptr, d_num, (int)n, c->stream));
-        if ((rc = c->cub_tmp.reserve(tb))) return rc;
-        if ((rc = c->scratch.reserve((size_t)(n + 1) * 4))) return rc;
-        tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceSelect::Flagged(c->cub_tmp.p, tb, ids, flag, c->scratch.as<uint32_t>(), d_num, (int)n,
-                                                    c->stream));
-        uint64_t k = 0;
-        if ((rc = read_back_u64(c, d_num, 4, &k))) return rc;
-        k = (uint32_t)k;
-        host_counts[r] = k;
-        if (k) {
-            GNNPE_REQUIRE(dev_ids && used + k <= cap, GNNPE_ERR_ARG, "gnnpe_halo_need: id buffer too small (%llu needed)",
-                          (unsigned long long)(used + k));
-            GNNPE_HIP_TRY(hipMemcpyAsync((uint32_t *)dev_ids + used, c->scratch.p, k * 4, hipMemcpyDeviceToDevice,
-                                         c->stream));
-        }
-        used += k;
+        host_counts[r] = c->h_pinned[r];
+        used += host_counts[r];
     }
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (used) {
+        GNNPE_REQUIRE(dev_ids && used <= cap, GNNPE_ERR_ARG, "gnnpe_halo_need: id buffer too small (%llu needed)",
+                      (unsigned long long)used);
+        GNNPE_HIP_TRY(hipMemcpyAsync(dev_ids, ids_out, used * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     return GNNPE_OK;
 }
 

@@ -305,13 +305,28 @@ __global__ void k_mark_needed(uint64_t cnt, const uint32_t *__restrict__ nbrs, u
         mark[nbrs[q]] = 1;
 }
 
-// flag[v] = 1 iff v is needed, not held, and owned by rank r (slab bounds over the processing order)
-__global__ void k_flag_owner(uint32_t n, const uint8_t *__restrict__ mark, const uint8_t *__restrict__ present,
-                             const uint32_t *__restrict__ rank, uint32_t lo, uint32_t hi, uint8_t *__restrict__ flag)
+// key[v] = owning rank of v (slab bounds over the processing order) if v is needed and not held, else 255;
+// ids[v] = v; hist[r] counts the needed vertices per owner.  A stable 8-bit radix sort of (key, id) then
+// yields the request lists grouped by owner with ascending ids.
+__global__ void k_need_owner(uint32_t n, uint32_t n_ranks, const uint32_t *__restrict__ bounds,
+                             const uint8_t *__restrict__ mark, const uint8_t *__restrict__ present,
+                             const uint32_t *__restrict__ rank, uint8_t *__restrict__ key, uint32_t *__restrict__ ids,
+                             unsigned long long *__restrict__ hist)
 {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t rk = rank[v];
-        flag[v] = (mark[v] && !present[v] && rk >= lo && rk < hi) ? 1 : 0;
+        uint8_t k = 255;
+        if (mark[v] && !present[v]) {
+            const uint32_t rk = rank[v];
+            uint32_t lo = 0, hi = n_ranks;  // largest r with bounds[r] <= rk
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bounds[mid] <= rk) lo = mid; else hi = mid;
+            }
+            k = (uint8_t)lo;
+            atomicAdd(&hist[lo], 1ull);
+        }
+        key[v] = k;
+        ids[v] = (uint32_t)v;
     }
 }
 

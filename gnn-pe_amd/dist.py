@@ -23,19 +23,29 @@ import torch
 import torch.distributed as dist
 
 
-def plan_slabs(offsets, sorted_nodes, n_ranks):
+def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None):
     """Cut the processing order into n_ranks contiguous slabs of roughly equal fill work.
 
-    Host-side prep (the analogue of the reference's partitioning script): the work of start s is
-    about (sum of its neighbours' degrees) x (fraction of vertices ranked after s), a cheap proxy
-    for count(s) = sum_b |{c in N(b): rank[c] > rank[s]}|.  Returns uint32 bounds[n_ranks+1]."""
+    Host-side prep (the analogue of the reference's partitioning script).  The paths of start s number
+    count(s) = sum_{b in N(s)} |{c in N(b): rank[c] > rank[s]}|, estimated as
+    (sum_{b in N(s)} (deg b - 1)) * (share of edge endpoints ranked after s): one pass over the adjacency (`nbrs`);
+    without the adjacency the neighbour degrees are replaced by the mean degree.
+    Returns uint32 bounds[n_ranks+1]."""
     n = len(sorted_nodes)
     offs = offsets.astype(np.int64)
     deg = np.diff(offs)
-    # sum of neighbour degrees per vertex needs the adjacency; approximate by deg * mean degree
-    mean_deg = max(float(deg.mean()) if n else 0.0, 1.0)
-    w = deg[sorted_nodes.astype(np.int64)].astype(np.float64) * mean_deg
-    w *= 1.0 - (np.arange(n, dtype=np.float64) + 0.5) / max(n, 1)
+    order = sorted_nodes.astype(np.int64)
+    if nbrs is not None and len(nbrs):
+        nd = (deg[nbrs.astype(np.int64)] - 1).astype(np.float64)
+        csum = np.concatenate([[0.0], np.cumsum(nd)])
+        two_hop = csum[offs[1:]] - csum[offs[:-1]]          # sum of (deg b - 1) over the neighbours of every vertex
+    else:
+        two_hop = deg.astype(np.float64) * max(float(deg.mean()) - 1.0 if n else 0.0, 1.0)
+    # a neighbour-of-neighbour is an edge endpoint, i.e. drawn proportionally to degree: the chance that it
+    # ranks after s is the share of edge endpoints held by later-ranked vertices, not the share of vertices
+    dsorted = deg[order].astype(np.float64)
+    later = (dsorted.sum() - np.cumsum(dsorted)) / max(dsorted.sum(), 1.0)
+    w = two_hop[order] * later
     w += 1e-3  # vertices without work still need a home
     cw = np.cumsum(w)
     targets = cw[-1] * np.arange(1, n_ranks) / n_ranks if n else np.zeros(0)

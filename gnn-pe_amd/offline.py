@@ -97,7 +97,7 @@ def main(argv=None):
     stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(stream)
     eng = binding.Engine(local_rank, stream=stream.cuda_stream)
-    bounds = plan_slabs(g["offsets"], sn, world)
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"])
     if world == 1:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
         owned_entries = len(g["nbrs"])
