@@ -834,13 +834,15 @@ int gnnpe_halo_need(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds, void
         hipLaunchKernelGGL(k_mark_needed, dim3(grid_for(c->nbr_owned)), dim3(kBlock), 0, c->stream, c->nbr_owned,
                            c->nbrs.as<uint32_t>(), mark);
     hipLaunchKernelGGL(k_need_owner, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, n_ranks, d_bounds, mark,
-                       c->present.as<uint8_t>(), c->rank.as<uint32_t>(), key_in, ids_in, d_hist);
+                       c->present.as<uint8_t>(), c->rank.as<uint32_t>(), key_in, ids_in);
     GNNPE_HIP_TRY(hipGetLastError());
     size_t tb = 0;
     GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key_in, key_out, ids_in, ids_out, (int)n, 0, 8, c->stream));
     if ((rc = c->cub_tmp.reserve(tb))) return rc;
     tb = c->cub_tmp.bytes;
     GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, key_in, key_out, ids_in, ids_out, (int)n, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_key_counts, dim3(1), dim3(64), 0, c->stream, n, n_ranks, key_out, d_hist);
+    GNNPE_HIP_TRY(hipGetLastError());
     GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, d_hist, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // bounds[] (caller memory) and the histogram are done
     uint64_t used = 0;

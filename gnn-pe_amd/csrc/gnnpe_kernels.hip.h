@@ -306,12 +306,11 @@ __global__ void k_mark_needed(uint64_t cnt, const uint32_t *__restrict__ nbrs, u
 }
 
 // key[v] = owning rank of v (slab bounds over the processing order) if v is needed and not held, else 255;
-// ids[v] = v; hist[r] counts the needed vertices per owner.  A stable 8-bit radix sort of (key, id) then
-// yields the request lists grouped by owner with ascending ids.
+// ids[v] = v.  A stable 8-bit radix sort of (key, id) then yields the request lists grouped by owner with
+// ascending ids; k_key_counts reads the group sizes off the sorted keys.
 __global__ void k_need_owner(uint32_t n, uint32_t n_ranks, const uint32_t *__restrict__ bounds,
                              const uint8_t *__restrict__ mark, const uint8_t *__restrict__ present,
-                             const uint32_t *__restrict__ rank, uint8_t *__restrict__ key, uint32_t *__restrict__ ids,
-                             unsigned long long *__restrict__ hist)
+                             const uint32_t *__restrict__ rank, uint8_t *__restrict__ key, uint32_t *__restrict__ ids)
 {
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
         uint8_t k = 255;
@@ -323,11 +322,29 @@ __global__ void k_need_owner(uint32_t n, uint32_t n_ranks, const uint32_t *__res
                 if (bounds[mid] <= rk) lo = mid; else hi = mid;
             }
             k = (uint8_t)lo;
-            atomicAdd(&hist[lo], 1ull);
         }
         key[v] = k;
         ids[v] = (uint32_t)v;
     }
+}
+
+// hist[r] = number of sorted keys equal to r (one thread per rank, two binary searches)
+__global__ void k_key_counts(uint32_t n, uint32_t n_ranks, const uint8_t *__restrict__ sorted_key,
+                             unsigned long long *__restrict__ hist)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranks) return;
+    uint32_t b[2];
+    for (int t = 0; t < 2; t++) {
+        const uint32_t want = r + t;  // first position with key >= want
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sorted_key[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        b[t] = lo;
+    }
+    hist[r] = b[1] - b[0];
 }
 
 // back to owned rows only: present := owned, halo degrees := 0
