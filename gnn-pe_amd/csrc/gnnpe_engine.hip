@@ -118,7 +118,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->pge_pg, &c->pge_plg};
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->pge_pg, &c->pge_plg};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -506,18 +506,24 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
 {
     const uint32_t e = c->have_table ? c->e : 2;
     int rc;
-    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))))
+    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))) ||
+        (rc = c->vinfo.reserve(((size_t)c->n + 1) * GNNPE_VINFO_STRIDE(e) * 8)))
         return rc;
     GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
     if (c->n_held) {
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-#define GNNPE_RR(EE)                                                                                              \
-    hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin, c->slab_end,  \
-                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),             \
-                       c->rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(), vde,             \
-                       c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>())
+#define GNNPE_RR(EE)                                                                                               \
+    do {                                                                                                           \
+        static_assert(sizeof(RankedNbr<EE>) == 8 + 8 * EE, "record size must match the host-side allocation");     \
+        hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
+                           c->rank.as<uint32_t>(), c->vinfo.as<double>());                                          \
+        hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin,            \
+                           c->slab_end, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),                     \
+                           c->nbrs.as<uint32_t>(), c->vinfo.as<double>(), c->revpos.as<uint32_t>(),                 \
+                           c->poffs.as<uint32_t>(), c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>());      \
+    } while (0)
         switch (e) {
         case 1: GNNPE_RR(1); break;
         case 2: GNNPE_RR(2); break;

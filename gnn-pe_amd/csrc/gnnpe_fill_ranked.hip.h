@@ -27,6 +27,22 @@ struct __attribute__((aligned(16))) RankedPair {
     uint64_t G;       // id-positions of N(b) with rank > rank[s]
 };
 
+// one gather per adjacency entry instead of two: {vde[v], rank[v]} side by side, VINFO_STRIDE(E) doubles per vertex
+// (E = 2 -> 32 bytes: one aligned half cache line)
+#define GNNPE_VINFO_STRIDE(E) ((E) + 2)
+template <int E>
+__global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const uint32_t *__restrict__ rank,
+                             double *__restrict__ vinfo)
+{
+    constexpr int S = GNNPE_VINFO_STRIDE(E);
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < E; k++) vinfo[v * S + k] = vde ? vde[v * E + k] : 0.0;
+        reinterpret_cast<uint64_t *>(vinfo)[v * S + E] = rank[v];
+        vinfo[v * S + E + 1] = 0.0;
+    }
+}
+
 template <int E> struct __attribute__((aligned(8))) RankedNbr {
     uint32_t id, idpos;
     double vde[E];
@@ -46,9 +62,9 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
                                                    uint32_t slab_begin, uint32_t slab_end,
                                                    const uint32_t *__restrict__ adj_start,
                                                    const uint32_t *__restrict__ adj_deg,
-                                                   const uint32_t *__restrict__ nbrs, const uint32_t *__restrict__ rank,
+                                                   const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
                                                    const uint32_t *__restrict__ revpos,
-                                                   const uint32_t *__restrict__ poffs, const double *__restrict__ vde,
+                                                   const uint32_t *__restrict__ poffs,
                                                    RankedNbr<E> *__restrict__ recs, RankedPair *__restrict__ pairs)
 {
     const unsigned lane = lane_id();
@@ -58,10 +74,17 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
         const uint32_t b = held ? held[w] : (uint32_t)w;
         const uint32_t st = adj_start[b], d = adj_deg[b];
         if (d == 0 || d > 64) continue;  // longer rows: the caller does not select this variant
+        constexpr int S = GNNPE_VINFO_STRIDE(E);
         uint32_t u = 0, r = 0, rp = kNoEdge;
+        double vu[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) vu[k] = 0.0;
         if (lane < d) {
             u = nbrs[st + lane];
-            r = rank[u];
+            const double *vi = vinfo + (uint64_t)u * S;
+#pragma unroll
+            for (int k = 0; k < E; k++) vu[k] = vi[k];
+            r = (uint32_t) reinterpret_cast<const uint64_t *>(vi)[E];
             rp = revpos[st + lane];
         }
         uint64_t G = 0;
@@ -73,7 +96,7 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             rec.id = u;
             rec.idpos = lane;
 #pragma unroll
-            for (int k = 0; k < E; k++) rec.vde[k] = vde ? vde[(uint64_t)u * E + k] : 0.0;
+            for (int k = 0; k < E; k++) rec.vde[k] = vu[k];
             recs[st + p] = rec;
             const uint32_t pi = pair_index(rp, r, slab_begin, slab_end, poffs);
             if (pi != kNoEdge) {
