@@ -336,6 +336,14 @@ class Engine:
                                                    C.byref(nb), hdr))
         return img.value, nb.value, list(hdr)
 
+    def build_box_index_device(self, cnt, dim, dev_boxes):
+        """cnt x 2*dim doubles (lo0, hi0, lo1, hi1, ...) -> same image format (GNN-PGE/include/custom.h:171-177)."""
+        img, nb = _vp(), C.c_uint64()
+        hdr = (C.c_int32 * 8)()
+        self._ck(self.lib.gnnpe_build_box_index_device(self.ctx, int(cnt), int(dim), _dev(dev_boxes), C.byref(img),
+                                                       C.byref(nb), hdr))
+        return img.value, nb.value, list(hdr)
+
     def build_index(self, pid, path):
         self._ck(self.lib.gnnpe_build_index(self.ctx, int(pid), path.encode()))
 

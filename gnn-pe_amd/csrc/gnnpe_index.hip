@@ -211,6 +211,194 @@ __global__ __launch_bounds__(64) void k_pack_inner(uint64_t n_child, uint64_t ch
     for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) dst[i] = reinterpret_cast<uint32_t *>(s_blk)[i];
 }
 
+// ---- fast path: 3-vertex paths with a compile-time embedding width (D = 3E) -------------------------
+// Same keys, same leaves and same bytes as the generic kernels above (tests/test_gpu_index.py builds
+// one partition both ways), but each point's coordinates are gathered once into registers, the two
+// passes over the points are single passes, and one wave assembles a leaf with dword LDS traffic only.
+template <int E> struct PathPoints {
+    static constexpr int D = 3 * E;
+    const uint32_t *vids;
+    const double *vde;
+    __device__ __forceinline__ void load(uint64_t p, double (&v)[D]) const
+    {
+        const uint32_t a = vids[p * 3], b = vids[p * 3 + 1], c = vids[p * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            v[k] = vde[(uint64_t)a * E + k];
+            v[E + k] = vde[(uint64_t)b * E + k];
+            v[2 * E + k] = vde[(uint64_t)c * E + k];
+        }
+    }
+};
+
+__device__ __forceinline__ double wave_min_f64(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ double wave_max_f64(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+__global__ void k_minmax_init(double *__restrict__ mn, double *__restrict__ mx)
+{
+    mn[threadIdx.x] = 1e300;
+    mx[threadIdx.x] = 0.0;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_minmax_paths(uint64_t cnt, PathPoints<E> S, double *__restrict__ mn,
+                                                      double *__restrict__ mx)
+{
+    constexpr int D = 3 * E;
+    double a[D], b[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        a[k] = 1e300;
+        b[k] = -1e300;
+    }
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
+        double v[D];
+        S.load(p, v);
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            a[k] = fmin(a[k], v[k]);
+            b[k] = fmax(b[k], v[k]);
+        }
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        const double lo = wave_min_f64(a[k]), hi = wave_max_f64(b[k]);
+        if (lane == 0 && hi >= 0.0) {  // a wave that saw no point keeps hi = -1e300
+            atomicMin(reinterpret_cast<unsigned long long *>(mn) + k, (unsigned long long)__double_as_longlong(lo));
+            atomicMax(reinterpret_cast<unsigned long long *>(mx) + k, (unsigned long long)__double_as_longlong(hi));
+        }
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void k_zorder_keys_paths(uint64_t cnt, PathPoints<E> S, uint32_t bits,
+                                                           const double *__restrict__ mn, const double *__restrict__ mx,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    constexpr int D = 3 * E;
+    const uint32_t qmax = (1u << bits) - 1u;
+    double lo[D], span[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+        lo[k] = mn[k];
+        span[k] = mx[k] - mn[k];
+    }
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
+        double v[D];
+        S.load(p, v);
+        uint64_t key = 0;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double c = 0.5 * (v[k] + v[k]);  // the generic kernel's box centre, for identical keys
+            const uint32_t q = span[k] > 0.0 ? (uint32_t)fmin((c - lo[k]) / span[k] * (double)qmax, (double)qmax) : 0u;
+            for (uint32_t t = 0; t < bits; t++) key |= (uint64_t)((q >> t) & 1u) << (t * D + (D - 1 - k));
+        }
+        keys[p] = key;
+        vals[p] = (uint32_t)p;
+    }
+}
+
+// One wave per leaf, kLeafWaves leaves in flight per workgroup, every wave looping over leaves.
+// The node block is assembled in a wave-private LDS window shifted by 3 bytes, so that the packed
+// format's odd offsets (entries start at byte 5, rtnode.cpp:1099-1117) fall on dword boundaries:
+//   window byte 3 = level, dword 1 = n_entries, entry i = dwords [2 + i*(4D+1), 2 + (i+1)*(4D+1))
+// and file dword w = (window dword w >> 24) | (window dword w+1 << 8).
+constexpr int kLeafWaves = 4;
+template <int E>
+__global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t cnt, uint64_t n_leaves, uint32_t F,
+                                                                        PathPoints<E> S,
+                                                                        const uint32_t *__restrict__ order,
+                                                                        char *__restrict__ image,
+                                                                        double *__restrict__ node_mbr)
+{
+    constexpr int D = 3 * E;
+    constexpr int kWin = kBlockLen / 4 + 4;  // dwords; the last window dwords feed the shifted reads of dword 1023
+    constexpr int kEnt = 4 * D + 1;          // dwords per entry
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *w = s_win[wv];
+    for (uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv; j < n_leaves; j += (uint64_t)gridDim.x * kLeafWaves) {
+        const uint64_t p0 = j * F;
+        const uint32_t ne = (uint32_t)min((uint64_t)F, cnt - p0);
+        double v[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) v[k] = 0.0;
+        uint32_t son = 0;
+        if ((uint32_t)lane < ne) {
+            son = order[p0 + lane];  // the path's index inside the partition (custom.h:243)
+            S.load(son, v);
+        }
+        if (lane == 0) {
+            w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
+            w[1] = ne;
+        }
+        // zero tail after the last entry
+        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;
+        if ((uint32_t)lane < ne) {
+            uint32_t *ent = w + 2 + lane * kEnt;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const uint64_t bits64 = (uint64_t)__double_as_longlong(v[k]);
+                const uint32_t x = (uint32_t)bits64, y = (uint32_t)(bits64 >> 32);
+                ent[4 * k] = x;      // bounces[2k]   (custom.h:246)
+                ent[4 * k + 1] = y;
+                ent[4 * k + 2] = x;  // bounces[2k+1] (custom.h:247)
+                ent[4 * k + 3] = y;
+            }
+            ent[4 * D] = son;
+        }
+        // node MBR for the parent level: lane k keeps dimension k
+        double my_lo = 0.0, my_hi = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double lo = wave_min_f64((uint32_t)lane < ne ? v[k] : 1e300);
+            const double hi = wave_max_f64((uint32_t)lane < ne ? v[k] : -1e300);
+            if (lane == k) {
+                my_lo = lo;
+                my_hi = hi;
+            }
+        }
+        if (lane < D) {
+            node_mbr[(j * D + lane) * 2] = my_lo;
+            node_mbr[(j * D + lane) * 2 + 1] = my_hi;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // node j -> file block j+1, 16 bytes per lane per round, streamed past the caches
+        uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);
+#pragma unroll
+        for (int r = 0; r < kBlockLen / 16 / 64; r++) {
+            const int c = lane + 64 * r;
+            const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
+            const uint32_t nx = w[4 * c + 4];
+            uint4 o;
+            o.x = (lo4.x >> 24) | (lo4.y << 8);
+            o.y = (lo4.y >> 24) | (lo4.z << 8);
+            o.z = (lo4.z >> 24) | (lo4.w << 8);
+            o.w = (lo4.w >> 24) | (nx << 8);
+            __builtin_nontemporal_store(o.x, &dst[c].x);
+            __builtin_nontemporal_store(o.y, &dst[c].y);
+            __builtin_nontemporal_store(o.z, &dst[c].z);
+            __builtin_nontemporal_store(o.w, &dst[c].w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // rows of `src` (n x L uint32) selected by idx -> dst
 __global__ void k_gather_rows_u32(uint64_t n, uint32_t L, const uint64_t *__restrict__ idx, uint64_t idx_base,
                                   const uint32_t *__restrict__ src, uint32_t *__restrict__ dst)
@@ -236,9 +424,10 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     const uint32_t D = S.D;
     const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);  // rtnode.cpp:27-28
-    GNNPE_REQUIRE(cap >= 3 && cap <= 64, GNNPE_ERR_UNSUPPORTED, "entry size for dim %u gives node capacity %u", D, cap);
-    // the reference splits a node on reaching capacity-1 (rtnode.cpp:528,576): keep <= capacity-2
-    const uint32_t F = cap - 2;
+    GNNPE_REQUIRE(cap >= 3, GNNPE_ERR_UNSUPPORTED, "entry size for dim %u gives node capacity %u", D, cap);
+    // the reference splits a node on reaching capacity-1 (rtnode.cpp:528,576): keep <= capacity-2; one lane
+    // assembles one entry, so very small entries (dim <= 3) fill a node to 64 instead
+    const uint32_t F = std::min(cap - 2, 64u);
     int rc;
 
     // level sizes: leaves, then parents until a single node remains; root must be internal
@@ -266,20 +455,35 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
         if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
         double *mn = reinterpret_cast<double *>(c->small.as<char>() + 256), *mx = mn + 64;
         GNNPE_REQUIRE(D <= 64, GNNPE_ERR_UNSUPPORTED, "dimension %u > 64", D);
-        std::vector<double> init(128);
-        for (int k = 0; k < 64; k++) {
-            init[k] = 1e300;
-            init[64 + k] = 0.0;
-        }
-        GNNPE_HIP_TRY(hipMemcpyAsync(mn, init.data(), 128 * 8, hipMemcpyHostToDevice, c->stream));
-        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // init[] is a stack/heap temporary
-        hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt, S,
-                           mn, mx);
+        const bool fast = !S.boxes && S.L == 3 && (S.e == 1 || S.e == 2 || S.e == 3 || S.e == 4 || S.e == 8);
+        const uint32_t wide_grid = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
+        hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, mn, mx);
         const uint32_t bits = std::max(1u, std::min(16u, 64u / D));
         if ((rc = c->idx_keys.reserve(cnt * 8 * 2)) || (rc = c->idx_vals.reserve(cnt * 4 * 2))) return rc;
         uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
         uint32_t *v_in = c->idx_vals.as<uint32_t>(), *v_out = v_in + cnt;
-        hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, S, bits, mn, mx, k_in, v_in);
+#define GNNPE_IDX_KEYS(EE)                                                                                         \
+    do {                                                                                                           \
+        PathPoints<EE> P = {S.vids, S.vde};                                                                        \
+        const uint32_t g = (uint32_t)std::min<uint64_t>(wide_grid, (cnt + 255) / 256);                             \
+        hipLaunchKernelGGL((k_minmax_paths<EE>), dim3(g), dim3(256), 0, c->stream, cnt, P, mn, mx);                \
+        hipLaunchKernelGGL((k_zorder_keys_paths<EE>), dim3(g), dim3(256), 0, c->stream, cnt, P, bits, mn, mx,      \
+                           k_in, v_in);                                                                            \
+    } while (0)
+        if (fast) {
+            switch (S.e) {
+            case 1: GNNPE_IDX_KEYS(1); break;
+            case 2: GNNPE_IDX_KEYS(2); break;
+            case 3: GNNPE_IDX_KEYS(3); break;
+            case 4: GNNPE_IDX_KEYS(4); break;
+            default: GNNPE_IDX_KEYS(8); break;
+            }
+        } else {
+            hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt,
+                               S, mn, mx);
+            hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, S, bits, mn, mx, k_in, v_in);
+        }
+#undef GNNPE_IDX_KEYS
         GNNPE_HIP_TRY(hipGetLastError());
         // 2. one radix sort over the used key bits
         size_t tb = 0;
@@ -294,7 +498,25 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
         for (uint64_t v : level_n) max_level = std::max(max_level, v);
         if ((rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8))) return rc;
         double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
-        hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, S, v_out, image, mbr_a);
+#define GNNPE_IDX_LEAVES(EE)                                                                                       \
+    do {                                                                                                           \
+        PathPoints<EE> P = {S.vids, S.vde};                                                                        \
+        const uint32_t g = (uint32_t)std::min<uint64_t>(wide_grid, (level_n[0] + kLeafWaves - 1) / kLeafWaves);    \
+        hipLaunchKernelGGL((k_pack_leaves_paths<EE>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt,           \
+                           level_n[0], F, P, v_out, image, mbr_a);                                                 \
+    } while (0)
+        if (fast) {
+            switch (S.e) {
+            case 1: GNNPE_IDX_LEAVES(1); break;
+            case 2: GNNPE_IDX_LEAVES(2); break;
+            case 3: GNNPE_IDX_LEAVES(3); break;
+            case 4: GNNPE_IDX_LEAVES(4); break;
+            default: GNNPE_IDX_LEAVES(8); break;
+            }
+        } else {
+            hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, S, v_out, image, mbr_a);
+        }
+#undef GNNPE_IDX_LEAVES
         uint64_t child0 = 0, node0 = level_n[0];
         for (size_t lv = 1; lv < level_n.size(); lv++) {
             hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,

@@ -50,6 +50,30 @@ def test_index_image_structure_and_contents(oracle, test_graph, e):
     eng.close()
 
 
+@pytest.mark.parametrize("e", [1, 2, 3, 4, 8])
+def test_path_index_kernels_match_generic_box_kernels(test_graph, e):
+    """The 3-vertex-path fast kernels and the generic (box) kernels must emit the same bytes: the same
+    points handed over as degenerate boxes lo = hi go through the generic key / leaf kernels."""
+    import torch
+    from gnnpe_amd import binding
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    dev = torch.device("cuda:0")
+    for cnt in (total, 100003, 39, 1):
+        sub = np.ascontiguousarray(ids[:cnt])
+        t = torch.from_numpy(sub.view(np.int32)).to(dev)
+        p, nb, hdr = eng.build_index_device(cnt, 3, t)
+        fast = eng.copy_to_host(p, nb).tobytes()
+        pts = vde[sub].reshape(cnt, 3 * e)
+        boxes = torch.from_numpy(np.ascontiguousarray(np.repeat(pts, 2, axis=1))).to(dev)
+        p2, nb2, hdr2 = eng.build_box_index_device(cnt, 3 * e, boxes)
+        assert nb2 == nb and hdr2 == hdr
+        assert eng.copy_to_host(p2, nb2).tobytes() == fast
+    eng.close()
+
+
 def test_index_small_and_empty_partitions(oracle):
     import torch
     from gnnpe_amd import binding
