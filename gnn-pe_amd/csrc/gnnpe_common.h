@@ -112,6 +112,9 @@ struct gnnpe_ctx {
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
     int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default; rows <= 64, else 3)
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
+    gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
+    bool vkey_valid = false;
+    uint32_t vkey_zb = 0, vkey_lb = 0;
     gnnpe::DevBuf rpairs, rrecs, vinfo;
     gnnpe::DevBuf pge_pg, pge_plg;  // GNN-PGE path groups (n x 4e doubles each)
     bool have_pge = false;

@@ -250,61 +250,53 @@ __global__ void k_minmax_init(double *__restrict__ mn, double *__restrict__ mx)
     mx[threadIdx.x] = 0.0;
 }
 
-template <int E>
-__global__ __launch_bounds__(256) void k_minmax_paths(uint64_t cnt, PathPoints<E> S, double *__restrict__ mn,
-                                                      double *__restrict__ mx)
+// ---- label-major sort key for 3-vertex paths ------------------------------------------------------
+// The online traversal opens a node only if the query path's label embedding lies inside the node's
+// label MBR AND the node's upper corner dominates the query's pde (custom.h:441-462); a leaf entry
+// matches only on identical labels (custom.h:408-413).  So leaves should hold ONE label triple where
+// possible, and be compact in pde inside it (scripts/index_key_study.py: 27 instead of 13 000 leaves
+// opened per query at 64 labels, 76 instead of 14 700 at 8):
+//   key = [label(a) | label(b) | label(c)]  (3 x lb bits)  then  Z-order of the path's 3E coordinates,
+//         each quantised to zb bits by its RANK among the vertices' values (equi-depth: skew-proof).
+// Both parts are per-vertex: vkey[v] = {low 32: the vertex' zb*E quantised bits spread to their
+// Z-order positions for the LAST path position, high 32: label}; position j shifts the low part left
+// by (2-j)*E.  A path key is three 8-byte gathers from an n x 8 byte table and a few shifts.
+__global__ void k_vkey_labels(uint32_t n, const uint32_t *__restrict__ labels, uint64_t *__restrict__ vkey)
 {
-    constexpr int D = 3 * E;
-    double a[D], b[D];
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        a[k] = 1e300;
-        b[k] = -1e300;
-    }
-    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
-        double v[D];
-        S.load(p, v);
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            a[k] = fmin(a[k], v[k]);
-            b[k] = fmax(b[k], v[k]);
-        }
-    }
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        const double lo = wave_min_f64(a[k]), hi = wave_max_f64(b[k]);
-        if (lane == 0 && hi >= 0.0) {  // a wave that saw no point keeps hi = -1e300
-            atomicMin(reinterpret_cast<unsigned long long *>(mn) + k, (unsigned long long)__double_as_longlong(lo));
-            atomicMax(reinterpret_cast<unsigned long long *>(mx) + k, (unsigned long long)__double_as_longlong(hi));
-        }
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
+        vkey[v] = (uint64_t)labels[v] << 32;
+}
+__global__ void k_vkey_column(uint32_t n, uint32_t e, uint32_t comp, const double *__restrict__ vde,
+                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        keys[v] = (uint64_t)__double_as_longlong(vde[v * e + comp]);  // embeddings are positive: bit order = value order
+        vals[v] = (uint32_t)v;
     }
 }
-
-template <int E>
-__global__ __launch_bounds__(256) void k_zorder_keys_paths(uint64_t cnt, PathPoints<E> S, uint32_t bits,
-                                                           const double *__restrict__ mn, const double *__restrict__ mx,
-                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// sorted position r of component `comp` -> zb-bit bucket -> bits spread at stride D = 3e
+__global__ void k_vkey_spread(uint32_t n, uint32_t e, uint32_t comp, uint32_t zb, const uint32_t *__restrict__ sorted_v,
+                              uint64_t *__restrict__ vkey)
 {
-    constexpr int D = 3 * E;
-    const uint32_t qmax = (1u << bits) - 1u;
-    double lo[D], span[D];
-#pragma unroll
-    for (int k = 0; k < D; k++) {
-        lo[k] = mn[k];
-        span[k] = mx[k] - mn[k];
+    const uint32_t D = 3 * e;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = (uint32_t)((r << zb) / n);
+        uint64_t s = 0;
+        for (uint32_t t = 0; t < zb; t++) s |= (uint64_t)((q >> t) & 1u) << (t * D + (e - 1 - comp));
+        vkey[sorted_v[r]] |= s;  // one writer per vertex per launch
     }
+}
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_path_keys(uint64_t cnt, const uint32_t *__restrict__ vids,
+                                                   const uint64_t *__restrict__ vkey, uint32_t e, uint32_t lb,
+                                                   uint32_t zbits, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const uint64_t lmask = (1ull << lb) - 1ull;
     for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
-        double v[D];
-        S.load(p, v);
-        uint64_t key = 0;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const double c = 0.5 * (v[k] + v[k]);  // the generic kernel's box centre, for identical keys
-            const uint32_t q = span[k] > 0.0 ? (uint32_t)fmin((c - lo[k]) / span[k] * (double)qmax, (double)qmax) : 0u;
-            for (uint32_t t = 0; t < bits; t++) key |= (uint64_t)((q >> t) & 1u) << (t * D + (D - 1 - k));
-        }
-        keys[p] = key;
+        const uint64_t ka = vkey[vids[p * 3]], kb = vkey[vids[p * 3 + 1]], kc = vkey[vids[p * 3 + 2]];
+        const uint64_t lab = ((((ka >> 32) & lmask) << lb | ((kb >> 32) & lmask)) << lb) | ((kc >> 32) & lmask);
+        const uint64_t z = ((ka & 0xFFFFFFFFull) << (2 * e)) | ((kb & 0xFFFFFFFFull) << e) | (kc & 0xFFFFFFFFull);
+        keys[p] = (KeyT)((lab << zbits) | z);
         vals[p] = (uint32_t)p;
     }
 }
@@ -416,6 +408,44 @@ using namespace gnnpe;
 
 extern "C" {
 
+// Per-vertex key parts of the label-major path key (see k_path_keys); rebuilt when the vde table changed.
+static int ensure_vkey(gnnpe_ctx *c)
+{
+    const uint32_t n = c->n, e = c->e, D = 3 * e;
+    uint32_t lb = 1;
+    while (lb < 21 && (1ull << lb) < c->n_labels) lb++;  // more than 2^21 labels: the low 21 bits still group well
+    uint32_t zb_cap = 0;
+    while (zb_cap < 4 && zb_cap * D + e <= 32) zb_cap++;  // the spread bits of one vertex live in 32 bits
+    uint32_t zb = std::min(2u, zb_cap);                   // 2 bits per dimension is where the study saturates
+    while (zb > 0 && 3 * lb + zb * D > 64) zb--;
+    const uint32_t passes = (3 * lb + zb * D + 7) / 8, width = 3 * lb + zb * D <= 32 ? 32 : 64;
+    while (zb < zb_cap && (3 * lb + (zb + 1) * D + 7) / 8 == passes && 3 * lb + (zb + 1) * D <= width) zb++;  // free bits
+    if (c->vkey_valid && c->vkey_zb == zb && c->vkey_lb == lb) return GNNPE_OK;
+    int rc;
+    if ((rc = c->vkey.reserve(((size_t)n + 1) * 8))) return rc;
+    uint64_t *vkey = c->vkey.as<uint64_t>();
+    hipLaunchKernelGGL(k_vkey_labels, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, c->labels.as<uint32_t>(), vkey);
+    if (zb && n) {
+        uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + n;
+        uint32_t *v_in = c->idx_vals.as<uint32_t>(), *v_out = v_in + n;
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)n, 0, 64, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        for (uint32_t comp = 0; comp < e; comp++) {
+            hipLaunchKernelGGL(k_vkey_column, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, e, comp, c->vde.as<double>(), k_in,
+                               v_in);
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)n, 0, 64, c->stream));
+            hipLaunchKernelGGL(k_vkey_spread, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, e, comp, zb, v_out, vkey);
+        }
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->vkey_valid = true;
+    c->vkey_zb = zb;
+    c->vkey_lb = lb;
+    return GNNPE_OK;
+}
+
 static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
 {
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
@@ -451,48 +481,60 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     if (cnt == 0) {
         GNNPE_HIP_TRY(hipMemsetAsync(image + kBlockLen, 0, kBlockLen, c->stream));  // level 0, 0 entries
     } else {
-        // 1. keys
-        if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
-        double *mn = reinterpret_cast<double *>(c->small.as<char>() + 256), *mx = mn + 64;
         GNNPE_REQUIRE(D <= 64, GNNPE_ERR_UNSUPPORTED, "dimension %u > 64", D);
-        const bool fast = !S.boxes && S.L == 3 && (S.e == 1 || S.e == 2 || S.e == 3 || S.e == 4 || S.e == 8);
+        const bool paths3 = !S.boxes && S.L == 3;  // GNN-PE's 3-vertex paths: label-major keys
+        const bool fast = paths3 && (S.e == 1 || S.e == 2 || S.e == 3 || S.e == 4 || S.e == 8);
         const uint32_t wide_grid = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
-        hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, mn, mx);
-        const uint32_t bits = std::max(1u, std::min(16u, 64u / D));
-        if ((rc = c->idx_keys.reserve(cnt * 8 * 2)) || (rc = c->idx_vals.reserve(cnt * 4 * 2))) return rc;
-        uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
+        const uint64_t sort_n = std::max<uint64_t>(cnt, paths3 ? c->n : 0);
+        if ((rc = c->idx_keys.reserve(sort_n * 8 * 2)) || (rc = c->idx_vals.reserve(sort_n * 4 * 2))) return rc;
         uint32_t *v_in = c->idx_vals.as<uint32_t>(), *v_out = v_in + cnt;
-#define GNNPE_IDX_KEYS(EE)                                                                                         \
-    do {                                                                                                           \
-        PathPoints<EE> P = {S.vids, S.vde};                                                                        \
-        const uint32_t g = (uint32_t)std::min<uint64_t>(wide_grid, (cnt + 255) / 256);                             \
-        hipLaunchKernelGGL((k_minmax_paths<EE>), dim3(g), dim3(256), 0, c->stream, cnt, P, mn, mx);                \
-        hipLaunchKernelGGL((k_zorder_keys_paths<EE>), dim3(g), dim3(256), 0, c->stream, cnt, P, bits, mn, mx,      \
-                           k_in, v_in);                                                                            \
-    } while (0)
-        if (fast) {
-            switch (S.e) {
-            case 1: GNNPE_IDX_KEYS(1); break;
-            case 2: GNNPE_IDX_KEYS(2); break;
-            case 3: GNNPE_IDX_KEYS(3); break;
-            case 4: GNNPE_IDX_KEYS(4); break;
-            default: GNNPE_IDX_KEYS(8); break;
+        if (paths3) {
+            // 1. keys: per-vertex parts (once per vde table), then three gathers per path
+            if ((rc = ensure_vkey(c))) return rc;
+            const uint32_t kbits = 3 * c->vkey_lb + c->vkey_zb * D;
+            const uint32_t g = (uint32_t)std::min<uint64_t>(wide_grid, (cnt + 255) / 256);
+            size_t tb = 0;
+            // 2. one radix sort over the used key bits, 32-bit keys when they fit
+            if (kbits <= 32) {
+                uint32_t *k_in = c->idx_keys.as<uint32_t>(), *k_out = k_in + cnt;
+                hipLaunchKernelGGL((k_path_keys<uint32_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,
+                                   c->vkey.as<uint64_t>(), S.e, c->vkey_lb, c->vkey_zb * D, k_in, v_in);
+                GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)kbits,
+                                                                c->stream));
+                if ((rc = c->cub_tmp.reserve(tb))) return rc;
+                tb = c->cub_tmp.bytes;
+                GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
+                                                                (int)kbits, c->stream));
+            } else {
+                uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
+                hipLaunchKernelGGL((k_path_keys<uint64_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,
+                                   c->vkey.as<uint64_t>(), S.e, c->vkey_lb, c->vkey_zb * D, k_in, v_in);
+                GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)kbits,
+                                                                c->stream));
+                if ((rc = c->cub_tmp.reserve(tb))) return rc;
+                tb = c->cub_tmp.bytes;
+                GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
+                                                                (int)kbits, c->stream));
             }
         } else {
+            // boxes (GNN-PGE): Z-order of the box centres on a uniform grid over their range
+            if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
+            double *mn = reinterpret_cast<double *>(c->small.as<char>() + 256), *mx = mn + 64;
+            uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
+            hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(64), 0, c->stream, mn, mx);
+            const uint32_t bits = std::max(1u, std::min(16u, 64u / D));
             hipLaunchKernelGGL(k_point_minmax, dim3(std::min<uint64_t>(1024, (cnt + 255) / 256)), dim3(256), 0, c->stream, cnt,
                                S, mn, mx);
             hipLaunchKernelGGL(k_zorder_keys, dim3(grid_for(cnt)), dim3(kBlock), 0, c->stream, cnt, S, bits, mn, mx, k_in, v_in);
+            size_t tb = 0;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
+                                                            (int)(bits * D), c->stream));
+            if ((rc = c->cub_tmp.reserve(tb))) return rc;
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
+                                                            (int)(bits * D), c->stream));
         }
-#undef GNNPE_IDX_KEYS
         GNNPE_HIP_TRY(hipGetLastError());
-        // 2. one radix sort over the used key bits
-        size_t tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)(bits * D),
-                                                        c->stream));
-        if ((rc = c->cub_tmp.reserve(tb))) return rc;
-        tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
-                                                        (int)(bits * D), c->stream));
         // 3. leaves, then one launch per upper level
         uint64_t max_level = 0;
         for (uint64_t v : level_n) max_level = std::max(max_level, v);

@@ -26,7 +26,7 @@ def _engine(binding, g, sn, mem, p, e):
     return eng
 
 
-@pytest.mark.parametrize("e", [2, 8])
+@pytest.mark.parametrize("e", [1, 2, 3, 5, 8])
 def test_index_image_structure_and_contents(oracle, test_graph, e):
     import torch
     from gnnpe_amd import binding
@@ -43,34 +43,35 @@ def test_index_image_structure_and_contents(oracle, test_graph, e):
     cap = (4096 - 5) // (16 * D + 4)
     assert d["dim"] == D and d["num_data"] == total and d["root_is_data"] == 0
     assert d["n_blocks"] == d["dnodes"] + d["inodes"] == hdr[1] and len(img) == (hdr[1] + 1) * 4096
-    assert d["dnodes"] == -(-total // (cap - 2))
+    assert d["dnodes"] == -(-total // min(cap - 2, 64))
     order = np.argsort(d["leaf_son"], kind="stable")
     assert np.array_equal(d["leaf_son"][order], np.arange(total))  # every path exactly once
     assert np.array_equal(d["leaf_pt"][order], vde[ids].reshape(total, D))  # lo = hi = pde row, bit exact
     eng.close()
 
 
-@pytest.mark.parametrize("e", [1, 2, 3, 4, 8])
-def test_path_index_kernels_match_generic_box_kernels(test_graph, e):
-    """The 3-vertex-path fast kernels and the generic (box) kernels must emit the same bytes: the same
-    points handed over as degenerate boxes lo = hi go through the generic key / leaf kernels."""
+def test_index_leaves_are_label_major(oracle, test_graph):
+    """Bulk-load order: paths sorted by their label triple first (the online traversal prunes on the label
+    MBR, custom.h:441-451), so left-to-right leaf entries carry non-decreasing label triples and all but a
+    few leaves hold a single triple."""
     import torch
     from gnnpe_amd import binding
-    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, e)
-    x, nx, vde = eng.vde()
+    g = test_graph
+    eng = _engine(binding, g, g["sorted_nodes"], g["membership"], 1, 2)
+    eng.vde(want=False)
     total = eng.count_paths(2)
     ids, _, _ = eng.fill_paths(pde=False)
-    dev = torch.device("cuda:0")
-    for cnt in (total, 100003, 39, 1):
-        sub = np.ascontiguousarray(ids[:cnt])
-        t = torch.from_numpy(sub.view(np.int32)).to(dev)
-        p, nb, hdr = eng.build_index_device(cnt, 3, t)
-        fast = eng.copy_to_host(p, nb).tobytes()
-        pts = vde[sub].reshape(cnt, 3 * e)
-        boxes = torch.from_numpy(np.ascontiguousarray(np.repeat(pts, 2, axis=1))).to(dev)
-        p2, nb2, hdr2 = eng.build_box_index_device(cnt, 3 * e, boxes)
-        assert nb2 == nb and hdr2 == hdr
-        assert eng.copy_to_host(p2, nb2).tobytes() == fast
+    t = torch.from_numpy(ids.view(np.int32)).to(torch.device("cuda:0"))
+    p, nb, hdr = eng.build_index_device(total, 3, t)
+    d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+    lab = g["labels"].astype(np.int64)[ids[d["leaf_son"]]]  # tree walk = left-to-right leaf order
+    n_labels = int(g["labels"].max()) + 1
+    triple = (lab[:, 0] * n_labels + lab[:, 1]) * n_labels + lab[:, 2]
+    assert np.all(np.diff(triple) >= 0)
+    F = (4096 - 5) // (16 * 6 + 4) - 2
+    n_leaves = -(-total // F)
+    mixed = sum(1 for j in range(n_leaves) if triple[j * F] != triple[min(total, (j + 1) * F) - 1])
+    assert mixed <= len(np.unique(triple))  # at most one straddling leaf per label triple
     eng.close()
 
 
