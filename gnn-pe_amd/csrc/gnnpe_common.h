@@ -114,7 +114,7 @@ struct gnnpe_ctx {
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     bool vkey_valid = false;
-    uint32_t vkey_zb = 0, vkey_lb = 0;
+    uint32_t vkey_zb = 0, vkey_lb = 0, vkey_sbits = 32;  // sbits 32 = wide (64-bit) table only
     gnnpe::DevBuf rpairs, rrecs, vinfo;
     gnnpe::DevBuf pge_pg, pge_plg;  // GNN-PGE path groups (n x 4e doubles each)
     bool have_pge = false;

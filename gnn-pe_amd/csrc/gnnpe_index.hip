@@ -219,30 +219,17 @@ template <int E> struct PathPoints {
     static constexpr int D = 3 * E;
     const uint32_t *vids;
     const double *vde;
-    __device__ __forceinline__ void load(uint64_t p, double (&v)[D]) const
+    __device__ __forceinline__ uint3 ids(uint64_t p) const { return make_uint3(vids[p * 3], vids[p * 3 + 1], vids[p * 3 + 2]); }
+    __device__ __forceinline__ void coords(uint3 t, double (&v)[D]) const
     {
-        const uint32_t a = vids[p * 3], b = vids[p * 3 + 1], c = vids[p * 3 + 2];
 #pragma unroll
         for (int k = 0; k < E; k++) {
-            v[k] = vde[(uint64_t)a * E + k];
-            v[E + k] = vde[(uint64_t)b * E + k];
-            v[2 * E + k] = vde[(uint64_t)c * E + k];
+            v[k] = vde[(uint64_t)t.x * E + k];
+            v[E + k] = vde[(uint64_t)t.y * E + k];
+            v[2 * E + k] = vde[(uint64_t)t.z * E + k];
         }
     }
 };
-
-__device__ __forceinline__ double wave_min_f64(double x)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, 64));
-    return x;
-}
-__device__ __forceinline__ double wave_max_f64(double x)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
-    return x;
-}
 
 __global__ void k_minmax_init(double *__restrict__ mn, double *__restrict__ mx)
 {
@@ -286,16 +273,23 @@ __global__ void k_vkey_spread(uint32_t n, uint32_t e, uint32_t comp, uint32_t zb
         vkey[sorted_v[r]] |= s;  // one writer per vertex per launch
     }
 }
-template <typename KeyT>
+// The table is narrowed to 32-bit words {label << sbits | spread bits} when both parts fit (n x 4 bytes
+// then stays L2-resident at a million vertices).
+__global__ void k_vkey_narrow(uint32_t n, uint32_t sbits, const uint64_t *__restrict__ vkey, uint32_t *__restrict__ vkey32)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
+        vkey32[v] = (uint32_t)((vkey[v] >> 32) << sbits) | (uint32_t)vkey[v];
+}
+template <typename KeyT, typename WordT>
 __global__ __launch_bounds__(256) void k_path_keys(uint64_t cnt, const uint32_t *__restrict__ vids,
-                                                   const uint64_t *__restrict__ vkey, uint32_t e, uint32_t lb,
+                                                   const WordT *__restrict__ vkey, uint32_t e, uint32_t lb, uint32_t sbits,
                                                    uint32_t zbits, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    const uint64_t lmask = (1ull << lb) - 1ull;
+    const uint64_t lmask = (1ull << lb) - 1ull, smask = (1ull << sbits) - 1ull;
     for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < cnt; p += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t ka = vkey[vids[p * 3]], kb = vkey[vids[p * 3 + 1]], kc = vkey[vids[p * 3 + 2]];
-        const uint64_t lab = ((((ka >> 32) & lmask) << lb | ((kb >> 32) & lmask)) << lb) | ((kc >> 32) & lmask);
-        const uint64_t z = ((ka & 0xFFFFFFFFull) << (2 * e)) | ((kb & 0xFFFFFFFFull) << e) | (kc & 0xFFFFFFFFull);
+        const uint64_t lab = ((((ka >> sbits) & lmask) << lb | ((kb >> sbits) & lmask)) << lb) | ((kc >> sbits) & lmask);
+        const uint64_t z = ((ka & smask) << (2 * e)) | ((kb & smask) << e) | (kc & smask);
         keys[p] = (KeyT)((lab << zbits) | z);
         vals[p] = (uint32_t)p;
     }
@@ -306,6 +300,9 @@ __global__ __launch_bounds__(256) void k_path_keys(uint64_t cnt, const uint32_t 
 // format's odd offsets (entries start at byte 5, rtnode.cpp:1099-1117) fall on dword boundaries:
 //   window byte 3 = level, dword 1 = n_entries, entry i = dwords [2 + i*(4D+1), 2 + (i+1)*(4D+1))
 // and file dword w = (window dword w >> 24) | (window dword w+1 << 8).
+// A point is three dependent random reads (sort order -> path tuple -> vde rows); the loop keeps three
+// leaves in flight per wave, one per stage, so an iteration costs one memory latency instead of three.
+// Lanes beyond a leaf's entry count (and waves past the last leaf) read element 0: harmless, branch-free.
 constexpr int kLeafWaves = 4;
 template <int E>
 __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t cnt, uint64_t n_leaves, uint32_t F,
@@ -320,23 +317,28 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *w = s_win[wv];
-    for (uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv; j < n_leaves; j += (uint64_t)gridDim.x * kLeafWaves) {
-        const uint64_t p0 = j * F;
-        const uint32_t ne = (uint32_t)min((uint64_t)F, cnt - p0);
-        double v[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) v[k] = 0.0;
-        uint32_t son = 0;
-        if ((uint32_t)lane < ne) {
-            son = order[p0 + lane];  // the path's index inside the partition (custom.h:243)
-            S.load(son, v);
-        }
+    const uint64_t stride = (uint64_t)gridDim.x * kLeafWaves;
+    auto entries = [&](uint64_t jj) -> uint32_t { return jj < n_leaves ? (uint32_t)min((uint64_t)F, cnt - jj * F) : 0u; };
+    auto son_of = [&](uint64_t jj) -> uint32_t { return (uint32_t)lane < entries(jj) ? order[jj * F + lane] : 0u; };
+
+    uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv;
+    uint32_t son_a = son_of(j), son_b = son_of(j + stride), son_c = son_of(j + 2 * stride);
+    uint3 ids_b = S.ids(son_b);
+    double v[D];
+    S.coords(S.ids(son_a), v);
+    for (; j < n_leaves; j += stride) {
+        // issue the next stage of the two leaves behind this one before touching this leaf's data
+        const uint32_t son_d = son_of(j + 3 * stride);
+        const uint3 ids_c = S.ids(son_c);
+        double v_b[D];
+        S.coords(ids_b, v_b);
+
+        const uint32_t ne = entries(j);
         if (lane == 0) {
             w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
             w[1] = ne;
         }
-        // zero tail after the last entry
-        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;
+        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero tail
         if ((uint32_t)lane < ne) {
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
@@ -348,26 +350,25 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
                 ent[4 * k + 2] = x;  // bounces[2k+1] (custom.h:247)
                 ent[4 * k + 3] = y;
             }
-            ent[4 * D] = son;
-        }
-        // node MBR for the parent level: lane k keeps dimension k
-        double my_lo = 0.0, my_hi = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const double lo = wave_min_f64((uint32_t)lane < ne ? v[k] : 1e300);
-            const double hi = wave_max_f64((uint32_t)lane < ne ? v[k] : -1e300);
-            if (lane == k) {
-                my_lo = lo;
-                my_hi = hi;
-            }
-        }
-        if (lane < D) {
-            node_mbr[(j * D + lane) * 2] = my_lo;
-            node_mbr[(j * D + lane) * 2 + 1] = my_hi;
+            ent[4 * D] = son_a;  // the path's index inside the partition (custom.h:243)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // node MBR for the parent level: lane k scans dimension k of the assembled entries (cross-lane
+        // reductions of 2D doubles cost ~20k cycles per leaf in ds_bpermute round trips; this is ~40 LDS reads)
+        if (lane < D) {
+            double lo = 1e300, hi = -1e300;
+#pragma unroll 8
+            for (uint32_t i = 0; i < ne; i++) {
+                const uint32_t *q = w + 2 + i * kEnt + 4 * lane;
+                const double x = __longlong_as_double((long long)(((uint64_t)q[1] << 32) | q[0]));
+                lo = fmin(lo, x);
+                hi = fmax(hi, x);
+            }
+            node_mbr[(j * D + lane) * 2] = lo;
+            node_mbr[(j * D + lane) * 2 + 1] = hi;
+        }
         // node j -> file block j+1, 16 bytes per lane per round, streamed past the caches
         uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);
 #pragma unroll
@@ -388,6 +389,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // rotate the pipeline
+        son_a = son_b;
+        son_b = son_c;
+        son_c = son_d;
+        ids_b = ids_c;
+#pragma unroll
+        for (int k = 0; k < D; k++) v[k] = v_b[k];
     }
 }
 
@@ -422,7 +430,7 @@ static int ensure_vkey(gnnpe_ctx *c)
     while (zb < zb_cap && (3 * lb + (zb + 1) * D + 7) / 8 == passes && 3 * lb + (zb + 1) * D <= width) zb++;  // free bits
     if (c->vkey_valid && c->vkey_zb == zb && c->vkey_lb == lb) return GNNPE_OK;
     int rc;
-    if ((rc = c->vkey.reserve(((size_t)n + 1) * 8))) return rc;
+    if ((rc = c->vkey.reserve(((size_t)n + 1) * 12))) return rc;  // wide table + narrow copy
     uint64_t *vkey = c->vkey.as<uint64_t>();
     hipLaunchKernelGGL(k_vkey_labels, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, c->labels.as<uint32_t>(), vkey);
     if (zb && n) {
@@ -439,6 +447,12 @@ static int ensure_vkey(gnnpe_ctx *c)
             hipLaunchKernelGGL(k_vkey_spread, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, e, comp, zb, v_out, vkey);
         }
     }
+    // narrow copy behind the wide one when label and spread bits share 32 bits
+    const uint32_t sbits = zb ? (zb - 1) * D + e : 0;
+    c->vkey_sbits = lb + sbits <= 32 ? sbits : 32;
+    if (c->vkey_sbits != 32)
+        hipLaunchKernelGGL(k_vkey_narrow, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, sbits, vkey,
+                           reinterpret_cast<uint32_t *>(vkey + n + 1));
     GNNPE_HIP_TRY(hipGetLastError());
     c->vkey_valid = true;
     c->vkey_zb = zb;
@@ -494,11 +508,20 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
             const uint32_t kbits = 3 * c->vkey_lb + c->vkey_zb * D;
             const uint32_t g = (uint32_t)std::min<uint64_t>(wide_grid, (cnt + 255) / 256);
             size_t tb = 0;
+#define GNNPE_PATH_KEYS(KT)                                                                                        \
+    do {                                                                                                           \
+        if (c->vkey_sbits != 32)                                                                                   \
+            hipLaunchKernelGGL((k_path_keys<KT, uint32_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,         \
+                               reinterpret_cast<const uint32_t *>(c->vkey.as<uint64_t>() + c->n + 1), S.e,         \
+                               c->vkey_lb, c->vkey_sbits, c->vkey_zb * D, k_in, v_in);                             \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_path_keys<KT, uint64_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,         \
+                               c->vkey.as<uint64_t>(), S.e, c->vkey_lb, 32u, c->vkey_zb * D, k_in, v_in);          \
+    } while (0)
             // 2. one radix sort over the used key bits, 32-bit keys when they fit
             if (kbits <= 32) {
                 uint32_t *k_in = c->idx_keys.as<uint32_t>(), *k_out = k_in + cnt;
-                hipLaunchKernelGGL((k_path_keys<uint32_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,
-                                   c->vkey.as<uint64_t>(), S.e, c->vkey_lb, c->vkey_zb * D, k_in, v_in);
+                GNNPE_PATH_KEYS(uint32_t);
                 GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)kbits,
                                                                 c->stream));
                 if ((rc = c->cub_tmp.reserve(tb))) return rc;
@@ -507,8 +530,7 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
                                                                 (int)kbits, c->stream));
             } else {
                 uint64_t *k_in = c->idx_keys.as<uint64_t>(), *k_out = k_in + cnt;
-                hipLaunchKernelGGL((k_path_keys<uint64_t>), dim3(g), dim3(256), 0, c->stream, cnt, S.vids,
-                                   c->vkey.as<uint64_t>(), S.e, c->vkey_lb, c->vkey_zb * D, k_in, v_in);
+                GNNPE_PATH_KEYS(uint64_t);
                 GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)cnt, 0, (int)kbits,
                                                                 c->stream));
                 if ((rc = c->cub_tmp.reserve(tb))) return rc;
@@ -516,6 +538,7 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
                 GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)cnt, 0,
                                                                 (int)kbits, c->stream));
             }
+#undef GNNPE_PATH_KEYS
         } else {
             // boxes (GNN-PGE): Z-order of the box centres on a uniform grid over their range
             if ((rc = c->small.reserve(256 + 2 * 64 * 8))) return rc;
