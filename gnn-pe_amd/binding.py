@@ -58,6 +58,7 @@ SIGNATURES = {
     "gnnpe_text_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_text_ids": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_select_partition": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, C.c_uint64, _vp, _u64p]),
+    "gnnpe_rows_checksum_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, _u64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                            C.POINTER(C.c_int32)]),
     "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
@@ -266,12 +267,14 @@ class Engine:
         ps = np.zeros(self.slab[1] - self.slab[0], np.uint64) if per_start else None
         self._ck(self.lib.gnnpe_count_paths(self.ctx, l, _ptr(ps, _u64p), C.byref(tot)))
         self.total = tot.value
+        self.l = l
         return (tot.value, ps) if per_start else tot.value
 
     # R2 + R5: emit half (gen_pde, custom.h:546-572)
-    def fill_paths(self, begin=0, end=None, ids=True, pde=True, pde_label=False, L=3):
+    def fill_paths(self, begin=0, end=None, ids=True, pde=True, pde_label=False, L=None):
         end = self.total if end is None else end
         cnt = end - begin
+        L = getattr(self, "l", 2) + 1 if L is None else L
         D = self.e * L
         v = np.zeros((cnt, L), np.uint32) if ids else None
         p = np.zeros((cnt, D)) if pde else None
@@ -282,6 +285,12 @@ class Engine:
     def fill_paths_device(self, begin, end, dev_vids=None, dev_pde=None, dev_pde_label=None):
         self._ck(self.lib.gnnpe_fill_paths_device(self.ctx, begin, end, _dev(dev_vids), _dev(dev_pde),
                                                   _dev(dev_pde_label)))
+
+    def rows_checksum_device(self, n_rows, L, dev_ids, first_id=0):
+        out = C.c_uint64()
+        self._ck(self.lib.gnnpe_rows_checksum_device(self.ctx, int(n_rows), int(L), _dev(dev_ids), int(first_id),
+                                                     C.byref(out)))
+        return out.value
 
     def path_partitions_device(self, begin, end, dev_part):
         self._ck(self.lib.gnnpe_path_partitions_device(self.ctx, begin, end, _dev(dev_part)))

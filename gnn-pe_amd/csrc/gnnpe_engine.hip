@@ -15,6 +15,7 @@
 #include "gnnpe_fill_middle.hip.h"
 #include "gnnpe_fill_start.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
+#include "gnnpe_fill_deep.hip.h"
 
 namespace gnnpe {
 
@@ -484,7 +485,8 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
 //   3 start       wave per start vertex over id-sorted rows          (gnnpe_fill_start.hip.h)
 //   4 ranked      wave per start vertex over rank-sorted records     (gnnpe_fill_ranked.hip.h)  default
 // Variant 4 needs rows of degree <= 64 and falls back to 3 otherwise.
-enum { kVarPairWave = 1, kVarMiddle = 2, kVarStart = 3, kVarRanked = 4 };
+// l = 3 (4-vertex paths, BASELINE config 5) has one implementation: gnnpe_fill_deep.hip.h.
+enum { kVarPairWave = 1, kVarMiddle = 2, kVarStart = 3, kVarRanked = 4, kVarDeep = 5 };
 
 static bool fast_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
@@ -562,8 +564,9 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_rank_arrays(c);
     if (rc) return rc;
-    // The reference enumerates 3-vertex paths whatever -l says; l=2 is the parity path.
-    GNNPE_REQUIRE(l == 2, GNNPE_ERR_UNSUPPORTED, "path length l=%u: only l=2 (3-vertex paths) is implemented", l);
+    // The reference enumerates 3-vertex paths whatever -l says; l=2 is the parity path, l=3 the
+    // intended generalisation with the depth fixed (gnnpe_fill_deep.hip.h).
+    GNNPE_REQUIRE(l == 2 || l == 3, GNNPE_ERR_UNSUPPORTED, "path length l=%u: only l=2 and l=3 are implemented", l);
     const uint32_t sb = c->slab_begin, se = c->slab_end, len = se - sb;
     const uint32_t e = c->have_table ? c->e : 2;
     c->counted = false;
@@ -572,6 +575,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     // kernel; the ranked variant needs every held row to fit one 64-bit id-position set
     int var = c->fill_variant;
     if (!fast_e(e)) var = kVarPairWave;
+    if (l == 3) var = kVarDeep;
     if (var == kVarRanked && c->n) {
         uint32_t mx = 0;
         if ((rc = max_held_degree(c, &mx))) return rc;
@@ -600,13 +604,40 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         if (c->nbr_used)
             hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                                c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
-        GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (var == kVarPairWave) {
+        if (var == kVarDeep && (rc = c->ecnt.reserve((ne + 2) * 8))) return rc;  // 64-bit pair counts
+        GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * (var == kVarDeep ? 8 : 4), c->stream));
+        if (var == kVarPairWave || var == kVarDeep) {
             if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4))) return rc;
             if (len)
                 hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
                                    c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
                                    c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
+        }
+        if (var == kVarDeep) {
+            // the emit walk with the stores compiled out; rows two hops from the slab must be on this device
+            if ((rc = c->small.reserve(256))) return rc;
+            uint32_t *d_missing = c->small.as<uint32_t>() + 16;
+            GNNPE_HIP_TRY(hipMemsetAsync(d_missing, 0xFF, 4, c->stream));
+            FillParams P = {};
+            P.erow = c->erow.as<uint32_t>();
+            P.pnbr = c->pnbr.as<uint32_t>();
+            P.adj_start = c->adj_start.as<uint32_t>();
+            P.adj_deg = c->adj_deg.as<uint32_t>();
+            P.nbrs = c->nbrs.as<uint32_t>();
+            P.nbr_rank = c->nbr_rank.as<uint32_t>();
+            P.sorted = c->sorted.as<uint32_t>();
+            P.n_edges = ne;
+            P.slab_begin = sb;
+            P.e = e;
+            hipLaunchKernelGGL((k_deep3<false>), dim3(grid_for(ne * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+                               c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(),
+                               c->ecnt.as<uint64_t>(), d_missing);
+            uint64_t miss = 0;
+            if ((rc = read_back_u64(c, d_missing, 4, &miss))) return rc;
+            GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,
+                          "l=3: the adjacency row of vertex %u (two hops from the slab) is not on this device",
+                          (uint32_t)miss);
+        } else if (var == kVarPairWave) {
             hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
                                c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
                                c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
@@ -635,6 +666,14 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
         tb = c->cub_tmp.bytes;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+    } else if (var == kVarDeep) {
+        size_t tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, c->ecnt.as<uint64_t>(), c->eoff.as<uint64_t>(),
+                                                      (int64_t)(ne + 1), c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, c->ecnt.as<uint64_t>(), c->eoff.as<uint64_t>(),
+                                                      (int64_t)(ne + 1), c->stream));
     } else if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) {
         return rc;
     }
@@ -659,7 +698,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->counted = true;
     c->counted_variant = var;
     // embeddings of the adjacency entries, when the vde table is already there (keeps it out of the fill)
-    if (c->have_vde && (var == kVarPairWave || var == kVarStart) && (rc = ensure_nbr_vde(c))) return rc;
+    if (c->have_vde && (var == kVarPairWave || var == kVarStart || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -683,7 +722,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     const uint32_t e = c->have_table ? c->e : 2;
     const uint32_t len = c->slab_end - c->slab_begin;
     int rc;
-    if (d_pde && (var == kVarPairWave || var == kVarStart) && (rc = ensure_nbr_vde(c))) return rc;
+    if (d_pde && (var == kVarPairWave || var == kVarStart || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (d_pde && var == kVarRanked && !c->ranked_vde_valid && (rc = build_ranked(c, c->n_edges))) return rc;
 
     FillParams P;
@@ -717,7 +756,10 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     case 4: LAUNCH(4); break;     \
     default: LAUNCH(8); break;    \
     }
-    if (var == kVarRanked) {
+    if (var == kVarDeep) {
+        hipLaunchKernelGGL((k_deep3<true>), dim3(grid_for(c->n_edges * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+                           (const uint8_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+    } else if (var == kVarRanked) {
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const StartRec *sr = c->srec.as<StartRec>();
         const RankedPair *rp = c->rpairs.as<RankedPair>();
@@ -785,15 +827,15 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     const uint64_t cnt = end - begin;
     if (!cnt) return GNNPE_OK;
-    const uint32_t e = c->have_table ? c->e : 2, D = 3 * e;
+    const uint32_t e = c->have_table ? c->e : 2, L = c->l + 1, D = L * e;
     DevBuf bv, bp, bl;
     int rc = GNNPE_OK;
-    if (hv) rc = bv.reserve(cnt * 3 * 4);
+    if (hv) rc = bv.reserve(cnt * L * 4);
     if (!rc && hpde) rc = bp.reserve(cnt * D * 8);
     if (!rc && hpdl) rc = bl.reserve(cnt * D * 8);
     if (!rc) rc = fill_device(c, begin, end, hv ? bv.p : nullptr, hpde ? bp.p : nullptr, hpdl ? bl.p : nullptr, nullptr);
     hipError_t he = hipSuccess;
-    if (!rc && hv) he = hipMemcpyAsync(hv, bv.p, cnt * 3 * 4, hipMemcpyDeviceToHost, c->stream);
+    if (!rc && hv) he = hipMemcpyAsync(hv, bv.p, cnt * L * 4, hipMemcpyDeviceToHost, c->stream);
     if (!rc && he == hipSuccess && hpde) he = hipMemcpyAsync(hpde, bp.p, cnt * D * 8, hipMemcpyDeviceToHost, c->stream);
     if (!rc && he == hipSuccess && hpdl) he = hipMemcpyAsync(hpdl, bl.p, cnt * D * 8, hipMemcpyDeviceToHost, c->stream);
     if (!rc && he == hipSuccess) he = hipStreamSynchronize(c->stream);
@@ -806,6 +848,22 @@ int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, d
     bp.release();
     bl.release();
     return rc;
+}
+
+int gnnpe_rows_checksum_device(gnnpe_ctx *c, uint64_t n_rows, uint32_t L, const void *dev_ids, uint64_t first_id,
+                               uint64_t *host_sum)
+{
+    GNNPE_REQUIRE(c && host_sum && L >= 1 && (n_rows == 0 || dev_ids), GNNPE_ERR_ARG, "gnnpe_rows_checksum_device: bad argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->small.reserve(256))) return rc;
+    unsigned long long *d_sum = reinterpret_cast<unsigned long long *>(c->small.as<char>() + 128);
+    GNNPE_HIP_TRY(hipMemsetAsync(d_sum, 0, 8, c->stream));
+    if (n_rows)
+        hipLaunchKernelGGL(k_rows_checksum, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, n_rows, L,
+                           (const uint32_t *)dev_ids, first_id, d_sum);
+    GNNPE_HIP_TRY(hipGetLastError());
+    return read_back_u64(c, d_sum, 8, host_sum);
 }
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)

@@ -1,0 +1,145 @@
+// gnnpe_fill_deep.hip.h -- 4-vertex paths (l = 3), BASELINE config 5's "deep path" case.
+//
+// The reference cannot run l != 2 (dfs is always started at depth path_length-2, main.cpp:95, and
+// the writer then reads a 4th column out of bounds), so this is the intended generalisation of
+// custom.h:66-92 with the depth fixed: simple paths (s, b, c, d) from every start in processing order,
+// neighbours ascending at every level, kept iff neither the path nor its reverse was kept before --
+// i.e. iff rank[d] > rank[s] (the reverse starts at d).  The CPU checker under tests/ restates both the
+// hash-set DFS and this closed form for any L; the GPU tests compare against them.
+//
+// One wave per directed (s, b) pair, as in variant 1.  The pair's candidates are the entries of N(c) for
+// every c in N(b) \ {s}, in (c ascending, position ascending) order = emission order.  c's are taken 64
+// at a time (one lane each: row start and degree), their degrees are scanned into a per-wave LDS prefix,
+// and the flattened candidate space is walked 64 candidates per step with every lane busy: a 6-step binary
+// search in the prefix maps candidate -> (c, j); keep = rank[d] > rank[s] and d != b (d != s is implied,
+// d != c and c != b hold in a simple graph); ballot/popcount gives the output slot.  The same walk with the
+// stores compiled out is the count pass: per-pair totals are 64-bit (hub pairs of a power-law graph pass 2^32).
+#pragma once
+
+#include "gnnpe_kernels.hip.h"
+
+namespace gnnpe {
+
+constexpr int kDeepWaves = 4;  // waves per workgroup
+
+template <bool kEmit>
+__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint8_t *__restrict__ present,
+                                                           uint64_t *__restrict__ pair_cnt,
+                                                           uint32_t *__restrict__ missing_row)
+{
+    __shared__ uint32_t s_off[kDeepWaves][65], s_st[kDeepWaves][64], s_c[kDeepWaves][64];
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t e = P.e, D = 4 * P.e;
+    for (; w < P.n_edges; w += nw) {
+        uint64_t base = 0;
+        if (kEmit) {
+            base = P.eoff[w];
+            const uint64_t nxt = P.eoff[w + 1];
+            if (nxt == base || base >= P.end || nxt <= P.begin) continue;
+        }
+        const uint32_t i = P.erow[w], b = P.pnbr[w];
+        const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+        const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
+        uint64_t running = 0;
+        for (uint32_t k0 = 0; k0 < bd; k0 += 64) {
+            // one lane per third vertex c
+            const uint32_t k = k0 + lane;
+            uint32_t c = 0, cd = 0, cst = 0;
+            if (k < bd) {
+                c = P.nbrs[bst + k];
+                if (c != s) {
+                    if (present && !present[c]) atomicMin(missing_row, c);  // 2-hop row not on this device
+                    else {
+                        cd = P.adj_deg[c];
+                        cst = P.adj_start[c];
+                    }
+                }
+            }
+            uint32_t incl = cd;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, 64);
+                if ((int)lane >= o) incl += t;
+            }
+            off[lane] = incl - cd;
+            rst[lane] = cst;
+            rc[lane] = c;
+            const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (lane == 0) off[64] = n_cand;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // flattened candidates, 64 per step
+            for (uint32_t q0 = 0; q0 < n_cand; q0 += 64) {
+                const uint32_t q = q0 + lane;
+                const bool act = q < n_cand;
+                uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1)
+                    if (off[lo + step] <= q) lo += step;
+                const uint32_t pos = rst[lo] + (q - off[lo]);
+                uint32_t d = 0, rd = 0;
+                if (act) {
+                    d = P.nbrs[pos];
+                    rd = P.nbr_rank[pos];
+                }
+                const bool keep = act && rd > thr && d != b;
+                const uint64_t mask = __ballot(keep);
+                if (kEmit) {
+                    const uint64_t slot = base + running + __popcll(mask & lt);
+                    if (keep && slot >= P.begin && slot < P.end) {
+                        const uint64_t o = slot - P.begin;
+                        const uint32_t cc = rc[lo];
+                        if (P.out_ids) *reinterpret_cast<uint4 *>(P.out_ids + o * 4) = make_uint4(s, b, cc, d);
+                        if (P.out_pde)
+                            for (uint32_t t = 0; t < e; t++) {
+                                P.out_pde[o * D + t] = P.vde[(uint64_t)s * e + t];
+                                P.out_pde[o * D + e + t] = P.vde[(uint64_t)b * e + t];
+                                P.out_pde[o * D + 2 * e + t] = P.vde[(uint64_t)cc * e + t];
+                                P.out_pde[o * D + 3 * e + t] = P.nbr_vde[(uint64_t)pos * e + t];
+                            }
+                        if (P.out_pdl)
+                            for (uint32_t t = 0; t < e; t++) {
+                                P.out_pdl[o * D + t] = P.x[(uint64_t)s * e + t];
+                                P.out_pdl[o * D + e + t] = P.x[(uint64_t)b * e + t];
+                                P.out_pdl[o * D + 2 * e + t] = P.x[(uint64_t)cc * e + t];
+                                P.out_pdl[o * D + 3 * e + t] = P.x[(uint64_t)d * e + t];
+                            }
+                        if (P.out_part) P.out_part[o] = P.member[s];
+                    }
+                }
+                running += __popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (!kEmit && lane == 0) pair_cnt[w] = running;
+    }
+    if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) pair_cnt[P.n_edges] = 0;
+}
+
+// 64-bit checksum of a chunk of emitted rows (sum of per-row hashes; each hash includes the row's global path id, so order matters), so that outputs
+// too large to keep (config 5) can still be compared between runs, rank counts and the CPU checker.
+__global__ void k_rows_checksum(uint64_t n_rows, uint32_t L, const uint32_t *__restrict__ ids, uint64_t first_id,
+                                unsigned long long *__restrict__ sum)
+{
+    uint64_t acc = 0;
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t h = (first_id + r) * 0x9E3779B97F4A7C15ull;  // the row's global path id takes part: order matters
+        for (uint32_t k = 0; k < L; k++) {
+            h ^= ids[r * L + k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+        }
+        acc += h ^ (h >> 31);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, (unsigned long long)acc);
+}
+
+}  // namespace gnnpe

@@ -136,8 +136,10 @@ int gnnpe_vde_pack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, void *dev_
 int gnnpe_vde_unpack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, const void *dev_buf);
 
 /* ---- R2: path enumeration (dfs + VectorHash, custom.h:52-92; driver loop main.cpp:87-96) ------- */
-/* Counts the paths of the context's slab with l edges (l+1 vertices; the reference only works for
- * l=2).  host_per_start[i] (slab length entries, may be NULL) = number of paths whose
+/* Counts the paths of the context's slab with l edges (l+1 vertices).  l=2 is the reference's path (it
+ * only works for l=2); l=3 is the same rule with the DFS depth fixed (4-vertex simple paths,
+ * kept iff rank[last] > rank[first]; BASELINE config 5) and needs the adjacency rows two hops from the
+ * slab on the device.  host_per_start[i] (slab length entries, may be NULL) = number of paths whose
  * start is sorted_nodes[slab_begin+i]; *host_total = their sum.  Leaves the scanned offsets on the
  * device for gnnpe_fill_paths*. */
 int gnnpe_count_paths(gnnpe_ctx *ctx, uint32_t l, uint64_t *host_per_start, uint64_t *host_total);
@@ -151,6 +153,12 @@ int gnnpe_fill_paths(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, uint32_t *hos
                      double *host_pde_label);
 int gnnpe_fill_paths_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *dev_vids, void *dev_pde,
                             void *dev_pde_label);
+
+/* Order-sensitive 64-bit checksum of n_rows emitted rows (n_rows x L uint32 on the device) whose first
+ * row has global path id first_id; checksums of consecutive chunks ADD (mod 2^64).  For outputs too large
+ * to keep (config 5: count + checksum only) and for comparing rank counts. */
+int gnnpe_rows_checksum_device(gnnpe_ctx *ctx, uint64_t n_rows, uint32_t L, const void *dev_ids, uint64_t first_id,
+                               uint64_t *host_sum);
 
 /* Per path, the partition of its start vertex (membership[vids[0]]): what main.cpp:98-108 groups
  * partition_paths.txt by.  dev_part: (end-begin) uint32. */

@@ -1,0 +1,159 @@
+"""GPU tests of l=3 (4-vertex paths, BASELINE config 5).  The reference cannot run l != 2, so
+parity here is UNPINNED: the checker is the oracle's restatement of the reference DFS with the depth fixed
+(hash-set form and closed form, proven equal to each other on CPU in test_oracle_golden.py), plus the
+properties the enumeration must have at any size."""
+import numpy as np
+import pytest
+
+from conftest import small_cases
+from gnnpe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def binding():
+    from gnnpe_amd import binding as b
+    b.load()
+    return b
+
+
+def _engine(binding, g, sn, mem, p, e):
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    nl = int(g["labels"].max()) + 1 if len(g["labels"]) else 1
+    eng.set_label_table(binding.host_label_table(nl, e))
+    return eng
+
+
+def _checksum(ids, first_id=0):
+    """numpy restatement of k_rows_checksum"""
+    with np.errstate(over="ignore"):
+        C1, C2 = np.uint64(0x9E3779B97F4A7C15), np.uint64(0xBF58476D1CE4E5B9)
+        h = (np.arange(len(ids), dtype=np.uint64) + np.uint64(first_id)) * C1
+        for k in range(ids.shape[1]):
+            h ^= ids[:, k].astype(np.uint64) + C1 + (h << np.uint64(6)) + (h >> np.uint64(2))
+            h *= C2
+        return int((h ^ (h >> np.uint64(31))).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("ci", range(6))
+def test_small_graphs_l3_match_the_fixed_depth_dfs(binding, oracle, ci):
+    import torch
+    g = small_cases()[ci]
+    sn = g["sorted_nodes"]
+    e = 2
+    eng = _engine(binding, g, sn, np.zeros(len(sn), np.uint32), 1, e)
+    x, nx, vde = eng.vde()
+    total, per_start = eng.count_paths(3, per_start=True)
+    want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)  # the reference's dfs with the depth fixed
+    assert total == len(want)
+    assert np.array_equal(per_start, oracle.count_per_start(g["offsets"], g["nbrs"], sn, 4))
+    ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
+    assert ids.shape == (total, 4) and np.array_equal(ids, want)
+    opde, opdl, _, _ = oracle.gen_pde(want, e, g["offsets"], g["labels"], x, vde)
+    assert np.array_equal(pde, opde) and np.array_equal(pdl, opdl)
+    # arbitrary chunk boundaries give the same rows
+    if total > 10:
+        cuts = [0, 1, total // 3, total // 3 + 1, total - 1, total]
+        got = np.concatenate([eng.fill_paths(a, b, pde=False)[0] for a, b in zip(cuts[:-1], cuts[1:])])
+        assert np.array_equal(got, want)
+    # checksum of chunks adds up to the checksum of the whole
+    if total:
+        t = torch.from_numpy(ids.view(np.int32)).cuda()
+        whole = eng.rows_checksum_device(total, 4, t, 0)
+        assert whole == _checksum(want)
+        h = total // 2
+        parts = eng.rows_checksum_device(h, 4, t[:h], 0) + eng.rows_checksum_device(total - h, 4, t[h:], h)
+        assert parts % (1 << 64) == whole
+    eng.close()
+
+
+@pytest.mark.parametrize("e", [1, 8])
+def test_l3_wide_embeddings_and_partitions(binding, oracle, e):
+    import torch
+    g = synth.gnm_graph(400, 1600, n_labels=5, seed=11)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(g["n"], 3)
+    eng = _engine(binding, g, sn, mem, 3, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(3)
+    want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(want)
+    ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
+    assert np.array_equal(ids, want)
+    assert np.array_equal(pde, vde[want].reshape(total, 4 * e))
+    assert np.array_equal(pdl, x[want].reshape(total, 4 * e))
+    part = torch.empty(total, dtype=torch.int32, device="cuda")
+    eng.path_partitions_device(0, total, part)
+    eng.sync()
+    assert np.array_equal(part.cpu().numpy().astype(np.uint32), mem[want[:, 0]])
+    eng.close()
+
+
+def test_l3_hub_rows_beyond_one_wave(binding, oracle):
+    """degrees far above 64: several c-batches per pair and candidate rows longer than a wave"""
+    g = synth.powerlaw_graph(1500, 9000, exponent=2.0, max_degree=400, n_labels=4, seed=3)
+    assert np.diff(g["offsets"].astype(np.int64)).max() > 128
+    rng = np.random.default_rng(5)
+    sn = rng.permutation(g["n"]).astype(np.uint32)  # arbitrary processing order
+    eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2)
+    eng.vde(want=False)
+    total, per_start = eng.count_paths(3, per_start=True)
+    assert np.array_equal(per_start, oracle.count_per_start(g["offsets"], g["nbrs"], sn, 4))
+    want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(want)
+    chunk = 1 << 18
+    for b in range(0, total, chunk):
+        ids, _, _ = eng.fill_paths(b, min(total, b + chunk), pde=False)
+        assert np.array_equal(ids, want[b:b + chunk]), b
+    eng.close()
+
+
+def test_l3_properties_at_scale(binding):
+    """size-independent properties on a graph the CPU checker would take minutes for: simple paths, real edges,
+    rank[last] > rank[first], lexicographic order inside a start, counts consistent with the l=2 run"""
+    import torch
+    g = synth.gnm_graph(20000, 120000, n_labels=16, seed=21)
+    sn = synth.degree_order(g["offsets"])
+    rank = np.empty(g["n"], np.int64)
+    rank[sn] = np.arange(g["n"])
+    eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2)
+    eng.vde(want=False)
+    total, per_start = eng.count_paths(3, per_start=True)
+    assert int(per_start.sum()) == total
+    # total = number of 4-vertex simple paths (each undirected path once): sum over middle edges (b,c) of
+    # (deg b - 1)(deg c - 1) minus 3 x triangles; checked through the emitted rows instead of a formula
+    ids = torch.empty((total, 4), dtype=torch.int32, device="cuda")
+    eng.fill_paths_device(0, total, ids, None, None)
+    eng.sync()
+    v = ids.cpu().numpy().astype(np.int64)
+    assert np.all(rank[v[:, 3]] > rank[v[:, 0]])
+    for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)):
+        assert np.all(v[:, a] != v[:, b])
+    off, nb = g["offsets"].astype(np.int64), g["nbrs"].astype(np.int64)
+    edge_keys = np.repeat(np.arange(g["n"]), np.diff(off)) * g["n"] + nb
+    for a, b in ((0, 1), (1, 2), (2, 3)):
+        assert np.all(np.isin(v[:, a] * g["n"] + v[:, b], edge_keys))
+    # emission order: starts in processing order; inside a start rows ascend lexicographically
+    assert np.all(np.diff(rank[v[:, 0]]) >= 0)
+    key = (v[:, 1] * g["n"] + v[:, 2]) * g["n"] + v[:, 3]
+    same = v[1:, 0] == v[:-1, 0]
+    assert np.all(np.diff(key)[same] > 0)
+    # every row once: (s,b,c,d) unique and its reverse absent
+    fwd = ((v[:, 0] * g["n"] + v[:, 1]) * g["n"] + v[:, 2]) * g["n"] + v[:, 3]
+    rev = ((v[:, 3] * g["n"] + v[:, 2]) * g["n"] + v[:, 1]) * g["n"] + v[:, 0]
+    assert len(np.unique(fwd)) == total and not np.isin(rev, fwd).any()
+    # independent count: ordered simple 4-vertex walks / 2
+    deg = np.diff(off)
+    src = np.repeat(np.arange(g["n"]), deg)
+    tri = 0
+    nbr_sets = [set(nb[off[u]:off[u + 1]].tolist()) for u in range(g["n"])]
+    for u, w in zip(src.tolist(), nb.tolist()):
+        if u < w:
+            tri += len(nbr_sets[u] & nbr_sets[w])
+    # tri = sum over edges of common neighbours (3 x triangles): a path loses one choice per (middle edge, common neighbour)
+    expect = int(((deg[src] - 1) * (deg[nb] - 1)).sum()) // 2 - tri
+    assert total == expect
+    eng.close()
