@@ -629,7 +629,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
             P.n_edges = ne;
             P.slab_begin = sb;
             P.e = e;
-            hipLaunchKernelGGL((k_deep3<false>), dim3(grid_for(ne * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+            hipLaunchKernelGGL((k_deep3<false, 0>), dim3(grid_for(ne * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
                                c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(),
                                c->ecnt.as<uint64_t>(), d_missing);
             uint64_t miss = 0;
@@ -757,8 +757,15 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     default: LAUNCH(8); break;    \
     }
     if (var == kVarDeep) {
-        hipLaunchKernelGGL((k_deep3<true>), dim3(grid_for(c->n_edges * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
-                           (const uint8_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+#define GNNPE_L(EE)                                                                                                \
+    hipLaunchKernelGGL((k_deep3<true, EE>), dim3(grid_for(c->n_edges * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P, \
+                       (const uint8_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr)
+        if (fast_e(e)) {
+            GNNPE_BY_E(GNNPE_L)
+        } else {
+            GNNPE_L(0);
+        }
+#undef GNNPE_L
     } else if (var == kVarRanked) {
         const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
         const StartRec *sr = c->srec.as<StartRec>();
@@ -896,8 +903,10 @@ int gnnpe_halo_need(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds, void
     GNNPE_HIP_TRY(hipMemsetAsync(mark, 0, n, c->stream));
     GNNPE_HIP_TRY(hipMemsetAsync(d_hist, 0, 64 * 8, c->stream));
     GNNPE_HIP_TRY(hipMemcpyAsync(d_bounds, bounds, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    if (c->nbr_owned)
-        hipLaunchKernelGGL(k_mark_needed, dim3(grid_for(c->nbr_owned)), dim3(kBlock), 0, c->stream, c->nbr_owned,
+    // every vertex referenced by a row on the device (owned rows on the first hop; owned + 1-hop rows when the
+    // caller asks again without dropping the halo: the 2-hop rows l=3 needs)
+    if (c->nbr_used)
+        hipLaunchKernelGGL(k_mark_needed, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                            c->nbrs.as<uint32_t>(), mark);
     hipLaunchKernelGGL(k_need_owner, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, n_ranks, d_bounds, mark,
                        c->present.as<uint8_t>(), c->rank.as<uint32_t>(), key_in, ids_in);

@@ -8,7 +8,8 @@ concatenation of per-slab id lists, for any R (SURVEY 8(e) "Invariant").
 
 Each rank holds the adjacency rows of its own start vertices only.  One step is:
   1. halo exchange  -- all-to-all-v of the adjacency lists of the 1-hop middle vertices
-                       (requests, degrees, neighbour lists: three all-to-all-v over RCCL/xGMI),
+                       (requests, degrees, neighbour lists: three all-to-all-v over RCCL/xGMI);
+                       l=3 (4-vertex paths) repeats it once for the rows two hops out,
   2. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
   3. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
   4. fill           -- local, into caller-provided device buffers.
@@ -72,11 +73,11 @@ class SlabBuild:
     """Per-rank state of the distributed offline build.  `eng` already holds this rank's rows
     (load_rows), the replicated order (set_order), slab (set_slab) and label table."""
 
-    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None):
+    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None, l=2):
         """nbr_capacity: most neighbour entries this rank can RECEIVE (<= 2m); owned_entries: size
         of its own rows -- every peer may ask for all of them, so the send buffer holds
-        (world-1) x owned_entries."""
-        self.eng, self.n, self.e = eng, int(n), int(e)
+        (world-1) x owned_entries.  l: edges per path (2, or 3 = one more halo hop)."""
+        self.eng, self.n, self.e, self.l = eng, int(n), int(e), int(l)
         self.bounds = np.ascontiguousarray(bounds, np.uint32)
         self.rank, self.world, self.device, self.group = rank, world, device, group
         i32 = dict(dtype=torch.int32, device=device)
@@ -122,8 +123,13 @@ class SlabBuild:
         dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
 
     def exchange_halo(self):
+        self.eng.rows_drop_halo()
+        self.stats.update(halo_rows=0, halo_entries=0, served_rows=0, served_entries=0)
+        for _ in range(self.l - 1):  # l=2: rows of the middle vertices; l=3: also the rows they reference
+            self._exchange_hop()
+
+    def _exchange_hop(self):
         eng, R = self.eng, self.world
-        eng.rows_drop_halo()
         need_counts = [int(x) for x in eng.halo_need(self.bounds, self.need, self.n)]
         n_need = sum(need_counts)
         # 1. how many rows does every peer want from me
@@ -150,7 +156,8 @@ class SlabBuild:
         eng.rows_pack(n_req, req, self.pack, self.send_cap)
         self._a2a(self.nbr_in[:n_recv], self.pack[:n_send], recv_sizes, send_sizes)
         eng.rows_append(n_need, self.need[:n_need], deg_in, self.nbr_in[:n_recv], n_recv)
-        self.stats.update(halo_rows=n_need, halo_entries=n_recv, served_rows=n_req, served_entries=n_send)
+        for k, v in (("halo_rows", n_need), ("halo_entries", n_recv), ("served_rows", n_req), ("served_entries", n_send)):
+            self.stats[k] += v
 
     @staticmethod
     def _segment_sums(t, counts):
@@ -177,7 +184,7 @@ class SlabBuild:
                 eng.vde_unpack_slab(int(b[r]), int(b[r + 1]), self.vde_all[r])
 
     def count(self):
-        total = self.eng.count_paths(2)
+        total = self.eng.count_paths(self.l)
         mine = torch.tensor([total], dtype=torch.int64, device=self.device)
         self._allgather(self.tot_all, mine)
         tots = [int(x) for x in self.tot_all.tolist()]
@@ -199,6 +206,6 @@ class SlabBuild:
         return total, self.base
 
     def _count_single(self):
-        self.local_total = self.global_total = self.eng.count_paths(2)
+        self.local_total = self.global_total = self.eng.count_paths(self.l)
         self.base = 0
         return self.local_total

@@ -11,8 +11,9 @@
 // Deliberate differences from the reference (all fail-loud instead of silent):
 //   - missing membership.txt / partition directories are errors (the reference reads zeros /
 //     writes nothing: main.cpp:80,101,110 never check their streams);
-//   - `-l` other than 2 is refused: the reference enumerates 3-vertex paths whatever -l says and
-//     then prints garbage or truncated rows;
+//   - `-l 3` writes 4-vertex paths (the rule of custom.h:66-92 with the DFS depth fixed; BASELINE config 5),
+//     where the reference enumerates 3-vertex paths whatever -l says and prints a garbage 4th column
+//     (SURVEY D4); its online binary cannot read those files.  Other -l values are refused;
 //   - path counts beyond 2^32-1 are refused unless --allow-large (the reference's `ui` overflows).
 #include <sys/stat.h>
 
@@ -127,9 +128,11 @@ int main(int argc, char **argv)
     const auto t_start = Clock::now();
 
     // main.cpp:58-59: path_length += 1; pde_dim = vde_dim * path_length
-    if (o.path_length != 2)
-        die("-l " + std::to_string(o.path_length) + ": only -l 2 is supported (the reference always enumerates 3-vertex "
-            "paths and mis-prints them for any other -l)");
+    if (o.path_length != 2 && o.path_length != 3)
+        die("-l " + std::to_string(o.path_length) + ": only -l 2 and -l 3 are supported (the reference always enumerates "
+            "3-vertex paths and mis-prints them for any other -l)");
+    if (o.path_length == 3)
+        fprintf(stderr, "note: -l 3 writes 4-vertex paths; the reference's online binary only reads -l 2 files (SURVEY D4)\n");
     const uint32_t L = o.path_length + 1;
     if (o.answers != "MAX") {  // main.cpp:62-69 (MAX_LIMIT is an online-only knob)
         uint32_t lim;

@@ -60,8 +60,8 @@ def main(argv=None):
     ap.add_argument("--chunk", type=int, default=16 << 20, help="paths rendered per device pass")
     ap.add_argument("--timing", action="store_true")
     args = ap.parse_args(argv)
-    if args.l != 2:
-        raise SystemExit("-l: only 2 is supported (SURVEY D4)")
+    if args.l not in (2, 3):
+        raise SystemExit("-l: only 2 and 3 are supported (SURVEY D4)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -84,7 +84,7 @@ def main(argv=None):
 
     # R0 / R1 with the library's own loader; every rank reads the (small) text inputs, keeps only its rows
     g = binding.host_load_graph(args.graph)
-    n, L, e, p = g["n"], 3, args.e, args.p
+    n, L, e, p = g["n"], args.l + 1, args.e, args.p
     if rank == 0:
         print(f"|V|: {g['n']}, |E|: {g['m']}, |Σ|: {g['labels_count']}")
         print(f"Max Degree: {g['max_degree']}, Max Label Frequency: {g['max_label_frequency']}", flush=True)
@@ -108,7 +108,8 @@ def main(argv=None):
     eng.set_order(sn, mem, p)
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(max(g["labels_count"], 1), e))
-    sb = SlabBuild(eng, n, e, bounds, rank, world, device, nbr_capacity=len(g["nbrs"]), owned_entries=owned_entries)
+    sb = SlabBuild(eng, n, e, bounds, rank, world, device, nbr_capacity=len(g["nbrs"]), owned_entries=owned_entries,
+                   l=args.l)
     total, base = sb.step()  # halo exchange + vde + count; no fill yet
     P = sb.global_total
     if P > 0xFFFFFFFF:

@@ -104,8 +104,9 @@ int gnnpe_host_read_membership(const char *path, uint32_t n, uint32_t p, uint32_
 void gnnpe_host_free(void *ptr);
 
 /* ---- halo exchange helpers (device side of the RCCL all-to-all-v) ----------------- */
-/* List the vertices whose adjacency rows this context needs (neighbours of its slab's start
- * vertices) but does not hold, grouped by owning rank: owner r holds the slab
+/* List the vertices whose adjacency rows this context needs but does not hold -- every vertex referenced by
+ * a row it holds: after gnnpe_rows_drop_halo these are the neighbours of its slab's start vertices (all that
+ * l=2 needs); called again after gnnpe_rows_append they are the rows two hops out (l=3) -- grouped by owning rank: owner r holds the slab
  * [slab_bounds[r], slab_bounds[r+1]) of the processing order.  dev_ids receives the ids (capacity
  * cap entries), host_counts[r] the number per owner.  Ids are ascending inside each group. */
 int gnnpe_halo_need(gnnpe_ctx *ctx, uint32_t n_ranks, const uint32_t *host_slab_bounds, void *dev_ids,

@@ -32,7 +32,7 @@ class FakeEngine:
     def halo_need(self, bounds, buf, cap):
         held = self._held()
         need = set()
-        for nb in self.owned.values():
+        for nb in held.values():  # every vertex referenced by a row on the "device" (second call = second hop)
             need.update(int(x) for x in nb)
         need = np.array(sorted(v for v in need if v not in held), np.int64)
         owner = np.searchsorted(np.asarray(bounds, np.int64), self.rank[need], side="right") - 1 if len(need) else need
@@ -102,4 +102,4 @@ class FakeEngine:
         if out_ids is not None:
             out_ids[:len(p)] = torch.from_numpy(p.astype(np.int32))
         if out_pde is not None:
-            out_pde[:len(p)] = torch.from_numpy(self._vde[p.astype(np.int64)].reshape(len(p), 3 * self.e))
+            out_pde[:len(p)] = torch.from_numpy(self._vde[p.astype(np.int64)].reshape(len(p), p.shape[1] * self.e))

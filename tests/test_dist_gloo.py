@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, bounds):
+def _worker(rank, world, port, out_dir, bounds, l=2):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from fake_engine import FakeEngine
@@ -38,12 +38,13 @@ def _worker(rank, world, port, out_dir, bounds):
     eng = FakeEngine(Oracle(), g["n"], g["labels"], rows, roff, rnbr, sn, 2)
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     sb = SlabBuild(eng, g["n"], 2, bounds, rank, world, torch.device("cpu"), nbr_capacity=2 * g["m"],
-                   owned_entries=int(roff[-1]))
+                   owned_entries=int(roff[-1]), l=l)
+    L = l + 1
     res = []
     for rep in range(2):  # the step is repeatable
         total, base = sb.step()
-        ids = torch.zeros((max(total, 1), 3), dtype=torch.int32)
-        pde = torch.zeros((max(total, 1), 6), dtype=torch.float64)
+        ids = torch.zeros((max(total, 1), L), dtype=torch.int32)
+        pde = torch.zeros((max(total, 1), 2 * L), dtype=torch.float64)
         total2, base2 = sb.step(ids, pde)
         assert (total2, base2) == (total, base)
         res.append(dict(total=total, base=base, global_total=sb.global_total, ids=ids[:total].numpy(),
@@ -76,6 +77,24 @@ def test_slab_build_equals_single_rank(oracle, tmp_path, world, kind):
         assert np.array_equal(pde, vde[ref_ids].reshape(len(ref_ids), 6))
     if kind == "planned":  # partitioning must actually move rows between ranks
         assert all(res[r][0]["stats"]["halo_rows"] > 0 for r in range(world))
+
+
+def test_slab_build_l3_needs_the_second_hop(oracle, tmp_path):
+    """4-vertex paths: the rows two hops from the slab travel in a second exchange round; without it the
+    per-rank counts fall short of the single-rank enumeration."""
+    world = 2
+    g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    bounds = plan_slabs(g["offsets"], sn, world)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), bounds, 3), nprocs=world, join=True)
+    ref_ids = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    res = [pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(world)]
+    parts = [res[r][1] for r in range(world)]
+    ids = np.concatenate([p["ids"] for p in parts]).astype(np.uint32)
+    assert np.array_equal(ids, ref_ids)
+    assert np.array_equal(np.concatenate([p["pde"] for p in parts]), vde[ref_ids].reshape(len(ref_ids), 8))
+    assert all(p["global_total"] == len(ref_ids) for p in parts)
 
 
 def test_plan_slabs_balances_and_covers():

@@ -189,3 +189,30 @@ def test_empty_and_small_partitions_through_both_binaries(tmp_path):
         b = subprocess.check_output([ref_main_path(), "-f", ours + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
         na, nb = (int(re.search(r"Answer Number: (\d+)", t).group(1)) for t in (a, b))
         assert na == nb
+
+
+@pytest.mark.parametrize("gpus", [1, 3])
+def test_l3_files_match_the_oracle_writers(tmp_path, oracle, gpus):
+    """-l 3 (4-vertex paths, BASELINE config 5): no reference run exists for it, so the expected
+    bytes come from the oracle's restatement of the writers (main.cpp:98-119 are generic in the row width)
+    over the fixed-depth DFS."""
+    g = synth.gnm_graph(700, 2600, n_labels=6, seed=14)
+    rng = np.random.default_rng(14)
+    sn = rng.permutation(700).astype(np.uint32)
+    mem = rng.integers(0, 3, size=700).astype(np.uint32)
+    d = str(tmp_path / "ds")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 3)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "3", "-l", "3", "--chunk", "5000", "--gpus", str(gpus),
+                        "--same-device"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)
+    assert open(os.path.join(d, "gnn-pe", "all_paths.txt"), "rb").read() == oracle.format_all_paths(want)
+    for pid in range(3):
+        exp = str(tmp_path / f"exp{pid}.txt")
+        oracle.write_partition_paths(exp, want, mem, pid)
+        got = os.path.join(d, "gnn-pe", "partitions", f"partition-{pid}", "partition_paths.txt")
+        assert open(got, "rb").read() == open(exp, "rb").read()

@@ -70,7 +70,7 @@ def test_small_graphs_l3_match_the_fixed_depth_dfs(binding, oracle, ci):
     eng.close()
 
 
-@pytest.mark.parametrize("e", [1, 8])
+@pytest.mark.parametrize("e", [1, 5, 8])
 def test_l3_wide_embeddings_and_partitions(binding, oracle, e):
     import torch
     g = synth.gnm_graph(400, 1600, n_labels=5, seed=11)

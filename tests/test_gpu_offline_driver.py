@@ -66,3 +66,41 @@ def test_driver_files_match_reference_for_any_world_size(tmp_path, oracle, world
                                        os.path.join(GOLDEN, "test_graph", "query_graph.graph"), "-m", "online", "-p", "2"],
                                       text=True)
         assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_driver_l3_two_hop_halo(tmp_path, oracle, world):
+    """-l 3 through the rank-partitioned driver: the second halo round brings in the rows two hops from the slab;
+    files equal the oracle writers over the fixed-depth DFS (no reference run exists for l=3), and the
+    4-vertex index.dat satisfies the format validator."""
+    g = synth.gnm_graph(500, 1900, n_labels=5, seed=77)
+    rng = np.random.default_rng(77)
+    sn = rng.permutation(500).astype(np.uint32)
+    mem = rng.integers(0, 2, size=500).astype(np.uint32)
+    tmp = str(tmp_path / "ds")
+    os.makedirs(tmp)
+    synth.make_dataset_dir(tmp, 2)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), sn, mem)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    args = [DRIVER, "-f", tmp + "/", "-d", gp, "-p", "2", "-l", "3", "--index", "--chunk", "20000"]
+    env = dict(os.environ)
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)
+    assert open(os.path.join(tmp, "gnn-pe", "all_paths.txt"), "rb").read() == oracle.format_all_paths(want)
+    for pid in range(2):
+        d = os.path.join(tmp, "gnn-pe", "partitions", f"partition-{pid}")
+        exp = str(tmp_path / f"exp{pid}.txt")
+        oracle.write_partition_paths(exp, want, mem, pid)
+        assert open(os.path.join(d, "partition_paths.txt"), "rb").read() == open(exp, "rb").read()
+        info = oracle.index_validate(open(os.path.join(d, "index.dat"), "rb").read())
+        cnt = int((mem[want[:, 0]] == pid).sum())
+        assert info["num_data"] == cnt and info["dim"] == 8
+        assert np.array_equal(np.sort(info["leaf_son"]), np.arange(cnt))

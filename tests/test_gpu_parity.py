@@ -173,7 +173,9 @@ def test_edge_cases_and_errors(binding, oracle, variant):
     assert np.array_equal(ids, ref) and np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
     # error behaviour: fail loudly, never exit()
     with pytest.raises(binding.GnnpeError):
-        eng.count_paths(3)  # l != 2 unsupported (reference is broken there too)
+        eng.count_paths(4)  # only l=2 (reference) and l=3 (its fixed-depth generalisation)
+    assert eng.count_paths(3) == 0  # a star has no 4-vertex simple path
+    assert eng.count_paths(2) == hub * (hub - 1) // 2
     with pytest.raises(binding.GnnpeError):
         eng.set_order(np.zeros(hub + 1, np.uint32), np.zeros(hub + 1, np.uint32), 1)  # not a permutation
     with pytest.raises(binding.GnnpeError):

@@ -57,9 +57,9 @@ def test_input_validation_fails_loudly(tmp_path):
     g = synth.gnm_graph(50, 120, n_labels=3, seed=1)
     sn = synth.degree_order(g["offsets"])
     root, gp = _dataset(tmp_path, g, sn, np.zeros(50, np.uint32), 2)
-    # -l other than 2
-    r = _run("-f", root, "-d", gp, "-l", "3", "-p", "2")
-    assert r.returncode == 1 and "only -l 2" in r.stderr
+    # -l other than 2 or 3
+    r = _run("-f", root, "-d", gp, "-l", "4", "-p", "2")
+    assert r.returncode == 1 and "only -l 2 and -l 3" in r.stderr
     # online mode belongs to the reference binary
     r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2")
     assert r.returncode == 2
