@@ -22,7 +22,6 @@
 #include <unistd.h>
 
 #include <atomic>
-#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -620,7 +619,8 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
 }
 
 // Device image -> file: two pinned staging buffers, the copy-back of piece k+1 overlaps the write() of piece k
-// (the 22 GB of index.dat at config 3 are bound by PCIe + the copy into the page cache, not by the build).
+// (the 22 GB of index.dat at config 3 move at ~9 GB/s: buffered writes to ONE file serialise on its inode lock, so
+// the slices below mostly help filesystems without that lock; the device build itself is 3-5 ms per partition).
 static int write_device_image(gnnpe_ctx *c, const char *image, uint64_t nbytes, const char *path)
 {
     constexpr uint64_t kPiece = 64ull << 20;
@@ -733,7 +733,6 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
                   "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
     GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
-    auto T0 = std::chrono::steady_clock::now();
     const uint32_t L = c->l + 1;
     const uint64_t total = c->total_paths;
     // collect the partition's paths (vertex triples in path-id order): two passes over the slab in chunks
@@ -762,16 +761,8 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
     }
     void *image = nullptr;
     uint64_t nbytes = 0;
-    (void)hipStreamSynchronize(c->stream);
-    auto T1 = std::chrono::steady_clock::now();
     if (!rc) rc = gnnpe_build_index_device(c, cnt, L, mine.p, &image, &nbytes, nullptr);
-    auto T2 = std::chrono::steady_clock::now();
     if (!rc) rc = write_device_image(c, (const char *)image, nbytes, path);
-    auto T3 = std::chrono::steady_clock::now();
-    if (getenv("GNNPE_TIMING_DEBUG"))
-        fprintf(stderr, "index pid %u: select+gather %.3f s, build %.3f s, copy+write %.3f s (%.2f GB)\n", pid,
-                std::chrono::duration<double>(T1 - T0).count(), std::chrono::duration<double>(T2 - T1).count(),
-                std::chrono::duration<double>(T3 - T2).count(), nbytes / 1e9);
     (void)hipStreamSynchronize(c->stream);
     ids.release();
     part.release();
