@@ -78,7 +78,35 @@ class Oracle:
         L.orc_pge_write_bin.restype = C.c_int
         L.orc_pge_write_bin.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _u32p, _u32p, _f64p, _f64p, _f64p, _f64p,
                                         _f64p, C.c_double]
+        L.orc_offline_parallel.restype = C.c_uint64
+        L.orc_offline_parallel.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint32, C.c_int, _f64p, _u64p,
+                                           _u32p, _f64p, C.c_uint64]
+        L.orc_max_threads.restype = C.c_int
         self.L = L
+
+    # all-core CPU port of the device-resident pass (bench.py's second CPU baseline)
+    def max_threads(self):
+        return int(self.L.orc_max_threads())
+
+    def offline_parallel(self, offs, nbrs, labels, sorted_nodes, e, threads=0, ids=None, pde=None, want=True):
+        """Returns (P, vde, start_off, ids, pde); pass preallocated ids/pde to time the fill without allocation."""
+        n = len(offs) - 1
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        labels = np.ascontiguousarray(labels, np.uint32)
+        sn = np.ascontiguousarray(sorted_nodes, np.uint32)
+        vde = np.zeros((n, e))
+        so = np.zeros(n + 1, np.uint64)
+        cap = 0 if ids is None else len(ids)
+        P = self.L.orc_offline_parallel(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(labels, _u32p), _p(sn, _u32p), e, threads,
+                                        _p(vde, _f64p), _p(so, _u64p), _p(ids, _u32p) if ids is not None else None,
+                                        _p(pde, _f64p) if pde is not None else None, cap)
+        if ids is None and want:
+            ids = np.zeros((P, 3), np.uint32)
+            pde = np.zeros((P, 3 * e))
+            self.L.orc_offline_parallel(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(labels, _u32p), _p(sn, _u32p), e, threads,
+                                        _p(vde, _f64p), _p(so, _u64p), _p(ids, _u32p), _p(pde, _f64p), P)
+        return P, vde, so, ids, pde
 
     # R0 graph.cpp:163-242
     def load_graph(self, path):

@@ -13,6 +13,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 void orc_free(void *p) { free(p); }
 
@@ -626,4 +629,84 @@ int orc_pge_write_bin(const char *path, uint32_t n, uint32_t e, const uint32_t *
     }
     fclose(f);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * All-core CPU port of the device-resident pass (bench.py's second CPU baseline; SURVEY 8(d): "the build's
+ * optimised CPU path (closed form, OpenMP over all host cores)").  Same outputs as orc_gen_vde +
+ * orc_enumerate_closed(L=3) + orc_gen_pde, computed the way the GPU engine does: vde per vertex, per-start
+ * counts, one prefix sum, then every start writes its own slice of ids / pde.  l = 2 only.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t orc_offline_parallel(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *labels, const uint32_t *sorted_nodes, uint32_t e, int threads,
+                              double *vde, uint64_t *start_off /* n+1 */, uint32_t *ids, double *pde,
+                              uint64_t capacity)
+{
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    uint32_t max_label = 0;
+    for (uint32_t i = 0; i < n; i++) if (labels[i] > max_label) max_label = labels[i];
+    double *table = (double *)malloc(((size_t)max_label + 1) * e * sizeof(double));
+    for (uint32_t l = 0; l <= max_label; l++) orc_gen_vde_x(l, e, table + (size_t)l * e);
+    uint32_t *rank = make_rank(n, sorted_nodes);
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (uint32_t v = 0; v < n; v++) {
+        double acc[64];
+        for (uint32_t k = 0; k < e; k++) acc[k] = 0.0;
+        for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++)
+            for (uint32_t k = 0; k < e; k++) acc[k] += table[(size_t)labels[neighbors[j]] * e + k];
+        for (uint32_t k = 0; k < e; k++) vde[(size_t)v * e + k] = table[(size_t)labels[v] * e + k] + acc[k];
+    }
+#pragma omp parallel for schedule(dynamic, 256)
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = sorted_nodes[i];
+        uint64_t c = 0;
+        for (uint32_t j = offsets[s]; j < offsets[s + 1]; j++) {
+            const uint32_t b = neighbors[j];
+            for (uint32_t q = offsets[b]; q < offsets[b + 1]; q++) c += rank[neighbors[q]] > i;
+        }
+        start_off[i + 1] = c;
+    }
+    start_off[0] = 0;
+    for (uint32_t i = 0; i < n; i++) start_off[i + 1] += start_off[i];
+    const uint64_t P = start_off[n];
+    if (ids && P <= capacity) {
+#pragma omp parallel for schedule(dynamic, 256)
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t s = sorted_nodes[i];
+            uint64_t o = start_off[i];
+            for (uint32_t j = offsets[s]; j < offsets[s + 1]; j++) {
+                const uint32_t b = neighbors[j];
+                for (uint32_t q = offsets[b]; q < offsets[b + 1]; q++) {
+                    const uint32_t c = neighbors[q];
+                    if (rank[c] <= i) continue;
+                    ids[o * 3] = s;
+                    ids[o * 3 + 1] = b;
+                    ids[o * 3 + 2] = c;
+                    if (pde)
+                        for (uint32_t k = 0; k < e; k++) {
+                            pde[o * 3 * e + k] = vde[(size_t)s * e + k];
+                            pde[o * 3 * e + e + k] = vde[(size_t)b * e + k];
+                            pde[o * 3 * e + 2 * e + k] = vde[(size_t)c * e + k];
+                        }
+                    o++;
+                }
+            }
+        }
+    }
+    free(rank);
+    free(table);
+    return P;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }

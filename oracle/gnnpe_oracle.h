@@ -52,6 +52,14 @@ uint64_t orc_enumerate_closed(uint32_t n, const uint32_t *offsets, const uint32_
 void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
                          const uint32_t *sorted_nodes, uint32_t L, uint64_t *counts);
 
+/* All-core CPU port of the device-resident pass (vde + count + prefix + ids/pde fill, l=2, closed form, OpenMP):
+ * bench.py's second CPU baseline.  vde: n x e; start_off: n+1; ids: P x 3, pde: P x 3e (may be NULL); returns P and
+ * fills ids/pde only when P <= capacity.  threads <= 0: all cores. */
+uint64_t orc_offline_parallel(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
+                              const uint32_t *labels, const uint32_t *sorted_nodes, uint32_t e, int threads,
+                              double *vde, uint64_t *start_off, uint32_t *ids, double *pde, uint64_t capacity);
+int orc_max_threads(void);
+
 /* ---- R3: label feature (custom.h:492-511), libstdc++ mt19937 + generate_canonical ------- */
 void orc_gen_vde_x(uint32_t label, uint32_t e, double *x_out);
 

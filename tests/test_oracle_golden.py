@@ -147,3 +147,19 @@ def test_edge_cases(oracle):
     a = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
     b = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)
     assert len(a) > 0 and np.array_equal(a, b)
+
+
+def test_all_core_port_equals_the_sequential_restatement(oracle):
+    """bench.py's all-core CPU baseline (closed form, OpenMP) must produce exactly what the sequential oracle does."""
+    from gnnpe_amd import synth
+    g = synth.gnm_graph(3000, 20000, n_labels=11, seed=4)
+    rng = np.random.default_rng(4)
+    sn = rng.permutation(3000).astype(np.uint32)
+    for e in (2, 5):
+        P, vde, so, ids, pde = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, e, threads=4)
+        want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+        x, nx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)
+        assert P == len(want) and np.array_equal(ids, want)
+        assert np.array_equal(vde, ovde)
+        assert np.array_equal(pde, ovde[want].reshape(P, 3 * e))
+        assert np.array_equal(np.diff(so), oracle.count_per_start(g["offsets"], g["nbrs"], sn, 3))
