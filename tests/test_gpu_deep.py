@@ -157,3 +157,49 @@ def test_l3_properties_at_scale(binding):
     expect = int(((deg[src] - 1) * (deg[nb] - 1)).sum()) // 2 - tri
     assert total == expect
     eng.close()
+
+
+def test_l3_counts_and_slots_beyond_32_bits(binding):
+    """maximum sizes: more than 2^32 paths.  The count must equal the closed form over middle edges
+    sum_{b,c} [(deg b - 1)(deg c - 1) - |N(b) & N(c)|], and rows emitted around slot 2^32 must be valid and
+    consistent whatever the chunk boundaries are (64-bit offsets everywhere)."""
+    import torch
+    n, m = 4000, 800_000
+    g = synth.gnm_graph(n, m, n_labels=8, seed=9)
+    sn = synth.degree_order(g["offsets"])
+    rank = np.empty(n, np.int64)
+    rank[sn] = np.arange(n)
+    off, nb = g["offsets"].astype(np.int64), g["nbrs"].astype(np.int64)
+    deg = np.diff(off)
+    src = np.repeat(np.arange(n), deg)
+    A = np.zeros((n, n))
+    A[src, nb] = 1.0
+    common = float(((A @ A) * A).sum()) / 2.0  # sum over undirected edges of common neighbours (exact in f64)
+    expect = int(((deg[src] - 1) * (deg[nb] - 1)).sum()) // 2 - int(round(common))
+    assert expect > 1 << 32
+    eng = _engine(binding, g, sn, np.zeros(n, np.uint32), 1, 2)
+    eng.vde(want=False)
+    total, per_start = eng.count_paths(3, per_start=True)
+    assert total == expect and int(per_start.sum(dtype=np.uint64)) == total
+    lo = (1 << 32) - 1500
+    ids = torch.empty((3000, 4), dtype=torch.int32, device="cuda")
+    eng.fill_paths_device(lo, lo + 3000, ids, None, None)
+    eng.sync()
+    v = ids.cpu().numpy().astype(np.int64)
+    assert np.all(rank[v[:, 3]] > rank[v[:, 0]])
+    for a, b in ((0, 1), (1, 2), (2, 3)):
+        assert np.all(A[v[:, a], v[:, b]] == 1.0)
+    for a, b in ((0, 2), (0, 3), (1, 3)):
+        assert np.all(v[:, a] != v[:, b])
+    # the same rows from two chunks split exactly at 2^32
+    a = torch.empty((1500, 4), dtype=torch.int32, device="cuda")
+    b = torch.empty((1500, 4), dtype=torch.int32, device="cuda")
+    eng.fill_paths_device(lo, 1 << 32, a, None, None)
+    eng.fill_paths_device(1 << 32, lo + 3000, b, None, None)
+    eng.sync()
+    assert torch.equal(torch.cat([a, b]), ids)
+    # start vertex of slot 2^32 according to the per-start counts
+    cs = np.cumsum(per_start.astype(np.uint64))
+    i = int(np.searchsorted(cs, np.uint64(1 << 32), side="right"))
+    assert v[1500, 0] == sn[i]
+    eng.close()
