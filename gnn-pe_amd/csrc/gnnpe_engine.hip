@@ -522,11 +522,12 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
     do {                                                                                                           \
         static_assert(sizeof(RankedNbr<EE>) == 8 + 8 * EE, "record size must match the host-side allocation");     \
         hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
-                           c->rank.as<uint32_t>(), c->vinfo.as<double>());                                          \
-        hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held, c->slab_begin,            \
-                           c->slab_end, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),                     \
+                           c->rank.as<uint32_t>(), c->slab_begin, c->slab_end, c->poffs.as<uint32_t>(),             \
+                           c->vinfo.as<double>());                                                                  \
+        hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held,                           \
+                           c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),                                  \
                            c->nbrs.as<uint32_t>(), c->vinfo.as<double>(), c->revpos.as<uint32_t>(),                 \
-                           c->poffs.as<uint32_t>(), c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>());      \
+                           c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>());                               \
     } while (0)
         switch (e) {
         case 1: GNNPE_RR(1); break;

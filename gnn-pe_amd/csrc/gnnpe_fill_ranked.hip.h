@@ -27,18 +27,22 @@ struct __attribute__((aligned(16))) RankedPair {
     uint64_t G;       // id-positions of N(b) with rank > rank[s]
 };
 
-// one gather per adjacency entry instead of two: {vde[v], rank[v]} side by side, VINFO_STRIDE(E) doubles per vertex
-// (E = 2 -> 32 bytes: one aligned half cache line)
+// one gather per adjacency entry instead of three: {vde[v], rank[v], first pair slot of v as a start vertex} side
+// by side, VINFO_STRIDE(E) doubles per vertex (E = 2 -> 32 bytes: one aligned half cache line).  The kernel issues
+// about as many random requests per second as the chip sustains (6-8e10/s), so requests are what to save.
 #define GNNPE_VINFO_STRIDE(E) ((E) + 2)
 template <int E>
 __global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const uint32_t *__restrict__ rank,
+                             uint32_t slab_begin, uint32_t slab_end, const uint32_t *__restrict__ poffs,
                              double *__restrict__ vinfo)
 {
     constexpr int S = GNNPE_VINFO_STRIDE(E);
     for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int k = 0; k < E; k++) vinfo[v * S + k] = vde ? vde[v * E + k] : 0.0;
-        reinterpret_cast<uint64_t *>(vinfo)[v * S + E] = rank[v];
+        const uint32_t r = rank[v];
+        const uint32_t po = (r >= slab_begin && r < slab_end) ? poffs[r - slab_begin] : kNoEdge;  // kNoEdge: not a start here
+        reinterpret_cast<uint64_t *>(vinfo)[v * S + E] = ((uint64_t)po << 32) | r;
         vinfo[v * S + E + 1] = 0.0;
     }
 }
@@ -59,12 +63,10 @@ struct CntOfPair {
 //   pairs[index of (s = u_j, b)] = { adj_start + p_j + 1, G_j }              when u_j starts paths here
 template <int E>
 __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32_t *__restrict__ held,
-                                                   uint32_t slab_begin, uint32_t slab_end,
                                                    const uint32_t *__restrict__ adj_start,
                                                    const uint32_t *__restrict__ adj_deg,
                                                    const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
                                                    const uint32_t *__restrict__ revpos,
-                                                   const uint32_t *__restrict__ poffs,
                                                    RankedNbr<E> *__restrict__ recs, RankedPair *__restrict__ pairs)
 {
     const unsigned lane = lane_id();
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
         const uint32_t st = adj_start[b], d = adj_deg[b];
         if (d == 0 || d > 64) continue;  // longer rows: the caller does not select this variant
         constexpr int S = GNNPE_VINFO_STRIDE(E);
-        uint32_t u = 0, r = 0, rp = kNoEdge;
+        uint32_t u = 0, r = 0, rp = kNoEdge, po = kNoEdge;
         double vu[E];
 #pragma unroll
         for (int k = 0; k < E; k++) vu[k] = 0.0;
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             const double *vi = vinfo + (uint64_t)u * S;
 #pragma unroll
             for (int k = 0; k < E; k++) vu[k] = vi[k];
-            r = (uint32_t) reinterpret_cast<const uint64_t *>(vi)[E];
+            const uint64_t rw = reinterpret_cast<const uint64_t *>(vi)[E];
+            r = (uint32_t)rw;
+            po = (uint32_t)(rw >> 32);
             rp = revpos[st + lane];
         }
         uint64_t G = 0;
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
 #pragma unroll
             for (int k = 0; k < E; k++) rec.vde[k] = vu[k];
             recs[st + p] = rec;
-            const uint32_t pi = pair_index(rp, r, slab_begin, slab_end, poffs);
-            if (pi != kNoEdge) {
+            if (rp != kNoEdge && po != kNoEdge) {  // (u, b) is a pair of this slab: u starts here and its row is held
+                const uint32_t pi = po + rp;
                 RankedPair pr = {st + p + 1, 0u, G};
                 pairs[pi] = pr;
             }
