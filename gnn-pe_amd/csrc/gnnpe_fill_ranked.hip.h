@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
 // maps record -> pair), each lane reads ONE contiguous record, computes its slot from G, parks the
 // row (12 B ids + 24e B embeddings) in the wave's staging strip, and the strip is flushed with
 // consecutive lanes on consecutive 16-byte / 4-byte pieces (non-temporal).
-constexpr int kBatch = 128;
+// rows staged per wave: 128 at e <= 2; wider rows take 64 (the minimum: a pair holds up to 63 records) so that the
+// staging strips leave room for more than one workgroup per CU
+template <int E> struct FillBatch { static constexpr int rows = E <= 2 ? 128 : 64; };
 
 template <int E>
 __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
                                                      const RankedNbr<E> *__restrict__ recs, uint32_t slab_len)
 {
     constexpr int D = 3 * E;
+    constexpr int kBatch = FillBatch<E>::rows;
     __shared__ uint32_t s_cs[4][65], s_ss[4][64], s_b[4][64];
     __shared__ uint64_t s_G[4][64];
     __shared__ __attribute__((aligned(16))) double s_vb[4][64 * E];
