@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--embedding", dest="e", type=int, default=2)
     ap.add_argument("--labels", type=int, default=64)
     ap.add_argument("--seed", type=int, default=synth.SEED)
+    ap.add_argument("--powerlaw", action="store_true", help="power-law degrees (config-5 family) instead of G(n,m)")
+    ap.add_argument("--max-degree", type=int, default=500)
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
     ap.add_argument("--fill-variant", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +144,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     L, e = 3, args.e
-    g = synth.gnm_graph(args.n, args.m, n_labels=args.labels, seed=args.seed)
+    if args.powerlaw:
+        g = synth.powerlaw_graph(args.n, args.m, exponent=2.1, max_degree=args.max_degree, n_labels=args.labels, seed=args.seed)
+    else:
+        g = synth.gnm_graph(args.n, args.m, n_labels=args.labels, seed=args.seed)
     sn = synth.degree_order(g["offsets"])
     mem = synth.block_membership(args.n, max(world, 1))
 
@@ -250,7 +255,7 @@ def main():
                value=value, unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,
                dtype="u32 ids + f64 embeddings", data="synthetic",
-               config=dict(workload=f"G(n={args.n}, m={args.m}) seed {args.seed}, {args.labels} labels, l=2, e={e}, "
+               config=dict(workload=f"{'power-law' if args.powerlaw else 'G'}(n={args.n}, m={args.m}) seed {args.seed}, {args.labels} labels, l=2, e={e}, "
                                     f"degree-sorted order; {'ids only' if args.ids_only else 'ids + pde'}",
                            paths=global_total, parallelism=f"slab{world}", fill_variant=args.fill_variant),
                roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms")
