@@ -42,8 +42,19 @@ def ref_dump_path():
     return os.path.join(_HERE, "_ref", "ref_dump")
 
 
+def ref_online_path():
+    """oracle/ref_online.cpp harness: the reference's online filter (dump) / refinement (refine)."""
+    return os.path.join(_HERE, "_ref", "ref_online")
+
+
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+def bitmap_to_sets(bm, n):
+    """rows of a candidate bitmap (uint32 words, bit v%32 of word v//32) -> sorted id arrays"""
+    bits = np.unpackbits(np.ascontiguousarray(bm).view(np.uint8), axis=1, bitorder="little")[:, :n]
+    return [np.flatnonzero(r).astype(np.uint32) for r in bits]
 
 
 class Oracle:
@@ -82,7 +93,27 @@ class Oracle:
         L.orc_offline_parallel.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint32, C.c_int, _f64p, _u64p,
                                            _u32p, _f64p, C.c_uint64]
         L.orc_max_threads.restype = C.c_int
+        L.orc_filter_candidates.argtypes = [C.c_uint64, C.c_uint32, _u32p, C.c_uint32, _u32p, _u32p, _f64p, C.c_uint32,
+                                            C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_double, _u32p]
         self.L = L
+
+    # online filter (leaf test of Partition::query, custom.h:404-431)
+    def filter_candidates(self, paths, offs, labels, vde, q_vids, q_labels, q_degrees, q_pde, n_qv, eps=1e-6):
+        """Returns a list of sorted uint32 arrays, one per query vertex."""
+        paths = np.ascontiguousarray(paths, np.uint32)
+        P, Lp = paths.shape
+        n = len(offs) - 1
+        e = vde.shape[1]
+        words = (n + 31) // 32
+        bm = np.zeros((n_qv, words), np.uint32)
+        qv = np.ascontiguousarray(q_vids, np.uint32)
+        self.L.orc_filter_candidates(P, Lp, _p(paths, _u32p), n, _p(np.ascontiguousarray(offs, np.uint32), _u32p),
+                                     _p(np.ascontiguousarray(labels, np.uint32), _u32p),
+                                     _p(np.ascontiguousarray(vde, np.float64), _f64p), e, len(qv),
+                                     _p(qv, _u32p), _p(np.ascontiguousarray(q_labels, np.uint32), _u32p),
+                                     _p(np.ascontiguousarray(q_degrees, np.uint32), _u32p),
+                                     _p(np.ascontiguousarray(q_pde, np.float64), _f64p), eps, _p(bm, _u32p))
+        return bitmap_to_sets(bm, n)
 
     # all-core CPU port of the device-resident pass (bench.py's second CPU baseline)
     def max_threads(self):

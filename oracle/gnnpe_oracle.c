@@ -710,3 +710,38 @@ int orc_max_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f) row 4 -- the online FILTER, data side: Partition::query (custom.h:366-489).
+ * The best-first R-tree traversal only prunes; what it reports is defined by its leaf test
+ * (custom.h:404-431): a data path matches query path j iff, position by position, the labels are equal
+ * (:410) and the query degree does not exceed the data degree (:410), and in no embedding dimension the
+ * query's pde exceeds the data pde by more than epsilon (:422-425).  Every match inserts the data path's
+ * vertices into the candidate sets of the query path's vertices (:429-432).  The union over partitions
+ * (main.cpp:165-171) is therefore this test applied to every data path; verified equal to the reference's
+ * own candidate sets on Test/ (tests/golden/online_test_graph.bin, dumped by oracle/ref_online.cpp).
+ * bitmap: n_query_vertices x ceil(n/32) uint32, caller-zeroed; bit v of row u = v is a candidate of u.
+ * ------------------------------------------------------------------------------------------ */
+void orc_filter_candidates(uint64_t P, uint32_t L, const uint32_t *paths, uint32_t n, const uint32_t *offsets,
+                           const uint32_t *labels, const double *vde, uint32_t e, uint32_t n_qp,
+                           const uint32_t *q_vids, const uint32_t *q_labels, const uint32_t *q_degrees,
+                           const double *q_pde, double epsilon, uint32_t *bitmap)
+{
+    const uint64_t words = ((uint64_t)n + 31) / 32;
+    for (uint64_t p = 0; p < P; p++) {
+        const uint32_t *v = paths + p * L;
+        for (uint32_t j = 0; j < n_qp; j++) {
+            uint32_t k = 0;
+            for (; k < L; k++)
+                if (q_labels[j * L + k] != labels[v[k]] || q_degrees[j * L + k] > offsets[v[k] + 1] - offsets[v[k]]) break;
+            if (k != L) continue;
+            uint32_t t = 0;
+            for (; t < L * e; t++) {
+                const double q = q_pde[(size_t)j * L * e + t], d = vde[(size_t)v[t / e] * e + t % e];
+                if (q > d && fabs(q - d) > epsilon) break;
+            }
+            if (t != L * e) continue;
+            for (k = 0; k < L; k++) bitmap[q_vids[j * L + k] * words + v[k] / 32] |= 1u << (v[k] % 32);
+        }
+    }
+}

@@ -52,6 +52,12 @@ uint64_t orc_enumerate_closed(uint32_t n, const uint32_t *offsets, const uint32_
 void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
                          const uint32_t *sorted_nodes, uint32_t L, uint64_t *counts);
 
+/* ---- online filter, leaf test of Partition::query (custom.h:404-431) over every data path ---- */
+void orc_filter_candidates(uint64_t P, uint32_t L, const uint32_t *paths, uint32_t n, const uint32_t *offsets,
+                           const uint32_t *labels, const double *vde, uint32_t e, uint32_t n_qp,
+                           const uint32_t *q_vids, const uint32_t *q_labels, const uint32_t *q_degrees,
+                           const double *q_pde, double epsilon, uint32_t *bitmap);
+
 /* All-core CPU port of the device-resident pass (vde + count + prefix + ids/pde fill, l=2, closed form, OpenMP):
  * bench.py's second CPU baseline.  vde: n x e; start_off: n+1; ids: P x 3, pde: P x 3e (may be NULL); returns P and
  * fills ids/pde only when P <= capacity.  threads <= 0: all cores. */
