@@ -59,6 +59,10 @@ SIGNATURES = {
     "gnnpe_text_ids": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_select_partition": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, C.c_uint64, _vp, _u64p]),
     "gnnpe_rows_checksum_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, _u64p]),
+    "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
+                                        C.POINTER(_u32p), C.POINTER(_f64p)]),
+    "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
+                                          _f64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                            C.POINTER(C.c_int32)]),
     "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
@@ -155,6 +159,29 @@ def host_load_graph(path):
         lib.gnnpe_host_free(p)
     return dict(n=n.value, m=m.value, offsets=offs, nbrs=nbrs, labels=labels, labels_count=meta[0], max_degree=meta[1],
                 max_label_frequency=meta[2])
+
+
+def host_query_plan(path, e):
+    """Query side of the online filter (main.cpp:136-151) through the library's host planner.
+    Returns dict(n_vertices, vids, labels, degrees (n_paths x 3), pde (n_paths x 3e))."""
+    lib = load()
+    nv, npth = C.c_uint32(), C.c_uint32()
+    pv, pl, pd = _u32p(), _u32p(), _u32p()
+    pp = _f64p()
+    rc = lib.gnnpe_host_query_plan(path.encode(), int(e), C.byref(nv), C.byref(npth), C.byref(pv), C.byref(pl), C.byref(pd),
+                                   C.byref(pp))
+    if rc == -1:
+        raise FileNotFoundError(lib.gnnpe_last_error().decode())
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    k = npth.value
+    out = dict(n_vertices=nv.value)
+    for name, ptr in (("vids", pv), ("labels", pl), ("degrees", pd)):
+        out[name] = np.ctypeslib.as_array(ptr, shape=(max(k * 3, 1),)).copy()[: k * 3].reshape(k, 3)
+        lib.gnnpe_host_free(ptr)
+    out["pde"] = np.ctypeslib.as_array(pp, shape=(max(k * 3 * e, 1),)).copy()[: k * 3 * e].reshape(k, 3 * e)
+    lib.gnnpe_host_free(pp)
+    return out
 
 
 def host_read_membership(path, n, p):
@@ -291,6 +318,18 @@ class Engine:
         self._ck(self.lib.gnnpe_rows_checksum_device(self.ctx, int(n_rows), int(L), _dev(dev_ids), int(first_id),
                                                      C.byref(out)))
         return out.value
+
+    # online filter (Partition::query, custom.h:366-489)
+    def filter_candidates(self, plan, eps=1e-6):
+        """plan: dict from host_query_plan.  Returns (bitmap [n_query_vertices x ceil(n/32)] uint32, device ms)."""
+        nv = int(plan["n_vertices"])
+        bm = np.zeros((nv, (self.n + 31) // 32), np.uint32)
+        ms = C.c_double()
+        v, l, d = (_np(plan[k], np.uint32) for k in ("vids", "labels", "degrees"))
+        p = _np(plan["pde"], np.float64)
+        self._ck(self.lib.gnnpe_filter_candidates(self.ctx, len(v), _ptr(v, _u32p), _ptr(l, _u32p), _ptr(d, _u32p),
+                                                  _ptr(p, _f64p), nv, float(eps), _ptr(bm, _u32p), C.byref(ms)))
+        return bm, ms.value
 
     def path_partitions_device(self, begin, end, dev_part):
         self._ck(self.lib.gnnpe_path_partitions_device(self.ctx, begin, end, _dev(dev_part)))

@@ -7,6 +7,7 @@
 
 #include "../../include/gnnpe_hip.h"
 #include "graph_loader.h"
+#include "query_plan.h"
 
 namespace gnnpe {
 void set_error(const char *fmt, ...);
@@ -59,6 +60,40 @@ int gnnpe_host_read_membership(const char *path, uint32_t n, uint32_t p, uint32_
         memcpy(sorted_nodes, sn.data(), (size_t)n * 4);
         memcpy(membership, mem.data(), (size_t)n * 4);
     }
+    return 0;
+}
+
+int gnnpe_host_query_plan(const char *query_graph_path, uint32_t e, uint32_t *n_query_vertices, uint32_t *n_paths,
+                          uint32_t **vids, uint32_t **labels, uint32_t **degrees, double **pde)
+{
+    if (!query_graph_path || !n_query_vertices || !n_paths || !vids || !labels || !degrees || !pde) {
+        gnnpe::set_error("gnnpe_host_query_plan: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    gnnpe_host::StaticGraph q;
+    std::string err;
+    int rc = q.load(query_graph_path, &err);
+    if (rc != 0) {
+        gnnpe::set_error("%s", err.c_str());
+        return rc;
+    }
+    gnnpe_host::QueryPlan plan;
+    if ((rc = gnnpe_host::build_query_plan(q, e, &plan, &err)) != 0) {
+        gnnpe::set_error("%s", err.c_str());
+        return GNNPE_ERR_ARG;
+    }
+    auto dup32 = [](const std::vector<uint32_t> &v) {
+        uint32_t *p = (uint32_t *)malloc((v.size() + 1) * sizeof(uint32_t));
+        if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(uint32_t));
+        return p;
+    };
+    *n_query_vertices = plan.n_vertices;
+    *n_paths = plan.n_paths();
+    *vids = dup32(plan.vids);
+    *labels = dup32(plan.labels);
+    *degrees = dup32(plan.degrees);
+    *pde = (double *)malloc((plan.pde.size() + 1) * sizeof(double));
+    if (*pde && !plan.pde.empty()) memcpy(*pde, plan.pde.data(), plan.pde.size() * sizeof(double));
     return 0;
 }
 

@@ -206,6 +206,23 @@ int gnnpe_pge_groups(gnnpe_ctx *ctx, double *host_path_group, double *host_path_
  * (<f>gnn-pge/partitions/partition-i/index.dat). */
 int gnnpe_pge_build_index(gnnpe_ctx *ctx, uint64_t n_sel, const uint32_t *host_vertices, const char *path);
 
+/* ---- the online filter ------------------------------------------------------------ */
+/* Query side (host): what main.cpp:136-151 does to the query graph before it touches the index -- dfs_query
+ * (custom.h:94-119), gen_vde, gen_query_pde (custom.h:574-631: paths sorted by degree weight, greedy vertex
+ * cover).  Returns the plan's paths: vids / labels / degrees (n_paths x 3 uint32) and pde (n_paths x 3e doubles),
+ * malloc'ed (gnnpe_host_free). */
+int gnnpe_host_query_plan(const char *query_graph_path, uint32_t e, uint32_t *n_query_vertices, uint32_t *n_paths,
+                          uint32_t **vids, uint32_t **labels, uint32_t **degrees, double **pde);
+/* Data side (device): Partition::query (custom.h:366-489) for all partitions at once.  The R-tree traversal only
+ * prunes; its result is its leaf test (custom.h:404-431) applied to every data path, which is what this does with
+ * the context's enumerated paths (gnnpe_vde + gnnpe_count_paths(l=2) first; whole graph loaded).  host_bitmap:
+ * n_query_vertices x ceil(n/32) uint32, bit v of row u = data vertex v is a candidate of query vertex u -- the
+ * reference's candidate_set (main.cpp:165-171), ready for its refinement.  device_ms (may be NULL): enumeration +
+ * filter time on the device. */
+int gnnpe_filter_candidates(gnnpe_ctx *ctx, uint32_t n_paths, const uint32_t *q_vids, const uint32_t *q_labels,
+                            const uint32_t *q_degrees, const double *q_pde, uint32_t n_query_vertices, double epsilon,
+                            uint32_t *host_bitmap, double *device_ms);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

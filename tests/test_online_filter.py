@@ -55,3 +55,94 @@ def test_oracle_leaf_test_equals_the_reference_traversal(oracle, data_side, name
                                    plan["pde"], nq)
     for u in range(nq):
         assert np.array_equal(got[u], want[u]), (name, u)
+
+
+@pytest.mark.parametrize("name", QUERIES)
+def test_host_query_plan_equals_the_reference_plan(name):
+    """dfs_query + gen_vde + gen_query_pde restated in host C++ (same std::sort): plan identical to the dump, bit for bit"""
+    from gnnpe_amd import binding
+    nq, want, _ = load_dump(name)
+    plan = binding.host_query_plan(os.path.join(ONLINE, f"{name}.graph"), 2)
+    assert plan["n_vertices"] == nq
+    for k in ("vids", "labels", "degrees", "pde"):
+        assert np.array_equal(plan[k], want[k]), (name, k)
+
+
+def test_host_query_plan_errors():
+    from gnnpe_amd import binding
+    with pytest.raises(FileNotFoundError):
+        binding.host_query_plan("/nonexistent/q.graph", 2)
+
+
+def _engine(binding, g, e):
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(g["sorted_nodes"], g["membership"], 1)
+    eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1, e))
+    eng.vde(want=False)
+    eng.count_paths(2)
+    return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", QUERIES)
+def test_gpu_filter_equals_reference_candidates_and_refinement(oracle, test_graph, tmp_path, name):
+    """engine filter (enumerate + leaf test on the GPU, no index, no files) == the reference's candidate sets;
+    the reference's own refinement on the engine's candidates prints the reference's answer count"""
+    from gnnpe_amd import binding
+    from oracle import bitmap_to_sets, ref_online_path
+    nq, _, want = load_dump(name)
+    qpath = os.path.join(ONLINE, f"{name}.graph")
+    plan = binding.host_query_plan(qpath, 2)
+    eng = _engine(binding, test_graph, 2)
+    bm, ms = eng.filter_candidates(plan)
+    got = bitmap_to_sets(bm, eng.n)
+    for u in range(nq):
+        assert np.array_equal(got[u], want[u]), (name, u)
+    assert ms > 0
+    eng.close()
+    if not os.path.exists(ref_online_path()):
+        pytest.skip("oracle/_ref/ref_online not built")
+    cand = str(tmp_path / "cand.bin")
+    with open(cand, "wb") as f:
+        f.write(struct.pack("<I", nq))
+        for u in range(nq):
+            f.write(struct.pack("<I", len(got[u])))
+            f.write(got[u].astype("<u4").tobytes())
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    out = subprocess.check_output([ref_online_path(), str(tmp_path) + "/", graph, qpath, "1", "refine", cand], text=True)
+    answers = json.load(open(os.path.join(ONLINE, "answers.json")))
+    assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == answers[name]
+
+
+@pytest.mark.gpu
+def test_gpu_filter_random_graphs_against_the_oracle(oracle):
+    """other graphs, orders, embedding widths and epsilon edge: engine bitmap == oracle leaf test over every path"""
+    from gnnpe_amd import binding, synth
+    from oracle import bitmap_to_sets
+    rng = np.random.default_rng(8)
+    for e, n, m, nl in ((2, 800, 4000, 3), (3, 500, 3500, 2), (8, 300, 1500, 4)):
+        g = synth.gnm_graph(n, m, n_labels=nl, seed=int(rng.integers(1 << 30)))
+        g["sorted_nodes"] = rng.permutation(n).astype(np.uint32)
+        g["membership"] = np.zeros(n, np.uint32)
+        eng = _engine(binding, g, e)
+        x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)
+        paths = oracle.enumerate_closed(g["offsets"], g["nbrs"], g["sorted_nodes"], 3)
+        deg = np.diff(g["offsets"].astype(np.int64))
+        # query paths = sampled data paths (they match themselves), some with degrees / pde nudged across the thresholds
+        pick = paths[rng.integers(0, len(paths), 40)]
+        qv = np.arange(120, dtype=np.uint32).reshape(40, 3) % 17
+        ql = g["labels"][pick]
+        qd = deg[pick].astype(np.uint32)
+        qd[::5] += 1  # one degree too many: the path itself no longer qualifies
+        qp = vde[pick].reshape(40, 3 * e).copy()
+        qp[1::4] += 5e-7  # inside epsilon: still dominated
+        qp[2::4] += 2e-6  # outside epsilon
+        plan = dict(n_vertices=17, vids=qv, labels=ql, degrees=qd, pde=qp)
+        bm, _ = eng.filter_candidates(plan)
+        want = oracle.filter_candidates(paths, g["offsets"], g["labels"], vde, qv, ql, qd, qp, 17)
+        got = bitmap_to_sets(bm, n)
+        for u in range(17):
+            assert np.array_equal(got[u], want[u]), (e, u)
+        assert sum(len(w) for w in want) > 0
+        eng.close()
