@@ -98,6 +98,43 @@ def cpu_baseline_all_cores(sample_n, sample_m, e, seed):
                        f"(vde + count + prefix + ids/pde fill into preallocated memory, no text)", seconds=best)
 
 
+def online_filter_leg(eng, g, seed):
+    """Cut a connected 8-vertex query out of the data graph, plan it on the host, filter on the device."""
+    rng = np.random.default_rng(seed)
+    offs, nbrs = g["offsets"].astype(np.int64), g["nbrs"]
+    chosen = [int(rng.integers(g["n"]))]
+    while len(chosen) < 8:
+        u = chosen[int(rng.integers(len(chosen)))]
+        if offs[u + 1] > offs[u]:
+            w = int(nbrs[int(rng.integers(offs[u], offs[u + 1]))])
+            if w not in chosen:
+                chosen.append(w)
+        elif len(chosen) == 1:
+            chosen = [int(rng.integers(g["n"]))]
+    idx = {v: i for i, v in enumerate(chosen)}
+    edges = sorted({(min(idx[v], idx[int(w)]), max(idx[v], idx[int(w)])) for v in chosen for w in nbrs[offs[v]:offs[v + 1]]
+                    if int(w) in idx})
+    deg = np.zeros(8, np.int64)
+    for a, b in edges:
+        deg[a] += 1
+        deg[b] += 1
+    with tempfile.TemporaryDirectory() as wd:
+        qp = os.path.join(wd, "q.graph")
+        with open(qp, "w") as f:
+            f.write(f"t 8 {len(edges)}\n" + "".join(f"v {i} {int(g['labels'][v])} {int(deg[i])}\n" for i, v in enumerate(chosen))
+                    + "".join(f"e {a} {b}\n" for a, b in edges))
+        plan = binding.host_query_plan(qp, 2)
+    ms = []
+    for _ in range(3):
+        bm, t = eng.filter_candidates(plan)
+        ms.append(t)
+    cand = [int(np.unpackbits(r.view(np.uint8)).sum()) for r in bm]
+    return dict(device_ms=min(ms), query_vertices=8, query_edges=len(edges), plan_paths=int(len(plan["vids"])),
+                candidates_per_query_vertex=cand,
+                what="enumerate (ids) + leaf test of Partition::query (custom.h:404-431) on every path; no index, no files",
+                reference="re-parses all_paths.txt (~95 s per 2e7 paths, custom.h:546-572) and inserts/loads the R-tree first")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,6 +314,10 @@ def main():
         out["index_build"] = dict(wallclock_ms=min(ib), first_call_ms=ib[0], points=total, file_bytes=nbytes,
                                   node_blocks=hdr[1], leaves=hdr[4], where="device image of index.dat (not written to disk)",
                                   reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
+    # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
+    # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
+    if world == 1 and not args.no_index and not args.ids_only and e == 2:
+        out["online_filter"] = online_filter_leg(eng, g, args.seed)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))

@@ -6,7 +6,8 @@
 //   <f>/gnn-pe/all_paths.txt                       (written; main.cpp:110-119)
 // The enumeration, embeddings and text rendering run on MI355X GPUs through the C-ABI in
 // include/gnnpe_hip.h; this file is host orchestration and file I/O only.  `-m online` stays the
-// reference's own binary: it consumes the files written here unchanged.
+// reference's own binary: it consumes the files written here unchanged.  `-m filter -q <query.graph>` (an
+// addition) runs the filter half of the online step on the GPU and writes the candidate sets (run_filter).
 //
 // Deliberate differences from the reference (all fail-loud instead of silent):
 //   - missing membership.txt / partition directories are errors (the reference reads zeros /
@@ -120,6 +121,78 @@ struct Device {
     uint64_t total = 0, base = 0;
 };
 
+// -m filter: the FILTER half of the reference's `-m online` (main.cpp:121-171) on the GPU -- query plan on the host
+// (dfs_query / gen_query_pde), then the leaf test of Partition::query over every enumerated data path.  No
+// all_paths.txt, no index.dat: only the data graph and membership.txt (any order gives the same candidate sets).
+// Writes <f>gnn-pe/candidates.bin: uint32 n_query_vertices; per query vertex uint32 count + ascending data vertex
+// ids -- the reference's candidate_set, ready for its refinement (main.cpp:176-179).
+int run_filter(const Options &o)
+{
+    const auto t0 = Clock::now();
+    if (o.path_length != 2) die("-m filter: only -l 2 (the reference's online side only works for it)");
+    StaticGraph g;
+    std::string err;
+    int rc = g.load(o.data_graph, &err);
+    if (rc == -1) {
+        printf("%s\n", err.c_str());
+        exit(-1);
+    }
+    if (rc != 0) die(o.data_graph + ": " + err);
+    fputs(g.metadata_text().c_str(), stdout);
+    std::vector<uint32_t> sorted_nodes, membership;
+    if (gnnpe_host::read_membership(o.dataset_path + "gnn-pe/membership.txt", g.n, o.partition_num, &sorted_nodes,
+                                    &membership, &err) != 0)
+        die(err);
+    uint32_t n_qv = 0, n_qp = 0, *qv = nullptr, *ql = nullptr, *qd = nullptr;
+    double *qp = nullptr;
+    rc = gnnpe_host_query_plan(o.query_graph.c_str(), o.vde_dim, &n_qv, &n_qp, &qv, &ql, &qd, &qp);
+    if (rc == -1) {
+        printf("%s\n", gnnpe_last_error());
+        exit(-1);
+    }
+    if (rc != 0) die(o.query_graph + ": " + gnnpe_last_error());
+    printf("%u\n", n_qp);  // gen_query_pde prints the plan size (custom.h:629)
+    if (gnnpe_device_count() <= 0) die("no HIP device: this tool has no CPU fallback");
+    gnnpe_ctx *ctx = gnnpe_create(0);
+    if (!ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
+    const uint32_t n_labels = std::max<uint32_t>(g.labels_count, 1);
+    std::vector<double> table((size_t)n_labels * o.vde_dim);
+    check(gnnpe_host_label_table(n_labels, o.vde_dim, table.data()), "label table");
+    check(gnnpe_load_csr(ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
+    check(gnnpe_set_order(ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
+    check(gnnpe_set_label_table(ctx, n_labels, o.vde_dim, table.data()), "set_label_table");
+    check(gnnpe_vde(ctx, nullptr, nullptr, nullptr), "vde");
+    uint64_t P = 0;
+    check(gnnpe_count_paths(ctx, 2, nullptr, &P), "count_paths");
+    const uint64_t words = ((uint64_t)g.n + 31) / 32;
+    std::vector<uint32_t> bitmap((size_t)n_qv * words);
+    double ms = 0.0;
+    check(gnnpe_filter_candidates(ctx, n_qp, qv, ql, qd, qp, n_qv, 1e-6 /* custom.h:43 */, bitmap.data(), &ms), "filter");
+    gnnpe_destroy(ctx);
+    const std::string out = o.dataset_path + "gnn-pe/candidates.bin";
+    FILE *f = fopen(out.c_str(), "wb");
+    if (!f) die("cannot write " + out);
+    fwrite(&n_qv, 4, 1, f);
+    for (uint32_t u = 0; u < n_qv; u++) {
+        std::vector<uint32_t> ids;
+        for (uint64_t w = 0; w < words; w++)
+            for (uint32_t bits = bitmap[(size_t)u * words + w]; bits; bits &= bits - 1)
+                ids.push_back((uint32_t)(w * 32 + __builtin_ctz(bits)));
+        const uint32_t c = (uint32_t)ids.size();
+        fwrite(&c, 4, 1, f);
+        if (c) fwrite(ids.data(), 4, c, f);
+    }
+    if (fclose(f) != 0) die("write failed on " + out);
+    gnnpe_host_free(qv);
+    gnnpe_host_free(ql);
+    gnnpe_host_free(qd);
+    gnnpe_host_free(qp);
+    if (o.timing)
+        fprintf(stderr, "{\"paths\": %llu, \"query_paths\": %u, \"filter_device_ms\": %.3f, \"end_to_end_s\": %.3f}\n",
+                (unsigned long long)P, n_qp, ms, secs(t0, Clock::now()));
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -140,7 +213,9 @@ int main(int argc, char **argv)
     }
     if (o.partition_num == 0) die("-p must be >= 1");
     if (o.mode == "online")
-        die("-m online is the reference's own binary: run it on the files this tool wrote (INTEGRATION.md)", 2);
+        die("-m online is the reference's own binary: run it on the files this tool wrote (INTEGRATION.md); "
+            "-m filter runs its filter half on the GPU", 2);
+    if (o.mode == "filter") return run_filter(o);
     if (o.mode != "offline") return 0;  // the reference does nothing for other modes
 
     StaticGraph g;

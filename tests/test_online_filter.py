@@ -146,3 +146,37 @@ def test_gpu_filter_random_graphs_against_the_oracle(oracle):
             assert np.array_equal(got[u], want[u]), (e, u)
         assert sum(len(w) for w in want) > 0
         eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_filter_mode_and_reference_refinement(tmp_path):
+    """`gnnpe_main -m filter`: data graph + membership.txt + query graph -> candidates.bin; the reference's own
+    refinement on that file prints the reference's answer (no all_paths.txt, no index.dat involved)"""
+    from gnnpe_amd import synth
+    from oracle import ref_online_path
+    cli = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, 2)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), np.argsort(deg, kind="stable").astype(np.uint32),
+                           (np.arange(len(deg)) % 2).astype(np.uint32))
+    answers = json.load(open(os.path.join(ONLINE, "answers.json")))
+    for name in ("q0", "q3"):
+        qpath = os.path.join(ONLINE, f"{name}.graph")
+        r = subprocess.run([cli, "-f", tmp + "/", "-d", graph, "-q", qpath, "-m", "filter", "-p", "2", "--timing"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        nq, plan, want = load_dump(name)
+        assert r.stdout.splitlines()[-1] == str(len(plan["vids"]))  # the plan size, as gen_query_pde prints it
+        b = open(os.path.join(tmp, "gnn-pe", "candidates.bin"), "rb").read()
+        off = 4
+        assert struct.unpack_from("<I", b, 0)[0] == nq
+        for u in range(nq):
+            c, = struct.unpack_from("<I", b, off)
+            assert np.array_equal(np.frombuffer(b, np.uint32, c, off + 4), want[u])
+            off += 4 + 4 * c
+        if os.path.exists(ref_online_path()):
+            out = subprocess.check_output([ref_online_path(), tmp + "/", graph, qpath, "2", "refine",
+                                           os.path.join(tmp, "gnn-pe", "candidates.bin")], text=True)
+            assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == answers[name]
