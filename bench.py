@@ -173,12 +173,26 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    staged = same_device  # collectives over gloo with host staging instead of RCCL
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if same_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            try:  # RCCL over xGMI; one tiny all-to-all-v so that a broken setup shows up here, not mid-run
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                probe = torch.arange(world, dtype=torch.int32, device=device)
+                got = torch.empty_like(probe)
+                dist.all_to_all_single(got, probe, output_split_sizes=[1] * world, input_split_sizes=[1] * world)
+                torch.cuda.synchronize()
+                assert got.tolist() == [rank] * world
+            except Exception as ex:  # noqa: BLE001 -- report and carry on over gloo rather than lose the scaling run
+                print(f"[bench] rank {rank}: RCCL unavailable ({type(ex).__name__}: {ex}); collectives staged over gloo",
+                      file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                staged = True
 
     L, e = 3, args.e
     if args.powerlaw:
@@ -254,7 +268,7 @@ def main():
     want_mid = int((np.arange(args.n, dtype=np.int64) * (deg64 * (deg64 - 1) // 2)).sum())
     chk = torch.stack([out_ids[:total, 1].to(torch.int64).sum(), torch.tensor(total, device=device)]).to(torch.int64)
     if world > 1:
-        chk_h = chk.cpu() if same_device else chk
+        chk_h = chk.cpu() if staged else chk
         dist.all_reduce(chk_h, op=dist.ReduceOp.SUM)
         chk = chk_h
     got_mid, got_paths = (int(x) for x in chk.tolist())
@@ -262,7 +276,7 @@ def main():
         raise SystemExit(f"bench sanity check failed: paths {got_paths} (want {want_paths}), middle checksum {got_mid} "
                          f"(want {want_mid})")
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if same_device else device)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     global_total = sb.global_total
@@ -298,6 +312,7 @@ def main():
                roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms")
     if world > 1:
         out["halo"] = sb.stats
+        out["config"]["collectives"] = "gloo, staged through host memory" if staged else "rccl"
 
     # index-build wallclock (second half of BASELINE.json's metric): R*-tree file image of every path of
     # partition 0 (p = 1 at N = 1), bulk-loaded on the device; measured outside the timed steps
