@@ -61,6 +61,7 @@ SIGNATURES = {
     "gnnpe_rows_checksum_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, _u64p]),
     "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
                                         C.POINTER(_u32p), C.POINTER(_f64p)]),
+    "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
     "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
                                           _f64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
@@ -182,6 +183,19 @@ def host_query_plan(path, e):
     out["pde"] = np.ctypeslib.as_array(pp, shape=(max(k * 3 * e, 1),)).copy()[: k * 3 * e].reshape(k, 3 * e)
     lib.gnnpe_host_free(pp)
     return out
+
+
+def host_refine(g, query_path, bitmap, limit=0xFFFFFFFF):
+    """Refinement half of the online step on the host (custom.h:634-932): answer count from the filter's bitmap."""
+    lib = load()
+    out = C.c_uint64()
+    o, nb, lb = _np(g["offsets"], np.uint32), _np(g["nbrs"], np.uint32), _np(g["labels"], np.uint32)
+    bm = _np(bitmap, np.uint32)
+    rc = lib.gnnpe_host_refine(len(o) - 1, _ptr(o, _u32p), _ptr(nb, _u32p), _ptr(lb, _u32p), query_path.encode(),
+                               _ptr(bm, _u32p), int(limit), C.byref(out))
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    return out.value
 
 
 def host_read_membership(path, n, p):

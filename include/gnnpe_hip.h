@@ -223,6 +223,14 @@ int gnnpe_filter_candidates(gnnpe_ctx *ctx, uint32_t n_paths, const uint32_t *q_
                             const uint32_t *q_degrees, const double *q_pde, uint32_t n_query_vertices, double epsilon,
                             uint32_t *host_bitmap, double *device_ms);
 
+/* Refinement half of the reference's online step (custom.h:634-932), host side: the number of embeddings of the
+ * query graph in the data graph (injective, labels equal, query degree <= data degree, query edges on data edges)
+ * whose START vertex -- fewest candidates, ties to the larger degree, then the smaller id (custom.h:634-654) -- maps
+ * into its candidate set, counted up to `limit` (the reference's -n).  candidate_bitmap as written by
+ * gnnpe_filter_candidates. */
+int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs, const uint32_t *labels,
+                      const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit, uint64_t *answers);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

@@ -60,9 +60,12 @@ def test_input_validation_fails_loudly(tmp_path):
     # -l other than 2 or 3
     r = _run("-f", root, "-d", gp, "-l", "4", "-p", "2")
     assert r.returncode == 1 and "only -l 2 and -l 3" in r.stderr
-    # online mode belongs to the reference binary
-    r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2")
-    assert r.returncode == 2
+    # -m online: a missing query graph fails like the reference's loader (graph.cpp:166-169: message, exit(-1));
+    # with a query it gets as far as the device check (no CPU fallback)
+    r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2", "-q", os.path.join(root, "nope.graph"))
+    assert r.returncode == 255 and "Can not open the graph file" in r.stdout
+    r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2", "-q", gp)
+    assert (r.returncode == 1 and "no HIP device" in r.stderr) or (r.returncode == 0 and "Answer Number:" in r.stdout)
     # membership.txt missing / short / duplicate vertex / partition out of range
     os.rename(os.path.join(root, "gnn-pe", "membership.txt"), os.path.join(root, "gnn-pe", "m.bak"))
     r = _run("-f", root, "-d", gp, "-p", "2")

@@ -180,3 +180,88 @@ def test_cli_filter_mode_and_reference_refinement(tmp_path):
             out = subprocess.check_output([ref_online_path(), tmp + "/", graph, qpath, "2", "refine",
                                            os.path.join(tmp, "gnn-pe", "candidates.bin")], text=True)
             assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == answers[name]
+
+
+def _sets_to_bitmap(sets, n):
+    bm = np.zeros((len(sets), (n + 31) // 32), np.uint32)
+    for u, ids in enumerate(sets):
+        ids = np.asarray(ids, np.int64)
+        np.bitwise_or.at(bm[u], ids >> 5, (np.uint32(1) << (ids & 31).astype(np.uint32)))
+    return bm
+
+
+@pytest.mark.parametrize("name", QUERIES)
+def test_host_refinement_reproduces_the_reference_answers(test_graph, name):
+    """candidate sets dumped from the reference -> the product's own refinement -> the reference's answer count"""
+    from gnnpe_amd import binding
+    nq, _, cand = load_dump(name)
+    answers = json.load(open(os.path.join(ONLINE, "answers.json")))
+    qpath = os.path.join(ONLINE, f"{name}.graph")
+    bm = _sets_to_bitmap(cand, len(test_graph["labels"]))
+    assert binding.host_refine(test_graph, qpath, bm) == answers[name]
+    assert binding.host_refine(test_graph, qpath, bm, limit=7) == min(7, answers[name])  # the reference's -n
+
+
+def test_host_refinement_equals_reference_refinement_on_random_cases(oracle, tmp_path):
+    """random graphs, random connected queries, candidate sets from the oracle filter (sometimes thinned so that the
+    start-vertex rule matters): product refinement == oracle/_ref/ref_online ... refine"""
+    from gnnpe_amd import binding, synth
+    from oracle import ref_online_path
+    sys_path = os.path.join(ROOT, "tests", "golden")
+    import sys
+    sys.path.insert(0, sys_path)
+    from make_golden_online import cut_query
+    if not os.path.exists(ref_online_path()):
+        pytest.skip("oracle/_ref/ref_online not built")
+    rng = np.random.default_rng(12)
+    seen_answers = 0
+    for trial in range(6):
+        n = 400
+        g = synth.gnm_graph(n, 2400, n_labels=3, seed=100 + trial)
+        gp = str(tmp_path / f"g{trial}.graph")
+        synth.write_graph_file(gp, g)
+        qtext = cut_query(g["offsets"].astype(np.int64), g["nbrs"], g["labels"], int(rng.integers(3, 7)), rng)
+        qp = str(tmp_path / f"q{trial}.graph")
+        open(qp, "w").write(qtext)
+        plan = binding.host_query_plan(qp, 2)
+        sn = synth.degree_order(g["offsets"])
+        paths = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+        x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+        cand = oracle.filter_candidates(paths, g["offsets"], g["labels"], vde, plan["vids"], plan["labels"],
+                                        plan["degrees"], plan["pde"], plan["n_vertices"])
+        if trial % 2:  # thin the sets: only the start vertex' set may change the count
+            cand = [c[rng.random(len(c)) < 0.6] for c in cand]
+        cf = str(tmp_path / f"c{trial}.bin")
+        with open(cf, "wb") as f:
+            f.write(struct.pack("<I", len(cand)))
+            for c in cand:
+                f.write(struct.pack("<I", len(c)) + np.asarray(c, "<u4").tobytes())
+        out = subprocess.check_output([ref_online_path(), str(tmp_path) + "/", gp, qp, "1", "refine", cf], text=True)
+        want = int(re.search(r"Answer Number: (\d+)", out).group(1))
+        got = binding.host_refine(g, qp, _sets_to_bitmap(cand, n))
+        assert got == want, (trial, got, want)
+        seen_answers += want
+    assert seen_answers > 0
+
+
+@pytest.mark.gpu
+def test_cli_online_mode_prints_the_reference_answer_line(tmp_path):
+    """`gnnpe_main -m online`: GPU filter + host refinement from the data graph and membership.txt alone"""
+    from gnnpe_amd import synth
+    cli = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, 1)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), np.argsort(deg, kind="stable").astype(np.uint32),
+                           np.zeros(len(deg), np.uint32))
+    answers = json.load(open(os.path.join(ONLINE, "answers.json")))
+    for name in QUERIES:
+        r = subprocess.run([cli, "-f", tmp + "/", "-d", graph, "-q", os.path.join(ONLINE, f"{name}.graph"), "-m", "online",
+                            "-p", "1"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"Answer Number: (\d+) Query Time \(ms\): ([0-9.e+-]+)", r.stdout)
+        assert m and int(m.group(1)) == answers[name]
+    r = subprocess.run([cli, "-f", tmp + "/", "-d", graph, "-q", os.path.join(ONLINE, "q0.graph"), "-m", "online", "-p", "1",
+                        "-n", "1000"], capture_output=True, text=True)
+    assert "Answer Number: 1000 " in r.stdout
