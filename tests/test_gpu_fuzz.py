@@ -1,0 +1,84 @@
+"""Randomised differential test: many small random graphs (G(n,m) and power-law, isolated vertices, hubs above the
+64-neighbour limit of the ranked variant), arbitrary processing orders and partitions, every embedding width with and
+without a specialised kernel, l = 2 (every enumeration variant) and l = 3, random chunk boundaries -- engine through
+the C-ABI against the oracle, bit for bit (ids, partitions, vde, pde, pde_label, rendered text, index contents)."""
+import numpy as np
+import pytest
+
+from gnnpe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = list(range(24))
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(2, 400))
+    kind = seed % 3
+    if kind == 0:
+        m = int(rng.integers(0, min(n * (n - 1) // 2, 4 * n) + 1))
+        g = synth.gnm_graph(n, m, n_labels=int(rng.integers(1, 9)), seed=seed)
+    elif kind == 1:
+        n = max(n, 120)
+        g = synth.powerlaw_graph(n, int(rng.integers(n, 5 * n)), exponent=2.0, max_degree=int(rng.integers(70, 110)),
+                                 n_labels=int(rng.integers(1, 6)), seed=seed)
+    else:  # dense little graph: every row well above the average
+        n = int(rng.integers(5, 70))
+        g = synth.gnm_graph(n, n * (n - 1) // 3, n_labels=2, seed=seed)
+    p = int(rng.integers(1, 5))
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    e = int([1, 2, 3, 4, 5, 8][seed % 6])
+    return rng, g, sn, mem, p, e
+
+
+@pytest.mark.parametrize("seed", CASES)
+def test_random_case_matches_the_oracle(oracle, seed):
+    import torch
+    from gnnpe_amd import binding
+    rng, g, sn, mem, p, e = _case(seed)
+    n = g["n"]
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1 if n else 1, e))
+    x, nx, vde = eng.vde()
+    ox, onx, ovde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)
+    assert np.array_equal(x, ox) and np.array_equal(nx, onx) and np.array_equal(vde, ovde)
+    for l in (2, 3):
+        L = l + 1
+        want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, L)
+        for variant in ((1, 2, 3, 4) if l == 2 else (4,)):
+            eng.set_fill_variant(variant)
+            total, per_start = eng.count_paths(l, per_start=True)
+            assert total == len(want), (l, variant)
+            assert np.array_equal(per_start, oracle.count_per_start(g["offsets"], g["nbrs"], sn, L))
+            if total == 0:
+                continue
+            # the whole range in random chunks
+            cuts = np.unique(np.concatenate([[0, total], rng.integers(0, total + 1, 3)]))
+            ids = np.concatenate([eng.fill_paths(int(a), int(b), pde=False)[0] for a, b in zip(cuts[:-1], cuts[1:])])
+            assert np.array_equal(ids, want), (l, variant)
+        if len(want) == 0:
+            continue
+        ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
+        assert np.array_equal(pde, ovde[want].reshape(len(want), L * e))
+        assert np.array_equal(pdl, ox[want].reshape(len(want), L * e))
+        dev = torch.device("cuda:0")
+        t = torch.from_numpy(ids.view(np.int32)).to(dev)
+        part = torch.empty(len(want), dtype=torch.int32, device=dev)
+        eng.path_partitions_device(0, len(want), part)
+        eng.sync()
+        assert np.array_equal(part.cpu().numpy().astype(np.uint32), mem[want[:, 0]])
+        text = torch.empty(len(want) * (11 * L + 1) + 64, dtype=torch.uint8, device=dev)
+        nb = eng.text_paths(len(want), L, t, text, text.numel())
+        eng.sync()
+        assert bytes(text[:nb].cpu().numpy()) == oracle.format_all_paths(want)[len(str(len(want))) + 1:]
+        if 16 * L * e + 4 <= (4096 - 5) // 3:  # a node must hold at least 3 entries
+            img, nbytes, hdr = eng.build_index_device(len(want), L, t)
+            d = oracle.index_validate(eng.copy_to_host(img, nbytes).tobytes())
+            order = np.argsort(d["leaf_son"], kind="stable")
+            assert np.array_equal(d["leaf_son"][order], np.arange(len(want)))
+            assert np.array_equal(d["leaf_pt"][order], ovde[want].reshape(len(want), L * e))
+    eng.close()
