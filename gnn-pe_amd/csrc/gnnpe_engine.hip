@@ -513,7 +513,12 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
     if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))) ||
         (rc = c->vinfo.reserve(((size_t)c->n + 1) * GNNPE_VINFO_STRIDE(e) * 8)))
         return rc;
-    GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
+    // pairs whose middle row is not on the device stay empty; with the whole graph loaded every pair is written by
+    // k_rows_rank and only the scan's sentinel entry needs clearing
+    if (c->rows_identity)
+        GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.as<RankedPair>() + ne, 0, sizeof(RankedPair), c->stream));
+    else
+        GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
     if (c->n_held) {
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
