@@ -62,6 +62,7 @@ SIGNATURES = {
     "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
                                         C.POINTER(_u32p), C.POINTER(_f64p)]),
     "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
+    "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
     "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
                                           _f64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
@@ -332,6 +333,11 @@ class Engine:
         self._ck(self.lib.gnnpe_rows_checksum_device(self.ctx, int(n_rows), int(L), _dev(dev_ids), int(first_id),
                                                      C.byref(out)))
         return out.value
+
+    def set_degrees(self, degrees):
+        d = _np(degrees, np.uint32)
+        assert len(d) == self.n
+        self._ck(self.lib.gnnpe_set_degrees(self.ctx, _ptr(d, _u32p)))
 
     # online filter (Partition::query, custom.h:366-489)
     def filter_candidates(self, plan, eps=1e-6):

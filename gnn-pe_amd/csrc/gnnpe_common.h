@@ -113,6 +113,8 @@ struct gnnpe_ctx {
     int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default; rows <= 64, else 3)
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
+    gnnpe::DevBuf deg_all;          // online filter on a slab: degree of EVERY vertex (gnnpe_set_degrees)
+    bool have_deg_all = false;
     bool vkey_valid = false;
     uint32_t vkey_zb = 0, vkey_lb = 0, vkey_sbits = 32;  // sbits 32 = wide (64-bit) table only
     gnnpe::DevBuf rpairs, rrecs, vinfo;

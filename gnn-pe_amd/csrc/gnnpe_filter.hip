@@ -58,6 +58,18 @@ using namespace gnnpe;
 
 extern "C" {
 
+int gnnpe_set_degrees(gnnpe_ctx *c, const uint32_t *host_degrees)
+{
+    GNNPE_REQUIRE(c && host_degrees && c->have_graph, GNNPE_ERR_ARG, "gnnpe_set_degrees: load the rows first");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->deg_all.reserve(((size_t)c->n + 1) * 4))) return rc;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->deg_all.p, host_degrees, (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_deg_all = true;
+    return GNNPE_OK;
+}
+
 int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vids, const uint32_t *q_labels,
                             const uint32_t *q_degrees, const double *q_pde, uint32_t n_query_vertices, double epsilon,
                             uint32_t *host_bitmap, double *device_ms)
@@ -67,7 +79,8 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
     GNNPE_REQUIRE(n_paths <= (uint32_t)kMaxPlan, GNNPE_ERR_UNSUPPORTED, "query plan of %u paths (limit %d)", n_paths, kMaxPlan);
     GNNPE_REQUIRE(c->counted && c->have_vde && c->l == 2, GNNPE_ERR_ARG,
                   "gnnpe_filter_candidates: call gnnpe_vde and gnnpe_count_paths(l = 2) first");
-    GNNPE_REQUIRE(c->rows_identity, GNNPE_ERR_UNSUPPORTED, "the filter needs the whole graph on the device (gnnpe_load_csr)");
+    GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
+                  "the filter needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
     for (uint32_t i = 0; i < n_paths * 3; i++)
         GNNPE_REQUIRE(q_vids[i] < n_query_vertices, GNNPE_ERR_ARG, "query path vertex %u >= %u", q_vids[i], n_query_vertices);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
@@ -99,7 +112,8 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
         const uint64_t cnt = std::min(total, b + chunk) - b;
         if ((rc = gnnpe_fill_paths_device(c, b, b + cnt, ids.p, nullptr, nullptr))) break;
         hipLaunchKernelGGL(k_filter_paths, dim3(grid_for(cnt)), dim3(256), 0, c->stream, cnt, ids.as<uint32_t>(),
-                           c->labels.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->vde.as<double>(), e, n_paths, d_vids,
+                           c->labels.as<uint32_t>(), c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>(),
+                           c->vde.as<double>(), e, n_paths, d_vids,
                            d_lab, d_deg, d_pde, epsilon, words, bm.as<uint32_t>());
         he = hipGetLastError();
     }

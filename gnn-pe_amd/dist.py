@@ -13,7 +13,8 @@ Each rank holds the adjacency rows of its own start vertices only.  One step is:
   2. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
   3. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
   4. fill           -- local, into caller-provided device buffers.
-There is no reduction across ranks anywhere.
+There is no reduction across ranks anywhere on the offline side; the online filter (`filter`) ORs the ranks'
+candidate bitmaps.
 
 torch.distributed supplies the collectives (backend "nccl" = RCCL on GPUs, "gloo" in the CPU
 tests); the engine behind `eng` is the C-ABI library (`binding.Engine`).  Tests substitute an
@@ -204,6 +205,20 @@ class SlabBuild:
         if out_ids is not None or out_pde is not None or out_pde_label is not None:
             self.eng.fill_paths_device(0, total, out_ids, out_pde, out_pde_label)
         return total, self.base
+
+    def filter(self, plan, eps=1e-6):
+        """Online filter over the whole partitioned graph: every rank tests its own slab's paths
+        (call after step(): halo, vde and counts in place; slab-only engines need eng.set_degrees), then the
+        candidate bitmaps are OR-ed across ranks -- the one reduction of the online side, the analogue of the union
+        over partitions in main.cpp:165-171.  Returns the global bitmap [n_query_vertices x ceil(n/32)] uint32."""
+        bm, _ = self.eng.filter_candidates(plan, eps)
+        if self.world > 1:
+            t = torch.from_numpy(np.ascontiguousarray(bm).view(np.int32))
+            if dist.get_backend(self.group) != "gloo":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.BOR, group=self.group)
+            bm = t.cpu().numpy().view(np.uint32)
+        return bm
 
     def _count_single(self):
         self.local_total = self.global_total = self.eng.count_paths(self.l)

@@ -59,6 +59,8 @@ def main(argv=None):
     ap.add_argument("--index", action="store_true", help="also write partition-i/index.dat")
     ap.add_argument("--chunk", type=int, default=16 << 20, help="paths rendered per device pass")
     ap.add_argument("--timing", action="store_true")
+    ap.add_argument("-q", "--query", dest="query", default=None,
+                    help="also answer this query graph (filter on every rank's slab, bitmaps OR-ed, refinement on rank 0)")
     args = ap.parse_args(argv)
     if args.l not in (2, 3):
         raise SystemExit("-l: only 2 and 3 are supported (SURVEY D4)")
@@ -115,6 +117,18 @@ def main(argv=None):
     if P > 0xFFFFFFFF:
         raise SystemExit(f"{P} paths exceed the reference's 32-bit path ids")
     t_count = time.perf_counter()
+
+    # ---- optional: the online side over the partitioned graph (main.cpp:121-185 without the files) ----
+    if args.query:
+        if args.l != 2:
+            raise SystemExit("--query needs -l 2")
+        plan = binding.host_query_plan(args.query, e)
+        if world > 1:
+            eng.set_degrees(np.diff(g["offsets"].astype(np.int64)))  # slab-only engine: degrees of 2-hop vertices
+        bm = sb.filter(plan)
+        if rank == 0:
+            print(len(plan["vids"]))
+            print(f"Answer Number: {binding.host_refine(g, args.query, bm)}", flush=True)
 
     # ---- render this rank's share, chunk by chunk ----
     chunk = max(1, min(args.chunk, max(total, 1)))

@@ -219,6 +219,9 @@ int gnnpe_host_query_plan(const char *query_graph_path, uint32_t e, uint32_t *n_
  * n_query_vertices x ceil(n/32) uint32, bit v of row u = data vertex v is a candidate of query vertex u -- the
  * reference's candidate_set (main.cpp:165-171), ready for its refinement.  device_ms (may be NULL): enumeration +
  * filter time on the device. */
+/* A context that holds only a slab's rows (gnnpe_load_rows) filters its own paths once it knows the degree of every
+ * vertex (n uint32; the ranks' bitmaps are then OR-ed, dist.py).  Not needed after gnnpe_load_csr. */
+int gnnpe_set_degrees(gnnpe_ctx *ctx, const uint32_t *host_degrees);
 int gnnpe_filter_candidates(gnnpe_ctx *ctx, uint32_t n_paths, const uint32_t *q_vids, const uint32_t *q_labels,
                             const uint32_t *q_degrees, const double *q_pde, uint32_t n_query_vertices, double epsilon,
                             uint32_t *host_bitmap, double *device_ms);

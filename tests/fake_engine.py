@@ -103,3 +103,19 @@ class FakeEngine:
             out_ids[:len(p)] = torch.from_numpy(p.astype(np.int32))
         if out_pde is not None:
             out_pde[:len(p)] = torch.from_numpy(self._vde[p.astype(np.int64)].reshape(len(p), p.shape[1] * self.e))
+
+    def filter_candidates(self, plan, eps=1e-6):
+        offs, nbrs = self._local_csr()
+        # degrees of ALL vertices (set_degrees on the real engine): the fake keeps the full degree table
+        full_offs = np.zeros(self.n + 1, np.uint32)
+        np.cumsum(self.full_degrees, out=full_offs[1:])
+        sets = self.o.filter_candidates(self._paths, full_offs, self.labels, self._vde, plan["vids"], plan["labels"],
+                                        plan["degrees"], plan["pde"], plan["n_vertices"], eps)
+        bm = np.zeros((plan["n_vertices"], (self.n + 31) // 32), np.uint32)
+        for u, ids in enumerate(sets):
+            ids = ids.astype(np.int64)
+            np.bitwise_or.at(bm[u], ids >> 5, np.uint32(1) << (ids & 31).astype(np.uint32))
+        return bm, 0.0
+
+    def set_degrees(self, degrees):
+        self.full_degrees = np.asarray(degrees, np.int64)

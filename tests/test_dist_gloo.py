@@ -24,6 +24,19 @@ def _free_port():
     return p
 
 
+def _query_plan(g):
+    """a plan made of a few data paths (they match themselves) -- same on every rank"""
+    from oracle import Oracle
+    orc = Oracle()
+    sn = synth.degree_order(g["offsets"])
+    paths = orc.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    x, nx, vde = orc.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    pick = paths[np.random.default_rng(3).integers(0, len(paths), 12)]
+    deg = np.diff(g["offsets"].astype(np.int64))
+    return dict(n_vertices=9, vids=(np.arange(36, dtype=np.uint32).reshape(12, 3) % 9), labels=g["labels"][pick],
+                degrees=deg[pick].astype(np.uint32), pde=vde[pick].reshape(12, 6))
+
+
 def _worker(rank, world, port, out_dir, bounds, l=2):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -49,6 +62,9 @@ def _worker(rank, world, port, out_dir, bounds, l=2):
         assert (total2, base2) == (total, base)
         res.append(dict(total=total, base=base, global_total=sb.global_total, ids=ids[:total].numpy(),
                         pde=pde[:total].numpy(), stats=dict(sb.stats)))
+    if l == 2:  # online filter across ranks: local leaf tests, bitmaps OR-ed
+        eng.set_degrees(np.diff(g["offsets"].astype(np.int64)))
+        res[-1]["filter"] = sb.filter(_query_plan(g))
     with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
         pickle.dump(res, f)
     dist.barrier()
@@ -75,6 +91,15 @@ def test_slab_build_equals_single_rank(oracle, tmp_path, world, kind):
         pde = np.concatenate([p["pde"] for p in parts])
         assert np.array_equal(ids, ref_ids)
         assert np.array_equal(pde, vde[ref_ids].reshape(len(ref_ids), 6))
+    # online filter: every rank ends with the same OR-ed bitmap = the single-rank leaf test over all paths
+    plan = _query_plan(g)
+    want = oracle.filter_candidates(ref_ids, g["offsets"], g["labels"], vde, plan["vids"], plan["labels"], plan["degrees"],
+                                    plan["pde"], 9)
+    from oracle import bitmap_to_sets
+    for r in range(world):
+        got = bitmap_to_sets(res[r][-1]["filter"], g["n"])
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert sum(len(w) for w in want) > 0
     if kind == "planned":  # partitioning must actually move rows between ranks
         assert all(res[r][0]["stats"]["halo_rows"] > 0 for r in range(world))
 

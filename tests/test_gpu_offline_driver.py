@@ -104,3 +104,27 @@ def test_driver_l3_two_hop_halo(tmp_path, oracle, world):
         cnt = int((mem[want[:, 0]] == pid).sum())
         assert info["num_data"] == cnt and info["dim"] == 8
         assert np.array_equal(np.sort(info["leaf_son"]), np.arange(cnt))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_driver_answers_a_query_across_ranks(tmp_path, world):
+    """online side over the slab-partitioned graph: per-rank filter, bitmaps OR-ed (all-reduce), refinement on rank 0
+    -> the reference's answer count for its sample query"""
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    query = os.path.join(GOLDEN, "test_graph", "query_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, 1)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), np.argsort(deg, kind="stable").astype(np.uint32),
+                           np.zeros(len(deg), np.uint32))
+    args = [DRIVER, "-f", tmp + "/", "-d", graph, "-p", "1", "-q", query]
+    env = dict(os.environ)
+    if world == 1:
+        cmd = [sys.executable] + args
+    else:
+        env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert int(re.search(r"Answer Number: (\d+)", r.stdout).group(1)) == 45426
