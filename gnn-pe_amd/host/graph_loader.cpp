@@ -1,10 +1,18 @@
-// graph_loader.cpp -- see graph_loader.h.  Single pass over the file bytes with a hand-rolled
-// tokenizer (the reference uses iostream extraction, ~1.3 s per 100K/1M graph).
+// graph_loader.cpp -- see graph_loader.h.  Hand-rolled tokenizer over the file bytes; the `e` lines (the bulk) are
+// parsed, scattered into the rows and sorted by a few host threads (the reference uses iostream extraction on one
+// thread, ~1.3 s per 100K/1M graph).
 #include "graph_loader.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 
 namespace gnnpe_host {
@@ -39,17 +47,38 @@ struct Cursor {
     }
 };
 
-bool read_file(const std::string &path, std::vector<char> *buf)
+// whole file mapped read-only (no copy; the parser threads fault the pages in)
+struct FileView {
+    const char *data = nullptr;
+    size_t size = 0;
+    bool mapped = false;
+    ~FileView()
+    {
+        if (mapped && data) munmap(const_cast<char *>(data), size);
+    }
+    size_t bytes() const { return size; }
+};
+
+bool read_file(const std::string &path, FileView *v)
 {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    buf->resize(sz > 0 ? (size_t)sz : 0);
-    size_t got = sz > 0 ? fread(buf->data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    buf->resize(got);
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return false;
+    }
+    v->size = (size_t)st.st_size;
+    if (v->size) {
+        void *p = mmap(nullptr, v->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) {
+            close(fd);
+            return false;
+        }
+        v->data = (const char *)p;
+        v->mapped = true;
+    }
+    close(fd);
     return true;
 }
 
@@ -57,12 +86,12 @@ bool read_file(const std::string &path, std::vector<char> *buf)
 
 int StaticGraph::load(const std::string &path, std::string *err)
 {
-    std::vector<char> buf;
+    FileView buf;
     if (!read_file(path, &buf)) {
         if (err) *err = "Can not open the graph file " + path + " .";  // graph.cpp:167
         return -1;
     }
-    Cursor c{buf.data(), buf.data() + buf.size()};
+    Cursor c{buf.data, buf.data + buf.size};
     char type;
     if (!c.next_char(&type) || !c.next_u32(&n) || !c.next_u32(&m)) {  // "t n m", graph.cpp:172
         if (err) *err = "malformed header (expected `t <vertices> <edges>`)";
@@ -71,76 +100,166 @@ int StaticGraph::load(const std::string &path, std::string *err)
     offsets.assign((size_t)n + 1, 0);
     neighbors.assign((size_t)m * 2, 0);
     labels.assign(n, 0);
-    std::vector<uint32_t> cursor(n, 0);
     std::unordered_map<uint32_t, uint32_t> freq;
     uint32_t max_label = 0, next_vertex = 0;
-    uint64_t filled = 0;
     max_degree = 0;
-    while (c.next_char(&type)) {
-        if (type == 'v') {  // graph.cpp:185-206
-            uint32_t id, label, degree;
-            if (!c.next_u32(&id) || !c.next_u32(&label) || !c.next_u32(&degree)) {
-                if (err) *err = "malformed `v` line";
-                return -2;
-            }
-            // offsets_[id+1] = offsets_[id] + degree (graph.cpp:192) only works for ascending dense ids
-            if (id != next_vertex || id >= n) {
-                if (err) *err = "`v` lines must list ids 0..n-1 in ascending order (got " + std::to_string(id) + ")";
-                return -2;
-            }
-            next_vertex++;
-            labels[id] = label;
-            if ((uint64_t)offsets[id] + degree > (uint64_t)m * 2) {
-                if (err) *err = "degree fields exceed 2*m";
-                return -2;
-            }
-            offsets[id + 1] = offsets[id] + degree;
-            max_degree = std::max(max_degree, degree);
-            auto it = freq.find(label);
-            if (it == freq.end()) {
-                freq.emplace(label, 1);
-                max_label = std::max(max_label, label);
-            } else {
-                it->second++;
-            }
-        } else if (type == 'e') {  // graph.cpp:207-219
-            uint32_t a, b;
-            if (!c.next_u32(&a) || !c.next_u32(&b)) {
-                if (err) *err = "malformed `e` line";
-                return -2;
-            }
-            if (next_vertex != n) {
-                if (err) *err = "`e` line before all `v` lines";
-                return -2;
-            }
-            if (a >= n || b >= n || cursor[a] >= degree(a) || cursor[b] >= degree(b)) {
-                if (err) *err = "edge " + std::to_string(a) + " " + std::to_string(b) + " does not fit the declared degrees";
-                return -2;
-            }
-            neighbors[offsets[a] + cursor[a]++] = b;
-            neighbors[offsets[b] + cursor[b]++] = a;
-            filled += 2;
-        } else {
-            if (err) *err = std::string("unexpected record type `") + type + "`";
+    // ---- `v` lines (graph.cpp:185-206): sequential, they build the offsets incrementally ----
+    const char *edge_begin = c.end;
+    while (true) {
+        c.skip_ws();
+        if (c.p >= c.end) break;
+        if (*c.p != 'v') {
+            edge_begin = c.p;
+            break;
+        }
+        c.p++;
+        uint32_t id, label, degree;
+        if (!c.next_u32(&id) || !c.next_u32(&label) || !c.next_u32(&degree)) {
+            if (err) *err = "malformed `v` line";
             return -2;
         }
+        // offsets_[id+1] = offsets_[id] + degree (graph.cpp:192) only works for ascending dense ids
+        if (id != next_vertex || id >= n) {
+            if (err) *err = "`v` lines must list ids 0..n-1 in ascending order (got " + std::to_string(id) + ")";
+            return -2;
+        }
+        next_vertex++;
+        labels[id] = label;
+        if ((uint64_t)offsets[id] + degree > (uint64_t)m * 2) {
+            if (err) *err = "degree fields exceed 2*m";
+            return -2;
+        }
+        offsets[id + 1] = offsets[id] + degree;
+        max_degree = std::max(max_degree, degree);
+        auto it = freq.find(label);
+        if (it == freq.end()) {
+            freq.emplace(label, 1);
+            max_label = std::max(max_label, label);
+        } else {
+            it->second++;
+        }
     }
+    if (edge_begin < c.end && *edge_begin == 'e' && next_vertex != n) {
+        if (err) *err = "`e` line before all `v` lines";
+        return -2;
+    }
+
+    // ---- `e` lines (graph.cpp:207-219): the bulk of the file, parsed by byte ranges cut at line ends.  The lists are
+    // sorted afterwards (graph.cpp:231-233), so the order in which the threads append to a row does not matter. ----
+    const size_t edge_bytes = (size_t)(c.end - edge_begin);
+    unsigned T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (edge_bytes < (1u << 20)) T = 1;
+    std::vector<const char *> cut(T + 1, c.end);
+    cut[0] = edge_begin;
+    for (unsigned t = 1; t < T; t++) {
+        const char *q = edge_begin + edge_bytes * t / T;
+        while (q < c.end && *q != '\n') q++;
+        cut[t] = q < c.end ? q + 1 : c.end;
+    }
+    std::vector<std::vector<uint32_t>> pairs(T);
+    std::vector<std::string> errs(T);
+    const uint32_t nn = n;
+    auto parse = [&](unsigned t) {
+        Cursor k{cut[t], cut[t + 1]};
+        std::vector<uint32_t> &out = pairs[t];
+        out.reserve((size_t)(cut[t + 1] - cut[t]) / 6);
+        char type;
+        while (k.next_char(&type)) {
+            if (type == 'e') {
+                uint32_t a, b;
+                if (!k.next_u32(&a) || !k.next_u32(&b)) {
+                    errs[t] = "malformed `e` line";
+                    return;
+                }
+                if (a >= nn || b >= nn) {
+                    errs[t] = "edge " + std::to_string(a) + " " + std::to_string(b) + " does not fit the declared degrees";
+                    return;
+                }
+                out.push_back(a);
+                out.push_back(b);
+            } else if (type == 'v') {
+                uint32_t id = 0;
+                k.next_u32(&id);
+                errs[t] = "`v` lines must list ids 0..n-1 in ascending order (got " + std::to_string(id) + ")";
+                return;
+            } else {
+                errs[t] = std::string("unexpected record type `") + type + "`";
+                return;
+            }
+        }
+    };
+    auto run = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto &x : th) x.join();
+    };
+    run(parse);
+    for (unsigned t = 0; t < T; t++)
+        if (!errs[t].empty()) {  // the earliest error in file order
+            if (err) *err = errs[t];
+            return -2;
+        }
+    // scatter into the rows: thread t owns the rows of a contiguous vertex range and scans all parsed pairs for them
+    // (sequential reads, writes confined to its own slice of `neighbors`; no atomics, no shared cache lines)
+    std::vector<uint32_t> cursor(n, 0);
+    auto fill = [&](unsigned t) {
+        const uint32_t lo = (uint32_t)((uint64_t)nn * t / T), hi = (uint32_t)((uint64_t)nn * (t + 1) / T);
+        for (unsigned src = 0; src < T; src++) {
+            const std::vector<uint32_t> &in = pairs[src];
+            for (size_t i = 0; i + 1 < in.size(); i += 2) {
+                const uint32_t a = in[i], b = in[i + 1];
+                for (int side = 0; side < 2; side++) {
+                    const uint32_t v = side ? b : a, w = side ? a : b;
+                    if (v < lo || v >= hi) continue;
+                    if (cursor[v] >= degree(v)) {
+                        if (errs[t].empty())
+                            errs[t] = "edge " + std::to_string(a) + " " + std::to_string(b) + " does not fit the declared degrees";
+                        return;
+                    }
+                    neighbors[offsets[v] + cursor[v]++] = w;
+                }
+            }
+        }
+    };
+    run(fill);
+    for (unsigned t = 0; t < T; t++)
+        if (!errs[t].empty()) {
+            if (err) *err = errs[t];
+            return -2;
+        }
+    uint64_t filled = 0;
+    for (unsigned t = 0; t < T; t++) filled += pairs[t].size();
     if (next_vertex != n || filled != (uint64_t)offsets[n]) {
         if (err) *err = "vertex / edge lines do not match the declared counts and degrees";
         return -2;
     }
+    pairs.clear();
     labels_count = std::max<uint32_t>((uint32_t)freq.size(), n ? max_label + 1 : 0);  // graph.cpp:223
     max_label_frequency = 0;
     for (auto &kv : freq) max_label_frequency = std::max(max_label_frequency, kv.second);
-    for (uint32_t v = 0; v < n; v++) {  // graph.cpp:231-233
-        std::sort(neighbors.begin() + offsets[v], neighbors.begin() + offsets[v + 1]);
-        // the closed-form enumeration needs a simple graph (SURVEY 8(a) preconditions)
-        for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++) {
-            if (neighbors[j] == v || (j > offsets[v] && neighbors[j] == neighbors[j - 1])) {
-                if (err) *err = "self-loop or duplicate edge at vertex " + std::to_string(v) + " (simple graphs only)";
-                return -2;
+    // graph.cpp:231-233: every list ascending; the closed-form enumeration needs a simple graph
+    std::atomic<uint32_t> next_block{0};
+    std::atomic<uint32_t> bad_vertex{0xFFFFFFFFu};
+    auto sort_rows = [&](unsigned) {
+        for (;;) {
+            const uint32_t v0 = next_block.fetch_add(4096, std::memory_order_relaxed);
+            if (v0 >= nn) return;
+            for (uint32_t v = v0; v < std::min(nn, v0 + 4096); v++) {
+                std::sort(neighbors.begin() + offsets[v], neighbors.begin() + offsets[v + 1]);
+                for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++)
+                    if (neighbors[j] == v || (j > offsets[v] && neighbors[j] == neighbors[j - 1])) {
+                        uint32_t cur = bad_vertex.load();
+                        while (v < cur && !bad_vertex.compare_exchange_weak(cur, v)) {}
+                        break;
+                    }
             }
         }
+    };
+    run(sort_rows);
+    if (bad_vertex.load() != 0xFFFFFFFFu) {
+        if (err) *err = "self-loop or duplicate edge at vertex " + std::to_string(bad_vertex.load()) + " (simple graphs only)";
+        return -2;
     }
     return 0;
 }
@@ -156,12 +275,12 @@ std::string StaticGraph::metadata_text() const
 int read_membership(const std::string &path, uint32_t n, uint32_t p, std::vector<uint32_t> *sorted_nodes,
                     std::vector<uint32_t> *membership, std::string *err)
 {
-    std::vector<char> buf;
+    FileView buf;
     if (!read_file(path, &buf)) {
         if (err) *err = "cannot open " + path;
         return -1;
     }
-    Cursor c{buf.data(), buf.data() + buf.size()};
+    Cursor c{buf.data, buf.data + buf.size};
     sorted_nodes->assign(n, 0);
     membership->assign(n, 0);
     std::vector<uint8_t> seen(n, 0);
