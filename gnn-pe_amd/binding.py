@@ -62,6 +62,8 @@ SIGNATURES = {
     "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
                                         C.POINTER(_u32p), C.POINTER(_f64p)]),
     "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
+    "gnnpe_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
+    "gnnpe_pinned_free": (None, [_vp]),
     "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
     "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
                                           _f64p]),

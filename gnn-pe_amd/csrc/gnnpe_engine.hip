@@ -147,6 +147,19 @@ int gnnpe_device_count(void)
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+int gnnpe_pinned_alloc(uint64_t bytes, void **host_ptr)
+{
+    GNNPE_REQUIRE(host_ptr, GNNPE_ERR_ARG, "gnnpe_pinned_alloc: null argument");
+    *host_ptr = nullptr;
+    GNNPE_HIP_TRY(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return GNNPE_OK;
+}
+
+void gnnpe_pinned_free(void *host_ptr)
+{
+    if (host_ptr) (void)hipHostFree(host_ptr);
+}
+
 int gnnpe_dev_alloc(gnnpe_ctx *c, uint64_t bytes, void **dev_ptr)
 {
     GNNPE_REQUIRE(c && dev_ptr, GNNPE_ERR_ARG, "null argument");

@@ -27,7 +27,7 @@ struct Options {
     uint32_t partition_num = 5, path_length = 2, vde_dim = 2;
     // extensions
     int gpus = 1;
-    uint64_t chunk_paths = 32ull << 20;
+    uint64_t chunk_paths = 8ull << 20;  // 8M paths per pass: small enough to pipeline render, copy-back and file writes
     bool allow_large = false, timing = false, sidecars = false, write_index = false;
     bool same_device = false;  // testing aid: all --gpus contexts on device 0
 };

@@ -42,6 +42,35 @@ namespace {
 
 using namespace cli;
 
+// Grow-only host buffer in pinned memory: device-to-host copies into it run at PCIe speed instead of through the
+// driver's pageable staging, and nothing is zero-filled on resize.
+struct HostBuf {
+    char *p = nullptr;
+    size_t cap = 0, len = 0;
+    ~HostBuf()
+    {
+        if (p) gnnpe_pinned_free(p);
+    }
+    void resize(size_t n)
+    {
+        if (n > cap) {
+            if (p) gnnpe_pinned_free(p);
+            p = nullptr;
+            cap = std::max(n + n / 8, (size_t)1 << 20);
+            void *q = nullptr;
+            if (gnnpe_pinned_alloc(cap, &q) != 0) die(std::string("pinned host buffer: ") + gnnpe_last_error());
+            p = (char *)q;
+        }
+        len = n;
+    }
+    char *data() { return p; }
+    void assign(const std::string &s)
+    {
+        resize(s.size());
+        memcpy(p, s.data(), s.size());
+    }
+};
+
 // Background writer: the GPU renders chunk k+1 while chunk k goes to the file.
 class FileSink {
 public:
@@ -52,13 +81,13 @@ public:
         setvbuf(f_, nullptr, _IOFBF, 8 << 20);
         th_ = std::thread([this] { run(); });
     }
-    std::vector<char> *acquire()
+    HostBuf *acquire()
     {  // a free buffer (two in flight)
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return pending_ < 2; });
         return &bufs_[next_++ & 1];
     }
-    void submit(std::vector<char> *b, size_t n)
+    void submit(HostBuf *b, size_t n)
     {
         std::unique_lock<std::mutex> lk(mu_);
         queue_.push_back({b, n});
@@ -81,14 +110,14 @@ public:
 private:
     void submit_copy(const std::string &s)
     {
-        std::vector<char> *b = acquire();
-        b->assign(s.begin(), s.end());
+        HostBuf *b = acquire();
+        b->assign(s);
         submit(b, s.size());
     }
     void run()
     {
         for (;;) {
-            std::pair<std::vector<char> *, size_t> item;
+            std::pair<HostBuf *, size_t> item;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [this] { return !queue_.empty() || done_; });
@@ -110,8 +139,8 @@ private:
     std::thread th_;
     std::mutex mu_;
     std::condition_variable cv_;
-    std::vector<std::pair<std::vector<char> *, size_t>> queue_;
-    std::vector<char> bufs_[2];
+    std::vector<std::pair<HostBuf *, size_t>> queue_;
+    HostBuf bufs_[2];
     int pending_ = 0, next_ = 0;
     bool done_ = false, failed_ = false;
     uint64_t bytes_ = 0;
@@ -348,7 +377,7 @@ int main(int argc, char **argv)
             check(gnnpe_path_partitions_device(ctx, b, e, d_part), "path_partitions");
             uint64_t nb = 0;
             check(gnnpe_text_paths(ctx, cnt, L, d_ids, d_text, text_cap, &nb), "text_paths");
-            std::vector<char> *buf = all_paths.acquire();
+            HostBuf *buf = all_paths.acquire();
             buf->resize(nb);
             check(gnnpe_copy_to_host(ctx, buf->data(), d_text, nb), "copy text");
             t_gpu += secs(g0, Clock::now());
@@ -358,7 +387,7 @@ int main(int argc, char **argv)
                 uint64_t k = 0, pb = 0;
                 check(gnnpe_select_partition(ctx, cnt, d_part, pid, devs[d].base + b, d_sel, &k), "select_partition");
                 check(gnnpe_text_ids(ctx, k, d_sel, d_text, text_cap, &pb), "text_ids");
-                std::vector<char> *pbuf = part_files[pid]->acquire();
+                HostBuf *pbuf = part_files[pid]->acquire();
                 pbuf->resize(pb);
                 check(gnnpe_copy_to_host(ctx, pbuf->data(), d_text, pb), "copy ids text");
                 t_gpu += secs(g1, Clock::now());

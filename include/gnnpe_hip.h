@@ -58,6 +58,9 @@ int gnnpe_dev_alloc(gnnpe_ctx *ctx, uint64_t bytes, void **dev_ptr);
 int gnnpe_dev_free(gnnpe_ctx *ctx, void *dev_ptr);
 int gnnpe_copy_to_host(gnnpe_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 int gnnpe_device_count(void);
+/* Page-locked host memory for buffers that receive gnnpe_copy_to_host / gnnpe_fill_paths output (PCIe-rate copies). */
+int gnnpe_pinned_alloc(uint64_t bytes, void **host_ptr);
+void gnnpe_pinned_free(void *host_ptr);
 
 /* ---- inputs ---------------------------------------------------------------------------------- */
 /* R0: the CSR that Static_Graph::loadGraphFromFile builds (graph.cpp:163-242; accessors
