@@ -124,3 +124,10 @@ struct gnnpe_ctx {
     // pinned host words for small read-backs
     uint64_t *h_pinned = nullptr;
 };
+
+namespace gnnpe {
+// gnnpe_engine.hip (it owns the ranked record types): online filter fused with the enumeration.  *done = false when the
+// context's counted variant has no fused path (the caller then filters emitted ids).  Plan arrays and bitmap on the device.
+int filter_fused(gnnpe_ctx *c, uint32_t n_qp, const uint32_t *d_vids, const uint32_t *d_labels, const uint32_t *d_degrees,
+                 const double *d_pde, double eps, uint64_t words, uint32_t *d_bitmap, bool *done);
+}  // namespace gnnpe

@@ -7,13 +7,15 @@
 // more than epsilon; each match inserts p's vertices into the candidate sets of j's vertices (custom.h:429-432),
 // and the sets of all partitions are united (main.cpp:165-171).  On the GPU the index is unnecessary: the test
 // is applied to every enumerated path, 2e8 paths against a plan of a few query paths in a few milliseconds,
-// with no files, no R-tree and no 100-second text re-parse (custom.h:546-572) in between.
+// with no files, no R-tree and no 100-second text re-parse (custom.h:546-572) in between.  With the ranked records of
+// variant 4 on the device the test is fused into the enumeration (gnnpe_filter_ranked.hip.h) and nothing is emitted;
+// k_filter_paths below is the general form over emitted ids (any degree, any embedding width).
 // Candidate sets are bitmaps: row u (query vertex) x ceil(n/32) words, bit v = data vertex v is a candidate.
 #include "gnnpe_common.h"
 
 namespace gnnpe {
 
-constexpr int kMaxPlan = 512;  // query paths held in LDS
+constexpr int kMaxPlan = 512;  // query paths held in LDS (same limit as kMaxPlanPaths of the fused kernel)
 
 __global__ __launch_bounds__(256) void k_filter_paths(uint64_t cnt, const uint32_t *__restrict__ ids,
                                                       const uint32_t *__restrict__ labels,
@@ -108,7 +110,10 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
     if (he == hipSuccess && device_ms) he = hipEventCreate(&ev1);
     if (he == hipSuccess && device_ms) he = hipEventRecord(ev0, c->stream);
     rc = GNNPE_OK;
-    for (uint64_t b = 0; he == hipSuccess && !rc && b < total && n_paths; b += chunk) {
+    bool fused = false;  // ranked records on the device: filter while enumerating, nothing is emitted
+    if (he == hipSuccess && n_paths)
+        rc = filter_fused(c, n_paths, d_vids, d_lab, d_deg, d_pde, epsilon, words, bm.as<uint32_t>(), &fused);
+    for (uint64_t b = 0; he == hipSuccess && !rc && !fused && b < total && n_paths; b += chunk) {
         const uint64_t cnt = std::min(total, b + chunk) - b;
         if ((rc = gnnpe_fill_paths_device(c, b, b + cnt, ids.p, nullptr, nullptr))) break;
         hipLaunchKernelGGL(k_filter_paths, dim3(grid_for(cnt)), dim3(256), 0, c->stream, cnt, ids.as<uint32_t>(),

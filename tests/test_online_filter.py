@@ -139,12 +139,15 @@ def test_gpu_filter_random_graphs_against_the_oracle(oracle):
         qp[1::4] += 5e-7  # inside epsilon: still dominated
         qp[2::4] += 2e-6  # outside epsilon
         plan = dict(n_vertices=17, vids=qv, labels=ql, degrees=qd, pde=qp)
-        bm, _ = eng.filter_candidates(plan)
         want = oracle.filter_candidates(paths, g["offsets"], g["labels"], vde, qv, ql, qd, qp, 17)
-        got = bitmap_to_sets(bm, n)
-        for u in range(17):
-            assert np.array_equal(got[u], want[u]), (e, u)
         assert sum(len(w) for w in want) > 0
+        for variant in (4, 3):  # 4: filter fused into the ranked enumeration; 3: filter over emitted ids
+            eng.set_fill_variant(variant)
+            eng.count_paths(2)
+            bm, _ = eng.filter_candidates(plan)
+            got = bitmap_to_sets(bm, n)
+            for u in range(17):
+                assert np.array_equal(got[u], want[u]), (e, variant, u)
         eng.close()
 
 
