@@ -65,6 +65,7 @@ SIGNATURES = {
     "gnnpe_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
     "gnnpe_pinned_free": (None, [_vp]),
     "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
+    "gnnpe_refine": (C.c_int, [_vp, C.c_char_p, _u32p, C.c_uint64, _u64p, _f64p]),
     "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
                                           _f64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
@@ -352,6 +353,13 @@ class Engine:
         self._ck(self.lib.gnnpe_filter_candidates(self.ctx, len(v), _ptr(v, _u32p), _ptr(l, _u32p), _ptr(d, _u32p),
                                                   _ptr(p, _f64p), nv, float(eps), _ptr(bm, _u32p), C.byref(ms)))
         return bm, ms.value
+
+    def refine(self, query_path, bitmap, limit=0xFFFFFFFF):
+        """Refinement on the device (custom.h:634-932): (answers, device ms) from the filter's candidate bitmap."""
+        out, ms = C.c_uint64(), C.c_double()
+        bm = _np(bitmap, np.uint32)
+        self._ck(self.lib.gnnpe_refine(self.ctx, query_path.encode(), _ptr(bm, _u32p), int(limit), C.byref(out), C.byref(ms)))
+        return out.value, ms.value
 
     def path_partitions_device(self, begin, end, dev_part):
         self._ck(self.lib.gnnpe_path_partitions_device(self.ctx, begin, end, _dev(dev_part)))

@@ -8,7 +8,7 @@
 // include/gnnpe_hip.h; this file is host orchestration and file I/O only.  `-m online` stays the
 // reference's own binary for anyone who wants it: it consumes the files written here unchanged.  This tool's own
 // `-m online -q <query.graph>` answers the query without any of those files: filter on the GPU, refinement on the
-// host (run_filter); `-m filter` stops after the filter and writes the candidate sets.
+// device too (run_filter); `-m filter` stops after the filter and writes the candidate sets.
 //
 // Deliberate differences from the reference (all fail-loud instead of silent):
 //   - missing membership.txt / partition directories are errors (the reference reads zeros /
@@ -34,7 +34,6 @@
 #include "../../include/gnnpe_hip.h"
 #include "cli_common.h"
 #include "graph_loader.h"
-#include "refine.h"
 
 using gnnpe_host::StaticGraph;
 
@@ -157,7 +156,7 @@ struct Device {
 // all_paths.txt, no index.dat: only the data graph and membership.txt (any order gives the same candidate sets).
 // Writes <f>gnn-pe/candidates.bin: uint32 n_query_vertices; per query vertex uint32 count + ascending data vertex
 // ids -- the reference's candidate_set, ready for its refinement (main.cpp:176-179).  -m online goes on with the
-// host refinement (host/refine.cpp) and prints the reference's answer line instead of writing the file.
+// refinement on the device (gnnpe_refine) and prints the reference's answer line instead of writing the file.
 int run_filter(const Options &o)
 {
     const auto t0 = Clock::now();
@@ -200,24 +199,16 @@ int run_filter(const Options &o)
     std::vector<uint32_t> bitmap((size_t)n_qv * words);
     double ms = 0.0;
     check(gnnpe_filter_candidates(ctx, n_qp, qv, ql, qd, qp, n_qv, 1e-6 /* custom.h:43 */, bitmap.data(), &ms), "filter");
-    gnnpe_destroy(ctx);
     if (o.mode == "online") {  // main.cpp:173-181: refinement on the candidate sets, then the answer line
-        std::vector<std::vector<uint32_t>> cand(n_qv);
-        for (uint32_t u = 0; u < n_qv; u++)
-            for (uint64_t w = 0; w < words; w++)
-                for (uint32_t bits = bitmap[(size_t)u * words + w]; bits; bits &= bits - 1)
-                    cand[u].push_back((uint32_t)(w * 32 + __builtin_ctz(bits)));
-        StaticGraph q;
-        if (q.load(o.query_graph, &err) != 0) die(o.query_graph + ": " + err);
         uint64_t limit = 0xFFFFFFFFull, answers = 0;  // MAX_LIMIT = UINT_MAX (main.cpp:62-69)
         if (o.answers != "MAX") {
             uint32_t lim;
             if (!parse_u32(o.answers, &lim)) die("-n must be MAX or an integer");
             limit = lim;
         }
-        const auto r0 = Clock::now();
-        if (gnnpe_host::refine_count(g, q, cand, limit, &answers, &err) != 0) die(err);
-        const double refine_ms = secs(r0, Clock::now()) * 1e3;
+        double refine_ms = 0.0;
+        check(gnnpe_refine(ctx, o.query_graph.c_str(), bitmap.data(), limit, &answers, &refine_ms), "refine");
+        gnnpe_destroy(ctx);
         printf("Answer Number: %llu Query Time (ms): %g\n", (unsigned long long)answers, ms + refine_ms);
         if (o.timing)
             fprintf(stderr, "{\"paths\": %llu, \"query_paths\": %u, \"filter_device_ms\": %.3f, \"refine_ms\": %.3f, "
@@ -229,6 +220,7 @@ int run_filter(const Options &o)
         gnnpe_host_free(qp);
         return 0;
     }
+    gnnpe_destroy(ctx);
     const std::string out = o.dataset_path + "gnn-pe/candidates.bin";
     FILE *f = fopen(out.c_str(), "wb");
     if (!f) die("cannot write " + out);

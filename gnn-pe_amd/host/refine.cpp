@@ -47,28 +47,22 @@ struct Search {
 
 }  // namespace
 
-int refine_count(const StaticGraph &data, const StaticGraph &query, const std::vector<std::vector<uint32_t>> &cand,
-                 uint64_t limit, uint64_t *answers, std::string *err)
+int build_match_order(const StaticGraph &query, const std::vector<uint64_t> &cnt, MatchOrder *out, std::string *err)
 {
     const uint32_t nq = query.n;
-    if (!answers || cand.size() != nq) {
-        if (err) *err = "refine_count: one candidate list per query vertex expected";
+    if (!out || cnt.size() != nq || nq == 0) {
+        if (err) *err = "build_match_order: one candidate count per query vertex expected";
         return -2;
     }
-    *answers = 0;
-    if (nq == 0 || limit == 0) return 0;
     // start vertex: fewest candidates, then larger degree, then smaller id (custom.h:634-654)
     uint32_t start = 0;
     for (uint32_t u = 1; u < nq; u++)
-        if (cand[u].size() < cand[start].size() ||
-            (cand[u].size() == cand[start].size() && query.degree(u) > query.degree(start)))
-            start = u;
-    Search s{data, query, {}, {}, {}, std::vector<uint32_t>(nq, 0), std::vector<uint8_t>(data.n, 0), 0, limit};
-    // a connected order from the start: always take the unvisited vertex with the most visited neighbours
+        if (cnt[u] < cnt[start] || (cnt[u] == cnt[start] && query.degree(u) > query.degree(start))) start = u;
+    out->order.assign(1, start);
+    out->pivot.assign(1, start);
+    out->back.clear();
+    out->back_off.assign(2, 0);
     std::vector<uint8_t> seen(nq, 0);
-    s.order.push_back(start);
-    s.pivot.push_back(start);
-    s.back.emplace_back();
     seen[start] = 1;
     for (uint32_t step = 1; step < nq; step++) {
         uint32_t best = nq, best_links = 0;
@@ -82,18 +76,39 @@ int refine_count(const StaticGraph &data, const StaticGraph &query, const std::v
             }
         }
         if (best == nq) {
-            if (err) *err = "refine_count: the query graph is not connected";
+            if (err) *err = "the query graph is not connected";
             return -2;
         }
         std::vector<uint32_t> earlier;
-        for (uint32_t w : s.order)
+        for (uint32_t w : out->order)
             if (std::binary_search(query.neighbors.begin() + query.offsets[best], query.neighbors.begin() + query.offsets[best + 1], w))
                 earlier.push_back(w);
-        s.order.push_back(best);
-        s.pivot.push_back(earlier[0]);
-        s.back.emplace_back(earlier.begin() + 1, earlier.end());
+        out->order.push_back(best);
+        out->pivot.push_back(earlier[0]);
+        out->back.insert(out->back.end(), earlier.begin() + 1, earlier.end());
+        out->back_off.push_back((uint32_t)out->back.size());
         seen[best] = 1;
     }
+    return 0;
+}
+
+int refine_count(const StaticGraph &data, const StaticGraph &query, const std::vector<std::vector<uint32_t>> &cand,
+                 uint64_t limit, uint64_t *answers, std::string *err)
+{
+    const uint32_t nq = query.n;
+    if (!answers || cand.size() != nq) {
+        if (err) *err = "refine_count: one candidate list per query vertex expected";
+        return -2;
+    }
+    *answers = 0;
+    if (nq == 0 || limit == 0) return 0;
+    std::vector<uint64_t> cnt(nq);
+    for (uint32_t u = 0; u < nq; u++) cnt[u] = cand[u].size();
+    MatchOrder mo;
+    if (build_match_order(query, cnt, &mo, err) != 0) return -2;
+    Search s{data, query, mo.order, mo.pivot, {}, std::vector<uint32_t>(nq, 0), std::vector<uint8_t>(data.n, 0), 0, limit};
+    for (uint32_t i = 0; i < nq; i++) s.back.emplace_back(mo.back.begin() + mo.back_off[i], mo.back.begin() + mo.back_off[i + 1]);
+    const uint32_t start = mo.order[0];
     for (uint32_t v : cand[start]) {
         if (s.count >= limit) break;
         if (v >= data.n) {

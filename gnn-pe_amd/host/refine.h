@@ -20,6 +20,15 @@
 
 namespace gnnpe_host {
 
+// The matching order both refinements (host below, device in csrc/gnnpe_refine.hip) walk: order[0] = the start vertex
+// (custom.h:634-654), then always the unvisited vertex with the most visited neighbours; pivot[i] = one earlier
+// neighbour of order[i] (extension goes through the data neighbours of its image), back = the other earlier
+// neighbours (edge checks), flattened with back_off[i]..back_off[i+1].
+struct MatchOrder {
+    std::vector<uint32_t> order, pivot, back, back_off;
+};
+int build_match_order(const StaticGraph &query, const std::vector<uint64_t> &candidate_counts, MatchOrder *out, std::string *err);
+
 // candidates[u] = ascending data vertex ids of query vertex u.  Returns 0 and *answers, or <0 with *err
 // (disconnected query graph, size mismatch).
 int refine_count(const StaticGraph &data, const StaticGraph &query, const std::vector<std::vector<uint32_t>> &candidates,

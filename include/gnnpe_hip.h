@@ -237,6 +237,11 @@ int gnnpe_filter_candidates(gnnpe_ctx *ctx, uint32_t n_paths, const uint32_t *q_
 int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs, const uint32_t *labels,
                       const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit, uint64_t *answers);
 
+/* The same count on the device: one thread per (start candidate, neighbour slot of its image), depth-first below that.
+ * Needs the whole graph on the device (gnnpe_load_csr); query graphs of up to 32 vertices.  device_ms may be NULL. */
+int gnnpe_refine(gnnpe_ctx *ctx, const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit,
+                 uint64_t *answers, double *device_ms);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

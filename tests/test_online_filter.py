@@ -268,3 +268,42 @@ def test_cli_online_mode_prints_the_reference_answer_line(tmp_path):
     r = subprocess.run([cli, "-f", tmp + "/", "-d", graph, "-q", os.path.join(ONLINE, "q0.graph"), "-m", "online", "-p", "1",
                         "-n", "1000"], capture_output=True, text=True)
     assert "Answer Number: 1000 " in r.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_refinement_equals_host_refinement_and_reference_answers(oracle, test_graph, tmp_path):
+    """gnnpe_refine (one thread per start candidate x neighbour slot) == host/refine.cpp == the reference's answers,
+    with and without an answer limit, on the golden queries and on random graph / query / thinned-candidate cases"""
+    from gnnpe_amd import binding, synth
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_online import cut_query
+    answers = json.load(open(os.path.join(ONLINE, "answers.json")))
+    eng = binding.Engine(0)
+    eng.load_csr(test_graph["offsets"], test_graph["nbrs"], test_graph["labels"])
+    for name in QUERIES:
+        nq, _, cand = load_dump(name)
+        bm = _sets_to_bitmap(cand, len(test_graph["labels"]))
+        qpath = os.path.join(ONLINE, f"{name}.graph")
+        got, ms = eng.refine(qpath, bm)
+        assert got == answers[name] and ms > 0
+        assert eng.refine(qpath, bm, limit=7)[0] == min(7, answers[name])
+    eng.close()
+    rng = np.random.default_rng(21)
+    total = 0
+    for trial in range(8):
+        n = 600
+        g = synth.gnm_graph(n, int(rng.integers(2000, 6000)), n_labels=int(rng.integers(1, 4)), seed=200 + trial)
+        qp = str(tmp_path / f"q{trial}.graph")
+        open(qp, "w").write(cut_query(g["offsets"].astype(np.int64), g["nbrs"], g["labels"], int(rng.integers(1, 8)), rng))
+        nq = int(open(qp).readline().split()[1])
+        cand = [np.flatnonzero(rng.random(n) < 0.5).astype(np.uint32) for _ in range(nq)]
+        bm = _sets_to_bitmap(cand, n)
+        eng = binding.Engine(0)
+        eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+        want = binding.host_refine(g, qp, bm)
+        assert eng.refine(qp, bm)[0] == want, trial
+        assert eng.refine(qp, bm, limit=3)[0] == min(3, want)
+        total += want
+        eng.close()
+    assert total > 0
