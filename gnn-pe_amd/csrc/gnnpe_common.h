@@ -114,6 +114,7 @@ struct gnnpe_ctx {
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf deg_all;          // online filter on a slab: degree of EVERY vertex (gnnpe_set_degrees)
+    gnnpe::DevBuf q_plan, q_bitmap, q_ids, q_work, q_tmp;  // online side: grow-only, so that a query allocates nothing
     bool have_deg_all = false;
     bool vkey_valid = false;
     uint32_t vkey_zb = 0, vkey_lb = 0, vkey_sbits = 32;  // sbits 32 = wide (64-bit) table only

@@ -89,11 +89,10 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
     const uint32_t e = c->e;
     const uint64_t words = ((uint64_t)c->n + 31) / 32, bm_bytes = (uint64_t)n_query_vertices * words * 4;
     const uint64_t total = c->total_paths, chunk = std::min<uint64_t>(std::max<uint64_t>(total, 1), 64ull << 20);
-    DevBuf ids, plan, bm;
+    DevBuf &ids = c->q_ids, &plan = c->q_plan, &bm = c->q_bitmap;  // context-owned: a query allocates nothing new
     int rc;
     const size_t np3 = (size_t)n_paths * 3;
-    if ((rc = ids.reserve(chunk * 12)) || (rc = plan.reserve(np3 * 12 + np3 * e * 8 + 64)) || (rc = bm.reserve(std::max<uint64_t>(bm_bytes, 4))))
-        return rc;
+    if ((rc = plan.reserve(np3 * 12 + np3 * e * 8 + 64)) || (rc = bm.reserve(std::max<uint64_t>(bm_bytes, 4)))) return rc;
     double *d_pde = plan.as<double>();  // doubles first (alignment), then the three uint32 arrays
     uint32_t *d_vids = reinterpret_cast<uint32_t *>(d_pde + np3 * e), *d_lab = d_vids + np3, *d_deg = d_lab + np3;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -113,6 +112,7 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
     bool fused = false;  // ranked records on the device: filter while enumerating, nothing is emitted
     if (he == hipSuccess && n_paths)
         rc = filter_fused(c, n_paths, d_vids, d_lab, d_deg, d_pde, epsilon, words, bm.as<uint32_t>(), &fused);
+    if (he == hipSuccess && !rc && !fused && n_paths) rc = ids.reserve(chunk * 12);
     for (uint64_t b = 0; he == hipSuccess && !rc && !fused && b < total && n_paths; b += chunk) {
         const uint64_t cnt = std::min(total, b + chunk) - b;
         if ((rc = gnnpe_fill_paths_device(c, b, b + cnt, ids.p, nullptr, nullptr))) break;
@@ -133,9 +133,6 @@ int gnnpe_filter_candidates(gnnpe_ctx *c, uint32_t n_paths, const uint32_t *q_vi
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamSynchronize(c->stream);
-    ids.release();
-    plan.release();
-    bm.release();
     if (!rc && he != hipSuccess) {
         set_error("gnnpe_filter_candidates: %s", hipGetErrorString(he));
         rc = GNNPE_ERR_HIP;

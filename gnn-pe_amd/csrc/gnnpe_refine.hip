@@ -168,24 +168,25 @@ int gnnpe_refine(gnnpe_ctx *c, const char *query_graph_path, const uint32_t *can
     const uint32_t n_cand = (uint32_t)cand.size();
     if (n_cand == 0) return GNNPE_OK;
 
-    DevBuf d_cand, d_deg, d_off, d_tmp, d_total;
-    if ((rc = d_cand.reserve((size_t)n_cand * 4)) || (rc = d_deg.reserve(((size_t)n_cand + 1) * 4)) ||
-        (rc = d_off.reserve(((size_t)n_cand + 1) * 8)) || (rc = d_total.reserve(8)))
-        return rc;
-    hipError_t he = hipMemcpyAsync(d_cand.p, cand.data(), (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream);
-    if (he == hipSuccess) he = hipMemsetAsync(d_total.p, 0, 8, c->stream);
+    // context-owned scratch, carved from one grow-only buffer: [total u64 | item_off u64 x (n+1) | cand u32 x n | deg u32 x (n+1)]
+    DevBuf &d_tmp = c->q_tmp;
+    if ((rc = c->q_work.reserve(8 + ((size_t)n_cand + 1) * 8 + (size_t)n_cand * 4 + ((size_t)n_cand + 1) * 4 + 64))) return rc;
+    unsigned long long *d_total = c->q_work.as<unsigned long long>();
+    uint64_t *item_off = reinterpret_cast<uint64_t *>(d_total + 1);
+    uint32_t *d_cand = reinterpret_cast<uint32_t *>(item_off + n_cand + 1), *d_deg = d_cand + n_cand;
+    hipError_t he = hipMemcpyAsync(d_cand, cand.data(), (size_t)n_cand * 4, hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) he = hipMemsetAsync(d_total, 0, 8, c->stream);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (he == hipSuccess && device_ms) he = hipEventCreate(&ev0);
     if (he == hipSuccess && device_ms) he = hipEventCreate(&ev1);
     if (he == hipSuccess && device_ms) he = hipEventRecord(ev0, c->stream);
     uint64_t n_items = n_cand;
-    uint64_t *item_off = d_off.as<uint64_t>();
     if (he == hipSuccess) {
         // items = (start candidate, neighbour slot); a single-vertex query has one item per candidate
-        hipLaunchKernelGGL(k_cand_degrees, dim3((n_cand + 256) / 256), dim3(256), 0, c->stream, n_cand, d_cand.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), d_deg.as<uint32_t>());
+        hipLaunchKernelGGL(k_cand_degrees, dim3((n_cand + 256) / 256), dim3(256), 0, c->stream, n_cand, d_cand,
+                           c->adj_deg.as<uint32_t>(), d_deg);
         size_t tb = 0;
-        hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *> in(d_deg.as<uint32_t>(),
+        hipcub::TransformInputIterator<uint64_t, hipcub::CastOp<uint64_t>, const uint32_t *> in(d_deg,
                                                                                                  hipcub::CastOp<uint64_t>());
         he = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, item_off, (int)(n_cand + 1), c->stream);
         if (he == hipSuccess && (rc = d_tmp.reserve(tb)) == 0)
@@ -204,12 +205,12 @@ int gnnpe_refine(gnnpe_ctx *c, const char *query_graph_path, const uint32_t *can
         if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
     }
     if (he == hipSuccess && !rc && n_items)
-        hipLaunchKernelGGL(k_refine, dim3(grid_for(n_items)), dim3(256), 0, c->stream, P, n_cand, d_cand.as<uint32_t>(), item_off,
+        hipLaunchKernelGGL(k_refine, dim3(grid_for(n_items)), dim3(256), 0, c->stream, P, n_cand, d_cand, item_off,
                            n_items, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),
-                           c->labels.as<uint32_t>(), (unsigned long long)limit, d_total.as<unsigned long long>());
+                           c->labels.as<uint32_t>(), (unsigned long long)limit, d_total);
     if (he == hipSuccess && !rc) he = hipGetLastError();
     if (he == hipSuccess && !rc && device_ms) he = hipEventRecord(ev1, c->stream);
-    if (he == hipSuccess && !rc) he = hipMemcpyAsync(c->h_pinned, d_total.p, 8, hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess && !rc) he = hipMemcpyAsync(c->h_pinned, d_total, 8, hipMemcpyDeviceToHost, c->stream);
     if (he == hipSuccess && !rc) he = hipStreamSynchronize(c->stream);
     if (he == hipSuccess && !rc) *answers = std::min<uint64_t>(*c->h_pinned, limit);
     if (he == hipSuccess && !rc && device_ms) {
@@ -220,11 +221,6 @@ int gnnpe_refine(gnnpe_ctx *c, const char *query_graph_path, const uint32_t *can
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     (void)hipStreamSynchronize(c->stream);
-    d_cand.release();
-    d_deg.release();
-    d_off.release();
-    d_tmp.release();
-    d_total.release();
     if (!rc && he != hipSuccess) {
         set_error("gnnpe_refine: %s", hipGetErrorString(he));
         rc = GNNPE_ERR_HIP;
