@@ -14,8 +14,8 @@
 // search in the prefix maps candidate -> (c, j); keep = rank[d] > rank[s] and d != b (d != s is implied,
 // d != c and c != b hold in a simple graph); ballot/popcount gives the output slot.  The kept rows of a step
 // are one contiguous piece of the output: (c, d, entry) are compacted into LDS and the wave then writes the
-// ids and the 4e doubles per row with consecutive lanes on consecutive elements (e = 8: 256-byte rows; one
-// lane per row reached 0.64 TB/s, this 3x that).  The same walk with the stores compiled out is the count
+// ids (16 bytes per lane) and the 4e doubles per row with consecutive lanes on consecutive 16-byte pieces (e = 8:
+// 256-byte rows; one lane per row reached 0.64 TB/s, this 4.9 TB/s).  The same walk with the stores compiled out is the count
 // pass: per-pair totals are 64-bit (hub pairs of a power-law graph pass 2^32).
 #pragma once
 
@@ -114,20 +114,32 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
                         const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
                         const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
                         const uint32_t rows = r_hi - r_lo;
-                        if (P.out_ids)
-                            for (uint32_t t = lane; t < rows * 4; t += 64) {
-                                const uint32_t r = r_lo + (t >> 2), k = t & 3u;
-                                P.out_ids[o0 * 4 + t] = k == 0 ? s : k == 1 ? b : k == 2 ? kc[r] : kd[r];
-                            }
-                        if (P.out_pde)
-                            for (uint32_t t = lane; t < rows * D; t += 64) {
+                        if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
+                            const uint32_t r = r_lo + lane;
+                            uint32_t *dst = P.out_ids + (o0 + lane) * 4;
+                            __builtin_nontemporal_store(s, dst);
+                            __builtin_nontemporal_store(b, dst + 1);
+                            __builtin_nontemporal_store(kc[r], dst + 2);
+                            __builtin_nontemporal_store(kd[r], dst + 3);
+                        }
+                        if (P.out_pde) {
+                            auto elem = [&](uint32_t t) -> double {
                                 const uint32_t r = r_lo + t / D, k = t % D, which = k / e, comp = k % e;
-                                const double v = which == 0   ? P.vde[(uint64_t)s * e + comp]
-                                                 : which == 1 ? P.vde[(uint64_t)b * e + comp]
-                                                 : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
-                                                              : P.nbr_vde[(uint64_t)kp[r] * e + comp];
-                                __builtin_nontemporal_store(v, P.out_pde + o0 * D + t);
+                                return which == 0   ? P.vde[(uint64_t)s * e + comp]
+                                       : which == 1 ? P.vde[(uint64_t)b * e + comp]
+                                       : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
+                                                    : P.nbr_vde[(uint64_t)kp[r] * e + comp];
+                            };
+                            // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
+                            typedef double dbl2 __attribute__((ext_vector_type(2)));
+                            dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
+                            for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
+                                dbl2 v;
+                                v.x = elem(2 * t2);
+                                v.y = elem(2 * t2 + 1);
+                                __builtin_nontemporal_store(v, dst + t2);
                             }
+                        }
                         if (P.out_pdl)
                             for (uint32_t t = lane; t < rows * D; t += 64) {
                                 const uint32_t r = r_lo + t / D, k = t % D, which = k / e, comp = k % e;
