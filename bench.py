@@ -261,6 +261,23 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # one more step, untimed, with a device sync after every phase: where the step time goes (reported, not `value`)
+    def phase(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, (time.perf_counter() - t) * 1e3
+    phases = {}
+    if world > 1:
+        _, phases["halo_exchange_ms"] = phase(sb.exchange_halo)
+        _, phases["vde_and_allgather_ms"] = phase(sb.exchange_vde)
+        t_, phases["count_ms"] = phase(sb.count)
+    else:
+        _, phases["vde_ms"] = phase(lambda: eng.vde(want=False))
+        t_, phases["count_ms"] = phase(sb._count_single)
+    _, phases["fill_ms"] = phase(lambda: eng.fill_paths_device(0, t_, out_ids, out_pde, None))
+
     # sanity of what was just timed (outside the timed region): global path count = sum C(deg, 2) and the
     # middle-vertex checksum sum_paths(b) = sum_v v * C(deg v, 2), both closed forms of the input graph
     deg64 = np.diff(g["offsets"].astype(np.int64))
@@ -309,7 +326,8 @@ def main():
                config=dict(workload=f"{'power-law' if args.powerlaw else 'G'}(n={args.n}, m={args.m}) seed {args.seed}, {args.labels} labels, l=2, e={e}, "
                                     f"degree-sorted order; {'ids only' if args.ids_only else 'ids + pde'}",
                            paths=global_total, parallelism=f"slab{world}", fill_variant=args.fill_variant),
-               roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms")
+               roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms",
+               phases_ms={k: round(v, 3) for k, v in phases.items()})
     if world > 1:
         out["halo"] = sb.stats
         out["config"]["collectives"] = "gloo, staged through host memory" if staged else "rccl"
