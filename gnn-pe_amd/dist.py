@@ -99,6 +99,7 @@ class SlabBuild:
         self.vde_all = torch.zeros((world, max(self.maxlen, 1), self.e), dtype=torch.float64, device=device)
         self.tot_all = torch.zeros(world, dtype=torch.int64, device=device)
         self.stats = {}
+        self._halo_plans = []  # per hop: what moves (ids, degrees, split sizes); see exchange_halo
 
     # Collectives.  With backend "nccl" (RCCL) device tensors go straight to the collective.  A gloo
     # group with device tensors (single-GPU debugging of the N>1 flow: several ranks sharing one
@@ -124,12 +125,23 @@ class SlabBuild:
         dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
 
     def exchange_halo(self):
+        """Adjacency rows of the halo: dropped and fetched again on every call.  WHAT has to move (which rows from
+        whom, their degrees, the all-to-all-v split sizes) depends only on the graph and the slabs, so it is worked
+        out once and kept as a persistent plan per hop -- like a persistent MPI request -- and later calls go
+        straight to pack -> all-to-all-v -> append: one collective and no host synchronisation per hop.
+        `invalidate_halo_plan()` after changing the graph, the order or the slabs."""
         self.eng.rows_drop_halo()
         self.stats.update(halo_rows=0, halo_entries=0, served_rows=0, served_entries=0)
-        for _ in range(self.l - 1):  # l=2: rows of the middle vertices; l=3: also the rows they reference
-            self._exchange_hop()
+        for hop in range(self.l - 1):  # l=2: rows of the middle vertices; l=3: also the rows they reference
+            if hop >= len(self._halo_plans):
+                self._halo_plans.append(self._plan_hop())
+            self._move_rows(self._halo_plans[hop])
 
-    def _exchange_hop(self):
+    def invalidate_halo_plan(self):
+        self._halo_plans = []
+
+    def _plan_hop(self):
+        """One hop of the halo, metadata only: three small all-to-all-v (counts, ids, degrees)."""
         eng, R = self.eng, self.world
         need_counts = [int(x) for x in eng.halo_need(self.bounds, self.need, self.n)]
         n_need = sum(need_counts)
@@ -148,16 +160,22 @@ class SlabBuild:
         eng.rows_degree(n_req, req, deg_out)
         deg_in = self.deg_in[:n_need]
         self._a2a(deg_in, deg_out, need_counts, req_counts)
-        # 4. the adjacency lists themselves
         send_sizes = self._segment_sums(deg_out, req_counts)
         recv_sizes = self._segment_sums(deg_in, need_counts)
         n_send, n_recv = sum(send_sizes), sum(recv_sizes)
         if n_send > self.send_cap or n_recv > self.cap:
             raise RuntimeError(f"halo buffers too small: send {n_send}/{self.send_cap}, recv {n_recv}/{self.cap}")
-        eng.rows_pack(n_req, req, self.pack, self.send_cap)
-        self._a2a(self.nbr_in[:n_recv], self.pack[:n_send], recv_sizes, send_sizes)
-        eng.rows_append(n_need, self.need[:n_need], deg_in, self.nbr_in[:n_recv], n_recv)
-        for k, v in (("halo_rows", n_need), ("halo_entries", n_recv), ("served_rows", n_req), ("served_entries", n_send)):
+        return dict(need=self.need[:n_need].clone(), req=req.clone(), deg_in=deg_in.clone(), n_need=n_need, n_req=n_req,
+                    send_sizes=send_sizes, recv_sizes=recv_sizes, n_send=n_send, n_recv=n_recv)
+
+    def _move_rows(self, p):
+        """4. the adjacency lists themselves: pack at the owner, one all-to-all-v, append at the requester."""
+        eng = self.eng
+        eng.rows_pack(p["n_req"], p["req"], self.pack, self.send_cap)
+        self._a2a(self.nbr_in[:p["n_recv"]], self.pack[:p["n_send"]], p["recv_sizes"], p["send_sizes"])
+        eng.rows_append(p["n_need"], p["need"], p["deg_in"], self.nbr_in[:p["n_recv"]], p["n_recv"])
+        for k, v in (("halo_rows", p["n_need"]), ("halo_entries", p["n_recv"]), ("served_rows", p["n_req"]),
+                     ("served_entries", p["n_send"])):
             self.stats[k] += v
 
     @staticmethod
