@@ -120,7 +120,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_ids, &c->q_work,
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_ids, &c->q_work,
                         &c->q_tmp, &c->pge_pg, &c->pge_plg};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -626,8 +626,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         if (c->nbr_used)
             hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                                c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
-        if (var == kVarDeep && (rc = c->ecnt.reserve((ne + 2) * 8))) return rc;  // 64-bit pair counts
-        GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * (var == kVarDeep ? 8 : 4), c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
         if (var == kVarPairWave || var == kVarDeep) {
             if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4))) return rc;
             if (len)
@@ -651,9 +650,25 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
             P.n_edges = ne;
             P.slab_begin = sb;
             P.e = e;
-            hipLaunchKernelGGL((k_deep3<false, 0>), dim3(grid_for(ne * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+            // work units: (pair, batch of 64 third vertices); ufirst = exclusive scan of the units per pair
+            if ((rc = c->ufirst.reserve((ne + 2) * 8))) return rc;
+            uint64_t *ufirst = c->ufirst.as<uint64_t>();
+            hipLaunchKernelGGL(k_deep_unit_counts, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne,
+                               c->pnbr.as<uint32_t>(), c->adj_deg.as<uint32_t>(), ufirst);
+            size_t tb = 0;
+            GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ufirst, ufirst, (int64_t)(ne + 1), c->stream));
+            if ((rc = c->cub_tmp.reserve(tb))) return rc;
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, ufirst, ufirst, (int64_t)(ne + 1), c->stream));
+            uint64_t nu = 0;
+            if ((rc = read_back_u64(c, ufirst + ne, 8, &nu))) return rc;
+            c->n_units = nu;
+            if ((rc = c->upair.reserve((nu + 1) * 4)) || (rc = c->uoff.reserve((nu + 2) * 8))) return rc;
+            hipLaunchKernelGGL(k_deep_unit_pairs, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne, ufirst,
+                               c->upair.as<uint32_t>());
+            hipLaunchKernelGGL((k_deep3<false, 0>), dim3(grid_for(nu * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
                                c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(),
-                               c->ecnt.as<uint64_t>(), d_missing);
+                               c->upair.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), (uint64_t)0, nu, d_missing);
             uint64_t miss = 0;
             if ((rc = read_back_u64(c, d_missing, 4, &miss))) return rc;
             GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,
@@ -689,13 +704,15 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
         tb = c->cub_tmp.bytes;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
     } else if (var == kVarDeep) {
+        // unit counts -> unit offsets (in place), then the pair offsets the per-start counts read
+        uint64_t *uoff = c->uoff.as<uint64_t>();
         size_t tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, c->ecnt.as<uint64_t>(), c->eoff.as<uint64_t>(),
-                                                      (int64_t)(ne + 1), c->stream));
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, uoff, uoff, (int64_t)(c->n_units + 1), c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
         tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, c->ecnt.as<uint64_t>(), c->eoff.as<uint64_t>(),
-                                                      (int64_t)(ne + 1), c->stream));
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, uoff, uoff, (int64_t)(c->n_units + 1), c->stream));
+        hipLaunchKernelGGL(k_deep_pair_offsets, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne,
+                           c->ufirst.as<uint64_t>(), uoff, c->eoff.as<uint64_t>());
     } else if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) {
         return rc;
     }
@@ -779,9 +796,18 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     default: LAUNCH(8); break;    \
     }
     if (var == kVarDeep) {
+        // only the units whose output overlaps [begin, end)
+        if ((rc = c->small.reserve(256))) return rc;
+        uint64_t *d_range = reinterpret_cast<uint64_t *>(c->small.as<char>() + 192);
+        hipLaunchKernelGGL(k_deep_unit_range, dim3(1), dim3(64), 0, c->stream, c->n_units, c->uoff.as<uint64_t>(), begin, end,
+                           d_range);
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, d_range, 16, hipMemcpyDeviceToHost, c->stream));
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+        const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
 #define GNNPE_L(EE)                                                                                                \
-    hipLaunchKernelGGL((k_deep3<true, EE>), dim3(grid_for(c->n_edges * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P, \
-                       (const uint8_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr)
+    hipLaunchKernelGGL((k_deep3<true, EE>), dim3(grid_for((u_hi - u_lo) * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P, \
+                       (const uint8_t *)nullptr, c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), \
+                       u_lo, u_hi, (uint32_t *)nullptr)
         if (fast_e(e)) {
             GNNPE_BY_E(GNNPE_L)
         } else {

@@ -7,7 +7,11 @@
 // i.e. iff rank[d] > rank[s] (the reverse starts at d).  The CPU checker under tests/ restates both the
 // hash-set DFS and this closed form for any L; the GPU tests compare against them.
 //
-// One wave per directed (s, b) pair, as in variant 1.  The pair's candidates are the entries of N(c) for
+// Work unit = one (s, b) pair x one batch of 64 third vertices c (a pair with deg(b) <= 64 is one unit; a hub middle
+// vertex gives ceil(deg/64) units), so that the millions of candidates behind a hub are spread over many waves instead
+// of one: `upair[u]` names the unit's pair, `ufirst[pair]` its first unit, and the count pass leaves one 64-bit count
+// per unit whose scan (`uoff`) is the unit's first output slot.
+// One wave per unit, walking like variant 1 walks a pair.  The pair's candidates are the entries of N(c) for
 // every c in N(b) \ {s}, in (c ascending, position ascending) order = emission order.  c's are taken 64
 // at a time (one lane each: row start and degree), their degrees are scanned into a per-wave LDS prefix,
 // and the flattened candidate space is walked 64 candidates per step with every lane busy: a 6-step binary
@@ -25,10 +29,54 @@ namespace gnnpe {
 
 constexpr int kDeepWaves = 4;  // waves per workgroup
 
+// units of a pair: one per 64 neighbours of the middle vertex, at least one
+__global__ void k_deep_unit_counts(uint64_t n_pairs, const uint32_t *__restrict__ pnbr, const uint32_t *__restrict__ adj_deg,
+                                   uint64_t *__restrict__ out)
+{
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w <= n_pairs; w += (uint64_t)gridDim.x * blockDim.x)
+        out[w] = w < n_pairs ? (uint64_t)max(1u, (adj_deg[pnbr[w]] + 63u) / 64u) : 0ull;
+}
+__global__ void k_deep_unit_pairs(uint64_t n_pairs, const uint64_t *__restrict__ ufirst, uint32_t *__restrict__ upair)
+{
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < n_pairs; w += (uint64_t)gridDim.x * blockDim.x)
+        for (uint64_t u = ufirst[w]; u < ufirst[w + 1]; u++) upair[u] = (uint32_t)w;
+}
+// eoff[pair] = first output slot of the pair = offset of its first unit (eoff[n_pairs] = total)
+__global__ void k_deep_pair_offsets(uint64_t n_pairs, const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
+                                    uint64_t *__restrict__ eoff)
+{
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w <= n_pairs; w += (uint64_t)gridDim.x * blockDim.x)
+        eoff[w] = uoff[ufirst[w]];
+}
+// units overlapping the output range [begin, end): out[0] = last unit starting at or before begin, out[1] = first unit
+// starting at or after end
+__global__ void k_deep_unit_range(uint64_t n_units, const uint64_t *__restrict__ uoff, uint64_t begin, uint64_t end,
+                                  uint64_t *__restrict__ out)
+{
+    if (threadIdx.x > 1 || blockIdx.x) return;
+    const uint64_t key = threadIdx.x ? end : begin;
+    uint64_t lo = 0, hi = n_units;  // uoff has n_units + 1 entries, non-decreasing
+    if (threadIdx.x == 0) {
+        while (hi - lo > 1) {  // largest u with uoff[u] <= begin
+            const uint64_t mid = (lo + hi) >> 1;
+            if (uoff[mid] <= key) lo = mid; else hi = mid;
+        }
+        out[0] = lo;
+    } else {
+        while (lo < hi) {  // smallest u with uoff[u] >= end
+            const uint64_t mid = (lo + hi) >> 1;
+            if (uoff[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        out[1] = lo;
+    }
+}
+
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
 template <bool kEmit, int E>
 __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint8_t *__restrict__ present,
-                                                           uint64_t *__restrict__ pair_cnt,
+                                                           const uint32_t *__restrict__ upair,
+                                                           const uint64_t *__restrict__ ufirst,
+                                                           uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end,
                                                            uint32_t *__restrict__ missing_row)
 {
     __shared__ uint32_t s_off[kDeepWaves][65], s_st[kDeepWaves][64], s_c[kDeepWaves][64];
@@ -37,21 +85,23 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
     uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
-    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    uint64_t u = u_begin + ((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6);
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
-    for (; w < P.n_edges; w += nw) {
+    for (; u < u_end; u += nw) {
         uint64_t base = 0;
         if (kEmit) {
-            base = P.eoff[w];
-            const uint64_t nxt = P.eoff[w + 1];
+            base = uoff[u];
+            const uint64_t nxt = uoff[u + 1];
             if (nxt == base || base >= P.end || nxt <= P.begin) continue;
         }
+        const uint32_t w = upair[u];
         const uint32_t i = P.erow[w], b = P.pnbr[w];
         const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
         const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
         uint64_t running = 0;
-        for (uint32_t k0 = 0; k0 < bd; k0 += 64) {
+        {
+            const uint32_t k0 = (uint32_t)(u - ufirst[w]) * 64u;  // this unit's 64 third vertices
             // one lane per third vertex c
             const uint32_t k = k0 + lane;
             uint32_t c = 0, cd = 0, cst = 0;
@@ -158,9 +208,9 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (!kEmit && lane == 0) pair_cnt[w] = running;
+        if (!kEmit && lane == 0) uoff[u] = running;  // counts; scanned in place by the caller
     }
-    if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) pair_cnt[P.n_edges] = 0;
+    if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) uoff[u_end] = 0;
 }
 
 // 64-bit checksum of a chunk of emitted rows (sum of per-row hashes; each hash includes the row's global path id, so order matters), so that outputs
