@@ -113,6 +113,7 @@ struct gnnpe_ctx {
     int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default; rows <= 64, else 3)
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
+    gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
     gnnpe::DevBuf ufirst, upair, uoff;  // l=3 work units: first unit of a pair, pair of a unit, output slot of a unit
     uint64_t n_units = 0;
     gnnpe::DevBuf deg_all;          // online filter on a slab: degree of EVERY vertex (gnnpe_set_degrees)

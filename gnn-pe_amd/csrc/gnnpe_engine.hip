@@ -120,7 +120,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_ids, &c->q_work,
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->rank_sorted, &c->adj_end, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_ids, &c->q_work,
                         &c->q_tmp, &c->pge_pg, &c->pge_plg};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -666,9 +666,25 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
             if ((rc = c->upair.reserve((nu + 1) * 4)) || (rc = c->uoff.reserve((nu + 2) * 8))) return rc;
             hipLaunchKernelGGL(k_deep_unit_pairs, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne, ufirst,
                                c->upair.as<uint32_t>());
-            hipLaunchKernelGGL((k_deep3<false, 0>), dim3(grid_for(nu * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
-                               c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(),
-                               c->upair.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), (uint64_t)0, nu, d_missing);
+            // every row's neighbour ranks in ascending order: the count is then one binary search per (s, b, c)
+            if ((rc = c->rank_sorted.reserve((c->nbr_used + 1) * 4)) || (rc = c->adj_end.reserve(((size_t)c->n + 1) * 4))) return rc;
+            if (c->nbr_used) {
+                hipLaunchKernelGGL(k_row_ends, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->adj_start.as<uint32_t>(),
+                                   c->adj_deg.as<uint32_t>(), c->adj_end.as<uint32_t>());
+                size_t ts = 0;
+                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
+                    nullptr, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n,
+                    c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
+                if ((rc = c->cub_tmp.reserve(ts))) return rc;
+                ts = c->cub_tmp.bytes;
+                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
+                    c->cub_tmp.p, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n,
+                    c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
+            }
+            hipLaunchKernelGGL(k_deep3_count, dim3(grid_for(nu * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+                               c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
+                               c->rank_sorted.as<uint32_t>(), c->upair.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), nu,
+                               d_missing);
             uint64_t miss = 0;
             if ((rc = read_back_u64(c, d_missing, 4, &miss))) return rc;
             GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,
@@ -805,9 +821,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
         const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
 #define GNNPE_L(EE)                                                                                                \
-    hipLaunchKernelGGL((k_deep3<true, EE>), dim3(grid_for((u_hi - u_lo) * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P, \
-                       (const uint8_t *)nullptr, c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), \
-                       u_lo, u_hi, (uint32_t *)nullptr)
+    hipLaunchKernelGGL((k_deep3<EE>), dim3(grid_for((u_hi - u_lo) * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,   \
+                       c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
         if (fast_e(e)) {
             GNNPE_BY_E(GNNPE_L)
         } else {

@@ -19,8 +19,8 @@
 // d != c and c != b hold in a simple graph); ballot/popcount gives the output slot.  The kept rows of a step
 // are one contiguous piece of the output: (c, d, entry) are compacted into LDS and the wave then writes the
 // ids (16 bytes per lane) and the 4e doubles per row with consecutive lanes on consecutive 16-byte pieces (e = 8:
-// 256-byte rows; one lane per row reached 0.64 TB/s, this 4.9 TB/s).  The same walk with the stores compiled out is the count
-// pass: per-pair totals are 64-bit (hub pairs of a power-law graph pass 2^32).
+// 256-byte rows; one lane per row reached 0.64 TB/s, this 4.9 TB/s).  The count pass (k_deep3_count) does not walk
+// candidates at all; its per-unit totals are 64-bit (hub pairs of a power-law graph pass 2^32).
 #pragma once
 
 #include "gnnpe_kernels.hip.h"
@@ -71,13 +71,62 @@ __global__ void k_deep_unit_range(uint64_t n_units, const uint64_t *__restrict__
     }
 }
 
+__global__ void k_row_ends(uint32_t n, const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
+                           uint32_t *__restrict__ adj_end)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
+        adj_end[v] = adj_start[v] + adj_deg[v];
+}
+
+// Count pass without walking candidates: with every row's neighbour RANKS sorted (one segmented sort per order), the
+// kept fourth vertices of (s, b, c) number |{d in N(c): rank d > rank s}| - [rank b > rank s] -- one binary search in
+// row c.  One wave per unit, one lane per third vertex.
+__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3_count(FillParams P, const uint8_t *__restrict__ present,
+                                                                 const uint32_t *__restrict__ rank,
+                                                                 const uint32_t *__restrict__ sorted_ranks,
+                                                                 const uint32_t *__restrict__ upair,
+                                                                 const uint64_t *__restrict__ ufirst,
+                                                                 uint64_t *__restrict__ uoff, uint64_t n_units,
+                                                                 uint32_t *__restrict__ missing_row)
+{
+    const unsigned lane = lane_id();
+    uint64_t u = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; u < n_units; u += nw) {
+        const uint32_t w = upair[u];
+        const uint32_t i = P.erow[w], b = P.pnbr[w];
+        const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+        const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
+        const uint32_t b_kept = rank[b] > thr ? 1u : 0u;  // b itself is a neighbour of every c and must not close the path
+        const uint32_t k = (uint32_t)(u - ufirst[w]) * 64u + lane;
+        uint32_t cnt = 0;
+        if (k < bd) {
+            const uint32_t c = P.nbrs[bst + k];
+            if (c != s) {
+                if (present && !present[c]) atomicMin(missing_row, c);  // 2-hop row not on this device
+                else {
+                    const uint32_t st = P.adj_start[c], d = P.adj_deg[c];
+                    uint32_t lo = 0, hi = d;  // first position with rank > thr
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (sorted_ranks[st + mid] <= thr) lo = mid + 1; else hi = mid;
+                    }
+                    cnt = d - lo - b_kept;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) uoff[u] = cnt;  // counts; scanned in place by the caller
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) uoff[n_units] = 0;
+}
+
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
-template <bool kEmit, int E>
-__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint8_t *__restrict__ present,
-                                                           const uint32_t *__restrict__ upair,
+template <int E>
+__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint32_t *__restrict__ upair,
                                                            const uint64_t *__restrict__ ufirst,
-                                                           uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end,
-                                                           uint32_t *__restrict__ missing_row)
+                                                           const uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end)
 {
     __shared__ uint32_t s_off[kDeepWaves][65], s_st[kDeepWaves][64], s_c[kDeepWaves][64];
     __shared__ uint32_t s_kc[kDeepWaves][64], s_kd[kDeepWaves][64], s_kp[kDeepWaves][64];  // kept rows of one step
@@ -89,12 +138,8 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
     for (; u < u_end; u += nw) {
-        uint64_t base = 0;
-        if (kEmit) {
-            base = uoff[u];
-            const uint64_t nxt = uoff[u + 1];
-            if (nxt == base || base >= P.end || nxt <= P.begin) continue;
-        }
+        const uint64_t base = uoff[u], nxt = uoff[u + 1];
+        if (nxt == base || base >= P.end || nxt <= P.begin) continue;
         const uint32_t w = upair[u];
         const uint32_t i = P.erow[w], b = P.pnbr[w];
         const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
@@ -107,12 +152,9 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
             uint32_t c = 0, cd = 0, cst = 0;
             if (k < bd) {
                 c = P.nbrs[bst + k];
-                if (c != s) {
-                    if (present && !present[c]) atomicMin(missing_row, c);  // 2-hop row not on this device
-                    else {
-                        cd = P.adj_deg[c];
-                        cst = P.adj_start[c];
-                    }
+                if (c != s) {  // (a missing 2-hop row was reported by the count pass)
+                    cd = P.adj_deg[c];
+                    cst = P.adj_start[c];
                 }
             }
             uint32_t incl = cd;
@@ -145,7 +187,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
                 }
                 const bool keep = act && rd > thr && d != b;
                 const uint64_t mask = __ballot(keep);
-                if (kEmit) {
+                {
                     // rows of this step occupy slots [slot0, slot0 + cnt): compact (c, d, entry) into LDS, then the
                     // wave writes the rows as one contiguous region, consecutive lanes on consecutive elements
                     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -208,9 +250,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (!kEmit && lane == 0) uoff[u] = running;  // counts; scanned in place by the caller
     }
-    if (!kEmit && blockIdx.x == 0 && threadIdx.x == 0) uoff[u_end] = 0;
 }
 
 // 64-bit checksum of a chunk of emitted rows (sum of per-row hashes; each hash includes the row's global path id, so order matters), so that outputs
