@@ -131,7 +131,7 @@ def online_filter_leg(eng, g, seed):
     cand = [int(np.unpackbits(r.view(np.uint8)).sum()) for r in bm]
     return dict(device_ms=min(ms), query_vertices=8, query_edges=len(edges), plan_paths=int(len(plan["vids"])),
                 candidates_per_query_vertex=cand,
-                what="leaf test of Partition::query (custom.h:404-431) on every path, fused with the ranked enumeration; no index, no files",
+                what="leaf test of Partition::query (custom.h:404-431) on every path, fused with the enumeration (nothing emitted); no index, no files",
                 reference="re-parses all_paths.txt (~95 s per 2e7 paths, custom.h:546-572) and inserts/loads the R-tree first")
 
 

@@ -117,7 +117,7 @@ struct gnnpe_ctx {
     gnnpe::DevBuf ufirst, upair, uoff;  // l=3 work units: first unit of a pair, pair of a unit, output slot of a unit
     uint64_t n_units = 0;
     gnnpe::DevBuf deg_all;          // online filter on a slab: degree of EVERY vertex (gnnpe_set_degrees)
-    gnnpe::DevBuf q_plan, q_bitmap, q_ids, q_work, q_tmp;  // online side: grow-only, so that a query allocates nothing
+    gnnpe::DevBuf q_plan, q_bitmap, q_work, q_tmp;  // online side: grow-only, so that a query allocates nothing
     bool have_deg_all = false;
     bool vkey_valid = false;
     uint32_t vkey_zb = 0, vkey_lb = 0, vkey_sbits = 32;  // sbits 32 = wide (64-bit) table only
@@ -128,10 +128,3 @@ struct gnnpe_ctx {
     // pinned host words for small read-backs
     uint64_t *h_pinned = nullptr;
 };
-
-namespace gnnpe {
-// gnnpe_engine.hip (it owns the ranked record types): online filter fused with the enumeration.  *done = false when the
-// context's counted variant has no fused path (the caller then filters emitted ids).  Plan arrays and bitmap on the device.
-int filter_fused(gnnpe_ctx *c, uint32_t n_qp, const uint32_t *d_vids, const uint32_t *d_labels, const uint32_t *d_degrees,
-                 const double *d_pde, double eps, uint64_t words, uint32_t *d_bitmap, bool *done);
-}  // namespace gnnpe

@@ -16,7 +16,6 @@
 #include "gnnpe_fill_start.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
 #include "gnnpe_fill_deep.hip.h"
-#include "gnnpe_filter_ranked.hip.h"
 
 namespace gnnpe {
 
@@ -120,7 +119,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
                       &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->rank_sorted, &c->adj_end, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_ids, &c->q_work,
+                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->rank_sorted, &c->adj_end, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_work,
                         &c->q_tmp, &c->pge_pg, &c->pge_plg};
     for (DevBuf *b : bufs) b->release();
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -935,41 +934,6 @@ int gnnpe_rows_checksum_device(gnnpe_ctx *c, uint64_t n_rows, uint32_t L, const 
     GNNPE_HIP_TRY(hipGetLastError());
     return read_back_u64(c, d_sum, 8, host_sum);
 }
-
-}  // extern "C"
-
-namespace gnnpe {
-int filter_fused(gnnpe_ctx *c, uint32_t n_qp, const uint32_t *d_vids, const uint32_t *d_labels, const uint32_t *d_degrees,
-                 const double *d_pde, double eps, uint64_t words, uint32_t *d_bitmap, bool *done)
-{
-    *done = false;
-    const uint32_t e = c->have_table ? c->e : 2, len = c->slab_end - c->slab_begin;
-    if (!c->counted || c->counted_variant != kVarRanked || c->l != 2 || !fast_e(e)) return GNNPE_OK;
-    int rc;
-    if (!c->ranked_vde_valid && (rc = build_ranked(c, c->n_edges))) return rc;  // the records carry vde[c]
-    *done = true;
-    if (!len || !n_qp) return GNNPE_OK;
-    const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
-    const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
-#define GNNPE_L(EE)                                                                                                 \
-    hipLaunchKernelGGL((k_filter_ranked<EE>), grid, block, 0, c->stream, c->srec.as<StartRec>(), len,               \
-                       c->rpairs.as<RankedPair>(), c->rrecs.as<RankedNbr<EE>>(), c->nbrs.as<uint32_t>(),             \
-                       c->labels.as<uint32_t>(), deg, c->vde.as<double>(), n_qp, d_vids, d_labels, d_degrees, d_pde,  \
-                       eps, words, d_bitmap)
-    switch (e) {
-    case 1: GNNPE_L(1); break;
-    case 2: GNNPE_L(2); break;
-    case 3: GNNPE_L(3); break;
-    case 4: GNNPE_L(4); break;
-    default: GNNPE_L(8); break;
-    }
-#undef GNNPE_L
-    GNNPE_HIP_TRY(hipGetLastError());
-    return GNNPE_OK;
-}
-}  // namespace gnnpe
-
-extern "C" {
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {

@@ -217,11 +217,11 @@ int gnnpe_pge_build_index(gnnpe_ctx *ctx, uint64_t n_sel, const uint32_t *host_v
 int gnnpe_host_query_plan(const char *query_graph_path, uint32_t e, uint32_t *n_query_vertices, uint32_t *n_paths,
                           uint32_t **vids, uint32_t **labels, uint32_t **degrees, double **pde);
 /* Data side (device): Partition::query (custom.h:366-489) for all partitions at once.  The R-tree traversal only
- * prunes; its result is its leaf test (custom.h:404-431) applied to every data path, which is what this does with
- * the context's enumerated paths (gnnpe_vde + gnnpe_count_paths(l=2) first; whole graph loaded).  host_bitmap:
+ * prunes; its result is its leaf test (custom.h:404-431) applied to every data path, which is what this does, fused
+ * with the enumeration of the context's slab (gnnpe_set_order + gnnpe_vde first; no counts, no emitted paths; a
+ * slab-only context also needs gnnpe_set_degrees and its halo rows).  host_bitmap:
  * n_query_vertices x ceil(n/32) uint32, bit v of row u = data vertex v is a candidate of query vertex u -- the
- * reference's candidate_set (main.cpp:165-171), ready for its refinement.  device_ms (may be NULL): enumeration +
- * filter time on the device. */
+ * reference's candidate_set (main.cpp:165-171), ready for its refinement.  device_ms (may be NULL): time on the device. */
 /* A context that holds only a slab's rows (gnnpe_load_rows) filters its own paths once it knows the degree of every
  * vertex (n uint32; the ranks' bitmaps are then OR-ed, dist.py).  Not needed after gnnpe_load_csr. */
 int gnnpe_set_degrees(gnnpe_ctx *ctx, const uint32_t *host_degrees);
