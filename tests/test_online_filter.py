@@ -141,13 +141,21 @@ def test_gpu_filter_random_graphs_against_the_oracle(oracle):
         plan = dict(n_vertices=17, vids=qv, labels=ql, degrees=qd, pde=qp)
         want = oracle.filter_candidates(paths, g["offsets"], g["labels"], vde, qv, ql, qd, qp, 17)
         assert sum(len(w) for w in want) > 0
-        for variant in (4, 3):  # 4: filter fused into the ranked enumeration; 3: filter over emitted ids
-            eng.set_fill_variant(variant)
-            eng.count_paths(2)
-            bm, _ = eng.filter_candidates(plan)
-            got = bitmap_to_sets(bm, n)
-            for u in range(17):
-                assert np.array_equal(got[u], want[u]), (e, variant, u)
+        bm, _ = eng.filter_candidates(plan)
+        got = bitmap_to_sets(bm, n)
+        for u in range(17):
+            assert np.array_equal(got[u], want[u]), (e, u)
+        eng.close()
+        # the filter needs the order and vde only -- no count, no emitted paths
+        eng = binding.Engine(0)
+        eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+        eng.set_order(g["sorted_nodes"], g["membership"], 1)
+        eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1, e))
+        with pytest.raises(binding.GnnpeError):
+            eng.filter_candidates(plan)  # vde missing
+        eng.vde(want=False)
+        got = bitmap_to_sets(eng.filter_candidates(plan)[0], n)
+        assert all(np.array_equal(got[u], want[u]) for u in range(17))
         eng.close()
 
 
