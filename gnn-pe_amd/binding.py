@@ -45,7 +45,7 @@ SIGNATURES = {
     "gnnpe_halo_need": (C.c_int, [_vp, C.c_uint32, _u32p, _vp, C.c_uint64, _u64p]),
     "gnnpe_rows_degree": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "gnnpe_rows_pack": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
-    "gnnpe_rows_append": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64]),
+    "gnnpe_rows_append": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_uint32]),
     "gnnpe_rows_drop_halo": (C.c_int, [_vp]),
     "gnnpe_vde": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
     "gnnpe_vde_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
@@ -79,6 +79,7 @@ SIGNATURES = {
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
 }
 
+ABI_VERSION = 2  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
 _lib = None
 
 
@@ -114,8 +115,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gnnpe_abi_version() != 1:
-        raise GnnpeError(f"ABI version {lib.gnnpe_abi_version()} != 1")
+    if lib.gnnpe_abi_version() != ABI_VERSION:
+        raise GnnpeError(f"ABI version {lib.gnnpe_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 
@@ -225,6 +226,7 @@ class Engine:
         self.e = 0
         self.slab = (0, 0)
         self.total = None
+        self.stream_handle = None  # None = the context's own stream
         if stream is not None:
             self.set_stream(stream)
 
@@ -246,6 +248,7 @@ class Engine:
     def set_stream(self, stream):
         """stream: raw hipStream_t as int (torch.cuda.current_stream().cuda_stream), or None."""
         self._ck(self.lib.gnnpe_set_stream(self.ctx, C.c_void_p(stream) if stream else None))
+        self.stream_handle = int(stream) if stream else None
 
     def sync(self):
         self._ck(self.lib.gnnpe_sync(self.ctx))
@@ -381,9 +384,10 @@ class Engine:
     def rows_pack(self, n_req, dev_ids, dev_out, cap):
         self._ck(self.lib.gnnpe_rows_pack(self.ctx, int(n_req), _dev(dev_ids), _dev(dev_out), int(cap)))
 
-    def rows_append(self, n_rows, dev_ids, dev_deg, dev_nbrs, n_nbrs):
+    def rows_append(self, n_rows, dev_ids, dev_deg, dev_nbrs, n_nbrs, min_rank=0):
+        """min_rank > 0: entries ranked before that processing position are dropped (last-hop halo rows)."""
         self._ck(self.lib.gnnpe_rows_append(self.ctx, int(n_rows), _dev(dev_ids), _dev(dev_deg), _dev(dev_nbrs),
-                                            int(n_nbrs)))
+                                            int(n_nbrs), int(min_rank)))
 
     def rows_drop_halo(self):
         self._ck(self.lib.gnnpe_rows_drop_halo(self.ctx))

@@ -38,6 +38,10 @@ void set_error(const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }  // locals on error paths and the context's members free themselves
     int reserve(size_t need)
     {
         if (need <= bytes) return GNNPE_OK;
@@ -86,7 +90,13 @@ struct gnnpe_ctx {
     bool rows_identity = true;  // rows == 0..n-1 (full CSR) vs. an owned-row list
     uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
-    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, rev, srec, prec, nbr_row;
+    gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, srec;
+    // rows longer than 64 entries ("hub" rows of the l=2 enumeration): ids and adjacency ranges; graph-only, rebuilt
+    // whenever rows are loaded / appended / dropped
+    gnnpe::DevBuf hub_rows, hub_beg, hub_end;
+    uint32_t n_hub = 0;
+    uint64_t hub_entries = 0;
+    int num_cus = 256;
     gnnpe::DevBuf text_len, text_off;  // R7 scratch
     gnnpe::DevBuf index_image, idx_keys, idx_vals, idx_mbr;  // R6 scratch + the assembled index.dat image
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
@@ -101,6 +111,7 @@ struct gnnpe_ctx {
     // ---- label table (R3) / vertex embeddings (R4) ----
     uint32_t n_labels = 0, e = 0;
     bool have_table = false, have_vde = false;
+    bool labels_checked = false;  // every label indexes the table (checked once per label / table upload)
     gnnpe::DevBuf xtab, x, nx, vde, nbr_vde;
     bool nbr_vde_valid = false;
 
@@ -110,7 +121,8 @@ struct gnnpe_ctx {
     uint64_t n_edges = 0;  // directed (start, middle) pairs of the slab
     uint64_t total_paths = 0;
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
-    int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default; rows <= 64, else 3)
+    int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default), 1 = generic pair-wave
+    bool slab_struct_valid = false;  // poffs / n_edges match the current graph, order and slab
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
@@ -122,6 +134,12 @@ struct gnnpe_ctx {
     bool vkey_valid = false;
     uint32_t vkey_zb = 0, vkey_lb = 0, vkey_sbits = 32;  // sbits 32 = wide (64-bit) table only
     gnnpe::DevBuf rpairs, rrecs, vinfo;
+    // row blocks of the ranked records: first 128-byte unit of every held row's block, total units; depends on the held
+    // rows and the record size (e, packed ids) only, so it is laid out when one of them changes
+    gnnpe::DevBuf rblock;
+    uint64_t rblock_units = 0;
+    bool rblock_valid = false;
+    uint32_t rblock_e = 0;
     gnnpe::DevBuf pge_pg, pge_plg;  // GNN-PGE path groups (n x 4e doubles each)
     bool have_pge = false;
 

@@ -12,8 +12,6 @@
 #include "gnnpe_common.h"
 #include "gnnpe_kernels.hip.h"
 #include "gnnpe_fill_pairwave.hip.h"
-#include "gnnpe_fill_middle.hip.h"
-#include "gnnpe_fill_start.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
 #include "gnnpe_fill_deep.hip.h"
 
@@ -73,6 +71,18 @@ static int ensure_rank_arrays(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+// blocks of a kernel that fit one CU (occupancy query, once per instantiation)
+template <class K> static int blocks_per_cu(K kernel)
+{
+    static int cached = 0;
+    if (!cached) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
+        cached = nb;
+    }
+    return cached;
+}
+
 }  // namespace gnnpe
 
 using namespace gnnpe;
@@ -109,6 +119,12 @@ gnnpe_ctx *gnnpe_create(int device_id)
         return nullptr;
     }
     c->stream = c->own_stream;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->num_cus = cus;
+    if (c->small.reserve(4096) != GNNPE_OK) {  // every small read-back slot lives here: one allocation for the context's life
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -117,11 +133,7 @@ void gnnpe_destroy(gnnpe_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->adj_start, &c->adj_deg, &c->present, &c->owned, &c->nbrs, &c->nbr_rank, &c->labels, &c->rows,
-                      &c->sorted, &c->rank, &c->member, &c->xtab, &c->x, &c->nx, &c->vde, &c->poffs, &c->erow,
-                      &c->pnbr, &c->ecnt, &c->eoff, &c->cub_tmp, &c->scratch, &c->mark, &c->small, &c->nbr_vde, &c->held, &c->revpos, &c->rev, &c->srec, &c->prec, &c->nbr_row, &c->text_len, &c->text_off, &c->index_image, &c->idx_keys, &c->idx_vals, &c->idx_mbr, &c->rpairs, &c->rrecs, &c->vinfo, &c->vkey, &c->rank_sorted, &c->adj_end, &c->ufirst, &c->upair, &c->uoff, &c->deg_all, &c->q_plan, &c->q_bitmap, &c->q_work,
-                        &c->q_tmp, &c->pge_pg, &c->pge_plg};
-    for (DevBuf *b : bufs) b->release();
+    // every DevBuf member releases itself in ~gnnpe_ctx
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -206,6 +218,58 @@ static void invalidate_derived(gnnpe_ctx *c)
     c->have_pge = false;
     c->nbr_vde_valid = false;
     c->counted = false;
+    c->slab_struct_valid = false;
+    c->labels_checked = false;
+}
+
+// Validation and the graph-only derived structure of the rows [first held row .., +n_new): reverse
+// positions and the hub-row list.  Synchronises the stream.
+static int finish_rows(gnnpe_ctx *c, uint64_t n_new, const uint32_t *dev_new_rows)
+{
+    int rc;
+    if ((rc = c->small.reserve(1024))) return rc;
+    uint32_t *d_bad = c->small.as<uint32_t>() + 8;
+    uint32_t *d_cnt = c->small.as<uint32_t>() + 10;
+    if (n_new) {
+        GNNPE_HIP_TRY(hipMemsetAsync(d_bad, 0xFF, 4, c->stream));
+        hipLaunchKernelGGL(k_validate_rows, dim3(grid_for(n_new * 16)), dim3(kBlock), 0, c->stream, c->n, n_new, dev_new_rows,
+                           c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), d_bad);
+        GNNPE_HIP_TRY(hipGetLastError());
+        uint64_t bad = 0;
+        if ((rc = read_back_u64(c, d_bad, 4, &bad))) return rc;
+        GNNPE_REQUIRE((uint32_t)bad == 0xFFFFFFFFu, GNNPE_ERR_ARG,
+                      "adjacency row of vertex %u is not a strictly ascending list of ids < n without a self-loop "
+                      "(the engine needs a simple graph with sorted rows, as graph.cpp:231-233 leaves them)", (uint32_t)bad);
+        hipLaunchKernelGGL(k_revpos, dim3(grid_for(n_new * 16)), dim3(kBlock), 0, c->stream, (uint32_t)n_new, dev_new_rows,
+                           c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                           c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>());
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    // hub rows over everything held
+    const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+    c->rblock_valid = false;
+    c->n_hub = 0;
+    c->hub_entries = 0;
+    if (c->n_held) {
+        GNNPE_HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_hub_list, dim3(grid_for(c->n_held)), dim3(kBlock), 0, c->stream, (uint64_t)c->n_held, held,
+                           c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), kHubDegree, d_cnt, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr);
+        uint64_t nh = 0;
+        if ((rc = read_back_u64(c, d_cnt, 4, &nh))) return rc;
+        if ((uint32_t)nh) {
+            const size_t by = ((size_t)(uint32_t)nh + 1) * 4;
+            if ((rc = c->hub_rows.reserve(by)) || (rc = c->hub_beg.reserve(by)) || (rc = c->hub_end.reserve(by))) return rc;
+            GNNPE_HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_hub_list, dim3(grid_for(c->n_held)), dim3(kBlock), 0, c->stream, (uint64_t)c->n_held, held,
+                               c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), kHubDegree, d_cnt,
+                               c->hub_rows.as<uint32_t>(), c->hub_beg.as<uint32_t>(), c->hub_end.as<uint32_t>());
+            GNNPE_HIP_TRY(hipGetLastError());
+            c->n_hub = (uint32_t)nh;
+        }
+    }
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
 }
 
 int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_t *nbrs, const uint32_t *labels)
@@ -227,27 +291,22 @@ int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_
                            c->scratch.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
                            c->present.as<uint8_t>());
     GNNPE_HIP_TRY(hipGetLastError());
-    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve((m2 + 1) * 4)) || (rc = c->nbr_row.reserve((m2 + 1) * 4))) return rc;
-    if (n) {
-        GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
-        // reverse positions: part of building the graph structure (depends on the graph only)
-        hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n * 16)), dim3(kBlock), 0, c->stream, n,
-                           (const uint32_t *)nullptr, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
-        GNNPE_HIP_TRY(hipGetLastError());
-    }
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve((m2 + 1) * 4))) return rc;
+    if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
+    c->have_graph = false;
     c->n = n;
-    c->have_graph = true;
     c->rows_identity = true;
     c->n_rows = n;
     c->n_held = n;
     c->nbr_used = c->nbr_owned = m2;
     c->nbr_cap = c->nbrs.bytes / 4;
-    if (!c->slab_set) {
-        c->slab_begin = 0;
-        c->slab_end = n;
-    }
+    // reverse positions and the hub list are part of the graph structure (they depend on the graph only)
+    if ((rc = finish_rows(c, n, nullptr))) return rc;
+    c->have_graph = true;
+    c->slab_begin = 0;  // a new graph starts with the whole order as its slab (no stale slab)
+    c->slab_end = n;
+    c->slab_set = false;
+    c->have_order = false;
     invalidate_derived(c);
     return GNNPE_OK;
 }
@@ -284,27 +343,22 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
         GNNPE_HIP_TRY(hipGetLastError());
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes)) || (rc = c->nbr_row.reserve(c->nbrs.bytes))) return rc;
+    if ((rc = c->owned.reserve((size_t)n + 1)) || (rc = c->revpos.reserve(c->nbrs.bytes))) return rc;
     // same stream as the kernels that read it: a null-stream copy would not order against c->stream
     if (n) GNNPE_HIP_TRY(hipMemcpyAsync(c->owned.p, c->present.p, n, hipMemcpyDeviceToDevice, c->stream));
-    if (n_rows) {
-        hipLaunchKernelGGL(k_revpos, dim3(grid_for((uint64_t)n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows,
-                           c->rows.as<uint32_t>(), c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
-        GNNPE_HIP_TRY(hipGetLastError());
-        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    c->have_graph = false;
     c->n = n;
-    c->have_graph = true;
     c->rows_identity = false;
     c->n_rows = n_rows;
     c->n_held = n_rows;
     c->nbr_used = c->nbr_owned = used;
     c->nbr_cap = c->nbrs.bytes / 4;
-    if (!c->slab_set) {
-        c->slab_begin = 0;
-        c->slab_end = n;
-    }
+    if ((rc = finish_rows(c, n_rows, c->rows.as<uint32_t>()))) return rc;
+    c->have_graph = true;
+    c->slab_begin = 0;
+    c->slab_end = n;
+    c->slab_set = false;
+    c->have_order = false;
     invalidate_derived(c);
     return GNNPE_OK;
 }
@@ -340,6 +394,7 @@ int gnnpe_set_order(gnnpe_ctx *c, const uint32_t *sorted_nodes, const uint32_t *
     c->p = p;
     c->have_order = true;
     c->counted = false;
+    c->slab_struct_valid = false;
     return GNNPE_OK;
 }
 
@@ -351,6 +406,7 @@ int gnnpe_set_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end)
     c->slab_end = end;
     c->slab_set = true;
     c->counted = false;
+    c->slab_struct_valid = false;
     return GNNPE_OK;
 }
 
@@ -366,6 +422,7 @@ int gnnpe_set_label_table(gnnpe_ctx *c, uint32_t n_labels, uint32_t e, const dou
     c->n_labels = n_labels;
     c->e = e;
     c->have_table = true;
+    c->labels_checked = false;
     c->counted = false;  // record layouts of the enumeration depend on e
     c->have_vde = false;
     c->nbr_vde_valid = false;
@@ -401,10 +458,11 @@ static int run_vde(gnnpe_ctx *c)
         c->have_vde = true;
         return GNNPE_OK;
     }
-    // every label must index the table (its size is the loader's labels_count, graph.cpp:223)
-    {
+    // every label must index the table (its size is the loader's labels_count, graph.cpp:223); checked once per
+    // label / table upload, not per step
+    if (!c->labels_checked) {
         size_t tb = 0;
-        if ((rc = c->small.reserve(256))) return rc;
+        if ((rc = c->small.reserve(1024))) return rc;
         uint32_t *d_max = c->small.as<uint32_t>();
         GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->labels.as<uint32_t>(), d_max, (int)n, c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
@@ -414,6 +472,7 @@ static int run_vde(gnnpe_ctx *c)
         if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
         GNNPE_REQUIRE((uint32_t)mx < c->n_labels, GNNPE_ERR_ARG, "label %u has no row in the %u-row label table",
                       (uint32_t)mx, c->n_labels);
+        c->labels_checked = true;
     }
     GNNPE_HIP_TRY(hipMemsetAsync(c->nx.p, 0, bytes, c->stream));
     GNNPE_HIP_TRY(hipMemsetAsync(c->vde.p, 0, bytes, c->stream));
@@ -494,18 +553,16 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
 }
 
 // ---- R2 / R5: enumeration ---------------------------------------------------------------------------
-// Four implementations with identical outputs:
-//   1 pair-wave   one wave per (s, b) pair, direct stores            (gnnpe_fill_pairwave.hip.h)
-//   2 middle      middle-vertex-centric count + fill                 (gnnpe_fill_middle.hip.h)
-//   3 start       wave per start vertex over id-sorted rows          (gnnpe_fill_start.hip.h)
-//   4 ranked      wave per start vertex over rank-sorted records     (gnnpe_fill_ranked.hip.h)  default
-// Variant 4 needs rows of degree <= 64 and falls back to 3 otherwise.
+//   4 ranked     one wave per start vertex over rank-sorted neighbour records, hub rows (degree > 64) streamed in id
+//                order by the same kernel (gnnpe_fill_ranked.hip.h)                                        default
+//   1 pair-wave  one wave per (s, b) pair, direct stores, run-time embedding width (gnnpe_fill_pairwave.hip.h): the
+//                generic form for widths without a specialised instantiation, and the A/B baseline
 // l = 3 (4-vertex paths, BASELINE config 5) has one implementation: gnnpe_fill_deep.hip.h.
-enum { kVarPairWave = 1, kVarMiddle = 2, kVarStart = 3, kVarRanked = 4, kVarDeep = 5 };
+enum { kVarPairWave = 1, kVarRanked = 4, kVarDeep = 5 };
 
 static bool fast_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
-// nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (variants 1 and 3 stream it)
+// nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (the pair-wave and l=3 kernels stream it)
 static int ensure_nbr_vde(gnnpe_ctx *c)
 {
     if (c->nbr_vde_valid) return GNNPE_OK;
@@ -520,16 +577,56 @@ static int ensure_nbr_vde(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-// variant 4: rank-sorted neighbour records + per-pair {suffix start, G}
+#define GNNPE_BY_E(e, LAUNCH)     \
+    switch (e) {                  \
+    case 1: LAUNCH(1); break;     \
+    case 2: LAUNCH(2); break;     \
+    case 3: LAUNCH(3); break;     \
+    case 4: LAUNCH(4); break;     \
+    default: LAUNCH(8); break;    \
+    }
+
+static bool packed_ids(const gnnpe_ctx *c) { return c->n <= (1u << kPackedIdBits); }
+static uint32_t rec_bytes(uint32_t e, bool packed) { return (packed ? 4u : 8u) + 8u * e; }
+
+// lay the row blocks out: header (8e bytes) + records, every block on a 128-byte boundary
+static int ensure_row_blocks(gnnpe_ctx *c, uint32_t e)
+{
+    if (c->rblock_valid && c->rblock_e == e) return GNNPE_OK;
+    int rc;
+    const uint32_t nh = c->n_held;
+    if ((rc = c->rblock.reserve(((size_t)c->n + 1) * 4)) || (rc = c->scratch.reserve(((size_t)nh + 2) * 8))) return rc;
+    uint32_t *units = c->scratch.as<uint32_t>(), *off = units + nh + 1;
+    const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+    hipLaunchKernelGGL(k_row_block_units, dim3(grid_for((uint64_t)nh + 1)), dim3(kBlock), 0, c->stream, nh, held,
+                       c->adj_deg.as<uint32_t>(), 8u * e, rec_bytes(e, packed_ids(c)), rec_bytes(e, false), units);
+    if ((rc = scan_u32(c, units, off, (uint64_t)nh + 1))) return rc;
+    uint64_t tot = 0;
+    if ((rc = read_back_u64(c, off + nh, 4, &tot))) return rc;
+    if (nh)
+        hipLaunchKernelGGL(k_row_block_starts, dim3(grid_for(nh)), dim3(kBlock), 0, c->stream, nh, held, off,
+                           c->rblock.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // scratch is reused by the caller
+    c->rblock_units = (uint32_t)tot;
+    c->rblock_valid = true;
+    c->rblock_e = e;
+    return GNNPE_OK;
+}
+
+// row blocks {vde[b] | records by descending rank} + per-pair {block, count, G}; hub rows: id-ordered records, counts
+// from a per-row sort of the ranks
 static int build_ranked(gnnpe_ctx *c, uint64_t ne)
 {
     const uint32_t e = c->have_table ? c->e : 2;
+    const bool packed = packed_ids(c);
     int rc;
-    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->nbr_used + 1) * (8 + 8 * (size_t)e))) ||
+    if ((rc = ensure_row_blocks(c, e))) return rc;
+    if ((rc = c->rpairs.reserve((ne + 1) * sizeof(RankedPair))) || (rc = c->rrecs.reserve((c->rblock_units + 1) * kRowAlign)) ||
         (rc = c->vinfo.reserve(((size_t)c->n + 1) * GNNPE_VINFO_STRIDE(e) * 8)))
         return rc;
     // pairs whose middle row is not on the device stay empty; with the whole graph loaded every pair is written by
-    // k_rows_rank and only the scan's sentinel entry needs clearing
+    // the row kernels and only the scan's sentinel entry needs clearing
     if (c->rows_identity)
         GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.as<RankedPair>() + ne, 0, sizeof(RankedPair), c->stream));
     else
@@ -538,44 +635,72 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
         const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+#define GNNPE_RRK(EE, PK)                                                                                           \
+    hipLaunchKernelGGL((k_rows_rank<EE, PK>), grid, block, 0, c->stream, c->n_held, held, c->adj_start.as<uint32_t>(), \
+                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->vinfo.as<double>(),                     \
+                       c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->rpairs.as<RankedPair>())
 #define GNNPE_RR(EE)                                                                                               \
     do {                                                                                                           \
-        static_assert(sizeof(RankedNbr<EE>) == 8 + 8 * EE, "record size must match the host-side allocation");     \
         hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
                            c->rank.as<uint32_t>(), c->slab_begin, c->slab_end, c->poffs.as<uint32_t>(),             \
                            c->vinfo.as<double>());                                                                  \
-        hipLaunchKernelGGL((k_rows_rank<EE>), grid, block, 0, c->stream, c->n_held, held,                           \
-                           c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),                                  \
-                           c->nbrs.as<uint32_t>(), c->vinfo.as<double>(), c->revpos.as<uint32_t>(),                 \
-                           c->rrecs.as<RankedNbr<EE>>(), c->rpairs.as<RankedPair>());                               \
+        if (packed) GNNPE_RRK(EE, true); else GNNPE_RRK(EE, false);                                                 \
     } while (0)
-        switch (e) {
-        case 1: GNNPE_RR(1); break;
-        case 2: GNNPE_RR(2); break;
-        case 3: GNNPE_RR(3); break;
-        case 4: GNNPE_RR(4); break;
-        default: GNNPE_RR(8); break;
-        }
+        GNNPE_BY_E(e, GNNPE_RR)
 #undef GNNPE_RR
+#undef GNNPE_RRK
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
+    if (c->n_hub) {
+        // hub rows (known since the rows were loaded): id-ordered records, the rows' ranks sorted per row, counts by
+        // binary search
+        if ((rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4)) || (rc = c->rank_sorted.reserve((c->nbr_used + 1) * 4))) return rc;
+        const dim3 grid(grid_for((uint64_t)c->n_hub * 64)), block(kBlock);
+#define GNNPE_HR(EE)                                                                                               \
+    hipLaunchKernelGGL((k_hub_records<EE>), grid, block, 0, c->stream, c->n_hub, c->hub_rows.as<uint32_t>(),        \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),              \
+                       c->vinfo.as<double>(), c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->nbr_rank.as<uint32_t>())
+        GNNPE_BY_E(e, GNNPE_HR)
+#undef GNNPE_HR
+        size_t ts = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
+            nullptr, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n_hub,
+            c->hub_beg.as<uint32_t>(), c->hub_end.as<uint32_t>(), 0, 32, c->stream));
+        if ((rc = c->cub_tmp.reserve(ts))) return rc;
+        ts = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
+            c->cub_tmp.p, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n_hub,
+            c->hub_beg.as<uint32_t>(), c->hub_end.as<uint32_t>(), 0, 32, c->stream));
+#define GNNPE_HP(EE)                                                                                               \
+    hipLaunchKernelGGL((k_hub_pairs<EE>), grid, block, 0, c->stream, c->n_hub, c->hub_rows.as<uint32_t>(),          \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),              \
+                       c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rank_sorted.as<uint32_t>(),              \
+                       c->rblock.as<uint32_t>(), c->rpairs.as<RankedPair>())
+        GNNPE_BY_E(e, GNNPE_HP)
+#undef GNNPE_HP
         GNNPE_HIP_TRY(hipGetLastError());
     }
     c->ranked_vde_valid = c->have_vde;
     return GNNPE_OK;
 }
 
-static int max_held_degree(gnnpe_ctx *c, uint32_t *out)
+// poffs[i] = first pair of the i-th start vertex of the slab (prefix sum of the slab rows' degrees), n_edges = their
+// number: the slab's own CSR offsets in processing order.  Depends on the graph, the order and the slab only, so it is
+// built when one of them changes, not per step.
+static int ensure_slab_struct(gnnpe_ctx *c)
 {
+    if (c->slab_struct_valid) return GNNPE_OK;
+    const uint32_t sb = c->slab_begin, len = c->slab_end - c->slab_begin;
     int rc;
-    if ((rc = c->small.reserve(256))) return rc;
-    uint32_t *d_max = c->small.as<uint32_t>() + 4;
-    size_t tb = 0;
-    GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(nullptr, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
-    if ((rc = c->cub_tmp.reserve(tb))) return rc;
-    tb = c->cub_tmp.bytes;
-    GNNPE_HIP_TRY(hipcub::DeviceReduce::Max(c->cub_tmp.p, tb, c->adj_deg.as<uint32_t>(), d_max, (int)c->n, c->stream));
-    uint64_t mx = 0;
-    if ((rc = read_back_u64(c, d_max, 4, &mx))) return rc;
-    *out = (uint32_t)mx;
+    if ((rc = c->poffs.reserve((size_t)(len + 2) * 4)) || (rc = c->scratch.reserve((size_t)(len + 2) * 8))) return rc;
+    uint32_t *pdeg = c->scratch.as<uint32_t>();
+    hipLaunchKernelGGL(k_slab_degrees, dim3(grid_for(len + 1)), dim3(kBlock), 0, c->stream, len, sb,
+                       c->sorted.as<uint32_t>(), c->adj_deg.as<uint32_t>(), pdeg);
+    if ((rc = scan_u32(c, pdeg, c->poffs.as<uint32_t>(), (uint64_t)len + 1))) return rc;
+    uint64_t w = 0;
+    if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
+    c->n_edges = (uint32_t)w;
+    c->slab_struct_valid = true;
     return GNNPE_OK;
 }
 
@@ -592,31 +717,18 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     const uint32_t e = c->have_table ? c->e : 2;
     c->counted = false;
 
-    // which implementation runs: embedding widths without a specialised kernel use the generic pair-wave
-    // kernel; the ranked variant needs every held row to fit one 64-bit id-position set
+    // which implementation runs: embedding widths without a specialised kernel use the generic pair-wave kernel
     int var = c->fill_variant;
     if (!fast_e(e)) var = kVarPairWave;
     if (l == 3) var = kVarDeep;
-    if (var == kVarRanked && c->n) {
-        uint32_t mx = 0;
-        if ((rc = max_held_degree(c, &mx))) return rc;
-        if (mx > 64) var = kVarStart;
-    }
 
     // 1. slab rows -> directed (s, b) pairs in emission order: pair index = poffs[i] + position of b in N(s)
-    if ((rc = c->poffs.reserve((size_t)(len + 2) * 4)) || (rc = c->scratch.reserve((size_t)(len + 2) * 8))) return rc;
-    uint32_t *pdeg = c->scratch.as<uint32_t>();
-    hipLaunchKernelGGL(k_slab_degrees, dim3(grid_for(len + 1)), dim3(kBlock), 0, c->stream, len, sb,
-                       c->sorted.as<uint32_t>(), c->adj_deg.as<uint32_t>(), pdeg);
-    if ((rc = scan_u32(c, pdeg, c->poffs.as<uint32_t>(), (uint64_t)len + 1))) return rc;
-    uint64_t w = 0;
-    if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
-    const uint64_t ne = (uint32_t)w;
-    c->n_edges = ne;
+    if ((rc = ensure_slab_struct(c))) return rc;
+    const uint64_t ne = c->n_edges;
     if ((rc = c->eoff.reserve((ne + 2) * 8))) return rc;
+    uint64_t w = 0;
 
     // 2. per-pair path counts
-    const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     if (var == kVarRanked) {
         if ((rc = build_ranked(c, ne))) return rc;
     } else {
@@ -626,16 +738,13 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
             hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used,
                                c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), c->nbr_rank.as<uint32_t>());
         GNNPE_HIP_TRY(hipMemsetAsync(c->ecnt.p, 0, (ne + 1) * 4, c->stream));
-        if (var == kVarPairWave || var == kVarDeep) {
-            if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4))) return rc;
-            if (len)
-                hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
-                                   c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                                   c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
-        }
+        if ((rc = c->erow.reserve((ne + 1) * 4)) || (rc = c->pnbr.reserve((ne + 1) * 4))) return rc;
+        if (len)
+            hipLaunchKernelGGL(k_perm_edges, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
+                               c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->nbrs.as<uint32_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>());
         if (var == kVarDeep) {
             // the emit walk with the stores compiled out; rows two hops from the slab must be on this device
-            if ((rc = c->small.reserve(256))) return rc;
             uint32_t *d_missing = c->small.as<uint32_t>() + 16;
             GNNPE_HIP_TRY(hipMemsetAsync(d_missing, 0xFF, 4, c->stream));
             FillParams P = {};
@@ -689,23 +798,10 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
             GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,
                           "l=3: the adjacency row of vertex %u (two hops from the slab) is not on this device",
                           (uint32_t)miss);
-        } else if (var == kVarPairWave) {
+        } else {  // kVarPairWave
             hipLaunchKernelGGL(k_count_edges, dim3(grid_for(ne * 16 + 1)), dim3(kBlock), 0, c->stream, ne, sb,
                                c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(), c->adj_start.as<uint32_t>(),
                                c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->ecnt.as<uint32_t>());
-        } else if (var == kVarMiddle) {
-            if ((rc = c->rev.reserve((c->nbr_used + 1) * 4))) return rc;
-            if (c->n_held)
-                hipLaunchKernelGGL(k_count_b, dim3(grid_for((uint64_t)c->n_held * 64)), dim3(kBlock), 0, c->stream,
-                                   c->n_held, held, sb, se, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                                   c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                                   c->rev.as<uint32_t>(), c->ecnt.as<uint32_t>());
-        } else {  // kVarStart
-            if (c->nbr_used)
-                hipLaunchKernelGGL(k_count_flat, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, sb,
-                                   se, c->nbr_row.as<uint32_t>(), c->adj_start.as<uint32_t>(),
-                                   c->adj_deg.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->revpos.as<uint32_t>(),
-                                   c->poffs.as<uint32_t>(), (uint32_t *)nullptr, c->ecnt.as<uint32_t>());
         }
         GNNPE_HIP_TRY(hipGetLastError());
     }
@@ -731,28 +827,22 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     } else if ((rc = scan_u32_to_u64(c, c->ecnt.as<uint32_t>(), c->eoff.as<uint64_t>(), ne + 1))) {
         return rc;
     }
-    if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
 
-    // 4. records that shorten the fill's dependent-load chain (variants 3 and 4)
-    if ((var == kVarStart || var == kVarRanked) && len) {
+    // 4. per-start records that shorten the emit kernel's dependent-load chain; enqueued before the one read-back
+    if (var == kVarRanked && len) {
         if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec)))) return rc;
-        if (var == kVarStart) {
-            if ((rc = c->prec.reserve((ne + 1) * sizeof(PairRec)))) return rc;
-            hipLaunchKernelGGL(k_pair_recs, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, sb,
-                               c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
-                               c->poffs.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->prec.as<PairRec>());
-        }
         hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
                            c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
                            c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
         GNNPE_HIP_TRY(hipGetLastError());
     }
+    if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
     c->total_paths = w;
     c->l = l;
     c->counted = true;
     c->counted_variant = var;
     // embeddings of the adjacency entries, when the vde table is already there (keeps it out of the fill)
-    if (c->have_vde && (var == kVarPairWave || var == kVarStart || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
+    if (c->have_vde && (var == kVarPairWave || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
@@ -776,7 +866,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     const uint32_t e = c->have_table ? c->e : 2;
     const uint32_t len = c->slab_end - c->slab_begin;
     int rc;
-    if (d_pde && (var == kVarPairWave || var == kVarStart || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
+    if (d_pde && (var == kVarPairWave || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (d_pde && var == kVarRanked && !c->ranked_vde_valid && (rc = build_ranked(c, c->n_edges))) return rc;
 
     FillParams P;
@@ -802,17 +892,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     P.out_pdl = (double *)d_pdl;
     P.out_part = (uint32_t *)d_part;
 
-#define GNNPE_BY_E(LAUNCH)        \
-    switch (e) {                  \
-    case 1: LAUNCH(1); break;     \
-    case 2: LAUNCH(2); break;     \
-    case 3: LAUNCH(3); break;     \
-    case 4: LAUNCH(4); break;     \
-    default: LAUNCH(8); break;    \
-    }
     if (var == kVarDeep) {
         // only the units whose output overlaps [begin, end)
-        if ((rc = c->small.reserve(256))) return rc;
         uint64_t *d_range = reinterpret_cast<uint64_t *>(c->small.as<char>() + 192);
         hipLaunchKernelGGL(k_deep_unit_range, dim3(1), dim3(64), 0, c->stream, c->n_units, c->uoff.as<uint64_t>(), begin, end,
                            d_range);
@@ -823,53 +904,47 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     hipLaunchKernelGGL((k_deep3<EE>), dim3(grid_for((u_hi - u_lo) * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,   \
                        c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
         if (fast_e(e)) {
-            GNNPE_BY_E(GNNPE_L)
+            GNNPE_BY_E(e, GNNPE_L)
         } else {
             GNNPE_L(0);
         }
 #undef GNNPE_L
     } else if (var == kVarRanked) {
-        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
+        // a resident grid: every wave walks its share of the start vertices (w, w + waves, ...), the next start's
+        // records in flight while the current one is emitted
         const StartRec *sr = c->srec.as<StartRec>();
-        const RankedPair *rp = c->rpairs.as<RankedPair>();
-#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_ranked<EE>), grid, block, 0, c->stream, P, sr, rp, c->rrecs.as<RankedNbr<EE>>(), len)
-        GNNPE_BY_E(GNNPE_L)
+        const bool packed = packed_ids(c);
+#define GNNPE_LK(KERN)                                                                                                  \
+    do {                                                                                                                \
+        auto kern = KERN;                                                                                               \
+        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)blocks_per_cu(kern) * c->num_cus; \
+        const dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, fit))), block(kBlock);                           \
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len); \
+    } while (0)
+#define GNNPE_L(EE)                                                                                                     \
+    do {                                                                                                                \
+        if (packed) GNNPE_LK((k_fill_ranked<EE, true, FillBatch<EE>::rows>));                                           \
+        else GNNPE_LK((k_fill_ranked<EE, false, FillBatch<EE>::rows>));                                                 \
+    } while (0)
+        // pde_label is gathered from the emitted ids; without an id output of the caller's they go to scratch
+        if (d_pdl && !d_vids) {
+            if ((rc = c->scratch.reserve((end - begin) * 12 + 16))) return rc;
+            P.out_ids = c->scratch.as<uint32_t>();
+        }
+        if (P.out_ids || d_pde) {
+            GNNPE_BY_E(e, GNNPE_L)
+        }
 #undef GNNPE_L
-    } else if (var == kVarStart) {
-        const dim3 grid(grid_for((uint64_t)len * 64)), block(kBlock);
-        const StartRec *sr = c->srec.as<StartRec>();
-        const PairRec *pr = c->prec.as<PairRec>();
-#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_s_rec<EE, (EE <= 2 ? 4 : (EE <= 4 ? 2 : 1))>), grid, block, 0, c->stream, P, sr, pr, len)
-        GNNPE_BY_E(GNNPE_L)
-#undef GNNPE_L
-    } else if (var == kVarMiddle) {
-        FillBParams B;
-        B.held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
-        B.adj_start = P.adj_start;
-        B.adj_deg = P.adj_deg;
-        B.nbrs = P.nbrs;
-        B.nbr_rank = P.nbr_rank;
-        B.rev = c->rev.as<uint32_t>();
-        B.member = P.member;
-        B.eoff = P.eoff;
-        B.vde = P.vde;
-        B.x = P.x;
-        B.n_held = c->n_held;
-        B.e = e;
-        B.begin = begin;
-        B.end = end;
-        B.out_ids = P.out_ids;
-        B.out_pde = P.out_pde;
-        B.out_pdl = P.out_pdl;
-        B.out_part = P.out_part;
-        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-#define GNNPE_L(EE) hipLaunchKernelGGL((k_fill_b<EE>), grid, block, 0, c->stream, B)
-        GNNPE_BY_E(GNNPE_L)
-#undef GNNPE_L
+#undef GNNPE_LK
+        if (d_part)
+            hipLaunchKernelGGL(k_start_parts, dim3(grid_for((uint64_t)len * 64)), dim3(kBlock), 0, c->stream, len, sr, begin, end,
+                               (uint32_t *)d_part);
+        if (d_pdl)
+            hipLaunchKernelGGL(k_pdl_from_ids, dim3(grid_for((end - begin) * 3 * e)), dim3(kBlock), 0, c->stream, end - begin,
+                               3u, e, P.out_ids, c->x.as<double>(), (double *)d_pdl);
     } else {  // kVarPairWave: runtime embedding width
         hipLaunchKernelGGL(k_fill_edge_wave, dim3(grid_for(c->n_edges * 64)), dim3(kBlock), 0, c->stream, P);
     }
-#undef GNNPE_BY_E
     GNNPE_HIP_TRY(hipGetLastError());
     return GNNPE_OK;
 }
@@ -937,7 +1012,7 @@ int gnnpe_rows_checksum_device(gnnpe_ctx *c, uint64_t n_rows, uint32_t L, const 
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)
 {
-    GNNPE_REQUIRE(c && variant >= kVarPairWave && variant <= kVarRanked, GNNPE_ERR_ARG, "fill variant must be 1..4");
+    GNNPE_REQUIRE(c && (variant == kVarPairWave || variant == kVarRanked), GNNPE_ERR_ARG, "fill variant must be 1 or 4");
     if (variant != c->fill_variant) c->counted = false;
     c->fill_variant = variant;
     return GNNPE_OK;
@@ -999,7 +1074,7 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
 {
     GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_drop_halo: no graph");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
-    if (c->rows_identity || c->nbr_used == c->nbr_owned) return GNNPE_OK;
+    if (c->rows_identity || c->n_held == c->n_rows) return GNNPE_OK;
     hipLaunchKernelGGL(k_drop_halo, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->owned.as<uint8_t>(),
                        c->present.as<uint8_t>(), c->adj_deg.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
@@ -1007,7 +1082,7 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
     c->n_held = c->n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
-    return GNNPE_OK;
+    return finish_rows(c, 0, nullptr);  // the hub list covers the held rows
 }
 
 int gnnpe_rows_degree(gnnpe_ctx *c, uint64_t n_req, const void *dev_ids, void *dev_deg)
@@ -1048,46 +1123,60 @@ int gnnpe_rows_pack(gnnpe_ctx *c, uint64_t n_req, const void *dev_ids, void *dev
 }
 
 int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const void *dev_deg, const void *dev_nbrs,
-                      uint64_t n_nbrs)
+                      uint64_t n_nbrs, uint32_t min_rank)
 {
     GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_append: no graph");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     if (!n_rows) return GNNPE_OK;
     GNNPE_REQUIRE(dev_ids && dev_deg && (dev_nbrs || !n_nbrs), GNNPE_ERR_ARG, "null argument");
-    GNNPE_REQUIRE(c->nbr_used + n_nbrs <= c->nbr_cap, GNNPE_ERR_ARG,
-                  "gnnpe_rows_append: neighbour buffer full (%llu + %llu > %llu); reserve more in gnnpe_load_rows",
-                  (unsigned long long)c->nbr_used, (unsigned long long)n_nbrs, (unsigned long long)c->nbr_cap);
-    int rc;
-    if ((rc = c->scratch.reserve((n_rows + 1) * 12 + 64))) return rc;
-    uint64_t *roff = c->scratch.as<uint64_t>();
-    uint32_t *deg = reinterpret_cast<uint32_t *>(roff + n_rows + 1);
-    GNNPE_HIP_TRY(hipMemcpyAsync(deg, dev_deg, n_rows * 4, hipMemcpyDeviceToDevice, c->stream));
-    GNNPE_HIP_TRY(hipMemsetAsync(deg + n_rows, 0, 4, c->stream));
-    if ((rc = scan_u32_to_u64(c, deg, roff, n_rows + 1))) return rc;
-    uint64_t tot = 0;
-    if ((rc = read_back_u64(c, roff + n_rows, 8, &tot))) return rc;
-    GNNPE_REQUIRE(tot == n_nbrs, GNNPE_ERR_ARG, "gnnpe_rows_append: degrees sum to %llu but %llu entries given",
-                  (unsigned long long)tot, (unsigned long long)n_nbrs);
-    if (n_nbrs)
-        GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.as<uint32_t>() + c->nbr_used, dev_nbrs, n_nbrs * 4, hipMemcpyDeviceToDevice,
-                                     c->stream));
+    GNNPE_REQUIRE(min_rank == 0 || c->have_order, GNNPE_ERR_ARG, "gnnpe_rows_append: min_rank needs gnnpe_set_order first");
     GNNPE_REQUIRE(!c->rows_identity && (uint64_t)c->n_held + n_rows <= c->n, GNNPE_ERR_ARG,
                   "gnnpe_rows_append: more rows than vertices");
+    int rc;
+    // scratch: src_off u64[n_rows+1] | dst_off u64[n_rows+1] | deg u32[n_rows+1] | kept u32[n_rows+1]
+    if ((rc = c->scratch.reserve((n_rows + 1) * 24 + 64))) return rc;
+    uint64_t *src_off = c->scratch.as<uint64_t>(), *dst_off = src_off + n_rows + 1;
+    uint32_t *deg = reinterpret_cast<uint32_t *>(dst_off + n_rows + 1), *kept = deg + n_rows + 1;
+    GNNPE_HIP_TRY(hipMemcpyAsync(deg, dev_deg, n_rows * 4, hipMemcpyDeviceToDevice, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(deg + n_rows, 0, 4, c->stream));
+    if ((rc = scan_u32_to_u64(c, deg, src_off, n_rows + 1))) return rc;
+    uint64_t tot = 0;
+    if ((rc = read_back_u64(c, src_off + n_rows, 8, &tot))) return rc;
+    GNNPE_REQUIRE(tot == n_nbrs, GNNPE_ERR_ARG, "gnnpe_rows_append: degrees sum to %llu but %llu entries given",
+                  (unsigned long long)tot, (unsigned long long)n_nbrs);
+    uint64_t n_keep = n_nbrs;
+    const uint64_t *roff = src_off;
+    if (min_rank > 0 && n_nbrs) {
+        // drop the entries ranked before the slab: they can never close a path of this rank
+        hipLaunchKernelGGL(k_rows_kept_counts, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows, src_off,
+                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), min_rank, kept);
+        if ((rc = scan_u32_to_u64(c, kept, dst_off, n_rows + 1))) return rc;
+        if ((rc = read_back_u64(c, dst_off + n_rows, 8, &n_keep))) return rc;
+        roff = dst_off;
+    }
+    GNNPE_REQUIRE(c->nbr_used + n_keep <= c->nbr_cap, GNNPE_ERR_ARG,
+                  "gnnpe_rows_append: neighbour buffer full (%llu + %llu > %llu); reserve more in gnnpe_load_rows",
+                  (unsigned long long)c->nbr_used, (unsigned long long)n_keep, (unsigned long long)c->nbr_cap);
+    if (roff == dst_off)
+        hipLaunchKernelGGL(k_rows_compact, dim3(grid_for(n_rows * 64)), dim3(kBlock), 0, c->stream, n_rows, src_off,
+                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), min_rank, dst_off,
+                           c->nbrs.as<uint32_t>() + c->nbr_used);
+    else if (n_nbrs)
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.as<uint32_t>() + c->nbr_used, dev_nbrs, n_nbrs * 4, hipMemcpyDeviceToDevice,
+                                     c->stream));
     GNNPE_HIP_TRY(hipMemcpyAsync(c->held.as<uint32_t>() + c->n_held, dev_ids, n_rows * 4, hipMemcpyDeviceToDevice,
                                  c->stream));
     hipLaunchKernelGGL(k_install_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, n_rows,
                        (const uint32_t *)dev_ids, roff, c->nbr_used, c->adj_start.as<uint32_t>(),
                        c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
-    hipLaunchKernelGGL(k_revpos, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, c->stream, (uint32_t)n_rows,
-                       (const uint32_t *)dev_ids, c->owned.as<uint8_t>(), c->adj_start.as<uint32_t>(),
-                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->revpos.as<uint32_t>(), c->nbr_row.as<uint32_t>());
     GNNPE_HIP_TRY(hipGetLastError());
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->nbr_used += n_nbrs;
+    const uint32_t first_new = c->n_held;
+    c->nbr_used += n_keep;
     c->n_held += (uint32_t)n_rows;
     c->nbr_vde_valid = false;
     c->counted = false;
-    return GNNPE_OK;
+    // validation, reverse positions and the hub list: graph structure, built when the rows arrive (synchronises)
+    return finish_rows(c, n_rows, c->held.as<uint32_t>() + first_new);
 }
 
 }  // extern "C"

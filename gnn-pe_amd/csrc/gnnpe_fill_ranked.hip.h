@@ -1,36 +1,37 @@
-// gnnpe_fill_ranked.hip.h -- enumeration variant 4 (default): rank-sorted neighbour records.
+// gnnpe_fill_ranked.hip.h -- the enumeration (R2 count + emit, R5 embeddings; custom.h:52-92, 546-572) at l = 2.
 //
-// Why: the wave-per-start fill over id-sorted rows (variant 3) is bound by the traffic it moves -- every (s, b) pair
-// re-reads the WHOLE neighbour list of b (ids, ranks, embeddings: 24 B per candidate, ~half of them
-// discarded by the rank test), 10-20 GB per launch next to 12 GB of output (profiles/r01_pmc_fill.json).
-// Here each row's neighbours are stored a second time as 8+8e-byte records {id, id-position, vde}
-// SORTED BY RANK.  The neighbours c of b with rank[c] > rank[s] are then exactly the records after
-// s's own position: one contiguous suffix, no rank stream, nothing read and thrown away.  The output
-// order inside a pair is ascending id, so every pair also carries G = the 64-bit set of id-positions
-// with greater rank: a kept record with id-position ip lands at slot popcount(G & ((1 << ip) - 1)).
-// Per-pair counts are popcount(G) -- the count pass needs no scan of candidates either.
+// Layout idea: every adjacency row of degree <= 64 is stored a second time as 8+8e-byte records {id, id-position,
+// vde} SORTED BY RANK (k_rows_rank).  The neighbours c of b with rank[c] > rank[s] are then exactly the records after
+// s's own position: one contiguous suffix, no rank stream, nothing read and thrown away.  The output order inside a
+// pair is ascending id, so every (s, b) pair also carries G = the 64-bit set of id-positions with greater rank: a kept
+// record with id-position ip lands at slot popcount(G & ((1 << ip) - 1)); the pair's count is popcount(G), so the
+// count pass scans no candidates either.  The pair record also carries vde[b], so the emit kernel has no dependent
+// gather: start record -> pair records -> neighbour records -> stores.
 //
-// Restriction: rows of degree <= 64 (one bit per id-position).  gnnpe_count_paths falls back to
-// variant 3 when the held graph has a longer row; on power-law inputs, where hub rows carry most paths and
-// stream well, variant 3 reaches the same fraction of the HBM peak (0.63) as this one does on G(n,m).
+// Rows longer than 64 ("hub" rows; Test/data_graph.graph has one of degree 168) keep id order: their records are
+// {id, rank, vde}, their pair counts come from a per-row sort of the ranks (hipCUB segmented sort, hubs only) and the
+// emit kernel streams them with a ballot compaction -- in the same launch, pair by pair, so one graph may mix both.
 #pragma once
 
 #include "gnnpe_kernels.hip.h"
 
 namespace gnnpe {
 
-// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)).
-// 16 bytes so the scattered store of the row kernel is ONE dwordx4; the middle vertex itself is
-// re-read from N(s) (contiguous) by the fill, the count is popcount(G).
+constexpr uint32_t kHubFlag = 0x80000000u;  // RankedPair::cnt bit: the pair's middle row is a hub row
+constexpr uint32_t kHubDegree = 64;         // rows longer than this are hub rows
+constexpr uint32_t kRowAlign = 128;         // row blocks start on L2 lines: the fabric fetches whole 128-byte lines
+
+// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)): 16 bytes, one
+// dwordx4 store scattered by the row kernel, one contiguous load per lane in the emit kernel
 struct __attribute__((aligned(16))) RankedPair {
-    uint32_t sstart;  // first kept record: adj_start[b] + (rank-position of s in N(b)) + 1
-    uint32_t pad;
-    uint64_t G;       // id-positions of N(b) with rank > rank[s]
+    uint32_t block;  // row block of b, in kRowAlign units: header vde[b], then the records
+    uint32_t cnt;    // paths of the pair = records to read from the front of the block (| kHubFlag: hub row)
+    uint64_t G;      // id-positions of N(b) with rank > rank[s]; hub: deg(b)
 };
 
 // one gather per adjacency entry instead of three: {vde[v], rank[v], first pair slot of v as a start vertex} side
-// by side, VINFO_STRIDE(E) doubles per vertex (E = 2 -> 32 bytes: one aligned half cache line).  The kernel issues
-// about as many random requests per second as the chip sustains (6-8e10/s), so requests are what to save.
+// by side, VINFO_STRIDE(E) doubles per vertex (E = 2 -> 32 bytes: one aligned half cache line).  The row kernel issues
+// about as many random requests per second as the chip sustains (5-8e10/s), so requests are what to save.
 #define GNNPE_VINFO_STRIDE(E) ((E) + 2)
 template <int E>
 __global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const uint32_t *__restrict__ rank,
@@ -48,36 +49,72 @@ __global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const u
     }
 }
 
-template <int E> struct __attribute__((aligned(8))) RankedNbr {
-    uint32_t id, idpos;
+// Neighbour records.  Wide: {id, id-position, vde} (hub rows: {id, rank, vde}); packed (graphs of up to 2^26
+// vertices): the id-position rides in the id's top 6 bits -- 4 bytes less per emitted path to fetch.
+template <int E> struct __attribute__((packed, aligned(4))) RecWide {
+    uint32_t id, aux;
     double vde[E];
 };
+template <int E> struct __attribute__((packed, aligned(4))) RecPacked {
+    uint32_t idp;
+    double vde[E];
+};
+constexpr uint32_t kPackedIdBits = 26;
+template <int E, bool PACKED> struct RecOf { typedef RecWide<E> type; };
+template <int E> struct RecOf<E, true> { typedef RecPacked<E> type; };
 
 struct CntOfPair {
-    __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)__popcll(p.G); }
+    __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)(p.cnt & ~kHubFlag); }
 };
+
+// 128-byte units of a held row's block: header (vde of the row's vertex) + its records
+__global__ void k_row_block_units(uint32_t n_held, const uint32_t *__restrict__ held, const uint32_t *__restrict__ adj_deg,
+                                  uint32_t hdr_bytes, uint32_t rec_bytes, uint32_t hub_rec_bytes,
+                                  uint32_t *__restrict__ units)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k <= n_held; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t u = 0;
+        if (k < n_held) {
+            const uint32_t d = adj_deg[held ? held[k] : (uint32_t)k];
+            const uint64_t bytes = hdr_bytes + (uint64_t)d * (d > kHubDegree ? hub_rec_bytes : rec_bytes);
+            u = d ? (uint32_t)((bytes + kRowAlign - 1) / kRowAlign) : 0u;
+        }
+        units[k] = u;
+    }
+}
+__global__ void k_row_block_starts(uint32_t n_held, const uint32_t *__restrict__ held, const uint32_t *__restrict__ off,
+                                   uint32_t *__restrict__ rblock)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_held; k += (uint64_t)gridDim.x * blockDim.x)
+        rblock[held ? held[k] : (uint32_t)k] = off[k];
+}
 
 // One wave per held row b (degree <= 64), one lane per neighbour u_j:
 //   G_j  = { i : rank[u_i] > rank[u_j] }          (d wave-uniform readlanes)
-//   p_j  = d - 1 - |G_j|                            rank-position of u_j inside the row
-//   recs[adj_start + p_j] = { u_j, j, vde[u_j] }    the row, sorted by rank
-//   pairs[index of (s = u_j, b)] = { adj_start + p_j + 1, G_j }              when u_j starts paths here
-template <int E>
+//   block[b] = [ vde[b] | records in DESCENDING rank order ]: u_j's record {u_j, j, vde[u_j]} sits at position |G_j|,
+//              so the neighbours ranked after any s are the block's FIRST |G_s| records -- every read of the emit
+//              kernel starts on the block's (line-aligned) first byte
+//   pairs[index of (s = u_j, b)] = { block, |G_j|, G_j }              when u_j starts paths here
+template <int E, bool PACKED>
 __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32_t *__restrict__ held,
                                                    const uint32_t *__restrict__ adj_start,
                                                    const uint32_t *__restrict__ adj_deg,
                                                    const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
                                                    const uint32_t *__restrict__ revpos,
-                                                   RankedNbr<E> *__restrict__ recs, RankedPair *__restrict__ pairs)
+                                                   const uint32_t *__restrict__ rblock, char *__restrict__ recs,
+                                                   RankedPair *__restrict__ pairs)
 {
+    typedef typename RecOf<E, PACKED>::type Rec;
     const unsigned lane = lane_id();
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int S = GNNPE_VINFO_STRIDE(E);
     for (; w < n_held; w += nw) {
         const uint32_t b = held ? held[w] : (uint32_t)w;
         const uint32_t st = adj_start[b], d = adj_deg[b];
-        if (d == 0 || d > 64) continue;  // longer rows: the caller does not select this variant
-        constexpr int S = GNNPE_VINFO_STRIDE(E);
+        if (d == 0 || d > kHubDegree) continue;  // hub rows: k_hub_records / k_hub_pairs
+        const uint32_t blk = rblock[b];
+        char *const base = recs + (uint64_t)blk * kRowAlign;
         uint32_t u = 0, r = 0, rp = kNoEdge, po = kNoEdge;
         double vu[E];
 #pragma unroll
@@ -92,161 +129,345 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             po = (uint32_t)(rw >> 32);
             rp = revpos[st + lane];
         }
+        if (lane < (unsigned)E) reinterpret_cast<double *>(base)[lane] = vinfo[(uint64_t)b * S + lane];  // header
         uint64_t G = 0;
         for (uint32_t i = 0; i < d; i++) G |= (uint64_t)(rl32(r, (int)i) > r ? 1u : 0u) << i;
         if (lane < d) {
             const uint32_t cnt = (uint32_t)__popcll(G);
-            const uint32_t p = d - 1 - cnt;
-            RankedNbr<E> rec;
-            rec.id = u;
-            rec.idpos = lane;
+            Rec rec;
+            if constexpr (PACKED) {
+                rec.idp = u | (lane << kPackedIdBits);
+            } else {
+                rec.id = u;
+                rec.aux = lane;
+            }
 #pragma unroll
             for (int k = 0; k < E; k++) rec.vde[k] = vu[k];
-            recs[st + p] = rec;
+            reinterpret_cast<Rec *>(base + 8 * E)[cnt] = rec;
             if (rp != kNoEdge && po != kNoEdge) {  // (u, b) is a pair of this slab: u starts here and its row is held
-                const uint32_t pi = po + rp;
-                RankedPair pr = {st + p + 1, 0u, G};
-                pairs[pi] = pr;
+                RankedPair pr = {blk, cnt, G};
+                pairs[po + rp] = pr;
             }
         }
     }
 }
 
-// One wave per start vertex s.  The pairs of s are taken in batches of whole pairs with at most kBatch
-// kept records; the batch's records are flattened over the lanes (binary search in the wave's LDS strip
-// maps record -> pair), each lane reads ONE contiguous record, computes its slot from G, parks the
-// row (12 B ids + 24e B embeddings) in the wave's staging strip, and the strip is flushed with
-// consecutive lanes on consecutive 16-byte / 4-byte pieces (non-temporal).
-// rows staged per wave: 128 at e <= 2; wider rows take 64 (the minimum: a pair holds up to 63 records) so that the
-// staging strips leave room for more than one workgroup per CU
-template <int E> struct FillBatch { static constexpr int rows = E <= 2 ? 128 : 64; };
-
+// Hub rows, pass 1 (one wave per hub row): header + records {id, rank, vde} in id order, and the row's neighbour ranks
+// as a stream for the per-row sort.
 template <int E>
-__global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
-                                                     const RankedPair *__restrict__ pairs,
-                                                     const RankedNbr<E> *__restrict__ recs, uint32_t slab_len)
+__global__ __launch_bounds__(256) void k_hub_records(uint32_t n_hub, const uint32_t *__restrict__ hub_rows,
+                                                     const uint32_t *__restrict__ adj_start,
+                                                     const uint32_t *__restrict__ adj_deg,
+                                                     const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
+                                                     const uint32_t *__restrict__ rblock, char *__restrict__ recs,
+                                                     uint32_t *__restrict__ nbr_rank)
 {
-    constexpr int D = 3 * E;
-    constexpr int kBatch = FillBatch<E>::rows;
-    __shared__ uint32_t s_cs[4][65], s_ss[4][64], s_b[4][64];
-    __shared__ uint64_t s_G[4][64];
-    __shared__ __attribute__((aligned(16))) double s_vb[4][64 * E];
-    __shared__ __attribute__((aligned(16))) uint32_t s_ids[4][kBatch * 3];
-    __shared__ __attribute__((aligned(16))) double s_pde[4][kBatch * D];
-    const unsigned lane = lane_id(), wv = wave_id();
+    const unsigned lane = lane_id();
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int S = GNNPE_VINFO_STRIDE(E);
+    for (; w < n_hub; w += nw) {
+        const uint32_t b = hub_rows[w];
+        const uint32_t st = adj_start[b], d = adj_deg[b];
+        char *const base = recs + (uint64_t)rblock[b] * kRowAlign;
+        if (lane < (unsigned)E) reinterpret_cast<double *>(base)[lane] = vinfo[(uint64_t)b * S + lane];
+        for (uint32_t j = lane; j < d; j += 64) {
+            const uint32_t u = nbrs[st + j];
+            const double *vi = vinfo + (uint64_t)u * S;
+            RecWide<E> rec;
+            rec.id = u;
+            rec.aux = (uint32_t) reinterpret_cast<const uint64_t *>(vi)[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) rec.vde[k] = vi[k];
+            reinterpret_cast<RecWide<E> *>(base + 8 * E)[j] = rec;
+            nbr_rank[st + j] = rec.aux;
+        }
+    }
+}
+
+// Hub rows, pass 2 (after the per-row sort of the ranks): pair (s = u_j, b) keeps the neighbours ranked after s --
+// deg(b) minus the number of neighbours ranked up to and including s.
+template <int E>
+__global__ __launch_bounds__(256) void k_hub_pairs(uint32_t n_hub, const uint32_t *__restrict__ hub_rows,
+                                                   const uint32_t *__restrict__ adj_start,
+                                                   const uint32_t *__restrict__ adj_deg,
+                                                   const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
+                                                   const uint32_t *__restrict__ revpos,
+                                                   const uint32_t *__restrict__ rank_sorted,
+                                                   const uint32_t *__restrict__ rblock, RankedPair *__restrict__ pairs)
+{
+    const unsigned lane = lane_id();
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int S = GNNPE_VINFO_STRIDE(E);
+    for (; w < n_hub; w += nw) {
+        const uint32_t b = hub_rows[w];
+        const uint32_t st = adj_start[b], d = adj_deg[b], blk = rblock[b];
+        for (uint32_t j = lane; j < d; j += 64) {
+            const uint32_t rp = revpos[st + j];
+            if (rp == kNoEdge) continue;
+            const uint32_t u = nbrs[st + j];
+            const uint64_t rw = reinterpret_cast<const uint64_t *>(vinfo + (uint64_t)u * S)[E];
+            const uint32_t r = (uint32_t)rw, po = (uint32_t)(rw >> 32);
+            if (po == kNoEdge) continue;
+            uint32_t lo = 0, hi = d;  // first position with a rank > r
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rank_sorted[st + mid] <= r) lo = mid + 1; else hi = mid;
+            }
+            RankedPair pr = {blk, (d - lo) | kHubFlag, (uint64_t)d};
+            pairs[po + rp] = pr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The emit kernel: one wave per start vertex s, all of whose paths are one contiguous run of the output.
+//   strip   : the pairs of s, 64 at a time, one lane each -- {row block, G, b} and the scan of their counts sit in a
+//             per-wave LDS strip.
+//   batch   : whole pairs with at most kBatch kept records.  The batch's records are flattened over the lanes (binary
+//             search in the strip maps record -> pair); a lane reads ONE record {c, id-position, vde[c]} from the
+//             front of the pair's row block and parks {c, pair slot, vde[c]} at its output row (from G) in the
+//             wave's staging rows (8+8e B per row; s, b, vde[s], vde[b] are not copied per row: the flush picks them
+//             out of the strip).  The lane on a pair's first record also reads the block's header, vde[b] -- same line.
+//   hub pair: streamed instead -- 64 id-ordered records per step, kept iff rank > rank[s], ballot compaction.
+//   flush   : rows -> global memory, consecutive lanes on consecutive 16-byte pieces of the pde rows and on
+//             consecutive 12-byte id rows, non-temporal.
+// Measured (config 3, profiles/r02*): the launch moves what the fabric can move for this read/write mix (20.4 GB at
+// 5.0 TB/s before the aligned blocks); waves per SIMD beyond 5 change nothing, spilling to reach 8 costs 6-25 %.
+// ------------------------------------------------------------------------------------------------------------------
+template <int E> struct FillBatch { static constexpr int rows = E <= 2 ? 128 : 64; };
+
+struct __attribute__((packed, aligned(4))) IdRow {
+    uint32_t s, b, c;
+};
+
+template <int E, bool PACKED, int kBatch>
+__global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
+                                                     const RankedPair *__restrict__ pairs,
+                                                     const char *__restrict__ recs, uint32_t slab_len)
+{
+    typedef typename RecOf<E, PACKED>::type Rec;
+    constexpr int D = 3 * E;
+    constexpr int EP = E + (E & 1);  // even number of doubles per LDS embedding slot (16-byte slots)
+    static_assert(kBatch >= 64 && kBatch % 64 == 0, "a pair holds up to 63 records; the hub path stages 64 per step");
+    __shared__ uint32_t s_cs[4][66], s_blk[4][64], s_b[4][64];
+    __shared__ uint64_t s_G[4][64];
+    __shared__ __attribute__((aligned(16))) double s_vb[4][64 * EP];
+    __shared__ __attribute__((aligned(16))) double s_vs[4][EP];
+    __shared__ uint32_t s_id[4][kBatch];
+    __shared__ uint8_t s_a[4][kBatch];
+    __shared__ __attribute__((aligned(16))) double s_v[4][kBatch * EP];
+    const unsigned lane = lane_id(), wv = wave_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t nw = (uint32_t)((gridDim.x * (uint64_t)blockDim.x) >> 6);
     const bool want_pde = P.out_pde != nullptr;
-    uint32_t *const my_ids = s_ids[wv];
-    double *const my_pde = s_pde[wv];
+    uint32_t *const cs = s_cs[wv], *const sblk = s_blk[wv], *const sb = s_b[wv], *const sid = s_id[wv];
+    uint64_t *const sG = s_G[wv];
+    uint8_t *const sa = s_a[wv];
+    double *const svb = s_vb[wv], *const svs = s_vs[wv], *const sv = s_v[wv];
 
-    for (; w < slab_len; w += nw) {
-        const StartRec sr = srec[w];
-        if (sr.end == sr.base || sr.base >= P.end || sr.end <= P.begin) continue;
-        const uint32_t s = sr.s, e0 = sr.e0, ds = sr.ds;
-        double vs[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) vs[k] = want_pde ? P.vde[(uint64_t)s * E + k] : 0.0;
-        uint64_t chunk_base = sr.base;  // output slot of the chunk's first row
-
-        for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            RankedPair pr = {0u, 0u, 0ull};
-            uint32_t bk = 0;
-            if (k < ds) {
-                pr = pairs[e0 + k];
-                bk = P.nbrs[sr.a_s + k];  // the k-th neighbour of s is the pair's middle vertex
+    // rows [0, nr) of the staging area -> output slots [slot0, slot0 + nr) clipped to [P.begin, P.end)
+    auto flush = [&](uint32_t s, uint64_t slot0, uint32_t nr_all) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t glo = max(slot0, P.begin), ghi = min(slot0 + nr_all, P.end);
+        if (ghi > glo) {
+            const uint32_t r0 = (uint32_t)(glo - slot0), nr = (uint32_t)(ghi - glo);
+            const uint64_t o = glo - P.begin;
+            if (P.out_ids) {
+                IdRow *dst = reinterpret_cast<IdRow *>(P.out_ids) + o;
+#pragma unroll 1
+                for (uint32_t g = lane; g < nr; g += 64) {
+                    IdRow t = {s, sb[sa[r0 + g]], sid[r0 + g]};
+                    dst[g] = t;
+                }
             }
-            const uint32_t pcnt = (uint32_t)__popcll(pr.G);
-            uint32_t incl = pcnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if (lane >= (unsigned)off) incl += t;
-            }
-            const uint32_t C = rl32(incl, 63);
-            s_cs[wv][lane] = incl - pcnt;
-            s_ss[wv][lane] = pr.sstart;
-            s_b[wv][lane] = bk;
-            s_G[wv][lane] = pr.G;
-            if (lane == 0) s_cs[wv][64] = C;
-            if (want_pde && k < ds) {
-#pragma unroll
-                for (int kk = 0; kk < E; kk++) s_vb[wv][lane * E + kk] = P.vde[(uint64_t)bk * E + kk];
-            }
-            __builtin_amdgcn_wave_barrier();
-
-            // batches of whole pairs: [kb, ke) with cs[ke] - cs[kb] <= kBatch (a pair holds <= 63 records)
-            uint32_t kb = 0;
-            while (kb < 64 && s_cs[wv][kb] < C) {
-                const uint32_t lo = s_cs[wv][kb];
-                // largest ke in (kb, 64] with cs[ke] - lo <= kBatch: lanes test ke = lane + 1
-                const bool fits = (lane + 1 > kb) && (s_cs[wv][lane + 1] - lo <= (uint32_t)kBatch);
-                const uint64_t m = __ballot(fits);
-                const uint32_t ke = 64u - (uint32_t)__clzll(m);  // m != 0: ke = kb + 1 always fits
-                const uint32_t hi = s_cs[wv][ke];
-                for (uint32_t f = lo + lane; f < hi; f += 64) {
-                    uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= f
-                    while (bnd - a > 1) {
-                        const uint32_t mid = (a + bnd) >> 1;
-                        if (s_cs[wv][mid] <= f) a = mid; else bnd = mid;
+            if (want_pde) {
+                if constexpr ((E & 1) == 0) {
+                    typedef double dbl2 __attribute__((ext_vector_type(2)));
+                    constexpr uint32_t H = E / 2, PR = 3 * H;  // 16-byte pieces per vertex / per row
+                    dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o * D);
+#pragma unroll 1
+                    for (uint32_t g = lane; g < nr * PR; g += 64) {
+                        const uint32_t row = r0 + g / PR, within = g % PR, which = within / H, sub = within % H;
+                        const double *src = which == 0 ? svs + 2 * sub
+                                            : which == 1 ? svb + (uint32_t)sa[row] * EP + 2 * sub
+                                                         : sv + row * EP + 2 * sub;
+                        __builtin_nontemporal_store(*reinterpret_cast<const dbl2 *>(src), &dst[g]);
                     }
-                    const RankedNbr<E> rec = recs[s_ss[wv][a] + (f - s_cs[wv][a])];
-                    const uint64_t below = s_G[wv][a] & ((1ull << rec.idpos) - 1ull);
-                    const uint32_t row = (s_cs[wv][a] - lo) + (uint32_t)__popcll(below);
-                    my_ids[row * 3 + 0] = s;
-                    my_ids[row * 3 + 1] = s_b[wv][a];
-                    my_ids[row * 3 + 2] = rec.id;
-                    if (want_pde) {
-#pragma unroll
-                        for (int k2 = 0; k2 < E; k2++) {
-                            my_pde[row * D + k2] = vs[k2];
-                            my_pde[row * D + E + k2] = s_vb[wv][a * E + k2];
-                            my_pde[row * D + 2 * E + k2] = rec.vde[k2];
-                        }
+                } else {
+                    double *dst = P.out_pde + o * D;
+#pragma unroll 1
+                    for (uint32_t g = lane; g < nr * D; g += 64) {
+                        const uint32_t row = r0 + g / D, within = g % D, which = within / E, sub = within % E;
+                        const double *src = which == 0 ? svs + sub : which == 1 ? svb + (uint32_t)sa[row] * EP + sub : sv + row * EP + sub;
+                        __builtin_nontemporal_store(*src, &dst[g]);
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                // flush rows [0, hi - lo) -> output slots chunk_base + lo ...
-                {
-                    const uint64_t fb = chunk_base + lo;
-                    const uint64_t glo = max(fb, P.begin), ghi = min(fb + (hi - lo), P.end);
-                    if (ghi > glo) {
-                        const uint32_t r0 = (uint32_t)(glo - fb), nr = (uint32_t)(ghi - glo);
-                        const uint64_t o = glo - P.begin;
-                        if (P.out_ids)
-                            for (uint32_t g = lane; g < nr * 3; g += 64)
-                                __builtin_nontemporal_store(my_ids[r0 * 3 + g], &P.out_ids[o * 3 + g]);
-                        if (want_pde) {
-                            if ((D & 1) == 0) {
-                                typedef double dbl2 __attribute__((ext_vector_type(2)));
-                                const dbl2 *src = reinterpret_cast<const dbl2 *>(my_pde + (size_t)r0 * D);
-                                dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o * D);
-                                for (uint32_t g = lane; g < nr * (D / 2); g += 64) __builtin_nontemporal_store(src[g], &dst[g]);
-                            } else {
-                                for (uint32_t g = lane; g < nr * D; g += 64) P.out_pde[o * D + g] = my_pde[(size_t)r0 * D + g];
-                            }
-                        }
-                        if (P.out_part)
-                            for (uint32_t g = lane; g < nr; g += 64) P.out_part[o + g] = sr.part;
-                        if (P.out_pdl) {
-                            for (uint32_t g = lane; g < nr; g += 64) {
-                                const uint32_t bb = my_ids[(r0 + g) * 3 + 1], cv = my_ids[(r0 + g) * 3 + 2];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    auto load_pairs = [&](const StartRec &sr, uint32_t k0, RankedPair &pr, uint32_t &bk) {
+        pr.block = 0;
+        pr.cnt = 0;
+        pr.G = 0;
+        bk = 0;
+        const uint32_t k = k0 + lane;
+        if (k < sr.ds) {
+            pr = pairs[sr.e0 + k];
+            bk = P.nbrs[sr.a_s + k];  // the k-th neighbour of s is the pair's middle vertex
+        }
+    };
+
+    // a wave's start vertices: w, w + nw, ... (wave-uniform, so the start record arrives through the scalar cache)
+    for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); w < slab_len;
+         w += nw) {
+        const StartRec sr = srec[w];
+        RankedPair pr;
+        uint32_t bk;
+        if (sr.end != sr.base && sr.base < P.end && sr.end > P.begin) {
+            const uint32_t s = sr.s, ds = sr.ds, thr = P.slab_begin + w;
+            if (want_pde && lane < (unsigned)E) svs[lane] = P.vde[(uint64_t)s * E + lane];
+            uint64_t chunk_base = sr.base;  // output slot of the strip's first row
+            for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
+                load_pairs(sr, k0, pr, bk);
+                const uint32_t pcnt = pr.cnt & ~kHubFlag;
+                uint32_t incl = pcnt;
 #pragma unroll
-                                for (int k2 = 0; k2 < E; k2++) {
-                                    P.out_pdl[(o + g) * D + k2] = P.x[(uint64_t)s * E + k2];
-                                    P.out_pdl[(o + g) * D + E + k2] = P.x[(uint64_t)bb * E + k2];
-                                    P.out_pdl[(o + g) * D + 2 * E + k2] = P.x[(uint64_t)cv * E + k2];
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off);
+                    if (lane >= (unsigned)off) incl += t;
+                }
+                const uint32_t C = rl32(incl, 63);
+                const uint64_t hubs = __ballot((pr.cnt & kHubFlag) != 0);
+                cs[lane] = incl - pcnt;
+                sblk[lane] = pr.block;
+                sb[lane] = bk;
+                sG[lane] = pr.G;
+                if (lane == 0) cs[64] = C;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // batches: whole pairs with at most kBatch kept records, or up to kBatch kept records of one hub pair
+                uint32_t kb = 0, hub_j = 0, hub_done = 0;
+                while (kb < 64 && cs[kb] < C) {
+                    const uint32_t lo = cs[kb];
+                    uint32_t nr, first_row;
+                    if ((hubs >> kb) & 1ull) {
+                        // hub pair: stream the id-ordered row from entry hub_j on, keep what ranks after s
+                        const char *const base = recs + (uint64_t)sblk[kb] * kRowAlign;
+                        const uint32_t d = (uint32_t)sG[kb];
+                        if (want_pde && hub_j == 0 && lane < (unsigned)E) svb[kb * EP + lane] = reinterpret_cast<const double *>(base)[lane];
+                        uint32_t fill = 0;
+#pragma unroll 1
+                        while (hub_j < d && fill + 64 <= (uint32_t)kBatch) {
+                            const uint32_t j = hub_j + lane;
+                            RecWide<E> rec;
+                            rec.id = 0;
+                            rec.aux = 0;
+                            if (j < d) rec = reinterpret_cast<const RecWide<E> *>(base + 8 * E)[j];
+                            const bool keep = j < d && rec.aux > thr;
+                            const uint64_t mask = __ballot(keep);
+                            if (keep) {
+                                const uint32_t row = fill + (uint32_t)__popcll(mask & lt);
+                                sid[row] = rec.id;
+                                sa[row] = (uint8_t)kb;
+                                if (want_pde) {
+#pragma unroll
+                                    for (int k2 = 0; k2 < E; k2++) sv[row * EP + k2] = rec.vde[k2];
+                                }
+                            }
+                            fill += (uint32_t)__popcll(mask);
+                            hub_j += 64;
+                        }
+                        nr = fill;
+                        first_row = lo + hub_done;
+                        hub_done += fill;
+                        if (hub_j >= d) {
+                            kb++;
+                            hub_j = 0;
+                            hub_done = 0;
+                        }
+                    } else {
+                        // whole pairs [kb, ke): cs[ke] - cs[kb] <= kBatch, no hub pair inside
+                        const uint32_t first_hub = (hubs >> kb) ? kb + (uint32_t)__builtin_ctzll(hubs >> kb) : 64u;
+                        const bool fits = (lane + 1 > kb) && (lane + 1 <= first_hub) && (cs[lane + 1] - lo <= (uint32_t)kBatch);
+                        const uint64_t m = __ballot(fits);
+                        const uint32_t ke = 64u - (uint32_t)__clzll(m);  // m != 0: ke = kb + 1 always fits (<= 63 records)
+                        const uint32_t hi = cs[ke];
+#pragma unroll 1
+                        for (uint32_t f = lo + lane; f < hi; f += 64) {
+                            uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= f
+                            while (bnd - a > 1) {
+                                const uint32_t mid = (a + bnd) >> 1;
+                                if (cs[mid] <= f) a = mid; else bnd = mid;
+                            }
+                            const uint32_t ca = cs[a];
+                            const char *const base = recs + (uint64_t)sblk[a] * kRowAlign;
+                            const Rec rec = reinterpret_cast<const Rec *>(base + 8 * E)[f - ca];
+                            uint32_t id, ip;
+                            if constexpr (PACKED) {
+                                id = rec.idp & ((1u << kPackedIdBits) - 1u);
+                                ip = rec.idp >> kPackedIdBits;
+                            } else {
+                                id = rec.id;
+                                ip = rec.aux;
+                            }
+                            const uint64_t below = sG[a] & ((1ull << ip) - 1ull);
+                            const uint32_t row = (ca - lo) + (uint32_t)__popcll(below);
+                            sid[row] = id;
+                            sa[row] = (uint8_t)a;
+                            if (want_pde) {
+#pragma unroll
+                                for (int k2 = 0; k2 < E; k2++) sv[row * EP + k2] = rec.vde[k2];
+                                if (f == ca) {  // first record of the pair: the header (vde[b]) is in the same line
+#pragma unroll
+                                    for (int k2 = 0; k2 < E; k2++) svb[a * EP + k2] = reinterpret_cast<const double *>(base)[k2];
                                 }
                             }
                         }
+                        nr = hi - lo;
+                        first_row = lo;
+                        kb = ke;
                     }
+                    flush(s, chunk_base + first_row, nr);
                 }
-                __builtin_amdgcn_wave_barrier();
-                kb = ke;
+                chunk_base += C;
             }
-            chunk_base += C;
         }
+    }
+}
+
+// Secondary outputs, from what the emit kernel wrote.  Partition of every path's start vertex (what main.cpp:98-108
+// groups partition_paths.txt by): one wave per start vertex fills its run.
+__global__ void k_start_parts(uint32_t slab_len, const StartRec *__restrict__ srec, uint64_t begin, uint64_t end,
+                              uint32_t *__restrict__ out_part)
+{
+    const unsigned lane = lane_id();
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w < slab_len; w += nw) {
+        const uint64_t lo = max(srec[w].base, begin), hi = min(srec[w].end, end);
+        const uint32_t part = srec[w].part;
+        for (uint64_t o = lo + lane; o < hi; o += 64) out_part[o - begin] = part;
+    }
+}
+// pde_label (gen_pde, custom.h:561-567): the label features x of the path's vertices, gathered from the emitted ids
+__global__ void k_pdl_from_ids(uint64_t n_rows, uint32_t L, uint32_t e, const uint32_t *__restrict__ ids,
+                               const double *__restrict__ x, double *__restrict__ out)
+{
+    const uint64_t D = (uint64_t)L * e, tot = n_rows * D;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / D;
+        const uint32_t k = (uint32_t)(i % D);
+        out[i] = x[(uint64_t)ids[r * L + k / e] * e + k % e];
     }
 }
 

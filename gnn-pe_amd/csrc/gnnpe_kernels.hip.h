@@ -198,8 +198,7 @@ __device__ __forceinline__ uint32_t rl32(uint32_t v, int l) { return (uint32_t)_
 // the adjacency lists (graph.cpp:231-233).  16 lanes per row, one binary search per entry.
 __global__ void k_revpos(uint32_t n_rows, const uint32_t *__restrict__ rows, const uint8_t *__restrict__ owned,
                          const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
-                         const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ revpos,
-                         uint32_t *__restrict__ nbr_row)
+                         const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ revpos)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
@@ -220,7 +219,49 @@ __global__ void k_revpos(uint32_t n_rows, const uint32_t *__restrict__ rows, con
                 if (lo < du && nbrs[lo0 + lo] == b) r = lo;
             }
             revpos[st + i] = r;
-            nbr_row[st + i] = b;  // row of every adjacency entry (lets kernels run one thread per entry)
+        }
+    }
+}
+
+// Load-time validation of adjacency rows handed over through the C-ABI (the loader's own output is valid by
+// construction, graph.cpp:231-233 sorts every list): neighbour ids < n, strictly ascending (sorted, no duplicate edge),
+// no self-loop.  Every kernel indexes per-vertex tables by neighbour id and binary-searches rows, and the closed-form
+// count assumes a simple graph.  bad[0] = smallest offending row (atomicMin), untouched when all rows are fine.
+__global__ void k_validate_rows(uint32_t n, uint64_t n_rows, const uint32_t *__restrict__ rows,
+                                const uint32_t *__restrict__ adj_start, const uint32_t *__restrict__ adj_deg,
+                                const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ bad)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < n_rows; g += ng) {
+        const uint32_t b = rows ? rows[g] : (uint32_t)g;
+        const uint32_t st = adj_start[b], d = adj_deg[b];
+        bool ok = true;
+        for (uint32_t i = sub; i < d; i += 16) {
+            const uint32_t u = nbrs[st + i];
+            if (u >= n || u == b || (i > 0 && nbrs[st + i - 1] >= u)) ok = false;
+        }
+        if (!ok) atomicMin(bad, b);
+    }
+}
+
+// Rows longer than `limit` (hub rows of the enumeration): their ids, and [begin, end) of their adjacency for the
+// per-row sorts.  Order of the list is arbitrary (atomic append); nothing downstream depends on it.
+__global__ void k_hub_list(uint64_t n_rows, const uint32_t *__restrict__ rows, const uint32_t *__restrict__ adj_start,
+                           const uint32_t *__restrict__ adj_deg, uint32_t limit, uint32_t *__restrict__ counter,
+                           uint32_t *__restrict__ hub_rows, uint32_t *__restrict__ hub_beg, uint32_t *__restrict__ hub_end)
+{
+    for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < n_rows; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = rows ? rows[g] : (uint32_t)g;
+        const uint32_t d = adj_deg[b];
+        if (d > limit) {
+            const uint32_t k = atomicAdd(counter, 1u);
+            if (hub_rows) {
+                hub_rows[k] = b;
+                hub_beg[k] = adj_start[b];
+                hub_end[k] = adj_start[b] + d;
+            }
         }
     }
 }
@@ -369,6 +410,58 @@ __global__ void k_rows_pack(uint64_t n_req, const uint32_t *__restrict__ ids, co
         const uint64_t o = roff[g];
         const uint32_t d = (uint32_t)(roff[g + 1] - o);
         for (uint32_t j = sub; j < d; j += 16) out[o + j] = nbrs[a + j];
+    }
+}
+
+// Truncated halo rows (multi-GPU): a rank whose slab starts at processing position min_rank never emits a path through
+// a neighbour ranked before it (kept iff rank[c] > rank[s] >= min_rank), so the entries with rank < min_rank of a halo
+// row are dropped when the row is installed.  kept[k] = entries of packed row k that stay; 16 lanes per row.
+__global__ void k_rows_kept_counts(uint64_t n_rows, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src,
+                                   const uint32_t *__restrict__ rank, uint32_t min_rank, uint32_t *__restrict__ kept)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    const uint64_t g_end = (n_rows + 3) & ~(uint64_t)3;  // whole waves take part in the shuffles
+    for (; g < g_end; g += ng) {
+        uint32_t cnt = 0;
+        if (g < n_rows) {
+            const uint64_t a = src_off[g], b = src_off[g + 1];
+            for (uint64_t q = a + sub; q < b; q += 16) cnt += rank[src[q]] >= min_rank ? 1u : 0u;
+        }
+        cnt += __shfl_xor(cnt, 8);
+        cnt += __shfl_xor(cnt, 4);
+        cnt += __shfl_xor(cnt, 2);
+        cnt += __shfl_xor(cnt, 1);
+        if (sub == 0 && g < n_rows) kept[g] = cnt;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) kept[n_rows] = 0;
+}
+
+// copy the kept entries of packed row k, in order, to dst[dst_off[k] ...): one wave per row
+__global__ void k_rows_compact(uint64_t n_rows, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src,
+                               const uint32_t *__restrict__ rank, uint32_t min_rank, const uint64_t *__restrict__ dst_off,
+                               uint32_t *__restrict__ dst)
+{
+    const unsigned lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w < n_rows; w += nw) {
+        const uint64_t a = src_off[w], b = src_off[w + 1];
+        uint64_t o = dst_off[w];
+        for (uint64_t q0 = a; q0 < b; q0 += 64) {
+            const uint64_t q = q0 + lane;
+            uint32_t u = 0;
+            bool keep = false;
+            if (q < b) {
+                u = src[q];
+                keep = rank[u] >= min_rank;
+            }
+            const uint64_t mask = __ballot(keep);
+            if (keep) dst[o + __popcll(mask & lt)] = u;
+            o += __popcll(mask);
+        }
     }
 }
 

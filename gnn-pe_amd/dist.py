@@ -6,15 +6,22 @@ processing order, rank r's paths are one contiguous range of global path ids: al
 the rank-order concatenation of the slabs' rows and partition_paths.txt the rank-order
 concatenation of per-slab id lists, for any R (SURVEY 8(e) "Invariant").
 
-Each rank holds the adjacency rows of its own start vertices only.  One step is:
-  1. halo exchange  -- all-to-all-v of the adjacency lists of the 1-hop middle vertices
-                       (requests, degrees, neighbour lists: three all-to-all-v over RCCL/xGMI);
-                       l=3 (4-vertex paths) repeats it once for the rows two hops out,
-  2. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
-  3. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
-  4. fill           -- local, into caller-provided device buffers.
-There is no reduction across ranks anywhere on the offline side; the online filter (`filter`) ORs the ranks'
-candidate bitmaps.
+Each rank holds the adjacency rows of its own start vertices.  Two kinds of work:
+
+  one-time (graph structure; `install_halo`, the distributed analogue of loading the graph):
+      all-to-all-v of the adjacency lists of the 1-hop middle vertices (requests, degrees, neighbour
+      lists: RCCL over xGMI); l=3 repeats it for the rows two hops out.  The rows of the LAST hop are
+      installed TRUNCATED: rank r never emits a path that ends on a vertex ranked before its slab
+      (kept iff rank[c] > rank[s] >= bounds[r]), so those entries are dropped on arrival -- later slabs
+      hold (and rank-sort, every step) only the upper part of every row.  Reverse positions and hub
+      flags of the halo rows are built on arrival.  The halo stays resident across steps, exactly like
+      the CSR of a single-GPU run (one rule for N = 1 and N > 1).
+  per step:
+      1. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
+      2. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
+      3. fill           -- local, into caller-provided device buffers.
+There is no reduction across ranks anywhere on the offline side; the online filter (`filter`) takes the union
+of the ranks' candidate bitmaps (all-gather + OR: RCCL has no bitwise reductions).
 
 torch.distributed supplies the collectives (backend "nccl" = RCCL on GPUs, "gloo" in the CPU
 tests); the engine behind `eng` is the C-ABI library (`binding.Engine`).  Tests substitute an
@@ -25,14 +32,8 @@ import torch
 import torch.distributed as dist
 
 
-def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None):
-    """Cut the processing order into n_ranks contiguous slabs of roughly equal fill work.
-
-    Host-side prep (the analogue of the reference's partitioning script).  The paths of start s number
-    count(s) = sum_{b in N(s)} |{c in N(b): rank[c] > rank[s]}|, estimated as
-    (sum_{b in N(s)} (deg b - 1)) * (share of edge endpoints ranked after s): one pass over the adjacency (`nbrs`);
-    without the adjacency the neighbour degrees are replaced by the mean degree.
-    Returns uint32 bounds[n_ranks+1]."""
+def _start_weights(offsets, sorted_nodes, nbrs):
+    """Estimated paths per start vertex, in processing order (see plan_slabs)."""
     n = len(sorted_nodes)
     offs = offsets.astype(np.int64)
     deg = np.diff(offs)
@@ -47,13 +48,53 @@ def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None):
     # ranks after s is the share of edge endpoints held by later-ranked vertices, not the share of vertices
     dsorted = deg[order].astype(np.float64)
     later = (dsorted.sum() - np.cumsum(dsorted)) / max(dsorted.sum(), 1.0)
-    w = two_hop[order] * later
-    w += 1e-3  # vertices without work still need a home
-    cw = np.cumsum(w)
-    targets = cw[-1] * np.arange(1, n_ranks) / n_ranks if n else np.zeros(0)
-    cuts = np.searchsorted(cw, targets).astype(np.int64)
-    bounds = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
-    return np.maximum.accumulate(bounds)
+    return two_hop[order] * later + 1e-3, dsorted  # vertices without work still need a home
+
+
+def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None, entry_cost=0.0):
+    """Cut the processing order into n_ranks contiguous slabs of roughly equal step time.
+
+    Host-side prep (the analogue of the reference's partitioning script).  The paths of start s number
+    count(s) = sum_{b in N(s)} |{c in N(b): rank[c] > rank[s]}|, estimated as
+    (sum_{b in N(s)} (deg b - 1)) * (share of edge endpoints ranked after s): one pass over the adjacency (`nbrs`);
+    without the adjacency the neighbour degrees are replaced by the mean degree.
+
+    entry_cost > 0 also charges every rank for the adjacency entries it rank-sorts per step, in units of emitted
+    paths per entry: a slab starting at position lo holds the truncated rows, i.e. ~ the edge endpoints ranked >= lo
+    (on a graph where every rank's halo is nearly every row).  Early slabs carry more entries, so they get fewer
+    paths.  Returns uint32 bounds[n_ranks+1]."""
+    n = len(sorted_nodes)
+    if n == 0 or n_ranks <= 1:
+        return np.array([0] + [n] * max(n_ranks, 1), np.uint32)
+    w, dsorted = _start_weights(offsets, sorted_nodes, nbrs)
+    cw = np.concatenate([[0.0], np.cumsum(w)])                       # paths before position i
+    ent = np.concatenate([(dsorted.sum() - np.cumsum(dsorted) + dsorted), [0.0]])  # endpoints ranked >= i
+
+    def cuts_for(T):
+        b = [0]
+        for _ in range(n_ranks - 1):
+            lo = b[-1]
+            budget = T - entry_cost * ent[lo]
+            hi = int(np.searchsorted(cw, cw[lo] + max(budget, 0.0), side="right")) - 1
+            b.append(min(max(hi, lo), n))
+        return b
+
+    if entry_cost <= 0.0:
+        targets = cw[-1] * np.arange(1, n_ranks) / n_ranks
+        cuts = np.searchsorted(cw[1:], targets).astype(np.int64)
+        bounds = np.concatenate([[0], cuts, [n]])
+    else:
+        lo_t, hi_t = 0.0, cw[-1] + entry_cost * ent[0]
+        for _ in range(60):  # smallest per-rank budget T whose first n_ranks-1 slabs leave the last one within T
+            T = 0.5 * (lo_t + hi_t)
+            b = cuts_for(T)
+            last = entry_cost * ent[b[-1]] + (cw[-1] - cw[b[-1]])
+            if last > T:
+                lo_t = T
+            else:
+                hi_t = T
+        bounds = np.array(cuts_for(hi_t) + [n])
+    return np.maximum.accumulate(bounds.astype(np.uint32))
 
 
 def owned_rows(g, sorted_nodes, bounds, r):
@@ -99,7 +140,15 @@ class SlabBuild:
         self.vde_all = torch.zeros((world, max(self.maxlen, 1), self.e), dtype=torch.float64, device=device)
         self.tot_all = torch.zeros(world, dtype=torch.int64, device=device)
         self.stats = {}
-        self._halo_plans = []  # per hop: what moves (ids, degrees, split sizes); see exchange_halo
+        self._halo_plans = []  # per hop: what moved (ids, degrees, split sizes)
+        self.halo_installed = False
+        # the engine enqueues on its stream and the collectives on torch's current stream: they must be the same one
+        if getattr(device, "type", "cpu") == "cuda" and hasattr(eng, "stream_handle"):
+            cur = torch.cuda.current_stream(device).cuda_stream
+            if eng.stream_handle != cur:
+                raise RuntimeError("SlabBuild: the engine's stream must be torch's current stream on this device "
+                                   "(Engine(..., stream=torch.cuda.current_stream().cuda_stream) inside a "
+                                   "torch.cuda.stream(...) block), otherwise collectives race the engine's kernels")
 
     # Collectives.  With backend "nccl" (RCCL) device tensors go straight to the collective.  A gloo
     # group with device tensors (single-GPU debugging of the N>1 flow: several ranks sharing one
@@ -124,21 +173,25 @@ class SlabBuild:
             return
         dist.all_gather_into_tensor(out_flat, inp_flat, group=self.group)
 
-    def exchange_halo(self):
-        """Adjacency rows of the halo: dropped and fetched again on every call.  WHAT has to move (which rows from
-        whom, their degrees, the all-to-all-v split sizes) depends only on the graph and the slabs, so it is worked
-        out once and kept as a persistent plan per hop -- like a persistent MPI request -- and later calls go
-        straight to pack -> all-to-all-v -> append: one collective and no host synchronisation per hop.
-        `invalidate_halo_plan()` after changing the graph, the order or the slabs."""
+    def install_halo(self, truncate=True):
+        """Adjacency rows of the halo: graph structure, fetched ONCE and kept resident (drop + fetch again when
+        called a second time, e.g. after changing the graph, the order or the slabs).  One hop for l=2, two for
+        l=3.  Per hop: three small all-to-all-v (counts, ids, degrees), then pack at the owners -> one all-to-all-v
+        of the neighbour lists -> append at the requester.  The last hop's rows are truncated to the entries ranked
+        >= this slab's first position (see the module docstring) unless truncate=False."""
         self.eng.rows_drop_halo()
-        self.stats.update(halo_rows=0, halo_entries=0, served_rows=0, served_entries=0)
-        for hop in range(self.l - 1):  # l=2: rows of the middle vertices; l=3: also the rows they reference
-            if hop >= len(self._halo_plans):
-                self._halo_plans.append(self._plan_hop())
-            self._move_rows(self._halo_plans[hop])
-
-    def invalidate_halo_plan(self):
         self._halo_plans = []
+        self.stats.update(halo_rows=0, halo_entries=0, served_rows=0, served_entries=0)
+        hops = self.l - 1
+        for hop in range(hops):  # l=2: rows of the middle vertices; l=3: also the rows they reference
+            p = self._plan_hop()
+            self._halo_plans.append(p)
+            last = hop == hops - 1
+            self._move_rows(p, int(self.bounds[self.rank]) if (truncate and last) else 0)
+        self.halo_installed = True
+
+    # round-1 name, kept for callers that re-fetch explicitly
+    exchange_halo = install_halo
 
     def _plan_hop(self):
         """One hop of the halo, metadata only: three small all-to-all-v (counts, ids, degrees)."""
@@ -168,12 +221,12 @@ class SlabBuild:
         return dict(need=self.need[:n_need].clone(), req=req.clone(), deg_in=deg_in.clone(), n_need=n_need, n_req=n_req,
                     send_sizes=send_sizes, recv_sizes=recv_sizes, n_send=n_send, n_recv=n_recv)
 
-    def _move_rows(self, p):
+    def _move_rows(self, p, min_rank=0):
         """4. the adjacency lists themselves: pack at the owner, one all-to-all-v, append at the requester."""
         eng = self.eng
         eng.rows_pack(p["n_req"], p["req"], self.pack, self.send_cap)
         self._a2a(self.nbr_in[:p["n_recv"]], self.pack[:p["n_send"]], p["recv_sizes"], p["send_sizes"])
-        eng.rows_append(p["n_need"], p["need"], p["deg_in"], self.nbr_in[:p["n_recv"]], p["n_recv"])
+        eng.rows_append(p["n_need"], p["need"], p["deg_in"], self.nbr_in[:p["n_recv"]], p["n_recv"], min_rank)
         for k, v in (("halo_rows", p["n_need"]), ("halo_entries", p["n_recv"]), ("served_rows", p["n_req"]),
                      ("served_entries", p["n_send"])):
             self.stats[k] += v
@@ -193,6 +246,7 @@ class SlabBuild:
         return out
 
     def exchange_vde(self):
+        """Per step: vde of the owned rows, then every rank's slab of the table (all-gather of n x e doubles)."""
         eng, R = self.eng, self.world
         b = self.bounds
         eng.vde(want=False)
@@ -213,9 +267,11 @@ class SlabBuild:
         return total
 
     def step(self, out_ids=None, out_pde=None, out_pde_label=None):
-        """One full pass of the hot path for this rank's slab; returns (local paths, global id base)."""
+        """One full pass of the hot path for this rank's slab; returns (local paths, global id base).  The halo rows
+        are fetched by the first call (or an explicit install_halo) and stay resident."""
         if self.world > 1:
-            self.exchange_halo()
+            if not self.halo_installed:
+                self.install_halo()
             self.exchange_vde()
         else:
             self.eng.vde(want=False)
@@ -231,11 +287,16 @@ class SlabBuild:
         over partitions in main.cpp:165-171.  Returns the global bitmap [n_query_vertices x ceil(n/32)] uint32."""
         bm, _ = self.eng.filter_candidates(plan, eps)
         if self.world > 1:
-            t = torch.from_numpy(np.ascontiguousarray(bm).view(np.int32))
+            # union of the ranks' bitmaps: all-gather + OR (RCCL/NCCL reject BOR/BAND/BXOR, so no all-reduce)
+            t = torch.from_numpy(np.ascontiguousarray(bm).view(np.int32)).reshape(-1)
             if dist.get_backend(self.group) != "gloo":
                 t = t.to(self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.BOR, group=self.group)
-            bm = t.cpu().numpy().view(np.uint32)
+            allb = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(allb.view(-1), t, group=self.group)
+            u = allb[0]
+            for r in range(1, self.world):
+                u = torch.bitwise_or(u, allb[r])
+            bm = u.cpu().numpy().view(np.uint32).reshape(bm.shape)
         return bm
 
     def _count_single(self):

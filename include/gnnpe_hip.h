@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNPE_ABI_VERSION 1
+#define GNNPE_ABI_VERSION 2
 
 #define GNNPE_OK 0
 #define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
@@ -118,9 +118,13 @@ int gnnpe_halo_need(gnnpe_ctx *ctx, uint32_t n_ranks, const uint32_t *host_slab_
 int gnnpe_rows_degree(gnnpe_ctx *ctx, uint64_t n_req, const void *dev_ids, void *dev_deg);
 /* Pack the adjacency lists of the requested rows back to back into dev_out (sum of degrees entries). */
 int gnnpe_rows_pack(gnnpe_ctx *ctx, uint64_t n_req, const void *dev_ids, void *dev_out, uint64_t cap);
-/* Install received halo rows: ids, their degrees, and the packed adjacency (all device memory). */
+/* Install received halo rows: ids, their degrees, and the packed adjacency (all device memory).  min_rank > 0 drops
+ * the entries whose neighbour comes before processing position min_rank: a rank whose slab starts there never emits a
+ * path that ends on one (kept iff rank[c] > rank[s]), so the LAST hop's halo rows can be truncated (l=2: the only hop;
+ * l=3: pass 0 for the first hop).  Rows are validated (ids < n, ascending, no self-loop) and their reverse positions
+ * and hub flags built here: the halo is graph structure and stays resident across steps. */
 int gnnpe_rows_append(gnnpe_ctx *ctx, uint64_t n_rows, const void *dev_ids, const void *dev_deg,
-                      const void *dev_nbrs, uint64_t n_nbrs);
+                      const void *dev_nbrs, uint64_t n_nbrs, uint32_t min_rank);
 
 /* Forget every appended halo row (back to the state right after gnnpe_load_rows), so the exchange
  * can be repeated. */
@@ -245,13 +249,11 @@ int gnnpe_refine(gnnpe_ctx *ctx, const char *query_graph_path, const uint32_t *c
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);
-/* Selects the enumeration implementation (call before gnnpe_count_paths).  All produce identical
- * outputs; they stay selectable for A/B measurements:
- *   1 one wave per (start, middle) pair, direct stores (first correct version)
- *   2 middle-vertex-centric count + fill (each adjacency row read once, scattered output runs)
- *   3 one wave per start vertex over the id-sorted rows (any degree)
- *   4 one wave per start vertex over rank-sorted neighbour records (default; rows of degree <= 64,
- *     otherwise 3 is used automatically) */
+/* Selects the enumeration implementation (call before gnnpe_count_paths).  Both produce identical outputs:
+ *   4 one wave per start vertex over rank-sorted neighbour records; rows longer than 64 are streamed in id order by
+ *     the same kernel (default)
+ *   1 one wave per (start, middle) pair, direct stores, run-time embedding width: the generic form used for widths
+ *     without a specialised instantiation (e not in {1,2,3,4,8}); selectable as the A/B baseline */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
 
 #ifdef __cplusplus

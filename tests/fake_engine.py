@@ -60,11 +60,12 @@ class FakeEngine:
             pos += len(nb)
         assert pos <= cap
 
-    def rows_append(self, n_rows, ids, deg, nbrs, n_nbrs):
+    def rows_append(self, n_rows, ids, deg, nbrs, n_nbrs, min_rank=0):
         pos = 0
         for k in range(n_rows):
             d = int(deg[k])
-            self.halo[int(ids[k])] = nbrs[pos:pos + d].numpy().astype(np.uint32)
+            row = nbrs[pos:pos + d].numpy().astype(np.uint32)
+            self.halo[int(ids[k])] = row[self.rank[row.astype(np.int64)] >= min_rank]  # truncated halo row
             pos += d
         assert pos == n_nbrs
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = binding.load()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.gnnpe_abi_version() == 1
+    assert lib.gnnpe_abi_version() == binding.ABI_VERSION
 
 
 def test_product_does_not_import_the_oracle():

@@ -49,7 +49,7 @@ def test_random_case_matches_the_oracle(oracle, seed):
     for l in (2, 3):
         L = l + 1
         want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, L)
-        for variant in ((1, 2, 3, 4) if l == 2 else (4,)):
+        for variant in ((1, 4) if l == 2 else (4,)):
             eng.set_fill_variant(variant)
             total, per_start = eng.count_paths(l, per_start=True)
             assert total == len(want), (l, variant)
