@@ -6,20 +6,29 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One STEP = one full pass of the hot path over the synthetic 1M-vertex / 10M-edge labelled graph
-(BASELINE.json configs[2]; l=2, e=2): [N>1: halo exchange + vde all-gather] -> vde -> count + scan
--> fill (path ids + fp64 path embeddings written to HBM).  Inputs (this rank's CSR rows, order,
-label table) are resident in HBM before the timed region.  N>1 partitions the SAME graph across the
-ranks (configs[3]), so scaling is "strong".  value = paths of all ranks / max-over-ranks step time.
+(BASELINE.json configs[2]; l=2, e=2): vde [N>1: + all-gather of the vde rows] -> count (rank-sorted row blocks,
+pair records, scan) -> fill (path ids + fp64 path embeddings written to HBM).  Inputs resident in HBM before the
+timed region: this rank's CSR rows with their reverse positions, the halo rows (N>1: fetched once by all-to-all-v
+when the graph is distributed -- graph structure, like the CSR itself), the processing order and the label table.
+N>1 partitions the SAME graph across the ranks (configs[3]), so scaling is "strong".
+value = paths of all ranks / max-over-ranks step time.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (k_fill_tiled): algorithmic bytes (92 B/path at l=2,e=2,
-                  SURVEY 8(d)) / its launch duration, timed live with events on the launch stream;
-  cpu_baseline -- the UNMODIFIED reference `main -m offline` (oracle/_ref/ref_main), single thread,
-                  on a bounded sample of the same generator (rank 0, N=1 only).
+  roofline     -- the dominant kernel (k_fill_ranked): algorithmic bytes (92 B/path at l=2,e=2) / its
+                  launch duration, timed live with events on the launch stream; `step_frac` = the same bytes over
+                  the whole step; `traffic` = HBM bytes per launch from this round's PMC passes (profiles/);
+  cpu_baseline -- the UNMODIFIED reference `main -m offline` (oracle/_ref/ref_main), single thread, on a bounded
+                  sample of the same generator (rank 0, N=1 only);
+  index_build  -- second half of the metric: R-tree image on the device AND the index.dat files on disk (p=1, p=8);
+  e2e          -- `gnnpe_main -m offline` wall-clock (load, emit, render, write) at configs 3 and 2;
+  phases_ms    -- one-time work (graph distribution) separated from the per-step phases.
+RCCL is mandatory for N>1: a failed init is an error (exit code != 0), never a silent downgrade.  Host-staged gloo
+collectives are an explicit debugging mode (GNNPE_BENCH_SAME_DEVICE=1: all ranks on device 0).
 """
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -33,6 +42,8 @@ import gnnpe_amd  # noqa: E402,F401
 from gnnpe_amd import binding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_fill.json")
 
 
 def bytes_per_path(L, e):
@@ -71,7 +82,9 @@ def cpu_baseline(sample_n, sample_m, seed):
         assert len(paths) == P
         kind = "port"
         sample += "; oracle hash-set DFS + text formatting"
-    return dict(value=P / dt, unit="paths/s", cores=1, kind=kind, sample=sample, seconds=dt)
+    return dict(value=P / dt, unit="paths/s", cores=1, kind=kind, sample=sample, seconds=dt,
+                note="the small sample flatters the reference: its hash set still fits the caches here; at the headline size "
+                     "(1M/10M, 2.0e8 paths) the same binary measured 1.14e5 paths/s (1 749 s, 29.9 GB RSS; BASELINE.md section 2.1)")
 
 
 def cpu_baseline_all_cores(sample_n, sample_m, e, seed):
@@ -102,26 +115,35 @@ def online_filter_leg(eng, g, seed):
     """Cut a connected 8-vertex query out of the data graph, plan it on the host, filter on the device."""
     rng = np.random.default_rng(seed)
     offs, nbrs = g["offsets"].astype(np.int64), g["nbrs"]
-    chosen = [int(rng.integers(g["n"]))]
-    while len(chosen) < 8:
-        u = chosen[int(rng.integers(len(chosen)))]
-        if offs[u + 1] > offs[u]:
-            w = int(nbrs[int(rng.integers(offs[u], offs[u + 1]))])
-            if w not in chosen:
-                chosen.append(w)
-        elif len(chosen) == 1:
-            chosen = [int(rng.integers(g["n"]))]
+    deg = np.diff(offs)
+    chosen = None
+    for _ in range(64):  # bounded: a start inside a component with fewer than 8 vertices is simply dropped
+        start = int(rng.integers(g["n"]))
+        comp, seen, tries = [start], {start}, 0
+        while len(comp) < 8 and tries < 512:
+            tries += 1
+            u = comp[int(rng.integers(len(comp)))]
+            if deg[u]:
+                w = int(nbrs[int(rng.integers(offs[u], offs[u + 1]))])
+                if w not in seen:
+                    seen.add(w)
+                    comp.append(w)
+        if len(comp) == 8:
+            chosen = comp
+            break
+    if chosen is None:
+        return dict(skipped="no connected 8-vertex subgraph found in 64 attempts")
     idx = {v: i for i, v in enumerate(chosen)}
     edges = sorted({(min(idx[v], idx[int(w)]), max(idx[v], idx[int(w)])) for v in chosen for w in nbrs[offs[v]:offs[v + 1]]
                     if int(w) in idx})
-    deg = np.zeros(8, np.int64)
+    qdeg = np.zeros(8, np.int64)
     for a, b in edges:
-        deg[a] += 1
-        deg[b] += 1
+        qdeg[a] += 1
+        qdeg[b] += 1
     with tempfile.TemporaryDirectory() as wd:
         qp = os.path.join(wd, "q.graph")
         with open(qp, "w") as f:
-            f.write(f"t 8 {len(edges)}\n" + "".join(f"v {i} {int(g['labels'][v])} {int(deg[i])}\n" for i, v in enumerate(chosen))
+            f.write(f"t 8 {len(edges)}\n" + "".join(f"v {i} {int(g['labels'][v])} {int(qdeg[i])}\n" for i, v in enumerate(chosen))
                     + "".join(f"e {a} {b}\n" for a, b in edges))
         plan = binding.host_query_plan(qp, 2)
     ms = []
@@ -133,6 +155,71 @@ def online_filter_leg(eng, g, seed):
                 candidates_per_query_vertex=cand,
                 what="leaf test of Partition::query (custom.h:404-431) on every path, fused with the enumeration (nothing emitted); no index, no files",
                 reference="re-parses all_paths.txt (~95 s per 2e7 paths, custom.h:546-572) and inserts/loads the R-tree first")
+
+
+def device_pass(torch, stream, local_rank, g, sn, labels, e, steps):
+    """The timed step (vde + count + fill, inputs resident) on another graph of the same family: the config-2 line."""
+    eng = binding.Engine(local_rank, stream=stream.cuda_stream)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(labels, e))
+    eng.vde(want=False)
+    total = eng.count_paths(2)
+    dev = torch.device("cuda", local_rank)
+    ids = torch.empty((max(total, 1), 3), dtype=torch.int32, device=dev)
+    pde = torch.empty((max(total, 1), 3 * e), dtype=torch.float64, device=dev)
+    fill = []
+    for it in range(steps + 2):
+        if it == 2:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        eng.vde(want=False)
+        t = eng.count_paths(2)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        eng.fill_paths_device(0, t, ids, pde, None)
+        ev1.record()
+        if it >= 2:
+            fill.append((ev0, ev1))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    fms = float(np.mean([a.elapsed_time(b) for a, b in fill]))
+    assert total == synth.expected_paths_l2(g["offsets"])
+    eng.close()
+    bpp = bytes_per_path(3, e)
+    return dict(workload=f"config 2: G(n={g['n']}, m={g['m']}), l=2, e={e}, ids + pde", paths=total, ms_per_step=ms,
+                value=total / (ms / 1e3), unit="paths/s", fill_ms=fms, fill_frac=total * bpp / (fms / 1e3) / 1e9 / HBM_PEAK_GBS)
+
+
+def e2e_leg(g, sn, p, index, label):
+    """Wall-clock of `gnnpe_main -m offline` on text inputs (load + emit + render + file writes [+ index.dat])."""
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    P = synth.expected_paths_l2(g["offsets"])
+    need = P * 34 + (P * 120 if index else 0) + (400 << 20)
+    if free < need:
+        return dict(skipped=f"{label}: needs {need >> 30} GiB of scratch disk, {free >> 30} GiB free")
+    with tempfile.TemporaryDirectory() as wd:
+        gp = os.path.join(wd, "g.graph")
+        synth.write_graph_file(gp, g)
+        synth.make_dataset_dir(wd, p)
+        synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), sn, synth.block_membership(g["n"], p))
+        args = [CLI, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", str(p), "--timing"] + (["--index"] if index else [])
+        t0 = time.perf_counter()
+        r = subprocess.run(args, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return dict(error=r.stderr[-500:])
+        t = json.loads(r.stderr.strip().splitlines()[-1])
+        hdr = int(open(os.path.join(wd, "gnn-pe", "all_paths.txt")).readline())
+        assert hdr == P == t["paths"], (hdr, P)
+        out = dict(workload=label, partitions=p, seconds=dt, paths=P, paths_per_s=P / dt, in_process_s=t["end_to_end_s"],
+                   load_s=t["load_s"], setup_s=t.get("setup_s"), vde_count_s=t["vde_count_s"],
+                   emit_render_copy_s=t.get("emit_render_copy_s"), write_total_s=t.get("write_total_s"),
+                   text_bytes=t["all_paths_bytes"] + t["partition_bytes"])
+        if index:
+            sizes = [os.path.getsize(os.path.join(wd, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) for i in range(p)]
+            out.update(index_build_s=t["index_build_s"], index_bytes=int(sum(sizes)))
+        return out
 
 
 def main():
@@ -148,10 +235,13 @@ def main():
     ap.add_argument("--powerlaw", action="store_true", help="power-law degrees (config-5 family) instead of G(n,m)")
     ap.add_argument("--max-degree", type=int, default=500)
     ap.add_argument("--ids-only", action="store_true", help="emit path ids only (28 B/path variant)")
-    ap.add_argument("--fill-variant", type=int, default=4)
+    ap.add_argument("--fill-variant", type=int, default=4, choices=(1, 4))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-index", action="store_true")
+    ap.add_argument("--no-index", action="store_true", help="skip the index-build, online-filter and end-to-end legs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
+    ap.add_argument("--entry-cost", type=float, default=2.0,
+                    help="N>1 slab planning: cost of one rank-sorted adjacency entry in emitted paths (0 = equal path counts)")
     args = ap.parse_args()
 
     import torch
@@ -173,26 +263,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    staged = same_device  # collectives over gloo with host staging instead of RCCL
+    staged = same_device  # collectives over gloo with host staging instead of RCCL: explicit, for every rank alike
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if same_device:
+        if staged:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            try:  # RCCL over xGMI; one tiny all-to-all-v so that a broken setup shows up here, not mid-run
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-                probe = torch.arange(world, dtype=torch.int32, device=device)
-                got = torch.empty_like(probe)
-                dist.all_to_all_single(got, probe, output_split_sizes=[1] * world, input_split_sizes=[1] * world)
-                torch.cuda.synchronize()
-                assert got.tolist() == [rank] * world
-            except Exception as ex:  # noqa: BLE001 -- report and carry on over gloo rather than lose the scaling run
-                print(f"[bench] rank {rank}: RCCL unavailable ({type(ex).__name__}: {ex}); collectives staged over gloo",
-                      file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                staged = True
+            # RCCL over xGMI, or no number at all: any failure here ends the run with a non-zero exit code on every
+            # rank (the probe is a collective, so no rank can pass it alone)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            probe = torch.arange(world, dtype=torch.int32, device=device)
+            got = torch.empty_like(probe)
+            dist.all_to_all_single(got, probe, output_split_sizes=[1] * world, input_split_sizes=[1] * world)
+            torch.cuda.synchronize()
+            if got.tolist() != [rank] * world:
+                raise SystemExit(f"rank {rank}: RCCL all-to-all-v probe returned {got.tolist()}")
 
     L, e = 3, args.e
     if args.powerlaw:
@@ -209,19 +294,28 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     eng = binding.Engine(local_rank, stream=stream.cuda_stream)
-    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"])
-    owned_entries = 2 * args.m
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], entry_cost=args.entry_cost if world > 1 else 0.0)
+    owned_entries = len(g["nbrs"])
+    one_time = {}
+    t_load = time.perf_counter()
     if world == 1:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     else:
         rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
         owned_entries = int(roff[-1])
-        eng.load_rows(args.n, g["labels"], rows, roff, rnbr, nbr_capacity=2 * args.m + owned_entries)
+        eng.load_rows(args.n, g["labels"], rows, roff, rnbr, nbr_capacity=len(g["nbrs"]))
     eng.set_order(sn, mem, max(world, 1))
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(args.labels, e))
     eng.set_fill_variant(args.fill_variant)
-    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=2 * args.m, owned_entries=owned_entries)
+    torch.cuda.synchronize()
+    one_time["load_rows_revpos_ms"] = (time.perf_counter() - t_load) * 1e3
+    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=len(g["nbrs"]), owned_entries=owned_entries)
+    if world > 1:  # distribute the graph: the halo rows arrive once and stay (like the CSR of a single-GPU run)
+        t_h = time.perf_counter()
+        sb.install_halo()
+        torch.cuda.synchronize()
+        one_time["halo_install_ms"] = (time.perf_counter() - t_h) * 1e3
 
     # first pass sizes the outputs (and every internal buffer); not timed
     total, base = sb.step()
@@ -232,7 +326,6 @@ def main():
 
     def one_step(timed):
         if world > 1:
-            sb.exchange_halo()
             sb.exchange_vde()
             t = sb.count()
         else:
@@ -268,15 +361,14 @@ def main():
         r = fn()
         torch.cuda.synchronize()
         return r, (time.perf_counter() - t) * 1e3
-    phases = {}
+    per_step = {}
     if world > 1:
-        _, phases["halo_exchange_ms"] = phase(sb.exchange_halo)
-        _, phases["vde_and_allgather_ms"] = phase(sb.exchange_vde)
-        t_, phases["count_ms"] = phase(sb.count)
+        _, per_step["vde_and_allgather_ms"] = phase(sb.exchange_vde)
+        t_, per_step["count_ms"] = phase(sb.count)
     else:
-        _, phases["vde_ms"] = phase(lambda: eng.vde(want=False))
-        t_, phases["count_ms"] = phase(sb._count_single)
-    _, phases["fill_ms"] = phase(lambda: eng.fill_paths_device(0, t_, out_ids, out_pde, None))
+        _, per_step["vde_ms"] = phase(lambda: eng.vde(want=False))
+        t_, per_step["count_ms"] = phase(sb._count_single)
+    _, per_step["fill_ms"] = phase(lambda: eng.fill_paths_device(0, t_, out_ids, out_pde, None))
 
     # sanity of what was just timed (outside the timed region): global path count = sum C(deg, 2) and the
     # middle-vertex checksum sum_paths(b) = sum_v v * C(deg v, 2), both closed forms of the input graph
@@ -303,23 +395,25 @@ def main():
     fill_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ms])) if fill_ms else float("nan")
     bpp = (4 * L + 16) if args.ids_only else bytes_per_path(L, e)
     achieved = total * bpp / (fill_avg_ms / 1e3) / 1e9
-    # HBM traffic of the fill launch from the committed PMC passes (profiles/, same command and config);
-    # FETCH_SIZE carries the gfx950 x2 correction for wide streams, so this is an upper bound
+    # HBM traffic of the fill launch from this round's PMC passes (profiles/, same command and config): WRITE_SIZE +
+    # the fabric read requests by size (TCC_EA0_RDREQ_{32,64,128}B); counters cannot be collected inside this run
     traffic, traffic_note = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_fill.json")
-    if (os.path.exists(pmc) and world == 1 and args.fill_variant == 4 and not args.ids_only
+    if (os.path.exists(PMC_FILE) and world == 1 and args.fill_variant == 4 and not args.ids_only and not args.powerlaw
             and (args.n, args.m, e) == (1_000_000, 10_000_000, 2)):
-        d = json.load(open(pmc))["derived"]
-        traffic = d["traffic_bytes_high"] / 1e9
-        traffic_note = (f"GB per launch from profiles/r01_pmc_fill.json: WRITE_SIZE {d['write_bytes'] / 1e9:.1f} + "
-                        f"2 x FETCH_SIZE {d['fetch_bytes_raw'] / 1e9:.1f} (raw sum {d['traffic_bytes_low'] / 1e9:.1f})")
-    kname = {1: "k_fill_edge_wave", 2: "k_fill_b", 3: "k_fill_s_rec", 4: "k_fill_ranked"}[args.fill_variant]
+        d = json.load(open(PMC_FILE)).get("derived", {})
+        if "traffic_bytes" in d:
+            traffic = d["traffic_bytes"] / 1e9
+            traffic_note = (f"GB per launch from {os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command): "
+                            f"written {d['write_bytes'] / 1e9:.2f} + read {d['read_bytes'] / 1e9:.2f} (128-byte fabric requests)")
+    kname = {1: "k_fill_edge_wave", 4: "k_fill_ranked"}[args.fill_variant]
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, bytes_per_path=bpp,
-                    paths_per_launch=total, launch_ms=fill_avg_ms)
+                    paths_per_launch=total, launch_ms=fill_avg_ms,
+                    step_frac=(global_total * bpp / (ms_per_step / 1e3) / 1e9) / (HBM_PEAK_GBS * world),
+                    step_frac_note="the same algorithmic bytes over the whole step (vde + count + scan + fill), per GPU")
 
     out = dict(metric="offline paths-embedded/sec + index-build wallclock, 1M-V/10M-E l=2",
-               value_is="paths-embedded/sec of one device-resident pass (halo+vde+count+scan+fill)",
+               value_is="paths-embedded/sec of one device-resident pass (vde [+ all-gather] + count + scan + fill)",
                value=value, unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,
                dtype="u32 ids + f64 embeddings", data="synthetic",
@@ -327,16 +421,21 @@ def main():
                                     f"degree-sorted order; {'ids only' if args.ids_only else 'ids + pde'}",
                            paths=global_total, parallelism=f"slab{world}", fill_variant=args.fill_variant),
                roofline=roofline, sanity="path count and middle-vertex checksum match the closed forms",
-               phases_ms={k: round(v, 3) for k, v in phases.items()})
+               phases_ms=dict(one_time={k: round(v, 3) for k, v in one_time.items()},
+                              per_step={k: round(v, 3) for k, v in per_step.items()},
+                              note="one_time = distributing / loading the graph structure (rows, reverse positions, halo rows); "
+                                   "per_step = what `value` times"))
     if world > 1:
-        out["halo"] = sb.stats
-        out["config"]["collectives"] = "gloo, staged through host memory" if staged else "rccl"
+        out["halo"] = dict(sb.stats, owned_entries=owned_entries, slab=[int(bounds[rank]), int(bounds[rank + 1])],
+                           local_paths=int(total), note="rank 0's share; halo rows are truncated to the slab's rank range")
+        out["config"]["collectives"] = "gloo, staged through host memory (GNNPE_BENCH_SAME_DEVICE=1)" if staged else "rccl"
 
-    # index-build wallclock (second half of BASELINE.json's metric): R*-tree file image of every path of
-    # partition 0 (p = 1 at N = 1), bulk-loaded on the device; measured outside the timed steps
-    if world == 1 and not args.no_index and not args.ids_only:
+    legs = world == 1 and not args.no_index and not args.ids_only
+    # index-build wallclock (second half of BASELINE.json's metric), measured outside the timed steps.
+    # (a) device image: R*-tree file image of every path (p = 1), bulk-loaded on the device
+    if legs:
         ib = []
-        for _ in range(2):
+        for _ in range(3):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -344,14 +443,40 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             ib.append(ev0.elapsed_time(ev1))
-        out["index_build"] = dict(wallclock_ms=min(ib), first_call_ms=ib[0], points=total, file_bytes=nbytes,
-                                  node_blocks=hdr[1], leaves=hdr[4], where="device image of index.dat (not written to disk)",
+        out["index_build"] = dict(wallclock_ms=min(ib[1:]), points=total, file_bytes=nbytes, node_blocks=hdr[1], leaves=hdr[4],
+                                  where="device image of index.dat; the files on disk are timed under e2e",
+                                  first_call_ms=ib[0],
+                                  first_call_note="the first call allocates the image and the sort buffers (grow-only, ~25 GB of hipMalloc) "
+                                                  "and loads the kernels; later calls only enqueue kernels",
                                   reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
     # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
-    if world == 1 and not args.no_index and not args.ids_only and e == 2:
+    if legs and e == 2:
         out["online_filter"] = online_filter_leg(eng, g, args.seed)
+    eng.close()
+    del out_ids, out_pde
+    torch.cuda.empty_cache()
+    g2 = None
+    if legs and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
+        g2 = synth.gnm_graph(100_000, 1_000_000, n_labels=args.labels, seed=args.seed)
+        out["config2"] = device_pass(torch, stream, local_rank, g2, synth.degree_order(g2["offsets"]), args.labels, e, args.steps)
     if rank == 0:
+        # (b) files on disk + end-to-end wall-clock of the drop-in CLI
+        if legs and not args.no_e2e and not args.powerlaw and os.path.exists(CLI):
+            big = (args.n, args.m) == (1_000_000, 10_000_000)
+            name = "config 3: G(1M, 10M)" if big else f"G({args.n}, {args.m})"
+            e2e = {}
+            e2e["text_p1"] = e2e_leg(g, sn, 1, False, name + ", p=1, text files only")
+            e2e["text_index_p1"] = e2e_leg(g, sn, 1, True, name + ", p=1, text files + index.dat")
+            e2e["text_index_p8"] = e2e_leg(g, sn, 8, True, name + ", p=8, text files + 8 x index.dat")
+            if big and g2 is not None:
+                e2e["config2_text_index_p1"] = e2e_leg(g2, synth.degree_order(g2["offsets"]), 1, True,
+                                                       "config 2: G(100K, 1M), p=1, text files + index.dat")
+            e2e["reference"] = "BASELINE.md: config 3 offline 1 749 s, config 2 offline 158.8 s (1 thread); its index build is ~96 us per insert"
+            out["e2e"] = e2e
+            if "index_build" in out:
+                out["index_build"]["files"] = {k: dict(seconds=v.get("index_build_s"), bytes=v.get("index_bytes"))
+                                               for k, v in e2e.items() if isinstance(v, dict) and "index_build_s" in v}
         if world == 1 and not args.no_cpu_baseline:
             sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))
             out["cpu_baseline"] = cpu_baseline(sn_, sm_, args.seed)
@@ -362,7 +487,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

@@ -32,6 +32,10 @@ SIGNATURES = {
     "gnnpe_dev_free": (C.c_int, [_vp, _vp]),
     "gnnpe_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "gnnpe_device_count": (C.c_int, []),
+    "gnnpe_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "gnnpe_copy_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "gnnpe_gather_rows_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, _vp, _vp]),
+    "gnnpe_write_device_file": (C.c_int, [_vp, _vp, C.c_uint64, C.c_char_p]),
     "gnnpe_load_csr": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p]),
     "gnnpe_load_rows": (C.c_int, [_vp, C.c_uint32, _u32p, C.c_uint32, _u32p, _u64p, _u32p, C.c_uint64]),
     "gnnpe_set_order": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32]),

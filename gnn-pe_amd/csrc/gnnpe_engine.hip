@@ -154,6 +154,22 @@ int gnnpe_sync(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+int gnnpe_get_stream(gnnpe_ctx *c, void **hip_stream)
+{
+    GNNPE_REQUIRE(c && hip_stream, GNNPE_ERR_ARG, "null argument");
+    *hip_stream = (void *)c->stream;
+    return GNNPE_OK;
+}
+
+int gnnpe_copy_device(gnnpe_ctx *c, void *dev_dst, const void *dev_src, uint64_t bytes)
+{
+    GNNPE_REQUIRE(c && (bytes == 0 || (dev_dst && dev_src)), GNNPE_ERR_ARG, "null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    // hipMemcpyDefault: source and destination may live on different devices of this process (peer copy over xGMI)
+    if (bytes) GNNPE_HIP_TRY(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDefault, c->stream));
+    return GNNPE_OK;
+}
+
 int gnnpe_device_count(void)
 {
     int n = 0;

@@ -726,6 +726,26 @@ int gnnpe_build_box_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t dim, const
     return build_image(c, cnt, S, dev_image, nbytes, hdr_out);
 }
 
+int gnnpe_write_device_file(gnnpe_ctx *c, const void *dev_src, uint64_t nbytes, const char *path)
+{
+    GNNPE_REQUIRE(c && path && (dev_src || !nbytes), GNNPE_ERR_ARG, "gnnpe_write_device_file: null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return write_device_image(c, (const char *)dev_src, nbytes, path);
+}
+
+int gnnpe_gather_rows_device(gnnpe_ctx *c, uint64_t k, uint32_t L, const void *dev_sel, uint64_t sel_base, const void *dev_rows,
+                             void *dev_out)
+{
+    GNNPE_REQUIRE(c && L >= 1 && (k == 0 || (dev_sel && dev_rows && dev_out)), GNNPE_ERR_ARG, "gnnpe_gather_rows_device: null argument");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (k)
+        hipLaunchKernelGGL(k_gather_rows_u32, dim3(grid_for(k * L)), dim3(kBlock), 0, c->stream, k, L, (const uint64_t *)dev_sel,
+                           sel_base, (const uint32_t *)dev_rows, (uint32_t *)dev_out);
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
 int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
 {
     GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");

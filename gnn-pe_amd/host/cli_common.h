@@ -29,7 +29,8 @@ struct Options {
     int gpus = 1;
     uint64_t chunk_paths = 8ull << 20;  // 8M paths per pass: small enough to pipeline render, copy-back and file writes
     bool allow_large = false, timing = false, sidecars = false, write_index = false;
-    bool same_device = false;  // testing aid: all --gpus contexts on device 0
+    bool same_device = false;  // testing aid: all --gpus contexts on device 0 (halo by device copies: RCCL needs distinct GPUs)
+    std::string transport = "rccl";  // --gpus N > 1: "rccl" (ncclSend/ncclRecv over xGMI) or "copy" (device-to-device copies)
 };
 
 static const char *g_tool = "gnnpe_main";
@@ -70,13 +71,19 @@ inline Options parse_args(int argc, char **argv, const char *tool = "gnnpe_main"
         char key = 0;
         if (a == "-h" || a == "--help") {
             printf("%s -f <dataset dir/> -d <data.graph> -m offline -p <partitions> [-l 2] [-e 2]\n"
-                   "           [--gpus N] [--chunk PATHS] [--index] [--sidecars] [--timing] [--allow-large]\n", tool);
+                   "           [--gpus N] [--transport rccl|copy] [--chunk PATHS] [--index] [--sidecars] [--timing] [--allow-large]\n", tool);
             exit(0);
         }
         if (a == "--gpus" || a == "--chunk") {
             if (i + 1 >= argc) die(a + " needs a value");
             uint64_t v = strtoull(argv[++i], nullptr, 10);
             if (a == "--gpus") o.gpus = (int)v; else o.chunk_paths = v;
+            continue;
+        }
+        if (a == "--transport") {
+            if (i + 1 >= argc) die(a + " needs a value");
+            o.transport = argv[++i];
+            if (o.transport != "rccl" && o.transport != "copy") die("--transport must be rccl or copy");
             continue;
         }
         if (a == "--allow-large") { o.allow_large = true; continue; }

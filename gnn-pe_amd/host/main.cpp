@@ -34,6 +34,7 @@
 #include "../../include/gnnpe_hip.h"
 #include "cli_common.h"
 #include "graph_loader.h"
+#include "slab_offline.h"
 
 using gnnpe_host::StaticGraph;
 
@@ -287,21 +288,24 @@ int main(int argc, char **argv)
         if (!is_dir(partitions_path + "partition-" + std::to_string(i)))
             die("missing directory " + partitions_path + "partition-" + std::to_string(i) + "/ (the prep step creates it)");
 
-    // ---- device setup: one context per GPU, each holding the graph and a slab of the order ----
+    // ---- device setup ----
     const int ndev = gnnpe_device_count();
     if (ndev <= 0) die("no HIP device: this tool has no CPU fallback");
     if (o.gpus < 1 || (o.gpus > ndev && !o.same_device)) die("--gpus " + std::to_string(o.gpus) + " but " + std::to_string(ndev) + " device(s) present");
     std::vector<double> table((size_t)std::max<uint32_t>(g.labels_count, 1) * o.vde_dim);
     check(gnnpe_host_label_table(std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "label table");
-    std::vector<Device> devs(o.gpus);
-    for (int d = 0; d < o.gpus; d++) {
-        devs[d].ctx = gnnpe_create(o.same_device ? 0 : d);
-        if (!devs[d].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
-        check(gnnpe_load_csr(devs[d].ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
-        check(gnnpe_set_order(devs[d].ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
-        check(gnnpe_set_label_table(devs[d].ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()),
-              "set_label_table");
+    if (o.gpus > 1) {
+        // the north-star split: one thread + one GPU per slab of the order, each with its own rows only, halo by
+        // all-to-all-v, concurrent emit and pwrite (host/slab_offline.cpp)
+        if (o.sidecars) die("--sidecars is a single-GPU option");
+        return slab::run_offline_slabs(o, g, sorted_nodes, membership, table, t_start, t_loaded);
     }
+    std::vector<Device> devs(1);
+    devs[0].ctx = gnnpe_create(0);
+    if (!devs[0].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
+    check(gnnpe_load_csr(devs[0].ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
+    check(gnnpe_set_order(devs[0].ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
+    check(gnnpe_set_label_table(devs[0].ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "set_label_table");
     const auto t_setup = Clock::now();
 
     // ---- R4 + R2 count on device 0 over the whole order: per-start counts size everything ----

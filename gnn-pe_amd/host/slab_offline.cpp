@@ -1,0 +1,676 @@
+// slab_offline.cpp -- `gnnpe_main -m offline --gpus N`: the north-star split of the offline step in the C++ host.
+//
+// The reference's offline loop (GNN-PE/src/main.cpp:87-119) walks membership.txt's order on one core.  Here the order is
+// cut into N contiguous slabs, one host thread + one GPU per slab:
+//   * every GPU loads ONLY its slab's adjacency rows (gnnpe_load_rows) -- per-device CSR bytes ~ 1/N + halo;
+//   * 1-hop halo (2 hops for -l 3): the rows of the middle vertices come from their owners by an all-to-all-v of
+//     device buffers -- RCCL ncclSend/ncclRecv inside one ncclGroup over xGMI, packed by gnnpe_rows_pack and installed
+//     (truncated to the slab's rank range on the last hop) by gnnpe_rows_append;
+//   * vde rows of every slab are all-gathered the same way; counts and byte sizes cross between the threads in host
+//     memory (one process, so these few words need no collective);
+//   * every rank emits, renders and pwrite()s its share of all_paths.txt / partition_paths.txt at its byte offset,
+//     concurrently; index.dat of partition i is built by rank i mod N from the tuples gathered with one more
+//     all-to-all-v.  The files are byte-identical for any N (tests/test_gpu_cli.py).
+// `--same-device` (single-GPU boxes, tests) puts every context on device 0; RCCL refuses duplicate devices in one
+// communicator, so the same exchange then runs as device-to-device copies between the contexts' buffers
+// (`--transport copy`, also usable across devices with peer access).
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "../../include/gnnpe_hip.h"
+#include "cli_common.h"
+#include "graph_loader.h"
+#include "slab_offline.h"
+
+namespace slab {
+
+using namespace cli;
+using gnnpe_host::StaticGraph;
+
+namespace {
+
+class Barrier {
+public:
+    explicit Barrier(int n) : n_(n) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        const uint64_t gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            gen_++;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lk, [&] { return gen_ != gen; });
+        }
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int n_, count_ = 0;
+    uint64_t gen_ = 0;
+};
+
+// librccl is loaded only when more than one device takes part: a single-GPU run never pays for it
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    void load()
+    {
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) die(std::string("cannot load librccl: ") + dlerror());
+#define GNNPE_SYM(field, name)                                          \
+    field = reinterpret_cast<decltype(field)>(dlsym(lib, name));        \
+    if (!field) die(std::string("librccl lacks ") + name)
+        GNNPE_SYM(GetUniqueId, "ncclGetUniqueId");
+        GNNPE_SYM(CommInitRank, "ncclCommInitRank");
+        GNNPE_SYM(CommDestroy, "ncclCommDestroy");
+        GNNPE_SYM(GroupStart, "ncclGroupStart");
+        GNNPE_SYM(GroupEnd, "ncclGroupEnd");
+        GNNPE_SYM(Send, "ncclSend");
+        GNNPE_SYM(Recv, "ncclRecv");
+        GNNPE_SYM(GetErrorString, "ncclGetErrorString");
+#undef GNNPE_SYM
+    }
+};
+
+// Collectives between the rank threads.  Device payloads move by RCCL (default) or by device-to-device copies; the
+// few host words (counts, sizes) are exchanged through shared memory.
+class Transport {
+public:
+    Transport(int n, bool use_rccl) : n_(n), rccl_on_(use_rccl), bar_(n), pub_(n), words_((size_t)n * n, 0), comms_(n, nullptr)
+    {
+        if (rccl_on_) rccl_.load();
+    }
+    int size() const { return n_; }
+    bool rccl() const { return rccl_on_; }
+    void barrier() { bar_.wait(); }
+
+    // called by every rank thread after its context exists (the thread's current device is the context's)
+    void init_rank(int r)
+    {
+        if (!rccl_on_) return;
+        if (r == 0 && rccl_.GetUniqueId(&uid_) != ncclSuccess) die("ncclGetUniqueId failed");
+        barrier();
+        ncclResult_t rc = rccl_.CommInitRank(&comms_[r], n_, uid_, r);
+        if (rc != ncclSuccess) die(std::string("ncclCommInitRank: ") + rccl_.GetErrorString(rc));
+        barrier();
+    }
+    void finish_rank(int r)
+    {
+        if (rccl_on_ && comms_[r]) rccl_.CommDestroy(comms_[r]);
+    }
+
+    // every rank contributes one word per peer; returns what the peers addressed to me: out[p] = word rank p gave for r
+    std::vector<uint64_t> exchange_words(int r, const std::vector<uint64_t> &to_peer)
+    {
+        for (int p = 0; p < n_; p++) words_[(size_t)r * n_ + p] = to_peer[p];
+        barrier();
+        std::vector<uint64_t> out(n_);
+        for (int p = 0; p < n_; p++) out[p] = words_[(size_t)p * n_ + r];
+        barrier();
+        return out;
+    }
+    // one word from every rank
+    std::vector<uint64_t> gather_word(int r, uint64_t v) { return exchange_words(r, std::vector<uint64_t>(n_, v)); }
+
+    // send[scount[0] | scount[1] | ...] -> recv[rcount[0] | rcount[1] | ...]; counts in elements of esize bytes
+    void all_to_all_v(int r, gnnpe_ctx *ctx, const void *send, const std::vector<uint64_t> &scount, void *recv,
+                      const std::vector<uint64_t> &rcount, size_t esize)
+    {
+        std::vector<uint64_t> soff(n_ + 1, 0), roff(n_ + 1, 0);
+        for (int p = 0; p < n_; p++) {
+            soff[p + 1] = soff[p] + scount[p];
+            roff[p + 1] = roff[p] + rcount[p];
+        }
+        if (rccl_on_) {
+            void *stream = nullptr;
+            check(gnnpe_get_stream(ctx, &stream), "get_stream");
+            rccl_.GroupStart();
+            for (int p = 0; p < n_; p++) {
+                if (p == r) continue;
+                if (scount[p]) nccl_ok(rccl_.Send((const char *)send + soff[p] * esize, scount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
+                if (rcount[p]) nccl_ok(rccl_.Recv((char *)recv + roff[p] * esize, rcount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
+            }
+            nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
+            if (scount[r]) check(gnnpe_copy_device(ctx, (char *)recv + roff[r] * esize, (const char *)send + soff[r] * esize, scount[r] * esize), "self copy");
+            check(gnnpe_sync(ctx), "sync");
+            return;
+        }
+        // copy transport: publish where my pieces are, pull the ones addressed to me
+        check(gnnpe_sync(ctx), "sync");  // my send buffer is complete
+        pub_[r].ptr = (const char *)send;
+        pub_[r].off = soff;
+        barrier();
+        for (int p = 0; p < n_; p++) {
+            const uint64_t cnt = pub_[p].off[r + 1] - pub_[p].off[r];
+            if (cnt != rcount[p]) die("all_to_all_v: split sizes disagree between ranks");
+            if (cnt) check(gnnpe_copy_device(ctx, (char *)recv + roff[p] * esize, pub_[p].ptr + pub_[p].off[r] * esize, cnt * esize), "peer copy");
+        }
+        check(gnnpe_sync(ctx), "sync");
+        barrier();  // nobody reuses a send buffer before every peer has read it
+    }
+
+    // every rank's `count` elements to every rank: recv holds the ranks' pieces back to back (counts[] from gather_word)
+    void all_gather_v(int r, gnnpe_ctx *ctx, const void *send, const std::vector<uint64_t> &counts, void *recv, size_t esize)
+    {
+        std::vector<uint64_t> off(n_ + 1, 0);
+        for (int p = 0; p < n_; p++) off[p + 1] = off[p] + counts[p];
+        if (rccl_on_) {
+            void *stream = nullptr;
+            check(gnnpe_get_stream(ctx, &stream), "get_stream");
+            rccl_.GroupStart();
+            for (int p = 0; p < n_; p++) {
+                if (p == r) continue;
+                if (counts[r]) nccl_ok(rccl_.Send(send, counts[r] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
+                if (counts[p]) nccl_ok(rccl_.Recv((char *)recv + off[p] * esize, counts[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
+            }
+            nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
+            if (counts[r]) check(gnnpe_copy_device(ctx, (char *)recv + off[r] * esize, send, counts[r] * esize), "self copy");
+            check(gnnpe_sync(ctx), "sync");
+            return;
+        }
+        check(gnnpe_sync(ctx), "sync");
+        pub_[r].ptr = (const char *)send;
+        barrier();
+        for (int p = 0; p < n_; p++)
+            if (counts[p]) check(gnnpe_copy_device(ctx, (char *)recv + off[p] * esize, pub_[p].ptr, counts[p] * esize), "peer copy");
+        check(gnnpe_sync(ctx), "sync");
+        barrier();
+    }
+
+private:
+    void nccl_ok(ncclResult_t rc, const char *what)
+    {
+        if (rc != ncclSuccess) die(std::string(what) + ": " + rccl_.GetErrorString(rc));
+    }
+    struct Pub {
+        const char *ptr = nullptr;
+        std::vector<uint64_t> off;
+    };
+    int n_;
+    bool rccl_on_;
+    Barrier bar_;
+    std::vector<Pub> pub_;
+    std::vector<uint64_t> words_;
+    Rccl rccl_;
+    ncclUniqueId uid_;
+    std::vector<ncclComm_t> comms_;
+};
+
+struct DevMem {  // device buffer of one context
+    gnnpe_ctx *ctx = nullptr;
+    void *p = nullptr;
+    DevMem(gnnpe_ctx *c, uint64_t bytes) : ctx(c) { check(gnnpe_dev_alloc(c, bytes, &p), "device allocation"); }
+    ~DevMem() { gnnpe_dev_free(ctx, p); }
+    DevMem(const DevMem &) = delete;
+    DevMem &operator=(const DevMem &) = delete;
+};
+
+struct PinnedBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    ~PinnedBuf() { if (p) gnnpe_pinned_free(p); }
+    void reserve(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) gnnpe_pinned_free(p);
+        void *q = nullptr;
+        cap = std::max(n + n / 8, (size_t)1 << 20);
+        if (gnnpe_pinned_alloc(cap, &q) != 0) die(std::string("pinned host buffer: ") + gnnpe_last_error());
+        p = (char *)q;
+    }
+};
+
+// Background pwrite()s of one rank: the GPU renders the next chunk while this one goes to its file offset.
+class RankWriter {
+public:
+    explicit RankWriter(int n_bufs) : bufs_(n_bufs), free_(n_bufs)
+    {
+        for (int i = 0; i < n_bufs; i++) free_[i] = i;
+        th_ = std::thread([this] { run(); });
+    }
+    int acquire(size_t bytes)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !free_.empty(); });
+        const int k = free_.back();
+        free_.pop_back();
+        lk.unlock();
+        bufs_[k].reserve(bytes);
+        return k;
+    }
+    char *data(int k) { return bufs_[k].p; }
+    void submit(int k, int fd, uint64_t offset, size_t bytes)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        queue_.push_back({k, fd, offset, bytes});
+        cv_.notify_all();
+    }
+    void close()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_ = true;
+            cv_.notify_all();
+        }
+        th_.join();
+        if (failed_) die("write error");
+    }
+
+private:
+    struct Item {
+        int k, fd;
+        uint64_t offset;
+        size_t bytes;
+    };
+    void run()
+    {
+        for (;;) {
+            Item it;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return !queue_.empty() || done_; });
+                if (queue_.empty()) return;
+                it = queue_.front();
+                queue_.pop_front();
+            }
+            size_t done = 0;
+            while (done < it.bytes) {
+                const ssize_t w = pwrite(it.fd, bufs_[it.k].p + done, it.bytes - done, (off_t)(it.offset + done));
+                if (w <= 0) {
+                    failed_ = true;
+                    break;
+                }
+                done += (size_t)w;
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                free_.push_back(it.k);
+                cv_.notify_all();
+            }
+        }
+    }
+    std::vector<PinnedBuf> bufs_;
+    std::vector<int> free_;
+    std::deque<Item> queue_;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool done_ = false, failed_ = false;
+};
+
+// decimal digits of the ids first .. first+cnt-1, each followed by '\n' (partition_paths.txt lines, main.cpp:102-106)
+uint64_t id_lines_bytes(uint64_t first, uint64_t cnt)
+{
+    uint64_t bytes = 0, lo = first, end = first + cnt, pow10 = 10;
+    unsigned digits = 1;
+    while (lo < end) {
+        while (lo >= pow10) {
+            pow10 *= 10;
+            digits++;
+        }
+        const uint64_t hi = std::min(end, pow10);
+        bytes += (hi - lo) * (digits + 1);
+        lo = hi;
+    }
+    return bytes;
+}
+
+// Slabs of (estimated) equal path counts: paths(s) ~ sum_{b in N(s)} (deg b - 1) x share of edge endpoints ranked after s
+// (same estimate as gnn-pe_amd/dist.py:plan_slabs).
+std::vector<uint32_t> plan_slabs(const StaticGraph &g, const std::vector<uint32_t> &sorted_nodes, int R)
+{
+    const uint32_t n = g.n;
+    std::vector<double> w(n);
+    double dsum = 0.0;
+    for (uint32_t v = 0; v < n; v++) dsum += g.offsets[v + 1] - g.offsets[v];
+    double later = dsum;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = sorted_nodes[i];
+        later -= g.offsets[s + 1] - g.offsets[s];
+        double two_hop = 0.0;
+        for (uint32_t q = g.offsets[s]; q < g.offsets[s + 1]; q++) {
+            const uint32_t b = g.neighbors[q];
+            two_hop += (double)(g.offsets[b + 1] - g.offsets[b]) - 1.0;
+        }
+        w[i] = two_hop * (dsum > 0 ? later / dsum : 0.0) + 1e-3;
+    }
+    std::vector<uint32_t> bounds(R + 1, n);
+    bounds[0] = 0;
+    const double tot = std::accumulate(w.begin(), w.end(), 0.0);
+    double acc = 0.0;
+    int next = 1;
+    for (uint32_t i = 0; i < n && next < R; i++) {
+        acc += w[i];
+        while (next < R && acc >= tot * next / R) bounds[next++] = i + 1;
+    }
+    for (int r = 1; r <= R; r++) bounds[r] = std::max(bounds[r], bounds[r - 1]);
+    return bounds;
+}
+
+struct Shared {
+    const Options *o;
+    const StaticGraph *g;
+    const std::vector<uint32_t> *sorted_nodes, *membership;
+    const std::vector<double> *table;
+    std::vector<uint32_t> bounds;
+    Transport *tp;
+    std::vector<int> part_fd;
+    int all_fd = -1;
+    uint64_t P = 0;
+    std::vector<uint64_t> part_total;
+    // reporting
+    std::vector<uint64_t> held_entries, owned_entries, halo_rows;
+    std::vector<double> t_halo, t_count, t_emit, t_index;
+    uint64_t bytes_all = 0, bytes_part = 0;
+};
+
+void rank_main(int r, Shared &S)
+{
+    const Options &o = *S.o;
+    const StaticGraph &g = *S.g;
+    Transport &tp = *S.tp;
+    const int R = tp.size();
+    const uint32_t n = g.n, L = o.path_length + 1, e = o.vde_dim, p = o.partition_num;
+    const std::vector<uint32_t> &sn = *S.sorted_nodes, &mem = *S.membership;
+    const uint32_t lo = S.bounds[r], hi = S.bounds[r + 1], n_own = hi - lo;
+    const uint64_t m2 = g.offsets[n];
+    const auto t0 = Clock::now();
+
+    gnnpe_ctx *ctx = gnnpe_create(o.same_device ? 0 : r);
+    if (!ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
+    tp.init_rank(r);
+
+    // ---- this rank's rows only ----
+    std::vector<uint32_t> rows(sn.begin() + lo, sn.begin() + hi);
+    std::vector<uint64_t> roff(n_own + 1, 0);
+    for (uint32_t k = 0; k < n_own; k++) roff[k + 1] = roff[k] + (g.offsets[rows[k] + 1] - g.offsets[rows[k]]);
+    std::vector<uint32_t> rnbr(roff[n_own]);
+    for (uint32_t k = 0; k < n_own; k++)
+        std::copy(g.neighbors.begin() + g.offsets[rows[k]], g.neighbors.begin() + g.offsets[rows[k] + 1], rnbr.begin() + roff[k]);
+    const uint64_t own_entries = roff[n_own];
+    S.owned_entries[r] = own_entries;
+    check(gnnpe_load_rows(ctx, n, g.labels.data(), n_own, rows.data(), roff.data(), rnbr.data(), m2), "load_rows");
+    check(gnnpe_set_order(ctx, sn.data(), mem.data(), p), "set_order");
+    check(gnnpe_set_slab(ctx, lo, hi), "set_slab");
+    check(gnnpe_set_label_table(ctx, std::max<uint32_t>(g.labels_count, 1), e, S.table->data()), "set_label_table");
+
+    // ---- halo: one all-to-all-v of adjacency lists per hop (graph structure: done once) ----
+    {
+        DevMem d_need(ctx, ((uint64_t)n + 1) * 4), d_degin(ctx, ((uint64_t)n + 1) * 4);
+        const uint64_t req_cap = (uint64_t)n_own * (uint64_t)std::max(R - 1, 1) + 1;
+        DevMem d_req(ctx, req_cap * 4), d_degout(ctx, req_cap * 4);
+        DevMem d_pack(ctx, (own_entries * (uint64_t)std::max(R - 1, 1) + 1) * 4), d_in(ctx, (m2 + 1) * 4);
+        std::vector<uint32_t> h_deg;
+        const int hops = (int)o.path_length - 1;
+        for (int hop = 0; hop < hops; hop++) {
+            std::vector<uint64_t> need(R, 0);
+            check(gnnpe_halo_need(ctx, (uint32_t)R, S.bounds.data(), d_need.p, n, need.data()), "halo_need");
+            const std::vector<uint64_t> req = tp.exchange_words(r, need);  // rows every peer wants from me
+            const uint64_t n_need = std::accumulate(need.begin(), need.end(), (uint64_t)0);
+            const uint64_t n_req = std::accumulate(req.begin(), req.end(), (uint64_t)0);
+            if (n_req >= req_cap) die("halo request buffer too small");
+            tp.all_to_all_v(r, ctx, d_need.p, need, d_req.p, req, 4);            // the requested vertex ids
+            check(gnnpe_rows_degree(ctx, n_req, d_req.p, d_degout.p), "rows_degree");
+            tp.all_to_all_v(r, ctx, d_degout.p, req, d_degin.p, need, 4);        // their degrees, back to the requester
+            auto segment_sums = [&](const void *dev, const std::vector<uint64_t> &counts, uint64_t tot) {
+                h_deg.resize(tot + 1);
+                check(gnnpe_copy_to_host(ctx, h_deg.data(), dev, tot * 4), "copy degrees");
+                std::vector<uint64_t> sums(R, 0);
+                uint64_t at = 0;
+                for (int q = 0; q < R; q++)
+                    for (uint64_t k = 0; k < counts[q]; k++) sums[q] += h_deg[at++];
+                return sums;
+            };
+            const std::vector<uint64_t> send_sizes = segment_sums(d_degout.p, req, n_req);
+            const std::vector<uint64_t> recv_sizes = segment_sums(d_degin.p, need, n_need);
+            const uint64_t n_send = std::accumulate(send_sizes.begin(), send_sizes.end(), (uint64_t)0);
+            const uint64_t n_recv = std::accumulate(recv_sizes.begin(), recv_sizes.end(), (uint64_t)0);
+            if (n_recv > m2) die("halo receive buffer too small");
+            check(gnnpe_rows_pack(ctx, n_req, d_req.p, d_pack.p, n_send + 1), "rows_pack");
+            tp.all_to_all_v(r, ctx, d_pack.p, send_sizes, d_in.p, recv_sizes, 4);  // the adjacency lists themselves
+            const uint32_t min_rank = hop == hops - 1 ? lo : 0u;  // last hop: entries ranked before the slab are never used
+            check(gnnpe_rows_append(ctx, n_need, d_need.p, d_degin.p, d_in.p, n_recv, min_rank), "rows_append");
+            S.halo_rows[r] += n_need;
+            S.held_entries[r] += n_recv;
+        }
+    }
+    S.held_entries[r] += own_entries;
+    const auto t1 = Clock::now();
+
+    // ---- vde of the owned rows, all-gather of the slabs' rows ----
+    {
+        check(gnnpe_vde(ctx, nullptr, nullptr, nullptr), "vde");
+        std::vector<uint64_t> counts(R);
+        for (int q = 0; q < R; q++) counts[q] = (uint64_t)(S.bounds[q + 1] - S.bounds[q]) * e;
+        DevMem d_send(ctx, (counts[r] + 1) * 8), d_all(ctx, ((uint64_t)n * e + 1) * 8);
+        check(gnnpe_vde_pack_slab(ctx, lo, hi, d_send.p), "vde_pack_slab");
+        tp.all_gather_v(r, ctx, d_send.p, counts, d_all.p, 8);
+        uint64_t off = 0;
+        for (int q = 0; q < R; q++) {
+            if (q != r && counts[q]) check(gnnpe_vde_unpack_slab(ctx, S.bounds[q], S.bounds[q + 1], (char *)d_all.p + off * 8), "vde_unpack_slab");
+            off += counts[q];
+        }
+        check(gnnpe_sync(ctx), "sync");
+    }
+
+    // ---- count; global id base and per-partition totals from the per-start counts ----
+    std::vector<uint64_t> per_start(std::max<uint32_t>(n_own, 1));
+    uint64_t total = 0;
+    check(gnnpe_count_paths(ctx, o.path_length, per_start.data(), &total), "count_paths");
+    const std::vector<uint64_t> totals = tp.gather_word(r, total);
+    uint64_t base = 0, P = 0;
+    for (int q = 0; q < R; q++) {
+        if (q < r) base += totals[q];
+        P += totals[q];
+    }
+    if (P > 0xFFFFFFFFull && !o.allow_large)
+        die(std::to_string(P) + " paths exceed the reference's 32-bit path ids (use --allow-large to write anyway)");
+    std::vector<uint64_t> my_part_cnt(p, 0), my_part_bytes(p, 0);
+    {
+        uint64_t id = base;
+        for (uint32_t i = 0; i < n_own; i++) {
+            const uint32_t pid = mem[rows[i]];
+            my_part_cnt[pid] += per_start[i];
+            my_part_bytes[pid] += id_lines_bytes(id, per_start[i]);
+            id += per_start[i];
+        }
+    }
+    const auto t2 = Clock::now();
+
+    // ---- sizing pass: bytes of this rank's rows of all_paths.txt (emit ids, count digits; nothing is rendered) ----
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(o.chunk_paths, 4ull << 20), std::max<uint64_t>(total, 1)));
+    const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
+    DevMem d_ids(ctx, chunk * L * 4), d_part(ctx, chunk * 4), d_sel(ctx, chunk * 8), d_text(ctx, text_cap);
+    uint64_t my_all_bytes = 0;
+    for (uint64_t b = 0; b < total; b += chunk) {
+        const uint64_t en = std::min(total, b + chunk);
+        uint64_t nb = 0;
+        check(gnnpe_fill_paths_device(ctx, b, en, d_ids.p, nullptr, nullptr), "fill_paths");
+        check(gnnpe_text_paths(ctx, en - b, L, d_ids.p, nullptr, 0, &nb), "text size");
+        my_all_bytes += nb;
+    }
+    // offsets of my bytes inside every file
+    const std::vector<uint64_t> all_sizes = tp.gather_word(r, my_all_bytes);
+    const std::string hdr_all = std::to_string(P) + "\n";
+    uint64_t all_off = hdr_all.size();
+    for (int q = 0; q < r; q++) all_off += all_sizes[q];
+    std::vector<uint64_t> part_off(p), part_tot(p, 0), part_bytes_tot(p, 0);
+    std::vector<std::string> part_hdr(p);
+    for (uint32_t pid = 0; pid < p; pid++) {
+        const std::vector<uint64_t> c = tp.gather_word(r, my_part_cnt[pid]), by = tp.gather_word(r, my_part_bytes[pid]);
+        for (int q = 0; q < R; q++) {
+            part_tot[pid] += c[q];
+            part_bytes_tot[pid] += by[q];
+        }
+        part_hdr[pid] = std::to_string(part_tot[pid]) + "\n";
+        part_off[pid] = part_hdr[pid].size();
+        for (int q = 0; q < r; q++) part_off[pid] += by[q];
+    }
+    const std::string partitions_path = o.dataset_path + "gnn-pe/partitions/";
+    if (r == 0) {  // create the files at their final size, headers first (main.cpp:102,113)
+        auto create = [&](const std::string &path, const std::string &hdr, uint64_t body) {
+            const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) die("cannot open " + path + " for writing");
+            if (pwrite(fd, hdr.data(), hdr.size(), 0) != (ssize_t)hdr.size() || ftruncate(fd, (off_t)(hdr.size() + body)) != 0)
+                die("cannot size " + path);
+            return fd;
+        };
+        uint64_t body = 0;
+        for (int q = 0; q < R; q++) body += all_sizes[q];
+        S.all_fd = create(o.dataset_path + "/gnn-pe/all_paths.txt", hdr_all, body);  // main.cpp:110 (sic: extra slash)
+        S.bytes_all = hdr_all.size() + body;
+        for (uint32_t pid = 0; pid < p; pid++) {
+            S.part_fd[pid] = create(partitions_path + "partition-" + std::to_string(pid) + "/partition_paths.txt", part_hdr[pid], part_bytes_tot[pid]);
+            S.bytes_part += part_hdr[pid].size() + part_bytes_tot[pid];
+        }
+        S.P = P;
+        S.part_total = part_tot;
+    }
+    tp.barrier();
+
+    // ---- emit + render + pwrite at this rank's offsets, all ranks concurrently ----
+    std::vector<DevMem *> keep(p, nullptr);  // --index: this rank's tuples of every partition, in path-id order
+    std::vector<uint64_t> keep_at(p, 0);
+    if (o.write_index)
+        for (uint32_t pid = 0; pid < p; pid++) keep[pid] = new DevMem(ctx, (my_part_cnt[pid] + 1) * L * 4);
+    {
+        RankWriter writer(4);
+        for (uint64_t b = 0; b < total; b += chunk) {
+            const uint64_t en = std::min(total, b + chunk), cnt = en - b;
+            uint64_t nb = 0;
+            check(gnnpe_fill_paths_device(ctx, b, en, d_ids.p, nullptr, nullptr), "fill_paths");
+            check(gnnpe_path_partitions_device(ctx, b, en, d_part.p), "path_partitions");
+            check(gnnpe_text_paths(ctx, cnt, L, d_ids.p, d_text.p, text_cap, &nb), "text_paths");
+            int k = writer.acquire(nb);
+            check(gnnpe_copy_to_host(ctx, writer.data(k), d_text.p, nb), "copy text");
+            writer.submit(k, S.all_fd, all_off, nb);
+            all_off += nb;
+            for (uint32_t pid = 0; pid < p; pid++) {
+                uint64_t kk = 0, pb = 0;
+                check(gnnpe_select_partition(ctx, cnt, d_part.p, pid, base + b, d_sel.p, &kk), "select_partition");
+                if (!kk) continue;
+                check(gnnpe_text_ids(ctx, kk, d_sel.p, d_text.p, text_cap, &pb), "text_ids");
+                k = writer.acquire(pb);
+                check(gnnpe_copy_to_host(ctx, writer.data(k), d_text.p, pb), "copy ids text");
+                writer.submit(k, S.part_fd[pid], part_off[pid], pb);
+                part_off[pid] += pb;
+                if (o.write_index) {
+                    check(gnnpe_gather_rows_device(ctx, kk, L, d_sel.p, base + b, d_ids.p, (char *)keep[pid]->p + keep_at[pid] * L * 4), "gather tuples");
+                    keep_at[pid] += kk;
+                }
+            }
+        }
+        writer.close();
+    }
+    const auto t3 = Clock::now();
+
+    // ---- index.dat of partition pid: built by rank pid mod R from every rank's tuples (one all-to-all-v each) ----
+    if (o.write_index) {
+        for (uint32_t pid = 0; pid < p; pid++) {
+            const int owner = (int)(pid % (uint32_t)R);
+            const std::vector<uint64_t> cnts = tp.gather_word(r, my_part_cnt[pid]);
+            std::vector<uint64_t> scount(R, 0), rcount(R, 0);
+            scount[owner] = my_part_cnt[pid] * L;
+            uint64_t tot = 0;
+            if (r == owner)
+                for (int q = 0; q < R; q++) {
+                    rcount[q] = cnts[q] * L;
+                    tot += cnts[q];
+                }
+            DevMem d_all(ctx, (tot + 1) * L * 4);
+            tp.all_to_all_v(r, ctx, keep[pid]->p, scount, d_all.p, rcount, 4);
+            delete keep[pid];
+            keep[pid] = nullptr;
+            if (r == owner) {
+                void *image = nullptr;
+                uint64_t nbytes = 0;
+                check(gnnpe_build_index_device(ctx, tot, L, d_all.p, &image, &nbytes, nullptr), "build_index");
+                check(gnnpe_write_device_file(ctx, image, nbytes, (partitions_path + "partition-" + std::to_string(pid) + "/index.dat").c_str()),
+                      "write index.dat");
+            }
+        }
+    }
+    tp.barrier();
+    const auto t4 = Clock::now();
+    S.t_halo[r] = secs(t0, t1);
+    S.t_count[r] = secs(t1, t2);
+    S.t_emit[r] = secs(t2, t3);
+    S.t_index[r] = secs(t3, t4);
+    tp.finish_rank(r);
+    gnnpe_destroy(ctx);
+}
+
+}  // namespace
+
+int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<uint32_t> &sorted_nodes,
+                      const std::vector<uint32_t> &membership, const std::vector<double> &table, Clock::time_point t_start,
+                      Clock::time_point t_loaded)
+{
+    const int R = o.gpus;
+    const bool use_rccl = !o.same_device && o.transport != "copy";
+    Transport tp(R, use_rccl);
+    Shared S;
+    S.o = &o;
+    S.g = &g;
+    S.sorted_nodes = &sorted_nodes;
+    S.membership = &membership;
+    S.table = &table;
+    S.bounds = plan_slabs(g, sorted_nodes, R);
+    S.tp = &tp;
+    S.part_fd.assign(o.partition_num, -1);
+    S.held_entries.assign(R, 0);
+    S.owned_entries.assign(R, 0);
+    S.halo_rows.assign(R, 0);
+    S.t_halo.assign(R, 0);
+    S.t_count.assign(R, 0);
+    S.t_emit.assign(R, 0);
+    S.t_index.assign(R, 0);
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; r++) th.emplace_back(rank_main, r, std::ref(S));
+    for (auto &t : th) t.join();
+    if (S.all_fd >= 0 && close(S.all_fd) != 0) die("write error on all_paths.txt");
+    for (int fd : S.part_fd)
+        if (fd >= 0 && close(fd) != 0) die("write error on partition_paths.txt");
+    if (o.timing) {
+        auto mx = [](const std::vector<double> &v) { return *std::max_element(v.begin(), v.end()); };
+        std::string per;
+        for (int r = 0; r < R; r++)
+            per += std::string(r ? ", " : "") + "{\"owned_entries\": " + std::to_string(S.owned_entries[r]) + ", \"held_entries\": " +
+                   std::to_string(S.held_entries[r]) + ", \"halo_rows\": " + std::to_string(S.halo_rows[r]) + "}";
+        fprintf(stderr,
+                "{\"paths\": %llu, \"gpus\": %d, \"transport\": \"%s\", \"load_s\": %.3f, \"setup_halo_s\": %.3f, \"vde_count_s\": %.3f, "
+                "\"emit_render_write_s\": %.3f, \"index_build_s\": %.3f, \"end_to_end_s\": %.3f, \"all_paths_bytes\": %llu, "
+                "\"partition_bytes\": %llu, \"csr_entries\": %llu, \"ranks\": [%s]}\n",
+                (unsigned long long)S.P, R, use_rccl ? "rccl" : "copy", secs(t_start, t_loaded), mx(S.t_halo), mx(S.t_count), mx(S.t_emit),
+                mx(S.t_index), secs(t_start, Clock::now()), (unsigned long long)S.bytes_all, (unsigned long long)S.bytes_part,
+                (unsigned long long)g.offsets[g.n], per.c_str());
+    }
+    return 0;
+}
+
+}  // namespace slab

@@ -17,15 +17,13 @@ SEED = 2022  # the reference's own seed (gnnpe.py:14)
 def _csr_from_edges(n, eu, ev):
     """Undirected simple edge list (u<v) -> CSR with ascending neighbour lists
     (what graph.cpp:211-233 builds from `e u v` lines)."""
-    src = np.concatenate([eu, ev])
-    dst = np.concatenate([ev, eu])
-    order = np.lexsort((dst, src))
-    src = src[order]
-    dst = dst[order]
-    deg = np.bincount(src, minlength=n).astype(np.uint32)
+    # one sort of the combined key src * n + dst (the edges are distinct, so this is the (src, dst) lexicographic order)
+    key = np.concatenate([eu.astype(np.int64) * n + ev, ev.astype(np.int64) * n + eu])
+    key.sort()
+    deg = np.bincount(key // n, minlength=n).astype(np.uint32)
     offs = np.zeros(n + 1, np.uint32)
     np.cumsum(deg, out=offs[1:])
-    return offs, dst.astype(np.uint32)
+    return offs, (key % n).astype(np.uint32)
 
 
 def gnm_graph(n, m, n_labels=64, seed=SEED):
@@ -105,22 +103,52 @@ def expected_paths_l2(offsets):
     return int((deg * (deg - 1) // 2).sum())
 
 
+def _render_lines(prefix, cols):
+    """b"<prefix> c0 c1 ...\n" for every row of the non-negative integer columns `cols`, as one bytes object
+    (vectorised decimal rendering: np.savetxt needs ~2 us per number)."""
+    n = len(cols[0])
+    width = 10  # ids and counts are < 2^32
+    pieces, keep = [], []
+    if prefix:
+        pieces.append(np.full((n, 1), ord(prefix), np.uint8))
+        keep.append(np.ones((n, 1), bool))
+    for ci, c in enumerate(cols):
+        c = np.asarray(c, np.int64)
+        if prefix or ci:
+            pieces.append(np.full((n, 1), ord(" "), np.uint8))
+            keep.append(np.ones((n, 1), bool))
+        pw = 10 ** np.arange(width - 1, -1, -1, dtype=np.int64)
+        digits = (c[:, None] // pw[None, :]) % 10
+        pieces.append((digits + ord("0")).astype(np.uint8))
+        lead = np.cumsum(digits != 0, axis=1) == 0   # leading zeros
+        lead[:, -1] = False                           # the value 0 keeps its last digit
+        keep.append(~lead)
+    pieces.append(np.full((n, 1), ord("\n"), np.uint8))
+    keep.append(np.ones((n, 1), bool))
+    return np.concatenate(pieces, axis=1)[np.concatenate(keep, axis=1)].tobytes()
+
+
 def write_graph_file(path, g):
     """Text `.graph` in the format graph.cpp:172-219 parses: `t n m`, `v id label degree`
     (ascending id, true degree), `e u v` (u<v, sorted)."""
     n, m = g["n"], g["m"]
     deg = np.diff(g["offsets"].astype(np.int64))
-    with open(path, "w") as f:
-        f.write(f"t {n} {m}\n")
-        vl = np.column_stack([np.arange(n), g["labels"], deg])
-        np.savetxt(f, vl, fmt="v %d %d %d")
-        np.savetxt(f, np.column_stack([g["eu"], g["ev"]]), fmt="e %d %d")
+    step = 1 << 21
+    with open(path, "wb") as f:
+        f.write(f"t {n} {m}\n".encode())
+        for a in range(0, n, step):
+            z = slice(a, min(a + step, n))
+            f.write(_render_lines("v", [np.arange(z.start, z.stop), g["labels"][z], deg[z]]))
+        for a in range(0, m, step):
+            z = slice(a, min(a + step, m))
+            f.write(_render_lines("e", [g["eu"][z], g["ev"][z]]))
 
 
 def write_membership(path, sorted_nodes, membership):
     """`membership.txt` as `gnnpe.py:74-76` writes it: line i = "<vertex> <partition>"."""
     sn = np.asarray(sorted_nodes, np.int64)
-    np.savetxt(path, np.column_stack([sn, np.asarray(membership, np.int64)[sn]]), fmt="%d %d")
+    with open(path, "wb") as f:
+        f.write(_render_lines("", [sn, np.asarray(membership, np.int64)[sn]]))
 
 
 def make_dataset_dir(root, p):

@@ -58,6 +58,11 @@ int gnnpe_dev_alloc(gnnpe_ctx *ctx, uint64_t bytes, void **dev_ptr);
 int gnnpe_dev_free(gnnpe_ctx *ctx, void *dev_ptr);
 int gnnpe_copy_to_host(gnnpe_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 int gnnpe_device_count(void);
+/* The context's stream as a hipStream_t (for callers that enqueue their own work behind the engine's, e.g. the RCCL
+ * send/recv of the C++ host's halo exchange), and an asynchronous device-to-device copy on it (either end may be memory
+ * of another device of this process). */
+int gnnpe_get_stream(gnnpe_ctx *ctx, void **hip_stream);
+int gnnpe_copy_device(gnnpe_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t bytes);
 /* Page-locked host memory for buffers that receive gnnpe_copy_to_host / gnnpe_fill_paths output (PCIe-rate copies). */
 int gnnpe_pinned_alloc(uint64_t bytes, void **host_ptr);
 void gnnpe_pinned_free(void *host_ptr);
@@ -198,6 +203,13 @@ int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const voi
  * (<f>gnn-pe/partitions/partition-<pid>/index.dat).  The reference online run then skips its insert
  * loop (custom.h:222-235 only tests that the file exists). */
 int gnnpe_build_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
+
+/* Pieces for callers that assemble a partition's tuples themselves (multi-GPU host: the tuples of partition pid come
+ * from every rank): rows of dev_rows (k x L uint32 selected by the global ids dev_sel[i] - sel_base) -> dev_out; and a
+ * device buffer written to a file through pinned staging buffers (copy-back overlapped with the writes). */
+int gnnpe_gather_rows_device(gnnpe_ctx *ctx, uint64_t k, uint32_t L, const void *dev_sel, uint64_t sel_base,
+                             const void *dev_rows, void *dev_out);
+int gnnpe_write_device_file(gnnpe_ctx *ctx, const void *dev_src, uint64_t nbytes, const char *path);
 
 /* Same file format over explicit rectangles: cnt x 2*dim doubles (lo0, hi0, lo1, hi1, ...), son = row. */
 int gnnpe_build_box_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t dim, const void *dev_boxes, void **dev_image,

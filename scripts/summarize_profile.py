@@ -42,15 +42,21 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"{rnd}_pmc_*"))):
 out = dict(kernel=f"{kernel}<2>",
            command="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-index (one rocprofv3 --pmc pass per counter set)",
            counters=counters)
-if "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
+if "WRITE_SIZE" in counters:
     wb = counters["WRITE_SIZE"]["mean"] * 1024
-    fb = counters["FETCH_SIZE"]["mean"] * 1024
-    out["derived"] = dict(
-        write_bytes=wb, fetch_bytes_raw=fb,
-        note="WRITE_SIZE/FETCH_SIZE are in KiB. FETCH_SIZE under-reports wide coalesced streams by 2x on gfx950 "
-             "(MI355X_MICROARCH.md, HBM); the fill reads 8+16-byte records per lane plus 16-byte pair records, so the "
-             "read side is bracketed: raw <= true <= 2x raw.",
-        traffic_bytes_low=wb + fb, traffic_bytes_high=wb + 2 * fb)
+    d = dict(write_bytes=wb)
+    if "TCC_EA0_RDREQ_sum" in counters:
+        # fabric read requests by size: what the L2 actually fetched (FETCH_SIZE tallies every request at 64 bytes,
+        # MI355X_MICROARCH.md section HBM; here nearly all of them are 128-byte line fills)
+        r128 = counters.get("TCC_EA0_RDREQ_128B_sum", {}).get("mean", 0.0)
+        r64 = counters.get("TCC_EA0_RDREQ_64B_sum", {}).get("mean", 0.0)
+        r32 = counters.get("TCC_EA0_RDREQ_32B_sum", {}).get("mean", 0.0)
+        rb = r128 * 128 + r64 * 64 + r32 * 32
+        d.update(read_bytes=rb, traffic_bytes=wb + rb,
+                 note="WRITE_SIZE is in KiB; read bytes = TCC_EA0_RDREQ_{32,64,128}B x their sizes (one number, no bracket)")
+    if "FETCH_SIZE" in counters:
+        d["fetch_size_raw_bytes"] = counters["FETCH_SIZE"]["mean"] * 1024
+    out["derived"] = d
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_fill.json"), "w"), indent=1)
 print("stats from", stats)
 for k, v in counters.items():

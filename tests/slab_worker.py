@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""One rank of a slab-partitioned run of the hot path, for the full-size multi-rank GPU tests (TEST INFRASTRUCTURE).
+
+Launched by tests/test_gpu_slabs_full.py through torch.distributed.run (or directly for one rank).  Every rank loads
+its slab's rows, installs the halo through dist.SlabBuild (the production exchange code), runs one step and writes
+<out>/rank<r>.json: local / global path counts, the id base, an order-sensitive checksum of what it emitted
+(gnnpe_rows_checksum_device, first_id = its global id base, so the ranks' checksums ADD to the single-rank one) and
+the outcome of the size-independent properties.
+
+Ranks share device 0 over gloo when GNNPE_BENCH_SAME_DEVICE=1 (single-GPU box); otherwise one GPU per rank over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import gnnpe_amd  # noqa: E402,F401
+from gnnpe_amd import binding, synth  # noqa: E402
+from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs  # noqa: E402
+
+M64 = (1 << 64) - 1
+
+
+def l2_properties(g, sn, dev, ids, pde, vde_ref, lo, hi):
+    """Size-independent properties of one rank's emitted rows (all on the device): starts inside the slab, rows
+    strictly increasing in (rank[s], b, c) (=> unique, reference order), (s,b) and (b,c) are edges, rank[c] > rank[s],
+    pde rows are the vde gather.  Returns a dict of booleans."""
+    n = g["n"]
+    rank = np.empty(n, np.int64)
+    rank[sn] = np.arange(n)
+    rank_t = torch.from_numpy(rank).to(dev)
+    s, b, c = ids[:, 0].long(), ids[:, 1].long(), ids[:, 2].long()
+    out = {}
+    out["starts_in_slab"] = bool(((rank_t[s] >= lo) & (rank_t[s] < hi)).all()) if len(s) else True
+    out["rank_c_gt_rank_s"] = bool((rank_t[c] > rank_t[s]).all())
+    key = (rank_t[s] * n + b) * n + c
+    out["strictly_increasing"] = bool((key[1:] > key[:-1]).all())
+    del key
+    deg = torch.from_numpy(np.diff(g["offsets"].astype(np.int64))).to(dev)
+    ekeys = torch.repeat_interleave(torch.arange(n, device=dev), deg) * n + torch.from_numpy(g["nbrs"].astype(np.int64)).to(dev)
+    ok = True
+    for u, v in ((s, b), (b, c)):
+        q = u * n + v
+        pos = torch.searchsorted(ekeys, q).clamp_(max=len(ekeys) - 1)
+        ok = ok and bool((ekeys[pos] == q).all())
+        del q, pos
+    out["edges_exist"] = ok
+    if pde is not None:
+        vt = torch.from_numpy(vde_ref).to(dev)
+        e = vt.shape[1]
+        ok = True
+        CH = 1 << 23
+        for k, col in enumerate((s, b, c)):
+            for a in range(0, len(col), CH):
+                z = slice(a, min(a + CH, len(col)))
+                ok = ok and bool((pde[z, e * k:e * (k + 1)] == vt[col[z]]).all())
+        out["pde_is_vde_gather"] = ok
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", required=True, help=".npz with offsets, nbrs, labels")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("-l", type=int, default=2)
+    ap.add_argument("-e", type=int, default=2)
+    ap.add_argument("--labels", type=int, default=64)
+    ap.add_argument("--props", type=int, default=1)
+    ap.add_argument("--sample", type=int, default=0, help="l=3: rows per rank to emit and checksum (0 = all)")
+    ap.add_argument("--ranges", default=None, help="world 1: JSON list of [begin, end) global id ranges to checksum")
+    ap.add_argument("--entry-cost", type=float, default=0.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    same = os.environ.get("GNNPE_BENCH_SAME_DEVICE") == "1"
+    if same:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    backend = "none"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if same else "nccl"
+        if same:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    z = np.load(args.graph)
+    g = dict(n=len(z["labels"]), offsets=z["offsets"], nbrs=z["nbrs"], labels=z["labels"])
+    n, L, e = g["n"], args.l + 1, args.e
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(n, max(world, 1))
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], entry_cost=args.entry_cost)
+
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    eng = binding.Engine(local_rank, stream=stream.cuda_stream)
+    owned_entries = len(g["nbrs"])
+    cap = len(g["nbrs"]) * (2 if args.l == 3 else 1)
+    if world == 1:
+        eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    else:
+        rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
+        owned_entries = int(roff[-1])
+        eng.load_rows(n, g["labels"], rows, roff, rnbr, nbr_capacity=cap + owned_entries)
+    eng.set_order(sn, mem, max(world, 1))
+    eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
+    eng.set_label_table(binding.host_label_table(args.labels, e))
+    sb = SlabBuild(eng, n, e, bounds, rank, world, dev, nbr_capacity=cap, owned_entries=owned_entries, l=args.l)
+    total, base = sb.step()
+    res = dict(rank=rank, world=world, backend=backend, total=int(total), base=int(base), global_total=int(sb.global_total),
+               slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats))
+
+    chunk = 1 << 24
+    if args.ranges is not None:  # single rank: checksum the requested global ranges
+        sums = []
+        buf = torch.empty((chunk, L), dtype=torch.int32, device=dev)
+        for a, b in json.loads(args.ranges):
+            acc = 0
+            for c0 in range(a, b, chunk):
+                c1 = min(c0 + chunk, b)
+                eng.fill_paths_device(c0, c1, buf, None, None)
+                acc = (acc + eng.rows_checksum_device(c1 - c0, L, buf, first_id=c0)) & M64
+            sums.append(acc)
+        res["range_checksums"] = sums
+    else:
+        emit = total if not args.sample else min(total, args.sample)
+        res["emitted"] = int(emit)
+        if args.l == 2 and args.props:
+            ids = torch.empty((max(emit, 1), L), dtype=torch.int32, device=dev)
+            pde = torch.empty((max(emit, 1), L * e), dtype=torch.float64, device=dev)
+            eng.fill_paths_device(0, emit, ids, pde, None)
+            torch.cuda.synchronize()
+            res["checksum"] = eng.rows_checksum_device(emit, L, ids, first_id=base)
+            ref = binding.Engine(local_rank)  # whole-graph context: the vde table every rank must agree with
+            ref.load_csr(g["offsets"], g["nbrs"], g["labels"])
+            ref.set_label_table(binding.host_label_table(args.labels, e))
+            _, _, vde_ref = ref.vde()
+            ref.close()
+            res["props"] = l2_properties(g, sn, dev, ids[:emit], pde[:emit], vde_ref, int(bounds[rank]), int(bounds[rank + 1]))
+            res["middle_sum"] = int(ids[:emit, 1].to(torch.int64).sum())
+        else:
+            buf = torch.empty((chunk, L), dtype=torch.int32, device=dev)
+            acc = 0
+            for c0 in range(0, emit, chunk):
+                c1 = min(c0 + chunk, emit)
+                eng.fill_paths_device(c0, c1, buf, None, None)
+                acc = (acc + eng.rows_checksum_device(c1 - c0, L, buf, first_id=base + c0)) & M64
+            res["checksum"] = acc
+    os.makedirs(args.out, exist_ok=True)
+    with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ import subprocess
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import GOLDEN, ROOT
 from gnnpe_amd import synth
@@ -127,9 +128,12 @@ def test_text_rendering_edge_values(oracle):
 
 
 @pytest.mark.parametrize("gpus", [2, 3, 8])
-def test_slab_split_writes_identical_files(tmp_path, gpus):
-    """SURVEY 8(e) invariant at process level: the files do not depend on the number of slabs.  The box
-    has one GPU, so the contexts share device 0 (--same-device); each still enumerates only its slab."""
+def test_slab_split_writes_identical_files(tmp_path, oracle, gpus):
+    """SURVEY 8(e) invariant at process level: the files do not depend on the number of slabs.  `gnnpe_main --gpus N`
+    is the north-star split in the C++ host: one thread per slab, each context loads ONLY its slab's rows, the halo
+    comes by all-to-all-v, every rank pwrite()s its bytes at its offset, index.dat of partition i is built by rank
+    i mod N.  The box has one GPU, so the contexts share device 0 (--same-device: the exchange then runs as
+    device-to-device copies; RCCL needs distinct devices and is covered by the >= 2 GPU test below)."""
     g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
     sn = synth.degree_order(g["offsets"])
     mem = synth.block_membership(3000, 4)
@@ -141,12 +145,51 @@ def test_slab_split_writes_identical_files(tmp_path, gpus):
         os.makedirs(d)
         synth.make_dataset_dir(d, 4)
         synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
-        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "4", "--gpus", str(n), "--same-device", "--chunk", "50000"],
-                           capture_output=True, text=True)
+        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "4", "--gpus", str(n), "--same-device", "--chunk", "50000",
+                            "--index", "--timing"], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         outs.append(d)
+        if n > 1:
+            t = json.loads(r.stderr.strip().splitlines()[-1])
+            assert t["gpus"] == n and t["transport"] == "copy"
+            own = [x["owned_entries"] for x in t["ranks"]]
+            held = [x["held_entries"] for x in t["ranks"]]
+            assert sum(own) == t["csr_entries"] == 2 * g["m"]           # the rows are partitioned, not replicated
+            assert all(h <= t["csr_entries"] for h in held) and all(x["halo_rows"] > 0 for x in t["ranks"])
+            assert held[-1] < t["csr_entries"]   # the last slab's halo rows arrive truncated to its rank range
     rel = ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(4)]
     for f in rel:
+        assert open(os.path.join(outs[0], f), "rb").read() == open(os.path.join(outs[1], f), "rb").read(), f
+    want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    for i in range(4):  # index.dat: consumer constraints + the leaf entries are exactly the partition's paths
+        cnt = int((mem[want[:, 0]] == i).sum())
+        for d in outs:
+            info = oracle.index_validate(open(os.path.join(d, f"gnn-pe/partitions/partition-{i}/index.dat"), "rb").read())
+            assert info["num_data"] == cnt and np.array_equal(np.sort(info["leaf_son"]), np.arange(cnt))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
+def test_slab_split_over_rccl(tmp_path):
+    """The same split with one GPU per slab and the halo over RCCL (ncclSend/ncclRecv); runs wherever the box shows
+    two or more GPUs."""
+    gpus = min(torch.cuda.device_count(), 8)
+    g = synth.gnm_graph(30000, 300000, n_labels=9, seed=17)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(g["n"], 4)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    outs = []
+    for n in (1, gpus):
+        d = str(tmp_path / f"n{n}")
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 4)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "4", "--gpus", str(n), "--timing"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        if n > 1:
+            assert json.loads(r.stderr.strip().splitlines()[-1])["transport"] == "rccl"
+        outs.append(d)
+    for f in ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(4)]:
         assert open(os.path.join(outs[0], f), "rb").read() == open(os.path.join(outs[1], f), "rb").read(), f
 
 

@@ -375,3 +375,31 @@ def test_power_law_graph_with_hubs(binding, oracle, variant):
     assert np.array_equal(ids, ref)
     assert np.array_equal(pde, ovde[ref].reshape(len(ref), 6))
     eng.close()
+
+
+def test_load_rejects_rows_the_kernels_cannot_handle(binding):
+    """C-ABI callers that skip the loader hand over raw arrays: neighbour ids >= n, unsorted rows, duplicate edges and
+    self-loops are refused at load time (the reference's loader sorts, graph.cpp:231-233; its hash-set DFS tolerates
+    duplicates, the closed form here does not), naming the offending vertex."""
+    offs = np.array([0, 2, 3, 4, 4], np.uint32)
+    lab = np.zeros(4, np.uint32)
+    bad = {
+        "id >= n": np.array([1, 9, 0, 0], np.uint32),
+        "unsorted": np.array([2, 1, 0, 0], np.uint32),
+        "duplicate": np.array([1, 1, 0, 0], np.uint32),
+        "self-loop": np.array([0, 1, 0, 0], np.uint32),
+    }
+    for what, nb in bad.items():
+        eng = binding.Engine(0)
+        with pytest.raises(binding.GnnpeError, match="vertex 0"):
+            eng.load_csr(offs, nb, lab)
+        with pytest.raises(binding.GnnpeError, match="vertex 0"):
+            eng.load_rows(4, lab, np.array([0, 1], np.uint32), np.array([0, 2, 3], np.uint64), nb[:3], nbr_capacity=16)
+        eng.close()
+    eng = binding.Engine(0)
+    eng.load_csr(offs, np.array([1, 2, 0, 0], np.uint32), lab)  # valid again after a refused load
+    eng.set_slab(1, 3)
+    eng.load_csr(offs, np.array([1, 2, 0, 0], np.uint32), lab)  # a reload forgets the slab (and the order)
+    eng.set_order(np.arange(4, dtype=np.uint32), lab, 1)
+    assert eng.count_paths(2) == 1  # 1-0-2
+    eng.close()

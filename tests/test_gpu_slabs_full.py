@@ -1,0 +1,137 @@
+"""BASELINE configs 4 and 5 at their stated workloads, through the production slab code (dist.SlabBuild).
+
+config 4: synthetic 1M-vertex / 10M-edge graph, l=2 e=2, vertex-partitioned over 8 slab ranks with the 1-hop halo
+          exchange.  Asserted: the ranks' counts add up to sum C(deg, 2); their order-sensitive row checksums add up to
+          the single-rank checksum (i.e. the concatenation of the ranks' outputs IS the single-rank output); and on
+          every rank the size-independent properties of test_config3_1m_10m_properties hold for its own rows.
+config 5: synthetic 4M-vertex / 64M-edge power-law graph, l=3 e=8 (4-vertex paths; the reference cannot run l=3,
+          SURVEY D4: parity unpinned, the checker is the engine's single-rank run and the closed-form count).
+          Asserted: 8 slab ranks with the two-hop halo count exactly the paths one rank counts (2.4e13), and the first
+          rows every rank emits carry the same checksum as the same global id range emitted by one rank.
+
+The GPU box has one MI355X, so the ranks share device 0 and their collectives are staged over gloo
+(GNNPE_BENCH_SAME_DEVICE=1); with >= 2 GPUs visible the RCCL tests at the bottom run the same code over xGMI.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from gnnpe_amd import synth
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "slab_worker.py")
+M64 = (1 << 64) - 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, args, same_device=True, timeout=1500):
+    env = dict(os.environ)
+    if world == 1:
+        cmd = [sys.executable, WORKER] + args
+    else:
+        if same_device:
+            env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _results(out, world):
+    return [json.load(open(os.path.join(out, f"rank{r}.json"))) for r in range(world)]
+
+
+def _save(tmp_path, g):
+    p = str(tmp_path / "graph.npz")
+    np.savez(p, offsets=g["offsets"], nbrs=g["nbrs"], labels=g["labels"])
+    return p
+
+
+def _check_l2_slabs(tmp_path, g, world, same_device=True, entry_cost=0.0):
+    gp = _save(tmp_path, g)
+    out = str(tmp_path / f"w{world}")
+    _run(world, ["--graph", gp, "--out", out, "-l", "2", "-e", "2", "--entry-cost", str(entry_cost)], same_device)
+    res = _results(out, world)
+    want = synth.expected_paths_l2(g["offsets"])
+    assert sum(r["total"] for r in res) == want == res[0]["global_total"]
+    base = 0
+    for r in res:  # contiguous global id ranges in rank order
+        assert r["base"] == base and r["emitted"] == r["total"]
+        base += r["total"]
+        assert all(r["props"].values()), (r["rank"], r["props"])
+        assert r["halo"]["halo_rows"] > 0
+    deg = np.diff(g["offsets"].astype(np.int64))
+    assert sum(r["middle_sum"] for r in res) == int((np.arange(g["n"], dtype=np.int64) * (deg * (deg - 1) // 2)).sum())
+    # the concatenation of the ranks' rows is the single-rank output: checksums of consecutive chunks add
+    out1 = str(tmp_path / "w1")
+    _run(1, ["--graph", gp, "--out", out1, "-l", "2", "-e", "2", "--props", "0"])
+    one = _results(out1, 1)[0]
+    assert one["total"] == want
+    assert sum(r["checksum"] for r in res) & M64 == one["checksum"]
+    return res
+
+
+def test_config4_1m_10m_eight_slab_ranks(tmp_path):
+    g = synth.gnm_graph(1_000_000, 10_000_000)
+    res = _check_l2_slabs(tmp_path, g, 8)
+    # truncated halo rows: later slabs hold fewer entries than the first
+    assert res[-1]["halo"]["halo_entries"] < res[0]["halo"]["halo_entries"]
+
+
+def test_config4_work_balanced_slabs(tmp_path):
+    """Same invariants with the slabs planned for equal step time (entries rank-sorted per step are charged too)."""
+    g = synth.gnm_graph(200_000, 2_000_000)
+    _check_l2_slabs(tmp_path, g, 4, entry_cost=2.0)
+
+
+def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
+    g = synth.powerlaw_graph(4_000_000, 64_000_000, exponent=2.1, max_degree=3000)
+    gp = _save(tmp_path, g)
+    sample = 1 << 22
+    out8 = str(tmp_path / "w8")
+    _run(8, ["--graph", gp, "--out", out8, "-l", "3", "-e", "8", "--sample", str(sample)], timeout=2400)
+    res = _results(out8, 8)
+    total8 = sum(r["total"] for r in res)
+    ranges = [[r["base"], r["base"] + r["emitted"]] for r in res]
+    out1 = str(tmp_path / "w1")
+    _run(1, ["--graph", gp, "--out", out1, "-l", "3", "-e", "8", "--ranges", json.dumps(ranges)], timeout=2400)
+    one = _results(out1, 1)[0]
+    assert one["total"] == total8 == res[0]["global_total"] and total8 > 10 ** 13
+    base = 0
+    for r, want in zip(res, one["range_checksums"]):
+        assert r["base"] == base
+        base += r["total"]
+        assert r["checksum"] == want, r["rank"]
+
+
+# ---- RCCL over xGMI: only where the box shows at least two GPUs (the round's box has one) -------------------------
+needs2 = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")
+
+
+@needs2
+def test_slabs_over_rccl_two_gpus(tmp_path):
+    g = synth.gnm_graph(200_000, 2_000_000)
+    res = _check_l2_slabs(tmp_path, g, 2, same_device=False)
+    assert all(r["backend"] == "nccl" for r in res)
+
+
+@needs2
+def test_slabs_over_rccl_all_gpus(tmp_path):
+    world = min(torch.cuda.device_count(), 8)
+    g = synth.gnm_graph(1_000_000, 10_000_000)
+    res = _check_l2_slabs(tmp_path, g, world, same_device=False)
+    assert all(r["backend"] == "nccl" for r in res)
