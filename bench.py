@@ -240,8 +240,8 @@ def main():
     ap.add_argument("--no-index", action="store_true", help="skip the index-build, online-filter and end-to-end legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
-    ap.add_argument("--entry-cost", type=float, default=2.0,
-                    help="N>1 slab planning: cost of one rank-sorted adjacency entry in emitted paths (0 = equal path counts)")
+    ap.add_argument("--equal-paths", action="store_true",
+                    help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
     args = ap.parse_args()
 
     import torch
@@ -287,14 +287,14 @@ def main():
     sn = synth.degree_order(g["offsets"])
     mem = synth.block_membership(args.n, max(world, 1))
 
-    from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs
+    from gnnpe_amd.dist import STEP_COST_WEIGHTS, SlabBuild, owned_rows, plan_slabs
     # a dedicated (non-null) stream shared by torch and the engine, so torch events bracket the
     # engine's kernels (handle 0 = "context's own stream" in the C-ABI)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     eng = binding.Engine(local_rank, stream=stream.cuda_stream)
-    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], entry_cost=args.entry_cost if world > 1 else 0.0)
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], weights=(1.0, 0.0, 0.0) if args.equal_paths else STEP_COST_WEIGHTS)
     owned_entries = len(g["nbrs"])
     one_time = {}
     t_load = time.perf_counter()

@@ -66,6 +66,10 @@ SIGNATURES = {
     "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
                                         C.POINTER(_u32p), C.POINTER(_f64p)]),
     "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
+    "gnnpe_host_load_path_sidecar": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
+                                               C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_f64p),
+                                               C.POINTER(_f64p)]),
+    "gnnpe_host_write_paths_header": (C.c_int, [_vp, C.c_uint32, C.c_uint64]),
     "gnnpe_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
     "gnnpe_pinned_free": (None, [_vp]),
     "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
@@ -205,6 +209,26 @@ def host_refine(g, query_path, bitmap, limit=0xFFFFFFFF):
     if rc:
         raise GnnpeError(lib.gnnpe_last_error().decode())
     return out.value
+
+
+def host_load_path_sidecar(paths_bin, vde_bin, labels, degrees):
+    """gen_pde's per-path arrays (custom.h:546-572) from the binary sidecars of `gnnpe_main --sidecars`."""
+    lib = load()
+    lab, deg = _np(labels, np.uint32), _np(degrees, np.uint32)
+    P, L, e = C.c_uint64(), C.c_uint32(), C.c_uint32()
+    pv, pl, pd = _u32p(), _u32p(), _u32p()
+    pp, px = _f64p(), _f64p()
+    rc = lib.gnnpe_host_load_path_sidecar(paths_bin.encode(), vde_bin.encode(), len(lab), _ptr(lab, _u32p), _ptr(deg, _u32p),
+                                          C.byref(P), C.byref(L), C.byref(e), C.byref(pv), C.byref(pl), C.byref(pd), C.byref(pp),
+                                          C.byref(px))
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    n, Lv, D = P.value, L.value, L.value * e.value
+    out = {}
+    for name, ptr, w in (("vids", pv, Lv), ("labels", pl, Lv), ("degrees", pd, Lv), ("pde", pp, D), ("pde_label", px, D)):
+        out[name] = np.ctypeslib.as_array(ptr, shape=(max(n * w, 1),)).copy()[: n * w].reshape(n, w)
+        lib.gnnpe_host_free(ptr)
+    return out
 
 
 def host_read_membership(path, n, p):

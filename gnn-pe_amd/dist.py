@@ -51,7 +51,14 @@ def _start_weights(offsets, sorted_nodes, nbrs):
     return two_hop[order] * later + 1e-3, dsorted  # vertices without work still need a home
 
 
-def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None, entry_cost=0.0):
+# Step cost of a slab in units of one emitted path, fitted to per-rank kernel times of config 4 on one MI355X
+# (scripts/emulate_rank.py, N = 8): step_ms ~ 0.11 + 0.0191 P + 0.0738 O + 0.0247 H with P = paths (M), O = adjacency
+# entries of the slab's own rows (M: vde, pair records, per-pair work of the emit kernel), H = entries held and
+# rank-sorted per step (M: own + truncated halo rows).
+STEP_COST_WEIGHTS = (1.0, 3.9, 1.3)
+
+
+def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None, weights=(1.0, 0.0, 0.0), entry_cost=None):
     """Cut the processing order into n_ranks contiguous slabs of roughly equal step time.
 
     Host-side prep (the analogue of the reference's partitioning script).  The paths of start s number
@@ -59,42 +66,55 @@ def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None, entry_cost=0.0):
     (sum_{b in N(s)} (deg b - 1)) * (share of edge endpoints ranked after s): one pass over the adjacency (`nbrs`);
     without the adjacency the neighbour degrees are replaced by the mean degree.
 
-    entry_cost > 0 also charges every rank for the adjacency entries it rank-sorts per step, in units of emitted
-    paths per entry: a slab starting at position lo holds the truncated rows, i.e. ~ the edge endpoints ranked >= lo
-    (on a graph where every rank's halo is nearly every row).  Early slabs carry more entries, so they get fewer
-    paths.  Returns uint32 bounds[n_ranks+1]."""
+    weights = (w_paths, w_owned, w_held): cost of a slab [lo, hi) =
+        w_paths * paths + w_owned * (entries of its own rows) + w_held * (entries it holds),
+    the held entries estimated as own + (all other rows, truncated: the share of edge endpoints ranked >= lo).
+    (1, 0, 0) = equal path counts; STEP_COST_WEIGHTS = the fitted per-step kernel cost.  The last slabs own the
+    high-degree vertices (many entries, few paths each), so they get fewer paths.  Returns uint32 bounds[n_ranks+1]."""
     n = len(sorted_nodes)
     if n == 0 or n_ranks <= 1:
         return np.array([0] + [n] * max(n_ranks, 1), np.uint32)
+    if entry_cost is not None:  # round-2 draft interface: one weight on the held entries
+        weights = (1.0, 0.0, float(entry_cost))
+    w_p, w_o, w_h = (float(x) for x in weights)
     w, dsorted = _start_weights(offsets, sorted_nodes, nbrs)
-    cw = np.concatenate([[0.0], np.cumsum(w)])                       # paths before position i
-    ent = np.concatenate([(dsorted.sum() - np.cumsum(dsorted) + dsorted), [0.0]])  # endpoints ranked >= i
+    cw = np.concatenate([[0.0], np.cumsum(w)])          # paths before position i
+    dc = np.concatenate([[0.0], np.cumsum(dsorted)])    # adjacency entries owned before position i
+    tot_e = dc[-1]
+
+    if w_o == 0.0 and w_h == 0.0:
+        targets = cw[-1] * np.arange(1, n_ranks) / n_ranks
+        cuts = np.searchsorted(cw[1:], targets).astype(np.int64)
+        return np.maximum.accumulate(np.concatenate([[0], cuts, [n]]).astype(np.uint32))
+
+    def cost(lo, hi):
+        own = dc[hi] - dc[lo]
+        share = (tot_e - dc[lo]) / max(tot_e, 1.0)       # edge endpoints ranked >= lo
+        return w_p * (cw[hi] - cw[lo]) + w_o * own + w_h * (own + (tot_e - own) * share)
 
     def cuts_for(T):
         b = [0]
         for _ in range(n_ranks - 1):
             lo = b[-1]
-            budget = T - entry_cost * ent[lo]
-            hi = int(np.searchsorted(cw, cw[lo] + max(budget, 0.0), side="right")) - 1
-            b.append(min(max(hi, lo), n))
+            a, z = lo, n                                  # largest hi with cost(lo, hi) <= T
+            while a < z:
+                mid = (a + z + 1) >> 1
+                if cost(lo, mid) <= T:
+                    a = mid
+                else:
+                    z = mid - 1
+            b.append(a)
         return b
 
-    if entry_cost <= 0.0:
-        targets = cw[-1] * np.arange(1, n_ranks) / n_ranks
-        cuts = np.searchsorted(cw[1:], targets).astype(np.int64)
-        bounds = np.concatenate([[0], cuts, [n]])
-    else:
-        lo_t, hi_t = 0.0, cw[-1] + entry_cost * ent[0]
-        for _ in range(60):  # smallest per-rank budget T whose first n_ranks-1 slabs leave the last one within T
-            T = 0.5 * (lo_t + hi_t)
-            b = cuts_for(T)
-            last = entry_cost * ent[b[-1]] + (cw[-1] - cw[b[-1]])
-            if last > T:
-                lo_t = T
-            else:
-                hi_t = T
-        bounds = np.array(cuts_for(hi_t) + [n])
-    return np.maximum.accumulate(bounds.astype(np.uint32))
+    lo_t, hi_t = 0.0, cost(0, n)
+    for _ in range(50):  # smallest budget T whose first n_ranks-1 slabs leave a last slab within T
+        T = 0.5 * (lo_t + hi_t)
+        b = cuts_for(T)
+        if cost(b[-1], n) > T:
+            lo_t = T
+        else:
+            hi_t = T
+    return np.maximum.accumulate(np.array(cuts_for(hi_t) + [n], np.uint32))
 
 
 def owned_rows(g, sorted_nodes, bounds, r):

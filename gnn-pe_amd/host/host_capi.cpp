@@ -1,8 +1,16 @@
 // host_capi.cpp -- C-ABI wrappers around the host loader (R0 / R1) so that non-C++ callers (the Python
 // multi-GPU driver) use the SAME loader code as gnnpe_main.  Compiled into libgnnpe_hip.so.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gnnpe_hip.h"
@@ -130,5 +138,133 @@ int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs,
 }
 
 void gnnpe_host_free(void *ptr) { free(ptr); }
+
+// ---- the online side's data load from binary sidecars ---------------------------------------------------
+// `gnnpe_main --sidecars` leaves <f>gnn-pe/paths.bin (the rows of all_paths.txt as uint32 tuples) and <f>gnn-pe/vde.bin
+// (x, nx, vde of every vertex).  The reference's online start re-parses the text (gen_pde, custom.h:546-572: ~95 s per
+// 2e7 paths); this returns the same per-path vectors -- vids, labels, degrees, pde, pde_label -- as flat arrays.
+static const char kPathsMagic[8] = {'G', 'N', 'N', 'P', 'E', 'P', 'T', 'H'};
+
+int gnnpe_host_write_paths_header(void *file, uint32_t L, uint64_t n_paths)
+{
+    FILE *f = (FILE *)file;
+    const uint32_t version = 1;
+    if (!f || fwrite(kPathsMagic, 1, 8, f) != 8 || fwrite(&version, 4, 1, f) != 1 || fwrite(&L, 4, 1, f) != 1 ||
+        fwrite(&n_paths, 8, 1, f) != 1) {
+        gnnpe::set_error("paths.bin: cannot write the header");
+        return GNNPE_ERR_IO;
+    }
+    return 0;
+}
+
+int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uint32_t n, const uint32_t *labels,
+                                 const uint32_t *degrees, uint64_t *n_paths, uint32_t *L_out, uint32_t *e_out, uint32_t **vids,
+                                 uint32_t **plabels, uint32_t **pdegrees, double **pde, double **pde_label)
+{
+    if (!paths_bin || !vde_bin || !labels || !degrees || !n_paths || !L_out || !e_out || !vids || !plabels || !pdegrees || !pde ||
+        !pde_label) {
+        gnnpe::set_error("gnnpe_host_load_path_sidecar: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    *vids = *plabels = *pdegrees = nullptr;
+    *pde = *pde_label = nullptr;
+    // vde.bin: uint32 n, e; x[n*e], nx[n*e], vde[n*e]
+    FILE *fv = fopen(vde_bin, "rb");
+    if (!fv) {
+        gnnpe::set_error("cannot open %s", vde_bin);
+        return GNNPE_ERR_IO;
+    }
+    uint32_t hv[2] = {0, 0};
+    if (fread(hv, 4, 2, fv) != 2 || hv[0] != n || hv[1] == 0 || hv[1] > 32) {
+        fclose(fv);
+        gnnpe::set_error("%s: header (n=%u, e=%u) does not match a graph of %u vertices", vde_bin, hv[0], hv[1], n);
+        return GNNPE_ERR_ARG;
+    }
+    const uint32_t e = hv[1];
+    std::vector<double> x((size_t)n * e), vde((size_t)n * e);
+    bool ok = fread(x.data(), 8, x.size(), fv) == x.size() && fseek(fv, (long)((size_t)n * e * 8), SEEK_CUR) == 0 &&
+              fread(vde.data(), 8, vde.size(), fv) == vde.size();
+    fclose(fv);
+    if (!ok) {
+        gnnpe::set_error("%s: truncated", vde_bin);
+        return GNNPE_ERR_IO;
+    }
+    // paths.bin: magic, version, L, P, then P x L uint32
+    const int fd = open(paths_bin, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) {
+        if (fd >= 0) close(fd);
+        gnnpe::set_error("cannot open %s", paths_bin);
+        return GNNPE_ERR_IO;
+    }
+    char *map = st.st_size ? (char *)mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : (char *)MAP_FAILED;
+    close(fd);
+    if (map == MAP_FAILED || st.st_size < 24 || memcmp(map, kPathsMagic, 8) != 0) {
+        if (map != MAP_FAILED) munmap(map, (size_t)st.st_size);
+        gnnpe::set_error("%s: not a paths.bin sidecar", paths_bin);
+        return GNNPE_ERR_ARG;
+    }
+    uint32_t version, L;
+    uint64_t P;
+    memcpy(&version, map + 8, 4);
+    memcpy(&L, map + 12, 4);
+    memcpy(&P, map + 16, 8);
+    if (version != 1 || L < 1 || L > 16 || (uint64_t)st.st_size != 24 + P * L * 4) {
+        munmap(map, (size_t)st.st_size);
+        gnnpe::set_error("%s: bad header (version %u, L %u, %llu paths, %lld bytes)", paths_bin, version, L, (unsigned long long)P,
+                         (long long)st.st_size);
+        return GNNPE_ERR_ARG;
+    }
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(map + 24);
+    const size_t D = (size_t)L * e;
+    uint32_t *o_v = (uint32_t *)malloc((P * L + 1) * 4), *o_l = (uint32_t *)malloc((P * L + 1) * 4), *o_d = (uint32_t *)malloc((P * L + 1) * 4);
+    double *o_p = (double *)malloc((P * D + 1) * 8), *o_x = (double *)malloc((P * D + 1) * 8);
+    if (!o_v || !o_l || !o_d || !o_p || !o_x) {
+        free(o_v); free(o_l); free(o_d); free(o_p); free(o_x);
+        munmap(map, (size_t)st.st_size);
+        gnnpe::set_error("gnnpe_host_load_path_sidecar: out of memory for %llu paths", (unsigned long long)P);
+        return GNNPE_ERR_ARG;
+    }
+    // the loop of gen_pde (custom.h:553-568), split over the host's cores
+    const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    std::vector<uint32_t> bad(nt, 0xFFFFFFFFu);
+    auto work = [&](unsigned t) {
+        const uint64_t a = P * t / nt, b = P * (t + 1) / nt;
+        for (uint64_t i = a; i < b; i++)
+            for (uint32_t j = 0; j < L; j++) {
+                const uint32_t v = src[i * L + j];
+                if (v >= n) {
+                    bad[t] = v;
+                    return;
+                }
+                o_v[i * L + j] = v;
+                o_l[i * L + j] = labels[v];
+                o_d[i * L + j] = degrees[v];
+                for (uint32_t k = 0; k < e; k++) {
+                    o_p[i * D + (size_t)j * e + k] = vde[(size_t)v * e + k];
+                    o_x[i * D + (size_t)j * e + k] = x[(size_t)v * e + k];
+                }
+            }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto &t : th) t.join();
+    munmap(map, (size_t)st.st_size);
+    for (unsigned t = 0; t < nt; t++)
+        if (bad[t] != 0xFFFFFFFFu) {
+            free(o_v); free(o_l); free(o_d); free(o_p); free(o_x);
+            gnnpe::set_error("%s: vertex id %u >= n = %u", paths_bin, bad[t], n);
+            return GNNPE_ERR_ARG;
+        }
+    *n_paths = P;
+    *L_out = L;
+    *e_out = e;
+    *vids = o_v;
+    *plabels = o_l;
+    *pdegrees = o_d;
+    *pde = o_p;
+    *pde_label = o_x;
+    return 0;
+}
 
 }  // extern "C"

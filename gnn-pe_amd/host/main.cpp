@@ -356,6 +356,16 @@ int main(int argc, char **argv)
         part_files.push_back(new FileSink(partitions_path + "partition-" + std::to_string(i) + "/partition_paths.txt"));
         part_files[i]->write_now(std::to_string(part_count[i]) + "\n");
     }
+    // --sidecars: the rows again as uint32 tuples (paths.bin), so that an online start can skip the text re-parse of
+    // gen_pde (custom.h:546-572); read back by gnnpe_host_load_path_sidecar
+    FILE *paths_bin = nullptr;
+    std::vector<uint32_t> ids_host;
+    if (o.sidecars) {
+        paths_bin = fopen((o.dataset_path + "gnn-pe/paths.bin").c_str(), "wb");
+        if (!paths_bin) die("cannot write paths.bin");
+        setvbuf(paths_bin, nullptr, _IOFBF, 8 << 20);
+        check(gnnpe_host_write_paths_header(paths_bin, L, P), "paths.bin");
+    }
     double t_gpu = 0.0;
     for (int d = 0; d < o.gpus; d++) {
         gnnpe_ctx *ctx = devs[d].ctx;
@@ -378,6 +388,11 @@ int main(int argc, char **argv)
             check(gnnpe_copy_to_host(ctx, buf->data(), d_text, nb), "copy text");
             t_gpu += secs(g0, Clock::now());
             all_paths.submit(buf, nb);
+            if (paths_bin) {
+                ids_host.resize(cnt * L);
+                check(gnnpe_copy_to_host(ctx, ids_host.data(), d_ids, cnt * L * 4), "copy ids");
+                if (fwrite(ids_host.data(), 4, cnt * L, paths_bin) != cnt * L) die("write error on paths.bin");
+            }
             for (uint32_t pid = 0; pid < o.partition_num; pid++) {
                 const auto g1 = Clock::now();
                 uint64_t k = 0, pb = 0;
@@ -402,7 +417,8 @@ int main(int argc, char **argv)
     }
     const auto t_written = Clock::now();
 
-    if (o.sidecars) {  // ignored by the reference; carrier for the embedding parity check
+    if (paths_bin && fclose(paths_bin) != 0) die("write error on paths.bin");
+    if (o.sidecars) {  // ignored by the reference; carrier for the embedding parity check and the online data load
         FILE *f = fopen((o.dataset_path + "gnn-pe/vde.bin").c_str(), "wb");
         if (!f) die("cannot write vde.bin");
         uint32_t hdr[2] = {g.n, o.vde_dim};

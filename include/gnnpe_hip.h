@@ -258,6 +258,18 @@ int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs,
 int gnnpe_refine(gnnpe_ctx *ctx, const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit,
                  uint64_t *answers, double *device_ms);
 
+/* ---- the online side's data load ------------------------------------------------------- */
+/* `gnnpe_main --sidecars` leaves <f>gnn-pe/paths.bin (magic "GNNPEPTH", uint32 version = 1, uint32 L, uint64 P, then the
+ * P x L uint32 rows of all_paths.txt) and <f>gnn-pe/vde.bin (uint32 n, e; x, nx, vde: n x e doubles each).  This returns
+ * what gen_pde (custom.h:546-572) builds by re-parsing the text -- per path vids / labels / degrees (P x L uint32) and
+ * pde / pde_label (P x L*e doubles; labels[] and degrees[] are the graph's, `vertices[vid].label/.degree`) -- as flat
+ * malloc'ed arrays (gnnpe_host_free).  Host only, no GPU.  gnnpe_host_write_paths_header writes the 24-byte header to an
+ * open FILE* (the writer side, used by the CLI). */
+int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uint32_t n, const uint32_t *labels,
+                                 const uint32_t *degrees, uint64_t *n_paths, uint32_t *L, uint32_t *e, uint32_t **vids,
+                                 uint32_t **path_labels, uint32_t **path_degrees, double **pde, double **pde_label);
+int gnnpe_host_write_paths_header(void *file, uint32_t L, uint64_t n_paths);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

@@ -3,10 +3,27 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${1:-r01}
+R=${1:-r02}
 i=0
-for set in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum"; do
+for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/${R}_pmcidx_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${R}_pmcidx_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/${R}_pmcidx_$i -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > gpurun_out/${R}_pmcidx_$i.log 2>&1
   echo "pmc set $i rc=$?"
 done
+python3 - <<'PY'
+import csv, glob, os
+R = os.environ.get("R", "r02")
+for d in sorted(glob.glob(f"gpurun_out/{R}_pmcidx_*")):
+    if not os.path.isdir(d): continue
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+        per = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "k_pack_leaves_paths" in k or "k_path_keys" in k:
+                key = (k.split("(")[0][-40:], r["Counter_Name"])
+                per.setdefault(key, {}).setdefault(r["Dispatch_Id"], 0.0)
+                per[key][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for (k, c), v in sorted(per.items()):
+            vals = list(v.values())
+            print(f"{k:42s} {c:32s} mean {sum(vals)/len(vals):.4g} over {len(vals)} launches")
+PY

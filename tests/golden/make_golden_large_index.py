@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Large index.dat through the untouched consumer (TEST INFRASTRUCTURE).
+
+BASELINE config 2 -- G(100K, 1M), l=2, e=2, p=1: 2.0e7 paths, 5.4e5 node blocks -- exercises what Test/ (15K blocks)
+cannot: the reference online side's 100 000-entry heap (GNN-PE/include/heap/heap.h:3) and its block-id-indexed arrays
+(custom.h:261,264,379).
+
+  part A (this container, CPU only, ~40 min):  the reference does everything itself -- `ref_main -m offline`, then
+         `ref_main -m online`, whose first run builds index.dat by 2e7 R*-tree inserts -- and prints Answer Number.
+  part B (GPU box, ~3 min):  `gnnpe_main -m offline --index` writes the text files and the bulk-loaded index.dat;
+         the SAME reference online binary consumes them.  Same Answer Number, no heap overflow (exit code 0).
+
+    python tests/golden/make_golden_large_index.py A      # writes large_index/reference.json + query.graph
+    python tests/golden/make_golden_large_index.py B      # on the GPU box; writes large_index/ours.json
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import gnnpe_amd  # noqa: E402,F401
+from gnnpe_amd import synth  # noqa: E402
+from oracle import ref_main_path  # noqa: E402
+
+OUT = os.path.join(HERE, "large_index")
+QUERY = os.path.join(OUT, "query.graph")
+N, M = 100_000, 1_000_000
+
+
+def make_query(g, seed=7):
+    """A connected 6-vertex query cut out of the data graph (deterministic)."""
+    rng = np.random.default_rng(seed)
+    offs, nbrs = g["offsets"].astype(np.int64), g["nbrs"]
+    while True:
+        comp = [int(rng.integers(g["n"]))]
+        for _ in range(400):
+            if len(comp) == 6:
+                break
+            u = comp[int(rng.integers(len(comp)))]
+            w = int(nbrs[int(rng.integers(offs[u], offs[u + 1]))]) if offs[u + 1] > offs[u] else u
+            if w not in comp:
+                comp.append(w)
+        if len(comp) == 6:
+            break
+    idx = {v: i for i, v in enumerate(comp)}
+    edges = sorted({(min(idx[v], idx[int(w)]), max(idx[v], idx[int(w)])) for v in comp for w in nbrs[offs[v]:offs[v + 1]] if int(w) in idx})
+    deg = np.zeros(6, np.int64)
+    for a, b in edges:
+        deg[a] += 1
+        deg[b] += 1
+    with open(QUERY, "w") as f:
+        f.write(f"t 6 {len(edges)}\n" + "".join(f"v {i} {int(g['labels'][v])} {int(deg[i])}\n" for i, v in enumerate(comp))
+                + "".join(f"e {a} {b}\n" for a, b in edges))
+
+
+def dataset(wd, g):
+    gp = os.path.join(wd, "g.graph")
+    synth.write_graph_file(gp, g)
+    synth.make_dataset_dir(wd, 1)
+    synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), np.zeros(g["n"], np.uint32))
+    return gp
+
+
+def online(wd, gp):
+    t0 = time.time()
+    r = subprocess.run([ref_main_path(), "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", "1"], capture_output=True, text=True)
+    m = re.search(r"Answer Number: (\d+)", r.stdout)
+    return dict(returncode=r.returncode, answer_number=int(m.group(1)) if m else None, seconds=round(time.time() - t0, 1),
+                stdout_tail=r.stdout[-300:])
+
+
+def main():
+    part = sys.argv[1] if len(sys.argv) > 1 else "A"
+    os.makedirs(OUT, exist_ok=True)
+    g = synth.gnm_graph(N, M)
+    with tempfile.TemporaryDirectory() as wd:
+        gp = dataset(wd, g)
+        idx = os.path.join(wd, "gnn-pe", "partitions", "partition-0", "index.dat")
+        if part == "A":
+            make_query(g)
+            t0 = time.time()
+            subprocess.check_call([ref_main_path(), "-f", wd + "/", "-d", gp, "-m", "offline", "-p", "1"], stdout=subprocess.DEVNULL)
+            off_s = round(time.time() - t0, 1)
+            res = online(wd, gp)
+            hdr = np.fromfile(idx, np.int32, 6)
+            res.update(offline_seconds=off_s, paths=int(open(os.path.join(wd, "gnn-pe", "all_paths.txt")).readline()),
+                       index_bytes=os.path.getsize(idx), node_blocks=int(hdr[1]), what="reference offline + its own insert-built R*-tree")
+            json.dump(res, open(os.path.join(OUT, "reference.json"), "w"), indent=1)
+        else:
+            cli = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+            t0 = time.time()
+            subprocess.check_call([cli, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", "1", "--index"], stdout=subprocess.DEVNULL)
+            off_s = round(time.time() - t0, 2)
+            res = online(wd, gp)
+            hdr = np.fromfile(idx, np.int32, 6)
+            res.update(offline_seconds=off_s, index_bytes=os.path.getsize(idx), node_blocks=int(hdr[1]),
+                       what="gnnpe_main -m offline --index (bulk-loaded index.dat), consumed by the untouched reference online binary")
+            ref = json.load(open(os.path.join(OUT, "reference.json")))
+            res["matches_reference"] = res["returncode"] == 0 and res["answer_number"] == ref["answer_number"]
+            json.dump(res, open(os.path.join(os.environ.get("GNNPE_LARGE_INDEX_OUT", OUT), "ours.json"), "w"), indent=1)
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

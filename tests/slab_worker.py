@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--props", type=int, default=1)
     ap.add_argument("--sample", type=int, default=0, help="l=3: rows per rank to emit and checksum (0 = all)")
     ap.add_argument("--ranges", default=None, help="world 1: JSON list of [begin, end) global id ranges to checksum")
-    ap.add_argument("--entry-cost", type=float, default=0.0)
+    ap.add_argument("--weights", type=str, default="1,0,0", help="w_paths,w_owned,w_held of dist.plan_slabs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +99,7 @@ def main():
     n, L, e = g["n"], args.l + 1, args.e
     sn = synth.degree_order(g["offsets"])
     mem = synth.block_membership(n, max(world, 1))
-    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], entry_cost=args.entry_cost)
+    bounds = plan_slabs(g["offsets"], sn, world, g["nbrs"], weights=tuple(float(x) for x in args.weights.split(",")))
 
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)

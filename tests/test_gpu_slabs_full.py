@@ -61,10 +61,10 @@ def _save(tmp_path, g):
     return p
 
 
-def _check_l2_slabs(tmp_path, g, world, same_device=True, entry_cost=0.0):
+def _check_l2_slabs(tmp_path, g, world, same_device=True, weights="1,0,0"):
     gp = _save(tmp_path, g)
     out = str(tmp_path / f"w{world}")
-    _run(world, ["--graph", gp, "--out", out, "-l", "2", "-e", "2", "--entry-cost", str(entry_cost)], same_device)
+    _run(world, ["--graph", gp, "--out", out, "-l", "2", "-e", "2", "--weights", weights], same_device)
     res = _results(out, world)
     want = synth.expected_paths_l2(g["offsets"])
     assert sum(r["total"] for r in res) == want == res[0]["global_total"]
@@ -93,9 +93,12 @@ def test_config4_1m_10m_eight_slab_ranks(tmp_path):
 
 
 def test_config4_work_balanced_slabs(tmp_path):
-    """Same invariants with the slabs planned for equal step time (entries rank-sorted per step are charged too)."""
+    """Same invariants with the slabs planned for equal step time (dist.STEP_COST_WEIGHTS: own and held entries are
+    charged next to the paths, so the last slabs -- the high-degree vertices -- emit fewer paths)."""
+    from gnnpe_amd.dist import STEP_COST_WEIGHTS
     g = synth.gnm_graph(200_000, 2_000_000)
-    _check_l2_slabs(tmp_path, g, 4, entry_cost=2.0)
+    res = _check_l2_slabs(tmp_path, g, 4, weights=",".join(str(x) for x in STEP_COST_WEIGHTS))
+    assert res[-1]["total"] < res[0]["total"]
 
 
 def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
