@@ -434,17 +434,35 @@ def main():
     # index-build wallclock (second half of BASELINE.json's metric), measured outside the timed steps.
     # (a) device image: R*-tree file image of every path (p = 1), bulk-loaded on the device
     if legs:
-        ib = []
+        ib, ib_cached = [], []
         for _ in range(3):
+            eng.count_paths(2)  # untimed: a new count invalidates the cached pair order, so the timed call below rebuilds it
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev2 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            img, nbytes, hdr = eng.build_index_partition_device(0)
+            ev1.record()
+            eng.build_index_partition_device(0)  # second partition-build of the same count: pair order reused
+            ev2.record()
+            torch.cuda.synchronize()
+            ib.append(ev0.elapsed_time(ev1))
+            ib_cached.append(ev1.elapsed_time(ev2))
+        ib_tuple = []
+        for _ in range(2):  # the tuple-array build (what a caller without the enumeration state uses: distributed ranks)
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-            img, nbytes, hdr = eng.build_index_device(total, L, out_ids)
+            eng.build_index_device(total, L, out_ids)
             ev1.record()
             torch.cuda.synchronize()
-            ib.append(ev0.elapsed_time(ev1))
+            ib_tuple.append(ev0.elapsed_time(ev1))
         out["index_build"] = dict(wallclock_ms=min(ib[1:]), points=total, file_bytes=nbytes, node_blocks=hdr[1], leaves=hdr[4],
-                                  where="device image of index.dat; the files on disk are timed under e2e",
+                                  where="device image of index.dat (partition 0 of p = 1), pair-major build from the enumeration "
+                                        "state: pair sort + leaves + upper levels; the files on disk are timed under e2e",
+                                  next_partition_ms=min(ib_cached),
+                                  next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
+                                  tuple_array_build_ms=min(ib_tuple),
                                   first_call_ms=ib[0],
                                   first_call_note="the first call allocates the image and the sort buffers (grow-only, ~25 GB of hipMalloc) "
                                                   "and loads the kernels; later calls only enqueue kernels",

@@ -79,6 +79,7 @@ SIGNATURES = {
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                            C.POINTER(C.c_int32)]),
     "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
+    "gnnpe_build_index_partition_device": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), _u64p, C.POINTER(C.c_int32)]),
     "gnnpe_build_box_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                                C.POINTER(C.c_int32)]),
     "gnnpe_pge_groups": (C.c_int, [_vp, _f64p, _f64p]),
@@ -444,6 +445,13 @@ class Engine:
         hdr = (C.c_int32 * 8)()
         self._ck(self.lib.gnnpe_build_index_device(self.ctx, int(cnt), int(L), _dev(dev_vids), C.byref(img),
                                                    C.byref(nb), hdr))
+        return img.value, nb.value, list(hdr)
+
+    def build_index_partition_device(self, pid):
+        """index.dat image of partition pid straight from the enumeration state (pair-major build when eligible)."""
+        img, nb = _vp(), C.c_uint64()
+        hdr = (C.c_int32 * 8)()
+        self._ck(self.lib.gnnpe_build_index_partition_device(self.ctx, int(pid), C.byref(img), C.byref(nb), hdr))
         return img.value, nb.value, list(hdr)
 
     def build_box_index_device(self, cnt, dim, dev_boxes):

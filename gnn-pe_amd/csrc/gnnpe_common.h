@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/gnnpe_hip.h"
 
@@ -98,7 +99,13 @@ struct gnnpe_ctx {
     uint64_t hub_entries = 0;
     int num_cus = 256;
     gnnpe::DevBuf text_len, text_off;  // R7 scratch
-    gnnpe::DevBuf index_image, idx_keys, idx_vals, idx_mbr;  // R6 scratch + the assembled index.dat image
+    gnnpe::DevBuf index_image, idx_keys, idx_vals, idx_mbr;
+    // pair-major index build (gnnpe_index.hip): sorted pair records, prefix of their path counts, per-partition ranges;
+    // valid for one count (count_gen)
+    gnnpe::DevBuf px_recs, px_sorted, px_pref, px_pbase, px_first, px_tmp;
+    std::vector<uint64_t> px_bounds, px_points;  // first sorted pair / first point of every partition (p + 1 entries)
+    uint64_t count_gen = 0, px_gen = 0;
+    bool px_valid = false;  // R6 scratch + the assembled index.dat image
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
 
     // ---- order (R1) ----

@@ -856,6 +856,7 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     c->total_paths = w;
     c->l = l;
     c->counted = true;
+    c->count_gen++;
     c->counted_variant = var;
     // embeddings of the adjacency entries, when the vde table is already there (keeps it out of the fill)
     if (c->have_vde && (var == kVarPairWave || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;

@@ -14,20 +14,9 @@
 #pragma once
 
 #include "gnnpe_kernels.hip.h"
+#include "gnnpe_records.h"
 
 namespace gnnpe {
-
-constexpr uint32_t kHubFlag = 0x80000000u;  // RankedPair::cnt bit: the pair's middle row is a hub row
-constexpr uint32_t kHubDegree = 64;         // rows longer than this are hub rows
-constexpr uint32_t kRowAlign = 128;         // row blocks start on L2 lines: the fabric fetches whole 128-byte lines
-
-// per (s, b) pair, indexed by the pair's emission index (poffs[rank[s]] + position of b in N(s)): 16 bytes, one
-// dwordx4 store scattered by the row kernel, one contiguous load per lane in the emit kernel
-struct __attribute__((aligned(16))) RankedPair {
-    uint32_t block;  // row block of b, in kRowAlign units: header vde[b], then the records
-    uint32_t cnt;    // paths of the pair = records to read from the front of the block (| kHubFlag: hub row)
-    uint64_t G;      // id-positions of N(b) with rank > rank[s]; hub: deg(b)
-};
 
 // one gather per adjacency entry instead of three: {vde[v], rank[v], first pair slot of v as a start vertex} side
 // by side, VINFO_STRIDE(E) doubles per vertex (E = 2 -> 32 bytes: one aligned half cache line).  The row kernel issues
@@ -48,20 +37,6 @@ __global__ void k_pack_vinfo(uint32_t n, const double *__restrict__ vde, const u
         vinfo[v * S + E + 1] = 0.0;
     }
 }
-
-// Neighbour records.  Wide: {id, id-position, vde} (hub rows: {id, rank, vde}); packed (graphs of up to 2^26
-// vertices): the id-position rides in the id's top 6 bits -- 4 bytes less per emitted path to fetch.
-template <int E> struct __attribute__((packed, aligned(4))) RecWide {
-    uint32_t id, aux;
-    double vde[E];
-};
-template <int E> struct __attribute__((packed, aligned(4))) RecPacked {
-    uint32_t idp;
-    double vde[E];
-};
-constexpr uint32_t kPackedIdBits = 26;
-template <int E, bool PACKED> struct RecOf { typedef RecWide<E> type; };
-template <int E> struct RecOf<E, true> { typedef RecPacked<E> type; };
 
 struct CntOfPair {
     __host__ __device__ uint64_t operator()(const RankedPair &p) const { return (uint64_t)(p.cnt & ~kHubFlag); }

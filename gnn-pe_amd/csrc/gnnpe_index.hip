@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "gnnpe_common.h"
+#include "gnnpe_records.h"
 
 namespace gnnpe {
 
@@ -406,6 +407,242 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
     }
 }
 
+// ---- pair-major build: the partition's index straight from the enumeration's records ---------------------------------
+// The builder above starts from a tuple array and pays one random 12-byte read (a 128-byte line fill) and three vde row
+// gathers per point: 81 GB of line fills for 2.0e8 points (profiles/r02_pmc_index.txt).  A context that has just
+// enumerated the partition already holds everything in streams: the paths of a pair (s, b) are the first cnt records of
+// b's row block {c, id-position, vde[c]}, vde[b] is the block's header, and the path's index inside the partition is
+// the pair's first index + popcount(G below the id-position).  So the unit that is SORTED is the pair, not the path
+// (20 M instead of 200 M keys at config 3), with key = [partition | label(s) | label(b) | z-order of vde[s], vde[b]]
+// (per-vertex quantised parts, ensure_vkey), ties in path order; leaves take 38 consecutive points of the sorted pairs.
+// Which leaves a query opens: labels of s and b exact, their embeddings in one quantisation cell, c free --
+// scripts/index_key_study.py counts 55 leaves per query against 34 for the per-path label-major key and 10 087 in
+// path order (64 labels), at the same number of level-1 nodes.
+struct __attribute__((aligned(16))) PairX {
+    uint32_t s, b, block, cnt;
+    uint64_t G, son0;  // son0: index inside the partition of the pair's first path (the pair's paths follow in id order)
+};
+
+// partition-local first path index of every start vertex: starts sorted by partition, then an exclusive scan
+__global__ void k_px_start_parts(uint32_t len, const StartRec *__restrict__ srec, uint32_t *__restrict__ part, uint32_t *__restrict__ idx)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+        part[i] = srec[i].part;
+        idx[i] = (uint32_t)i;
+    }
+}
+__global__ void k_px_sorted_counts(uint32_t len, const StartRec *__restrict__ srec, const uint32_t *__restrict__ sorted_idx,
+                                   uint64_t *__restrict__ cnt)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k <= len; k += (uint64_t)gridDim.x * blockDim.x)
+        cnt[k] = k < len ? srec[sorted_idx[k]].end - srec[sorted_idx[k]].base : 0ull;
+}
+// pos[k] = paths before the k-th start of the partition-sorted list; the first start of a partition carries that
+// partition's offset, which is subtracted: pbase[start] = paths of the same partition before this start
+__global__ void k_px_pbase(uint32_t len, const uint32_t *__restrict__ sorted_part, const uint32_t *__restrict__ sorted_idx,
+                           const uint64_t *__restrict__ pos, uint64_t *__restrict__ pbase)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < len; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t pt = sorted_part[k];
+        uint64_t lo = 0, hi = k;  // first position of this partition in the sorted list
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (sorted_part[mid] < pt) lo = mid + 1; else hi = mid;
+        }
+        pbase[sorted_idx[k]] = pos[k] - pos[lo];
+    }
+}
+
+// one record + one sort key per pair, in pair (= path) order; 16 lanes per start vertex
+template <typename KeyT>
+__global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
+                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
+                           const uint64_t *__restrict__ pbase, uint32_t e, uint32_t lb, uint32_t sbits, uint32_t zbits,
+                           PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    const uint64_t lmask = (1ull << lb) - 1ull, smask = (1ull << sbits) - 1ull;
+    for (; g < len; g += ng) {
+        const StartRec sr = srec[g];
+        const uint64_t ks = vkey[sr.s];
+        for (uint32_t k = sub; k < sr.ds; k += 16) {
+            const uint32_t q = sr.e0 + k;
+            const RankedPair pr = pairs[q];
+            const uint32_t b = nbrs[sr.a_s + k];
+            const uint64_t kb = vkey[b];
+            const uint32_t cnt = pr.cnt & ~kHubFlag;
+            PairX x = {sr.s, b, pr.block, cnt, pr.G, pbase[g] + (eoff[q] - sr.base)};
+            px[q] = x;
+            // pairs without paths sort behind every partition (partition field = n_parts)
+            const uint64_t part = cnt ? sr.part : n_parts;
+            const uint64_t lab = (((part << lb) | ((ks >> 32) & lmask)) << lb) | ((kb >> 32) & lmask);
+            const uint64_t z = ((ks & smask) << (2 * e)) | ((kb & smask) << e);
+            keys[q] = (KeyT)((lab << zbits) | z);
+            vals[q] = q;
+        }
+    }
+}
+__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairX *__restrict__ px, PairX *__restrict__ out)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < ne; k += (uint64_t)gridDim.x * blockDim.x) out[k] = px[order[k]];
+}
+struct CntOfPairX {
+    __host__ __device__ uint64_t operator()(const PairX &p) const { return (uint64_t)p.cnt; }
+};
+// first sorted pair of every partition (bounds[n_parts] = first pair without paths)
+template <typename KeyT>
+__global__ void k_px_bounds(uint64_t ne, uint32_t n_parts, const KeyT *__restrict__ sorted_keys, uint32_t shift, uint64_t *__restrict__ bounds)
+{
+    const uint32_t pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt > n_parts) return;
+    uint64_t lo = 0, hi = ne;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (((uint64_t)sorted_keys[mid] >> shift) < pt) lo = mid + 1; else hi = mid;
+    }
+    bounds[pt] = lo;
+}
+// first[j] = sorted pair that holds the first point of leaf j (the largest k with pref[k] <= point index)
+__global__ void k_px_leaf_first(uint64_t n_leaves, uint32_t F, uint64_t r0, uint64_t r1, const uint64_t *__restrict__ pref,
+                                uint32_t *__restrict__ first)
+{
+    const uint64_t base = pref[r0];
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n_leaves; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g = base + j * F;
+        uint64_t lo = r0, hi = r1;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (pref[mid] <= g) lo = mid; else hi = mid;
+        }
+        first[j] = (uint32_t)lo;
+    }
+}
+
+// One wave per leaf.  The leaf's points are 38 consecutive points of the sorted pairs: lane t first holds sorted pair
+// first[j] + t (its record and its first point), then entry t: pair by binary search in the wave's strip, record r of the
+// pair's row block, vde[s] from the table (one row per pair, shared by its lanes), vde[b] from the block header.
+// Window assembly, node MBR and the shifted 16-byte stores are those of k_pack_leaves_paths.
+template <int E, bool PACKED>
+__global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint32_t F, uint64_t r0,
+                                                                        uint64_t r1, const uint64_t *__restrict__ pref,
+                                                                        const uint32_t *__restrict__ first,
+                                                                        const PairX *__restrict__ px, const char *__restrict__ recs,
+                                                                        const double *__restrict__ vde, char *__restrict__ image,
+                                                                        double *__restrict__ node_mbr)
+{
+    typedef typename RecOf<E, PACKED>::type Rec;
+    constexpr int D = 3 * E;
+    constexpr int kWin = kBlockLen / 4 + 4;
+    constexpr int kEnt = 4 * D + 1;
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
+    __shared__ uint32_t s_pp[kLeafWaves][64], s_s[kLeafWaves][64], s_blk[kLeafWaves][64];
+    __shared__ uint64_t s_G[kLeafWaves][64], s_son[kLeafWaves][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t *w = s_win[wv];
+    const uint64_t stride = (uint64_t)gridDim.x * kLeafWaves;
+    const uint64_t pbase = pref[r0];
+    for (uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv; j < n_leaves; j += stride) {
+        const uint64_t g0 = j * F;
+        const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - g0);
+        // the wave's strip of pairs
+        const uint64_t kk = (uint64_t)first[j] + lane;
+        uint32_t pp = 0xFFFFFFFFu;
+        if (kk < r1) {
+            const uint64_t rel = pref[kk] - pbase;
+            if (rel < g0 + ne) {
+                pp = (uint32_t)(rel >= g0 ? rel - g0 : 0u);  // first entry of the pair inside this leaf
+                const PairX x = px[kk];
+                s_s[wv][lane] = x.s;
+                s_blk[wv][lane] = x.block;
+                s_G[wv][lane] = x.G;
+                // records of the pair before this leaf's first point (the pair may have begun in the previous leaf)
+                s_son[wv][lane] = (x.son0 << 8) | (uint64_t)(rel >= g0 ? 0u : (uint32_t)(g0 - rel));
+            }
+        }
+        s_pp[wv][lane] = pp;
+        if (lane == 0) {
+            w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
+            w[1] = ne;
+        }
+        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero tail
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((uint32_t)lane < ne) {
+            uint32_t a = 0, bnd = 64;  // largest a with s_pp[a] <= lane (unused slots hold 0xFFFFFFFF)
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const uint32_t mid = (a + bnd) >> 1;
+                if (s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
+            }
+            const uint64_t sw = s_son[wv][a];
+            const uint32_t r = (uint32_t)lane - s_pp[wv][a] + (uint32_t)(sw & 0xFFu);  // record inside the pair's block
+            const char *const blk = recs + (uint64_t)s_blk[wv][a] * kRowAlign;
+            const Rec rec = reinterpret_cast<const Rec *>(blk + 8 * E)[r];
+            uint32_t id, ip;
+            if constexpr (PACKED) {
+                id = rec.idp & ((1u << kPackedIdBits) - 1u);
+                ip = rec.idp >> kPackedIdBits;
+            } else {
+                id = rec.id;
+                ip = rec.aux;
+            }
+            (void)id;
+            const uint32_t son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(s_G[wv][a] & ((1ull << ip) - 1ull)));
+            const double *vs = vde + (uint64_t)s_s[wv][a] * E;
+            const double *vb = reinterpret_cast<const double *>(blk);
+            uint32_t *ent = w + 2 + lane * kEnt;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const double val = k < E ? vs[k] : (k < 2 * E ? vb[k - E] : rec.vde[k - 2 * E]);
+                const uint64_t bits64 = (uint64_t)__double_as_longlong(val);
+                const uint32_t x = (uint32_t)bits64, y = (uint32_t)(bits64 >> 32);
+                ent[4 * k] = x;      // bounces[2k]   (custom.h:246)
+                ent[4 * k + 1] = y;
+                ent[4 * k + 2] = x;  // bounces[2k+1] (custom.h:247)
+                ent[4 * k + 3] = y;
+            }
+            ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < D) {  // node MBR for the parent level: lane k scans dimension k of the assembled entries
+            double lo = 1e300, hi = -1e300;
+#pragma unroll 8
+            for (uint32_t i = 0; i < ne; i++) {
+                const uint32_t *q = w + 2 + i * kEnt + 4 * lane;
+                const double x = __longlong_as_double((long long)(((uint64_t)q[1] << 32) | q[0]));
+                lo = fmin(lo, x);
+                hi = fmax(hi, x);
+            }
+            node_mbr[(j * D + lane) * 2] = lo;
+            node_mbr[(j * D + lane) * 2 + 1] = hi;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
+#pragma unroll
+        for (int rr = 0; rr < kBlockLen / 16 / 64; rr++) {
+            const int c = lane + 64 * rr;
+            const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
+            const uint32_t nx = w[4 * c + 4];
+            uint4 o;
+            o.x = (lo4.x >> 24) | (lo4.y << 8);
+            o.y = (lo4.y >> 24) | (lo4.z << 8);
+            o.z = (lo4.z >> 24) | (lo4.w << 8);
+            o.w = (lo4.w >> 24) | (nx << 8);
+            __builtin_nontemporal_store(o.x, &dst[c].x);
+            __builtin_nontemporal_store(o.y, &dst[c].y);
+            __builtin_nontemporal_store(o.z, &dst[c].z);
+            __builtin_nontemporal_store(o.w, &dst[c].w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // rows of `src` (n x L uint32) selected by idx -> dst
 __global__ void k_gather_rows_u32(uint64_t n, uint32_t L, const uint64_t *__restrict__ idx, uint64_t idx_base,
                                   const uint32_t *__restrict__ src, uint32_t *__restrict__ dst)
@@ -438,6 +675,8 @@ static int ensure_vkey(gnnpe_ctx *c)
     if (c->vkey_valid && c->vkey_zb == zb && c->vkey_lb == lb) return GNNPE_OK;
     int rc;
     if ((rc = c->vkey.reserve(((size_t)n + 1) * 12))) return rc;  // wide table + narrow copy
+    // the component sorts below run in the index scratch buffers
+    if ((rc = c->idx_keys.reserve(((size_t)n + 1) * 8 * 2)) || (rc = c->idx_vals.reserve(((size_t)n + 1) * 4 * 2))) return rc;
     uint64_t *vkey = c->vkey.as<uint64_t>();
     hipLaunchKernelGGL(k_vkey_labels, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, n, c->labels.as<uint32_t>(), vkey);
     if (zb && n) {
@@ -467,6 +706,56 @@ static int ensure_vkey(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+// one launch per upper level: parents packed from consecutive children
+static int pack_upper_levels(gnnpe_ctx *c, const std::vector<uint64_t> &level_n, uint32_t F, uint32_t D, char *image, double *mbr_a,
+                             double *mbr_b)
+{
+    uint64_t child0 = 0, node0 = level_n[0];
+    for (size_t lv = 1; lv < level_n.size(); lv++) {
+        hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,
+                           node0, F, D, (int)lv, mbr_a, image, mbr_b);
+        std::swap(mbr_a, mbr_b);
+        child0 = node0;
+        node0 += level_n[lv];
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+// header block (blk_file.cpp:38-39 + rtree.cpp:341-362): root_is_data is ONE byte, root follows at byte 25
+static int write_header(gnnpe_ctx *c, char *image, const int32_t hdr[8])
+{
+    char h[64];
+    memset(h, 0, sizeof(h));
+    memcpy(h, &hdr[0], 4);
+    memcpy(h + 4, &hdr[1], 4);
+    memcpy(h + 8, &hdr[2], 4);
+    memcpy(h + 12, &hdr[3], 4);
+    memcpy(h + 16, &hdr[4], 4);
+    memcpy(h + 20, &hdr[5], 4);
+    h[24] = (char)hdr[6];
+    memcpy(h + 25, &hdr[7], 4);
+    GNNPE_HIP_TRY(hipMemcpyAsync(image, h, 64, hipMemcpyHostToDevice, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+// level sizes: leaves, then parents until a single node remains; root must be internal (an empty tree is one empty leaf
+// that is the root, rtree.cpp:11-32)
+static uint64_t plan_levels(uint64_t cnt, uint32_t F, std::vector<uint64_t> &level_n)
+{
+    level_n.clear();
+    if (cnt == 0) {
+        level_n.push_back(1);
+    } else {
+        level_n.push_back((cnt + F - 1) / F);
+        do level_n.push_back((level_n.back() + F - 1) / F); while (level_n.back() > 1);
+    }
+    uint64_t n_nodes = 0;
+    for (uint64_t v : level_n) n_nodes += v;
+    return n_nodes;
+}
+
 static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
 {
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
@@ -481,16 +770,8 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     const uint32_t F = std::min(cap - 2, 64u);
     int rc;
 
-    // level sizes: leaves, then parents until a single node remains; root must be internal
     std::vector<uint64_t> level_n;
-    if (cnt == 0) {
-        level_n.push_back(1);  // the reference's empty tree: one empty leaf that is the root (rtree.cpp:11-32)
-    } else {
-        level_n.push_back((cnt + F - 1) / F);
-        do level_n.push_back((level_n.back() + F - 1) / F); while (level_n.back() > 1);
-    }
-    uint64_t n_nodes = 0;
-    for (uint64_t v : level_n) n_nodes += v;
+    const uint64_t n_nodes = plan_levels(cnt, F, level_n);
     GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
     const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
     if ((rc = c->index_image.reserve(image_bytes))) return rc;
@@ -589,29 +870,9 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
             hipLaunchKernelGGL(k_pack_leaves, dim3((uint32_t)level_n[0]), dim3(64), 0, c->stream, cnt, F, S, v_out, image, mbr_a);
         }
 #undef GNNPE_IDX_LEAVES
-        uint64_t child0 = 0, node0 = level_n[0];
-        for (size_t lv = 1; lv < level_n.size(); lv++) {
-            hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,
-                               node0, F, D, (int)lv, mbr_a, image, mbr_b);
-            std::swap(mbr_a, mbr_b);
-            child0 = node0;
-            node0 += level_n[lv];
-        }
-        GNNPE_HIP_TRY(hipGetLastError());
+        if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
     }
-    // header block (blk_file.cpp:38-39 + rtree.cpp:341-362): root_is_data is ONE byte, root follows at byte 25
-    char h[64];
-    memset(h, 0, sizeof(h));
-    memcpy(h, &hdr[0], 4);
-    memcpy(h + 4, &hdr[1], 4);
-    memcpy(h + 8, &hdr[2], 4);
-    memcpy(h + 12, &hdr[3], 4);
-    memcpy(h + 16, &hdr[4], 4);
-    memcpy(h + 20, &hdr[5], 4);
-    h[24] = (char)hdr[6];
-    memcpy(h + 25, &hdr[7], 4);
-    GNNPE_HIP_TRY(hipMemcpyAsync(image, h, 64, hipMemcpyHostToDevice, c->stream));
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = write_header(c, image, hdr))) return rc;
     *dev_image = image;
     *nbytes = image_bytes;
     if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
@@ -726,6 +987,175 @@ int gnnpe_build_box_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t dim, const
     return build_image(c, cnt, S, dev_image, nbytes, hdr_out);
 }
 
+// ---- pair-major build, host side -----------------------------------------------------------------------------------
+static bool fast_dim(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
+
+// the enumeration state this build reads: ranked records of an l = 2 count, no hub rows (their pairs are not
+// addressable by record index), records carrying the current vde table
+static bool pair_major_ok(const gnnpe_ctx *c)
+{
+    return c->counted && c->l == 2 && c->counted_variant == 4 && c->n_hub == 0 && c->have_vde && c->ranked_vde_valid &&
+           fast_dim(c->e) && c->total_paths < (1ull << 40);
+}
+
+static uint32_t bits_for(uint64_t max_value)
+{
+    uint32_t b = 0;
+    while (b < 63 && (1ull << b) <= max_value) b++;
+    return b;
+}
+
+// once per count: pairs sorted by [partition | label(s) | label(b) | z(s, b)], their records in that order, the prefix
+// of their path counts and every partition's range
+static int ensure_pair_order(gnnpe_ctx *c)
+{
+    if (c->px_valid && c->px_gen == c->count_gen) return GNNPE_OK;
+    int rc;
+    // ensure_vkey sorts the vertices' components in the index scratch buffers
+    if ((rc = c->idx_keys.reserve(((size_t)c->n + 1) * 8 * 2)) || (rc = c->idx_vals.reserve(((size_t)c->n + 1) * 4 * 2))) return rc;
+    if ((rc = ensure_vkey(c))) return rc;
+    const uint32_t len = c->slab_end - c->slab_begin, e = c->e, D = 3 * e, p = c->p;
+    const uint64_t ne = c->n_edges;
+    const StartRec *srec = c->srec.as<StartRec>();
+    // scratch layout (px_tmp): start sort {part_in, part_out, idx_in, idx_out: u32 x len}, counts / positions {u64 x (len + 1)},
+    // pair keys {u64 x ne x 2}, pair values {u32 x ne x 2}, device bounds {u64 x 2 (p + 1)}
+    const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
+                 o_pos = o_cnt + ((size_t)len + 2) * 8, o_keys = o_pos + ((size_t)len + 2) * 8, o_vals = o_keys + (ne + 1) * 16,
+                 o_bnd = o_vals + (ne + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
+    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((ne + 1) * sizeof(PairX))) ||
+        (rc = c->px_sorted.reserve((ne + 1) * sizeof(PairX))) || (rc = c->px_pref.reserve((ne + 2) * 8)) ||
+        (rc = c->px_pbase.reserve(((size_t)len + 1) * 8)))
+        return rc;
+    char *tmp = c->px_tmp.as<char>();
+    uint32_t *part_in = reinterpret_cast<uint32_t *>(tmp + o_part), *part_out = part_in + len + 1;
+    uint32_t *idx_in = reinterpret_cast<uint32_t *>(tmp + o_idx), *idx_out = idx_in + len + 1;
+    uint64_t *cnt = reinterpret_cast<uint64_t *>(tmp + o_cnt), *pos = reinterpret_cast<uint64_t *>(tmp + o_pos);
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(tmp + o_vals), *v_out = v_in + ne + 1;
+    uint64_t *d_bounds = reinterpret_cast<uint64_t *>(tmp + o_bnd);
+    size_t tb = 0;
+    // 1. partition-local index of every start vertex' first path
+    if (len) {
+        hipLaunchKernelGGL(k_px_start_parts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, srec, part_in, idx_in);
+        const int pb = (int)std::max(1u, bits_for(p));
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, part_in, part_out, idx_in, idx_out, (int)len, 0, pb, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, part_in, part_out, idx_in, idx_out, (int)len, 0, pb, c->stream));
+        hipLaunchKernelGGL(k_px_sorted_counts, dim3(grid_for((uint64_t)len + 1)), dim3(kBlock), 0, c->stream, len, srec, idx_out, cnt);
+        tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, pos, (int64_t)len + 1, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, cnt, pos, (int64_t)len + 1, c->stream));
+        hipLaunchKernelGGL(k_px_pbase, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, part_out, idx_out, pos, c->px_pbase.as<uint64_t>());
+    }
+    // 2. pair records + keys in pair order, sorted, permuted, scanned
+    const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * D, sbits = c->vkey_zb ? (c->vkey_zb - 1) * D + e : 0;
+    const uint32_t shift = 2 * lb + zbits, kbits = bits_for(p) + shift;
+    GNNPE_REQUIRE(kbits <= 64, GNNPE_ERR_UNSUPPORTED, "pair key needs %u bits", kbits);
+    PairX *px = c->px_recs.as<PairX>(), *pxs = c->px_sorted.as<PairX>();
+    GNNPE_HIP_TRY(hipMemsetAsync(pxs + ne, 0, sizeof(PairX), c->stream));  // sentinel of the scan
+#define GNNPE_PX_SORT(KT)                                                                                               \
+    do {                                                                                                                \
+        KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + ne + 1;                                        \
+        if (len)                                                                                                        \
+            hipLaunchKernelGGL((k_px_pairs<KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
+                               c->rpairs.as<RankedPair>(), c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(),              \
+                               c->vkey.as<uint64_t>(), c->px_pbase.as<uint64_t>(), e, lb, sbits, zbits, px, k_in, v_in); \
+        tb = 0;                                                                                                         \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)ne, 0, (int)kbits, c->stream)); \
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                   \
+        tb = c->cub_tmp.bytes;                                                                                          \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)ne, 0, (int)kbits, c->stream)); \
+        hipLaunchKernelGGL((k_px_bounds<KT>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, ne, p, k_out, shift, d_bounds); \
+    } while (0)
+    if (ne) {
+        if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
+        hipLaunchKernelGGL(k_px_permute, dim3(grid_for(ne)), dim3(kBlock), 0, c->stream, ne, v_out, px, pxs);
+    } else {
+        GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
+    }
+#undef GNNPE_PX_SORT
+    {
+        hipcub::TransformInputIterator<uint64_t, CntOfPairX, const PairX *> it(pxs, CntOfPairX());
+        tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    // 3. partition ranges and their first points, to the host
+    c->px_bounds.assign((size_t)p + 1, 0);
+    c->px_points.assign((size_t)p + 1, 0);
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->px_bounds.data(), d_bounds, ((size_t)p + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k <= p; k++)
+        GNNPE_HIP_TRY(hipMemcpyAsync(&c->px_points[k], c->px_pref.as<uint64_t>() + c->px_bounds[k], 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->px_valid = true;
+    c->px_gen = c->count_gen;
+    return GNNPE_OK;
+}
+
+static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+{
+    int rc;
+    if ((rc = ensure_pair_order(c))) return rc;
+    const uint64_t r0 = c->px_bounds[pid], r1 = c->px_bounds[pid + 1], cnt = c->px_points[pid + 1] - c->px_points[pid];
+    GNNPE_REQUIRE(cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu entries exceeds the format's int32 counts", (unsigned long long)cnt);
+    const uint32_t e = c->e, D = 3 * e;
+    const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);
+    const uint32_t F = std::min(cap - 2, 64u);
+    if (cnt == 0) {  // the reference's empty tree
+        LeafSrc S = {nullptr, c->vde.as<double>(), nullptr, 3, e, D};
+        return build_image(c, 0, S, dev_image, nbytes, hdr_out);
+    }
+    std::vector<uint64_t> level_n;
+    const uint64_t n_nodes = plan_levels(cnt, F, level_n);
+    GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
+    const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
+    uint64_t max_level = 0;
+    for (uint64_t v : level_n) max_level = std::max(max_level, v);
+    if ((rc = c->index_image.reserve(image_bytes)) || (rc = c->px_first.reserve((level_n[0] + 1) * 4)) ||
+        (rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8)))
+        return rc;
+    char *image = c->index_image.as<char>();
+    double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
+    GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
+    int32_t hdr[8] = {kBlockLen, (int32_t)n_nodes, (int32_t)D, (int32_t)cnt, (int32_t)level_n[0], (int32_t)(n_nodes - level_n[0]), 0,
+                      (int32_t)(n_nodes - 1)};
+    const uint64_t nl = level_n[0];
+    hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(nl)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
+                       c->px_first.as<uint32_t>());
+    const bool packed = c->n <= (1u << kPackedIdBits);
+    const uint32_t g = (uint32_t)std::min<uint64_t>(256 * 8, (nl + kLeafWaves - 1) / kLeafWaves);
+#define GNNPE_PXL(EE, PK)                                                                                               \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, F, r0, r1,    \
+                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairX>(), c->rrecs.as<char>(), \
+                       c->vde.as<double>(), image, mbr_a)
+#define GNNPE_PXE(EE)                                          \
+    do {                                                       \
+        if (packed) GNNPE_PXL(EE, true); else GNNPE_PXL(EE, false); \
+    } while (0)
+    switch (e) {
+    case 1: GNNPE_PXE(1); break;
+    case 2: GNNPE_PXE(2); break;
+    case 3: GNNPE_PXE(3); break;
+    case 4: GNNPE_PXE(4); break;
+    default: GNNPE_PXE(8); break;
+    }
+#undef GNNPE_PXE
+#undef GNNPE_PXL
+    GNNPE_HIP_TRY(hipGetLastError());
+    if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
+    if ((rc = write_header(c, image, hdr))) return rc;
+    *dev_image = image;
+    *nbytes = image_bytes;
+    if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
+    return GNNPE_OK;
+}
+
 int gnnpe_write_device_file(gnnpe_ctx *c, const void *dev_src, uint64_t nbytes, const char *path)
 {
     GNNPE_REQUIRE(c && path && (dev_src || !nbytes), GNNPE_ERR_ARG, "gnnpe_write_device_file: null argument");
@@ -746,18 +1176,13 @@ int gnnpe_gather_rows_device(gnnpe_ctx *c, uint64_t k, uint32_t L, const void *d
     return GNNPE_OK;
 }
 
-int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
+// the partition's paths as vertex tuples in path-id order (two passes over the slab in chunks): the tuple-array build's input
+static int collect_partition_tuples(gnnpe_ctx *c, uint32_t pid, DevBuf &mine, uint64_t *cnt_out)
 {
-    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
-    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
-                  "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
-    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
-    GNNPE_HIP_TRY(hipSetDevice(c->device));
     const uint32_t L = c->l + 1;
     const uint64_t total = c->total_paths;
-    // collect the partition's paths (vertex triples in path-id order): two passes over the slab in chunks
     const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(total, 1), 64ull << 20);
-    DevBuf ids, part, sel, mine;
+    DevBuf ids, part, sel;
     int rc;
     if ((rc = ids.reserve(chunk * L * 4)) || (rc = part.reserve(chunk * 4)) || (rc = sel.reserve(chunk * 8))) return rc;
     uint64_t cnt = 0;
@@ -779,15 +1204,36 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
         }
         if (pass == 0 && !rc) rc = mine.reserve(std::max<uint64_t>(cnt, 1) * L * 4);
     }
+    (void)hipStreamSynchronize(c->stream);  // the chunk buffers are released on return
+    *cnt_out = cnt;
+    return rc;
+}
+
+int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+{
+    GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
+                  "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
+    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    if (pair_major_ok(c)) return build_partition_image(c, pid, dev_image, nbytes, hdr_out);
+    // hub rows, l = 3 or the generic enumeration: the partition's tuples, then the tuple-array build
+    DevBuf mine;
+    uint64_t cnt = 0;
+    int rc = collect_partition_tuples(c, pid, mine, &cnt);
+    if (!rc) rc = gnnpe_build_index_device(c, cnt, c->l + 1, mine.p, dev_image, nbytes, hdr_out);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
+{
+    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
     void *image = nullptr;
     uint64_t nbytes = 0;
-    if (!rc) rc = gnnpe_build_index_device(c, cnt, L, mine.p, &image, &nbytes, nullptr);
+    int rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr);
     if (!rc) rc = write_device_image(c, (const char *)image, nbytes, path);
     (void)hipStreamSynchronize(c->stream);
-    ids.release();
-    part.release();
-    sel.release();
-    mine.release();
     return rc;
 }
 

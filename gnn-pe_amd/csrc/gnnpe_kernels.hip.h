@@ -10,6 +10,8 @@
 
 #include <cstdint>
 
+#include "gnnpe_records.h"
+
 namespace gnnpe {
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
@@ -187,7 +189,6 @@ struct FillParams {
     uint32_t *out_part;
 };
 
-constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
 constexpr uint64_t kNoOff = ~0ull;
 
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -318,11 +319,6 @@ __device__ __forceinline__ void emit_path(const PT &P, uint64_t pos, uint32_t s,
     if (P.out_part) P.out_part[o] = P.member[s];
 }
 
-struct __attribute__((aligned(16))) StartRec {
-    uint64_t base, end;  // first / one-past-last output slot of this start vertex
-    uint32_t e0, ds, s, part;
-    uint32_t a_s, pad0, pad1, pad2;  // adj_start[s]: N(s) = the middle vertices of its pairs, in pair order
-};
 
 __global__ void k_start_recs(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
                              const uint32_t *__restrict__ member, const uint32_t *__restrict__ adj_start,

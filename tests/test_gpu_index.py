@@ -127,3 +127,89 @@ def test_reference_online_consumes_prebuilt_index(tmp_path, oracle, p):
     assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
     # the reference skipped its ~40 s insert loop because index.dat already existed (custom.h:222-235)
     assert dt < 25, dt
+
+
+# ---- pair-major build: the partition's image straight from the enumeration state (no tuple array) ---------------------
+def _partition_paths(ref, mem, pid):
+    sel = np.flatnonzero(mem[ref[:, 0]] == pid)
+    return ref[sel]
+
+
+@pytest.mark.parametrize("e,p", [(2, 1), (2, 3), (1, 2), (3, 1), (4, 2), (8, 1)])
+def test_pair_major_partition_images(oracle, e, p):
+    """Hub-free graph (every row <= 64): gnnpe_build_index_partition_device sorts the (s, b) pairs and reads the points out
+    of the row blocks.  Every consumer constraint holds, every path of the partition is a leaf entry exactly once with
+    son = its index inside the partition (the line number in partition_paths.txt, custom.h:205-216,243) and
+    lo = hi = its pde row, bit for bit."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(4000, 36000, n_labels=7, seed=5 + e)
+    assert np.diff(g["offsets"].astype(np.int64)).max() <= 64
+    rng = np.random.default_rng(e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)          # arbitrary processing order
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)  # arbitrary partition of the vertices
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    assert total == len(ref)
+    D = 3 * e
+    F = min((4096 - 5) // (16 * D + 4) - 2, 64)
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["dim"] == D and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
+        assert d["dnodes"] == -(-len(mine) // F)
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), D))
+    # leaves are pair-major: left to right, the (label s, label b) of the entries never decreases
+    mine = _partition_paths(ref, mem, 0)
+    d = oracle.index_validate(eng.copy_to_host(*eng.build_index_partition_device(0)[:2]).tobytes())
+    lab = g["labels"].astype(np.int64)[mine[d["leaf_son"]]]
+    assert np.all(np.diff(lab[:, 0] * 7 + lab[:, 1]) >= 0)
+    eng.close()
+
+
+def test_pair_major_falls_back_with_hub_rows(oracle, test_graph):
+    """Test/data_graph.graph has a row of degree 168: the partition build collects the tuples and takes the tuple-array
+    path; same contract."""
+    from gnnpe_amd import binding
+    g = test_graph
+    eng = _engine(binding, g, g["sorted_nodes"], g["membership"], 1, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    p, nb, hdr = eng.build_index_partition_device(0)
+    d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+    o = np.argsort(d["leaf_son"], kind="stable")
+    assert d["num_data"] == total and np.array_equal(d["leaf_pt"][o], vde[ids].reshape(total, 6))
+    eng.close()
+
+
+def test_reference_online_consumes_pair_major_index(tmp_path):
+    """The untouched reference online binary on a hub-free graph: same Answer Number from the trees it inserts itself and
+    from the pair-major index.dat files of `gnnpe_main --index` (p = 3, arbitrary membership)."""
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    g = synth.gnm_graph(1500, 9000, n_labels=5, seed=21)
+    sn = synth.degree_order(g["offsets"])
+    rng = np.random.default_rng(21)
+    mem = rng.integers(0, 3, size=g["n"]).astype(np.uint32)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    q = os.path.join(GOLDEN, "test_graph", "query_graph.graph")
+    ans = []
+    for name in ("ref", "ours"):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 3)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        if name == "ref":
+            subprocess.check_call([ref_main_path(), "-f", d + "/", "-d", gp, "-m", "offline", "-p", "3"], stdout=subprocess.DEVNULL)
+        else:
+            r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "3", "--index"], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+        out = subprocess.check_output([ref_main_path(), "-f", d + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
+        ans.append(int(re.search(r"Answer Number: (\d+)", out).group(1)))
+    assert ans[0] == ans[1]
