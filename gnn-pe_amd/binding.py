@@ -51,6 +51,7 @@ SIGNATURES = {
     "gnnpe_rows_pack": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
     "gnnpe_rows_append": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, C.c_uint32]),
     "gnnpe_rows_drop_halo": (C.c_int, [_vp]),
+    "gnnpe_rows_held": (C.c_int, [_vp, _u64p, _u64p, _u32p]),
     "gnnpe_vde": (C.c_int, [_vp, _f64p, _f64p, _f64p]),
     "gnnpe_vde_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "gnnpe_vde_pack_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
@@ -417,6 +418,12 @@ class Engine:
         """min_rank > 0: entries ranked before that processing position are dropped (last-hop halo rows)."""
         self._ck(self.lib.gnnpe_rows_append(self.ctx, int(n_rows), _dev(dev_ids), _dev(dev_deg), _dev(dev_nbrs),
                                             int(n_nbrs), int(min_rank)))
+
+    def rows_held(self):
+        """(rows, neighbour entries, hub rows) on the device: own rows plus the installed (truncated) halo."""
+        r, e, h = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        self._ck(self.lib.gnnpe_rows_held(self.ctx, C.byref(r), C.byref(e), C.byref(h)))
+        return r.value, e.value, h.value
 
     def rows_drop_halo(self):
         self._ck(self.lib.gnnpe_rows_drop_halo(self.ctx))

@@ -154,6 +154,15 @@ int gnnpe_sync(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+int gnnpe_rows_held(gnnpe_ctx *c, uint64_t *n_rows, uint64_t *n_entries, uint32_t *n_hub_rows)
+{
+    GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_rows_held: no graph");
+    if (n_rows) *n_rows = c->n_held;
+    if (n_entries) *n_entries = c->nbr_used;
+    if (n_hub_rows) *n_hub_rows = c->n_hub;
+    return GNNPE_OK;
+}
+
 int gnnpe_get_stream(gnnpe_ctx *c, void **hip_stream)
 {
     GNNPE_REQUIRE(c && hip_stream, GNNPE_ERR_ARG, "null argument");

@@ -208,6 +208,8 @@ class SlabBuild:
             self._halo_plans.append(p)
             last = hop == hops - 1
             self._move_rows(p, int(self.bounds[self.rank]) if (truncate and last) else 0)
+        if hasattr(self.eng, "rows_held"):
+            self.stats["held_rows"], self.stats["held_entries"], self.stats["hub_rows"] = self.eng.rows_held()
         self.halo_installed = True
 
     # round-1 name, kept for callers that re-fetch explicitly

@@ -456,10 +456,9 @@ void rank_main(int r, Shared &S)
             const uint32_t min_rank = hop == hops - 1 ? lo : 0u;  // last hop: entries ranked before the slab are never used
             check(gnnpe_rows_append(ctx, n_need, d_need.p, d_degin.p, d_in.p, n_recv, min_rank), "rows_append");
             S.halo_rows[r] += n_need;
-            S.held_entries[r] += n_recv;
         }
     }
-    S.held_entries[r] += own_entries;
+    check(gnnpe_rows_held(ctx, nullptr, &S.held_entries[r], nullptr), "rows_held");  // own rows + truncated halo rows
     const auto t1 = Clock::now();
 
     // ---- vde of the owned rows, all-gather of the slabs' rows ----

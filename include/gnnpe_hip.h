@@ -131,6 +131,10 @@ int gnnpe_rows_pack(gnnpe_ctx *ctx, uint64_t n_req, const void *dev_ids, void *d
 int gnnpe_rows_append(gnnpe_ctx *ctx, uint64_t n_rows, const void *dev_ids, const void *dev_deg,
                       const void *dev_nbrs, uint64_t n_nbrs, uint32_t min_rank);
 
+/* What the context holds: adjacency rows (own + halo), their neighbour entries (halo rows count as installed, i.e.
+ * after truncation), rows longer than 64 entries.  Any output may be NULL. */
+int gnnpe_rows_held(gnnpe_ctx *ctx, uint64_t *n_rows, uint64_t *n_entries, uint32_t *n_hub_rows);
+
 /* Forget every appended halo row (back to the state right after gnnpe_load_rows), so the exchange
  * can be repeated. */
 int gnnpe_rows_drop_halo(gnnpe_ctx *ctx);

@@ -118,7 +118,7 @@ def main():
     sb = SlabBuild(eng, n, e, bounds, rank, world, dev, nbr_capacity=cap, owned_entries=owned_entries, l=args.l)
     total, base = sb.step()
     res = dict(rank=rank, world=world, backend=backend, total=int(total), base=int(base), global_total=int(sb.global_total),
-               slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats))
+               slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats), owned_entries=int(owned_entries))
 
     chunk = 1 << 24
     if args.ranges is not None:  # single rank: checksum the requested global ranges

@@ -155,8 +155,10 @@ def test_slab_split_writes_identical_files(tmp_path, oracle, gpus):
             own = [x["owned_entries"] for x in t["ranks"]]
             held = [x["held_entries"] for x in t["ranks"]]
             assert sum(own) == t["csr_entries"] == 2 * g["m"]           # the rows are partitioned, not replicated
-            assert all(h <= t["csr_entries"] for h in held) and all(x["halo_rows"] > 0 for x in t["ranks"])
-            assert held[-1] < t["csr_entries"]   # the last slab's halo rows arrive truncated to its rank range
+            assert all(o < h <= t["csr_entries"] for o, h in zip(own, held)) and all(x["halo_rows"] > 0 for x in t["ranks"])
+            # the halo rows of the later slabs arrive truncated to their rank range: what the last slab holds is its own
+            # rows plus LESS than every other entry of the graph
+            assert held[-1] < t["csr_entries"] and held[-1] - own[-1] < held[0] - own[0]
     rel = ["gnn-pe/all_paths.txt"] + [f"gnn-pe/partitions/partition-{i}/partition_paths.txt" for i in range(4)]
     for f in rel:
         assert open(os.path.join(outs[0], f), "rb").read() == open(os.path.join(outs[1], f), "rb").read(), f
@@ -166,6 +168,31 @@ def test_slab_split_writes_identical_files(tmp_path, oracle, gpus):
         for d in outs:
             info = oracle.index_validate(open(os.path.join(d, f"gnn-pe/partitions/partition-{i}/index.dat"), "rb").read())
             assert info["num_data"] == cnt and np.array_equal(np.sort(info["leaf_son"]), np.arange(cnt))
+
+
+def test_slab_split_config2_eight_slabs(tmp_path):
+    """BASELINE config 2 (100K / 1M, 2.0e7 paths, 540 MB of text) through `gnnpe_main --gpus 8`: byte-identical files for
+    one slab and for eight (each context holding only its slab's rows + the truncated halo)."""
+    g = synth.gnm_graph(100_000, 1_000_000)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(g["n"], 8)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    sums = []
+    for n in (1, 8):
+        d = str(tmp_path / f"n{n}")
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 8)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "8", "--gpus", str(n), "--same-device", "--timing"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        t = json.loads(r.stderr.strip().splitlines()[-1])
+        assert t["paths"] == synth.expected_paths_l2(g["offsets"])
+        sums.append([_md5(os.path.join(d, "gnn-pe", "all_paths.txt"))] +
+                    [_md5(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "partition_paths.txt")) for i in range(8)])
+        shutil.rmtree(d)
+    assert sums[0] == sums[1]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for RCCL")

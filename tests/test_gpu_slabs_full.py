@@ -88,8 +88,10 @@ def _check_l2_slabs(tmp_path, g, world, same_device=True, weights="1,0,0"):
 def test_config4_1m_10m_eight_slab_ranks(tmp_path):
     g = synth.gnm_graph(1_000_000, 10_000_000)
     res = _check_l2_slabs(tmp_path, g, 8)
-    # truncated halo rows: later slabs hold fewer entries than the first
-    assert res[-1]["halo"]["halo_entries"] < res[0]["halo"]["halo_entries"]
+    # truncated halo rows: the last slab holds fewer halo entries than it was sent, and fewer than the first slab
+    last, first = res[-1]["halo"], res[0]["halo"]
+    assert last["held_entries"] < last["halo_entries"] + (2 * g["m"] - last["halo_entries"])
+    assert last["held_entries"] - res[-1]["owned_entries"] < first["held_entries"] - res[0]["owned_entries"]
 
 
 def test_config4_work_balanced_slabs(tmp_path):
