@@ -543,25 +543,45 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     uint32_t *w = s_win[wv];
     const uint64_t stride = (uint64_t)gridDim.x * kLeafWaves;
     const uint64_t pbase = pref[r0];
-    for (uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv; j < n_leaves; j += stride) {
+    // Software pipeline over the wave's leaves j, j + stride, ...: the strip of the NEXT leaf (its pairs' first points and
+    // records) is loaded while the current leaf is assembled, and `first` is read one leaf further ahead through the
+    // scalar cache (j is wave-uniform), so a leaf costs one dependent memory round trip (its records) instead of three.
+    uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
+    auto first_of = [&](uint64_t jj) -> uint64_t { return jj < n_leaves ? (uint64_t)first[jj] : r1; };
+    auto load_strip = [&](uint64_t f, uint64_t *rel, PairX *x) {
+        const uint64_t kk = f + lane;
+        *rel = ~0ull;
+        x->s = x->b = x->block = x->cnt = 0;
+        x->G = x->son0 = 0;
+        if (kk < r1) {
+            *rel = pref[kk] - pbase;
+            *x = px[kk];
+        }
+    };
+    uint64_t f_next = first_of(j + stride), rel_cur;
+    PairX x_cur;
+    load_strip(first_of(j), &rel_cur, &x_cur);
+    for (; j < n_leaves; j += stride) {
         const uint64_t g0 = j * F;
         const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - g0);
+        const uint64_t f_next2 = first_of(j + 2 * stride);
+        uint64_t rel_nxt;
+        PairX x_nxt;
+        load_strip(f_next, &rel_nxt, &x_nxt);
         // the wave's strip of pairs
-        const uint64_t kk = (uint64_t)first[j] + lane;
         uint32_t pp = 0xFFFFFFFFu;
-        if (kk < r1) {
-            const uint64_t rel = pref[kk] - pbase;
-            if (rel < g0 + ne) {
-                pp = (uint32_t)(rel >= g0 ? rel - g0 : 0u);  // first entry of the pair inside this leaf
-                const PairX x = px[kk];
-                s_s[wv][lane] = x.s;
-                s_blk[wv][lane] = x.block;
-                s_G[wv][lane] = x.G;
-                // records of the pair before this leaf's first point (the pair may have begun in the previous leaf)
-                s_son[wv][lane] = (x.son0 << 8) | (uint64_t)(rel >= g0 ? 0u : (uint32_t)(g0 - rel));
-            }
+        if (rel_cur < g0 + ne) {
+            pp = (uint32_t)(rel_cur >= g0 ? rel_cur - g0 : 0u);  // first entry of the pair inside this leaf
+            s_s[wv][lane] = x_cur.s;
+            s_blk[wv][lane] = x_cur.block;
+            s_G[wv][lane] = x_cur.G;
+            // low byte: records of the pair before this leaf's first point (the pair may have begun in the previous leaf)
+            s_son[wv][lane] = (x_cur.son0 << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
         }
         s_pp[wv][lane] = pp;
+        rel_cur = rel_nxt;
+        x_cur = x_nxt;
+        f_next = f_next2;
         if (lane == 0) {
             w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
             w[1] = ne;

@@ -123,6 +123,17 @@ inline Options parse_args(int argc, char **argv, const char *tool = "gnnpe_main"
     return o;
 }
 
+// The reference's block file seeks with 32-bit offsets (`fseek(fp, (bnum - act_block) * blocklength, SEEK_CUR)`,
+// include/blockfile/blk_file.h:33): an index.dat of 2 GiB or more -- its own insert-built ones included -- breaks its
+// online run.  The file is still written (other consumers may read it); the user is told to use more partitions.
+inline void warn_if_index_too_large_for_reference(const std::string &path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0 && (uint64_t)st.st_size >= (1ull << 31))
+        fprintf(stderr, "%s: warning: %s is %.2f GiB; the reference's online binary cannot seek in index files of 2 GiB or more "
+                        "(blk_file.h:33) -- use a larger -p\n", g_tool, path.c_str(), st.st_size / 1073741824.0);
+}
+
 inline bool is_dir(const std::string &p)
 {
     struct stat st;

@@ -438,8 +438,11 @@ int main(int argc, char **argv)
             check(gnnpe_count_paths(ctx, o.path_length, nullptr, &t), "count_paths(all)");
         }
         for (uint32_t pid = 0; pid < o.partition_num; pid++)
-            check(gnnpe_build_index(ctx, pid, (partitions_path + "partition-" + std::to_string(pid) + "/index.dat").c_str()),
-                  "build_index");
+        {
+            const std::string ip = partitions_path + "partition-" + std::to_string(pid) + "/index.dat";
+            check(gnnpe_build_index(ctx, pid, ip.c_str()), "build_index");
+            warn_if_index_too_large_for_reference(ip);
+        }
         t_index = secs(i0, Clock::now());
     }
     for (auto &d : devs) gnnpe_destroy(d.ctx);

@@ -609,8 +609,9 @@ void rank_main(int r, Shared &S)
                 void *image = nullptr;
                 uint64_t nbytes = 0;
                 check(gnnpe_build_index_device(ctx, tot, L, d_all.p, &image, &nbytes, nullptr), "build_index");
-                check(gnnpe_write_device_file(ctx, image, nbytes, (partitions_path + "partition-" + std::to_string(pid) + "/index.dat").c_str()),
-                      "write index.dat");
+                const std::string ip = partitions_path + "partition-" + std::to_string(pid) + "/index.dat";
+                check(gnnpe_write_device_file(ctx, image, nbytes, ip.c_str()), "write index.dat");
+                warn_if_index_too_large_for_reference(ip);
             }
         }
     }

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Large index.dat through the untouched consumer (TEST INFRASTRUCTURE).
 
-BASELINE config 2 -- G(100K, 1M), l=2, e=2, p=1: 2.0e7 paths, 5.4e5 node blocks -- exercises what Test/ (15K blocks)
+G(70K, 700K), l=2, e=2, p=1: 1.4e7 paths, ~3.8e5 node blocks (1.5 GB of index.dat) -- exercises what Test/ (15K blocks)
 cannot: the reference online side's 100 000-entry heap (GNN-PE/include/heap/heap.h:3) and its block-id-indexed arrays
-(custom.h:261,264,379).
+(custom.h:261,264,379).  It is also about the largest single partition the reference can read at all: its block file
+seeks with 32-bit offsets (`fseek(fp, (bnum - act_block) * blocklength, SEEK_CUR)`, include/blockfile/blk_file.h:33),
+so an index.dat of 2 GiB or more breaks the consumer whoever wrote it.  At BASELINE config 2 with p = 1 (2.0e7 paths)
+the reference's OWN run dies that way: its insert-built tree reaches 2 147 819 520 bytes and `main -m online` ends
+with SIGSEGV after 1 968 s (large_index/reference_config2_p1_crash.json, recorded by part A of this script at that size).
 
   part A (this container, CPU only, ~40 min):  the reference does everything itself -- `ref_main -m offline`, then
          `ref_main -m online`, whose first run builds index.dat by 2e7 R*-tree inserts -- and prints Answer Number.
@@ -32,7 +36,7 @@ from oracle import ref_main_path  # noqa: E402
 
 OUT = os.path.join(HERE, "large_index")
 QUERY = os.path.join(OUT, "query.graph")
-N, M = 100_000, 1_000_000
+N, M = 70_000, 700_000
 
 
 def make_query(g, seed=7):
