@@ -102,7 +102,7 @@ struct gnnpe_ctx {
     gnnpe::DevBuf index_image, idx_keys, idx_vals, idx_mbr;
     // pair-major index build (gnnpe_index.hip): sorted pair records, prefix of their path counts, per-partition ranges;
     // valid for one count (count_gen)
-    gnnpe::DevBuf px_recs, px_sorted, px_pref, px_pbase, px_first, px_tmp;
+    gnnpe::DevBuf px_recs, px_sorted, px_pref, px_pbase, px_first, px_tmp, px_units, px_hubs;
     std::vector<uint64_t> px_bounds, px_points;  // first sorted pair / first point of every partition (p + 1 entries)
     uint64_t count_gen = 0, px_gen = 0;
     bool px_valid = false;  // R6 scratch + the assembled index.dat image

@@ -453,34 +453,106 @@ __global__ void k_px_pbase(uint32_t len, const uint32_t *__restrict__ sorted_par
     }
 }
 
-// one record + one sort key per pair, in pair (= path) order; 16 lanes per start vertex
-template <typename KeyT>
-__global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
-                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
-                           const uint64_t *__restrict__ pbase, uint32_t e, uint32_t lb, uint32_t sbits, uint32_t zbits,
-                           PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+// Sorted items are UNITS: a pair whose middle row has at most 64 entries is one unit (its records are addressed through
+// G), a hub pair is cut into units of 64 consecutive entries of the id-ordered hub row, each with the 64-bit mask of the
+// entries ranked after s (the r-th path of the unit is the r-th set bit).  PairX.cnt bit 31 marks a hub unit, whose
+// first record index rides in the high half of son0.
+constexpr uint32_t kUnitHub = 0x80000000u;
+
+// units of every pair (hub pairs: one per 64 row entries), and the list of hub pairs {pair, start}; 16 lanes per start
+__global__ void k_px_unit_counts(uint32_t len, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
+                                 uint32_t *__restrict__ ucount, uint32_t *__restrict__ hub_counter, uint2 *__restrict__ hub_list)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
     const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < len; g += ng) {
+        const uint32_t e0 = srec[g].e0, ds = srec[g].ds;
+        for (uint32_t k = sub; k < ds; k += 16) {
+            const RankedPair pr = pairs[e0 + k];
+            uint32_t u = 1;
+            if (pr.cnt & kHubFlag) {
+                u = ((uint32_t)pr.G + 63u) / 64u;
+                const uint32_t at = atomicAdd(hub_counter, 1u);
+                if (hub_list) hub_list[at] = make_uint2(e0 + k, (uint32_t)g);
+            }
+            ucount[e0 + k] = u;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t px_key(uint64_t part, uint64_t ks, uint64_t kb, uint32_t e, uint32_t lb, uint32_t sbits, uint32_t zbits)
+{
     const uint64_t lmask = (1ull << lb) - 1ull, smask = (1ull << sbits) - 1ull;
+    const uint64_t lab = (((part << lb) | ((ks >> 32) & lmask)) << lb) | ((kb >> 32) & lmask);
+    const uint64_t z = ((ks & smask) << (2 * e)) | ((kb & smask) << e);
+    return (lab << zbits) | z;
+}
+
+// one record + one sort key per ordinary pair, at the pair's unit slot; 16 lanes per start vertex
+template <typename KeyT>
+__global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
+                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
+                           const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst, uint32_t e, uint32_t lb,
+                           uint32_t sbits, uint32_t zbits, PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (; g < len; g += ng) {
         const StartRec sr = srec[g];
         const uint64_t ks = vkey[sr.s];
         for (uint32_t k = sub; k < sr.ds; k += 16) {
             const uint32_t q = sr.e0 + k;
             const RankedPair pr = pairs[q];
+            if (pr.cnt & kHubFlag) continue;  // k_px_hub_units
+            const uint64_t at = ufirst ? ufirst[q] : (uint64_t)q;
             const uint32_t b = nbrs[sr.a_s + k];
-            const uint64_t kb = vkey[b];
-            const uint32_t cnt = pr.cnt & ~kHubFlag;
-            PairX x = {sr.s, b, pr.block, cnt, pr.G, pbase[g] + (eoff[q] - sr.base)};
-            px[q] = x;
+            PairX x = {sr.s, b, pr.block, pr.cnt, pr.G, pbase[g] + (eoff[q] - sr.base)};
+            px[at] = x;
             // pairs without paths sort behind every partition (partition field = n_parts)
-            const uint64_t part = cnt ? sr.part : n_parts;
-            const uint64_t lab = (((part << lb) | ((ks >> 32) & lmask)) << lb) | ((kb >> 32) & lmask);
-            const uint64_t z = ((ks & smask) << (2 * e)) | ((kb & smask) << e);
-            keys[q] = (KeyT)((lab << zbits) | z);
-            vals[q] = q;
+            keys[at] = (KeyT)px_key(pr.cnt ? sr.part : n_parts, ks, vkey[b], e, lb, sbits, zbits);
+            vals[at] = (uint32_t)at;
+        }
+    }
+}
+
+// the units of the hub pairs: one wave per hub pair, 64 row entries per unit, kept mask by ballot
+template <int E, typename KeyT>
+__global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint32_t n_parts, uint32_t slab_begin,
+                                                      const uint2 *__restrict__ hub_list, const StartRec *__restrict__ srec,
+                                                      const RankedPair *__restrict__ pairs, const uint64_t *__restrict__ eoff,
+                                                      const uint32_t *__restrict__ nbrs, const char *__restrict__ recs,
+                                                      const uint64_t *__restrict__ vkey, const uint64_t *__restrict__ pbase,
+                                                      const uint64_t *__restrict__ ufirst, uint32_t lb, uint32_t sbits,
+                                                      uint32_t zbits, PairX *__restrict__ px, KeyT *__restrict__ keys,
+                                                      uint32_t *__restrict__ vals)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w < n_hub_pairs; w += nw) {
+        const uint32_t q = hub_list[w].x, g = hub_list[w].y;
+        const StartRec sr = srec[g];
+        const RankedPair pr = pairs[q];
+        const uint32_t d = (uint32_t)pr.G, thr = slab_begin + g, b = nbrs[sr.a_s + (q - sr.e0)];
+        const RecWide<E> *row = reinterpret_cast<const RecWide<E> *>(recs + (uint64_t)pr.block * kRowAlign + 8 * E);
+        const uint64_t key_ok = px_key(sr.part, vkey[sr.s], vkey[b], E, lb, sbits, zbits);
+        const uint64_t key_no = px_key(n_parts, vkey[sr.s], vkey[b], E, lb, sbits, zbits);
+        uint64_t son = pbase[g] + (eoff[q] - sr.base);
+        const uint64_t at0 = ufirst[q];
+        for (uint32_t u = 0; u * 64u < d; u++) {
+            const uint32_t j = u * 64u + lane;
+            const bool keep = j < d && row[j].aux > thr;
+            const uint64_t mask = __ballot(keep);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            if (lane == 0) {
+                PairX x = {sr.s, b, pr.block, cnt | kUnitHub, mask, son | ((uint64_t)(u * 64u) << 32)};
+                px[at0 + u] = x;
+                keys[at0 + u] = (KeyT)(cnt ? key_ok : key_no);
+                vals[at0 + u] = (uint32_t)(at0 + u);
+            }
+            son += cnt;
         }
     }
 }
@@ -489,7 +561,10 @@ __global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, co
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < ne; k += (uint64_t)gridDim.x * blockDim.x) out[k] = px[order[k]];
 }
 struct CntOfPairX {
-    __host__ __device__ uint64_t operator()(const PairX &p) const { return (uint64_t)p.cnt; }
+    __host__ __device__ uint64_t operator()(const PairX &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
+};
+struct U32ToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
 };
 // first sorted pair of every partition (bounds[n_parts] = first pair without paths)
 template <typename KeyT>
@@ -537,7 +612,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     constexpr int kWin = kBlockLen / 4 + 4;
     constexpr int kEnt = 4 * D + 1;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
-    __shared__ uint32_t s_pp[kLeafWaves][64], s_s[kLeafWaves][64], s_blk[kLeafWaves][64];
+    __shared__ uint32_t s_pp[kLeafWaves][64], s_s[kLeafWaves][64], s_blk[kLeafWaves][64], s_first[kLeafWaves][64];
     __shared__ uint64_t s_G[kLeafWaves][64], s_son[kLeafWaves][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *w = s_win[wv];
@@ -575,8 +650,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             s_s[wv][lane] = x_cur.s;
             s_blk[wv][lane] = x_cur.block;
             s_G[wv][lane] = x_cur.G;
-            // low byte: records of the pair before this leaf's first point (the pair may have begun in the previous leaf)
-            s_son[wv][lane] = (x_cur.son0 << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
+            // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
+            s_first[wv][lane] = (x_cur.cnt & kUnitHub) ? ((uint32_t)(x_cur.son0 >> 32) | kUnitHub) : 0u;
+            // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
+            s_son[wv][lane] = ((x_cur.son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
         }
         s_pp[wv][lane] = pp;
         rel_cur = rel_nxt;
@@ -598,25 +675,42 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 if (s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
             }
             const uint64_t sw = s_son[wv][a];
-            const uint32_t r = (uint32_t)lane - s_pp[wv][a] + (uint32_t)(sw & 0xFFu);  // record inside the pair's block
+            const uint32_t r = (uint32_t)lane - s_pp[wv][a] + (uint32_t)(sw & 0xFFu);  // point inside the unit
             const char *const blk = recs + (uint64_t)s_blk[wv][a] * kRowAlign;
-            const Rec rec = reinterpret_cast<const Rec *>(blk + 8 * E)[r];
-            uint32_t id, ip;
-            if constexpr (PACKED) {
-                id = rec.idp & ((1u << kPackedIdBits) - 1u);
-                ip = rec.idp >> kPackedIdBits;
+            const uint32_t fh = s_first[wv][a];
+            double vc[E];
+            uint32_t son;
+            if (fh & kUnitHub) {
+                // hub unit: the r-th entry ranked after s = the r-th set bit of the mask; paths follow in id order
+                uint64_t m = s_G[wv][a];
+                uint32_t rr = r, pos = 0;
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) {
+                    const uint32_t cbits = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
+                    if (rr >= cbits) {
+                        rr -= cbits;
+                        m >>= sh;
+                        pos += sh;
+                    }
+                }
+                const RecWide<E> rec = reinterpret_cast<const RecWide<E> *>(blk + 8 * E)[(fh & ~kUnitHub) + pos];
+#pragma unroll
+                for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
+                son = (uint32_t)(sw >> 8) + r;
             } else {
-                id = rec.id;
-                ip = rec.aux;
+                const Rec rec = reinterpret_cast<const Rec *>(blk + 8 * E)[r];
+                uint32_t ip;
+                if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
+#pragma unroll
+                for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
+                son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(s_G[wv][a] & ((1ull << ip) - 1ull)));
             }
-            (void)id;
-            const uint32_t son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(s_G[wv][a] & ((1ull << ip) - 1ull)));
             const double *vs = vde + (uint64_t)s_s[wv][a] * E;
             const double *vb = reinterpret_cast<const double *>(blk);
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double val = k < E ? vs[k] : (k < 2 * E ? vb[k - E] : rec.vde[k - 2 * E]);
+                const double val = k < E ? vs[k] : (k < 2 * E ? vb[k - E] : vc[k - 2 * E]);
                 const uint64_t bits64 = (uint64_t)__double_as_longlong(val);
                 const uint32_t x = (uint32_t)bits64, y = (uint32_t)(bits64 >> 32);
                 ent[4 * k] = x;      // bounces[2k]   (custom.h:246)
@@ -1010,11 +1104,10 @@ int gnnpe_build_box_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t dim, const
 // ---- pair-major build, host side -----------------------------------------------------------------------------------
 static bool fast_dim(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
-// the enumeration state this build reads: ranked records of an l = 2 count, no hub rows (their pairs are not
-// addressable by record index), records carrying the current vde table
+// the enumeration state this build reads: ranked records of an l = 2 count carrying the current vde table
 static bool pair_major_ok(const gnnpe_ctx *c)
 {
-    return c->counted && c->l == 2 && c->counted_variant == 4 && c->n_hub == 0 && c->have_vde && c->ranked_vde_valid &&
+    return c->counted && c->l == 2 && c->counted_variant == 4 && c->have_vde && c->ranked_vde_valid &&
            fast_dim(c->e) && c->total_paths < (1ull << 40);
 }
 
@@ -1025,38 +1118,71 @@ static uint32_t bits_for(uint64_t max_value)
     return b;
 }
 
-// once per count: pairs sorted by [partition | label(s) | label(b) | z(s, b)], their records in that order, the prefix
-// of their path counts and every partition's range
+// once per count: units (pairs; hub pairs cut into 64-entry units) sorted by [partition | label(s) | label(b) | z(s, b)],
+// their records in that order, the prefix of their path counts and every partition's range
 static int ensure_pair_order(gnnpe_ctx *c)
 {
     if (c->px_valid && c->px_gen == c->count_gen) return GNNPE_OK;
     int rc;
-    // ensure_vkey sorts the vertices' components in the index scratch buffers
-    if ((rc = c->idx_keys.reserve(((size_t)c->n + 1) * 8 * 2)) || (rc = c->idx_vals.reserve(((size_t)c->n + 1) * 4 * 2))) return rc;
     if ((rc = ensure_vkey(c))) return rc;
     const uint32_t len = c->slab_end - c->slab_begin, e = c->e, D = 3 * e, p = c->p;
     const uint64_t ne = c->n_edges;
     const StartRec *srec = c->srec.as<StartRec>();
+    const RankedPair *pairs = c->rpairs.as<RankedPair>();
+    size_t tb = 0;
+    // 0. units: one per ordinary pair; hub pairs (if the graph has hub rows) one per 64 row entries
+    uint64_t nu = ne, n_hub_pairs = 0;
+    const uint64_t *ufirst = nullptr;
+    if (c->n_hub && ne) {
+        if ((rc = c->px_units.reserve((ne + 2) * 12 + 64))) return rc;
+        uint64_t *uf = c->px_units.as<uint64_t>();
+        uint32_t *ucount = reinterpret_cast<uint32_t *>(uf + ne + 1);
+        uint32_t *d_hubs = c->small.as<uint32_t>() + 520;  // byte 2080 of the context's small buffer
+        for (int pass = 0; pass < 2; pass++) {
+            GNNPE_HIP_TRY(hipMemsetAsync(d_hubs, 0, 4, c->stream));
+            GNNPE_HIP_TRY(hipMemsetAsync(ucount + ne, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_px_unit_counts, dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, srec, pairs,
+                               ucount, d_hubs, pass ? c->px_hubs.as<uint2>() : (uint2 *)nullptr);
+            GNNPE_HIP_TRY(hipGetLastError());
+            if (pass == 0) {
+                uint32_t h = 0;
+                GNNPE_HIP_TRY(hipMemcpyAsync(&h, d_hubs, 4, hipMemcpyDeviceToHost, c->stream));
+                GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+                n_hub_pairs = h;
+                if (!n_hub_pairs) break;
+                if ((rc = c->px_hubs.reserve((n_hub_pairs + 1) * 8))) return rc;
+            }
+        }
+        hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t *> it(ucount, U32ToU64());
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, uf, (int64_t)(ne + 1), c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, uf, (int64_t)(ne + 1), c->stream));
+        GNNPE_HIP_TRY(hipMemcpyAsync(&nu, uf + ne, 8, hipMemcpyDeviceToHost, c->stream));
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+        ufirst = uf;
+    }
+    GNNPE_REQUIRE(nu < (1ull << 31), GNNPE_ERR_RANGE, "%llu sort units exceed the 32-bit unit ids", (unsigned long long)nu);
     // scratch layout (px_tmp): start sort {part_in, part_out, idx_in, idx_out: u32 x len}, counts / positions {u64 x (len + 1)},
-    // pair keys {u64 x ne x 2}, pair values {u32 x ne x 2}, device bounds {u64 x 2 (p + 1)}
+    // unit keys {u64 x nu x 2}, unit values {u32 x nu x 2}, device bounds {u64 x (p + 1)}
     const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
-                 o_pos = o_cnt + ((size_t)len + 2) * 8, o_keys = o_pos + ((size_t)len + 2) * 8, o_vals = o_keys + (ne + 1) * 16,
-                 o_bnd = o_vals + (ne + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
-    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((ne + 1) * sizeof(PairX))) ||
-        (rc = c->px_sorted.reserve((ne + 1) * sizeof(PairX))) || (rc = c->px_pref.reserve((ne + 2) * 8)) ||
+                 o_pos = o_cnt + ((size_t)len + 2) * 8, o_keys = o_pos + ((size_t)len + 2) * 8, o_vals = o_keys + (nu + 1) * 16,
+                 o_bnd = o_vals + (nu + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
+    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((nu + 1) * sizeof(PairX))) ||
+        (rc = c->px_sorted.reserve((nu + 1) * sizeof(PairX))) || (rc = c->px_pref.reserve((nu + 2) * 8)) ||
         (rc = c->px_pbase.reserve(((size_t)len + 1) * 8)))
         return rc;
     char *tmp = c->px_tmp.as<char>();
     uint32_t *part_in = reinterpret_cast<uint32_t *>(tmp + o_part), *part_out = part_in + len + 1;
     uint32_t *idx_in = reinterpret_cast<uint32_t *>(tmp + o_idx), *idx_out = idx_in + len + 1;
     uint64_t *cnt = reinterpret_cast<uint64_t *>(tmp + o_cnt), *pos = reinterpret_cast<uint64_t *>(tmp + o_pos);
-    uint32_t *v_in = reinterpret_cast<uint32_t *>(tmp + o_vals), *v_out = v_in + ne + 1;
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(tmp + o_vals), *v_out = v_in + nu + 1;
     uint64_t *d_bounds = reinterpret_cast<uint64_t *>(tmp + o_bnd);
-    size_t tb = 0;
     // 1. partition-local index of every start vertex' first path
     if (len) {
         hipLaunchKernelGGL(k_px_start_parts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, srec, part_in, idx_in);
         const int pb = (int)std::max(1u, bits_for(p));
+        tb = 0;
         GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, part_in, part_out, idx_in, idx_out, (int)len, 0, pb, c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
         tb = c->cub_tmp.bytes;
@@ -1069,40 +1195,55 @@ static int ensure_pair_order(gnnpe_ctx *c)
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, cnt, pos, (int64_t)len + 1, c->stream));
         hipLaunchKernelGGL(k_px_pbase, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, part_out, idx_out, pos, c->px_pbase.as<uint64_t>());
     }
-    // 2. pair records + keys in pair order, sorted, permuted, scanned
+    // 2. unit records + keys, sorted, permuted, scanned
     const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * D, sbits = c->vkey_zb ? (c->vkey_zb - 1) * D + e : 0;
     const uint32_t shift = 2 * lb + zbits, kbits = bits_for(p) + shift;
     GNNPE_REQUIRE(kbits <= 64, GNNPE_ERR_UNSUPPORTED, "pair key needs %u bits", kbits);
     PairX *px = c->px_recs.as<PairX>(), *pxs = c->px_sorted.as<PairX>();
-    GNNPE_HIP_TRY(hipMemsetAsync(pxs + ne, 0, sizeof(PairX), c->stream));  // sentinel of the scan
+    GNNPE_HIP_TRY(hipMemsetAsync(pxs + nu, 0, sizeof(PairX), c->stream));  // sentinel of the scan
+#define GNNPE_PX_HUB(KT, EE)                                                                                            \
+    hipLaunchKernelGGL((k_px_hub_units<EE, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,             \
+                       (uint32_t)n_hub_pairs, p, c->slab_begin, c->px_hubs.as<uint2>(), srec, pairs, c->eoff.as<uint64_t>(), \
+                       c->nbrs.as<uint32_t>(), c->rrecs.as<char>(), c->vkey.as<uint64_t>(), c->px_pbase.as<uint64_t>(), ufirst, \
+                       lb, sbits, zbits, px, k_in, v_in)
 #define GNNPE_PX_SORT(KT)                                                                                               \
     do {                                                                                                                \
-        KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + ne + 1;                                        \
+        KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                        \
         if (len)                                                                                                        \
             hipLaunchKernelGGL((k_px_pairs<KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
-                               c->rpairs.as<RankedPair>(), c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(),              \
-                               c->vkey.as<uint64_t>(), c->px_pbase.as<uint64_t>(), e, lb, sbits, zbits, px, k_in, v_in); \
+                               pairs, c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(),           \
+                               c->px_pbase.as<uint64_t>(), ufirst, e, lb, sbits, zbits, px, k_in, v_in);                \
+        if (n_hub_pairs) {                                                                                              \
+            switch (e) {                                                                                                \
+            case 1: GNNPE_PX_HUB(KT, 1); break;                                                                         \
+            case 2: GNNPE_PX_HUB(KT, 2); break;                                                                         \
+            case 3: GNNPE_PX_HUB(KT, 3); break;                                                                         \
+            case 4: GNNPE_PX_HUB(KT, 4); break;                                                                         \
+            default: GNNPE_PX_HUB(KT, 8); break;                                                                        \
+            }                                                                                                           \
+        }                                                                                                               \
         tb = 0;                                                                                                         \
-        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)ne, 0, (int)kbits, c->stream)); \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
         if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                   \
         tb = c->cub_tmp.bytes;                                                                                          \
-        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)ne, 0, (int)kbits, c->stream)); \
-        hipLaunchKernelGGL((k_px_bounds<KT>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, ne, p, k_out, shift, d_bounds); \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
+        hipLaunchKernelGGL((k_px_bounds<KT>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, nu, p, k_out, shift, d_bounds); \
     } while (0)
-    if (ne) {
+    if (nu) {
         if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
-        hipLaunchKernelGGL(k_px_permute, dim3(grid_for(ne)), dim3(kBlock), 0, c->stream, ne, v_out, px, pxs);
+        hipLaunchKernelGGL(k_px_permute, dim3(grid_for(nu)), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
     } else {
         GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
     }
 #undef GNNPE_PX_SORT
+#undef GNNPE_PX_HUB
     {
         hipcub::TransformInputIterator<uint64_t, CntOfPairX, const PairX *> it(pxs, CntOfPairX());
         tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
         tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
     }
     GNNPE_HIP_TRY(hipGetLastError());
     // 3. partition ranges and their first points, to the host

@@ -204,9 +204,10 @@ int gnnpe_select_partition(gnnpe_ctx *ctx, uint64_t n, const void *dev_part, uin
 int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const void *dev_vids, void **dev_image,
                              uint64_t *nbytes, int32_t hdr_out[8]);
 /* The image of partition `pid` straight from the enumeration state of the context (after gnnpe_vde + gnnpe_count_paths):
- * no tuple array.  For an l = 2 count without hub rows the tree is built pair-major -- the (s, b) pairs are sorted by
- * [label(s) | label(b) | z-order of vde[s], vde[b]] and the leaves read their points out of the pairs' row blocks --
- * otherwise the partition's tuples are collected and handed to gnnpe_build_index_device.  Same file format, same
+ * no tuple array.  For an l = 2 count the tree is built pair-major -- the (s, b) pairs (hub pairs: their 64-entry units)
+ * are sorted by [label(s) | label(b) | z-order of vde[s], vde[b]] and the leaves read their points out of the pairs' row
+ * blocks -- otherwise (l = 3, generic enumeration kernel) the partition's tuples are collected and handed to
+ * gnnpe_build_index_device.  Same file format, same
  * consumer constraints; the image stays valid until the next index call on the context. */
 int gnnpe_build_index_partition_device(gnnpe_ctx *ctx, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8]);
 /* Whole job for partition `pid` of the context's slab: build (gnnpe_build_index_partition_device), write `path`

@@ -171,19 +171,46 @@ def test_pair_major_partition_images(oracle, e, p):
     eng.close()
 
 
-def test_pair_major_falls_back_with_hub_rows(oracle, test_graph):
-    """Test/data_graph.graph has a row of degree 168: the partition build collects the tuples and takes the tuple-array
-    path; same contract."""
+def test_pair_major_with_hub_rows(oracle, test_graph):
+    """Test/data_graph.graph has a row of degree 168: its pairs are cut into units of 64 row entries with a kept mask, and
+    sorted with the ordinary pairs.  Same contract: every path once, son = its index, lo = hi = its pde row."""
     from gnnpe_amd import binding
     g = test_graph
     eng = _engine(binding, g, g["sorted_nodes"], g["membership"], 1, 2)
     x, nx, vde = eng.vde()
     total = eng.count_paths(2)
+    assert eng.rows_held()[2] >= 1  # hub rows present
     ids, _, _ = eng.fill_paths(pde=False)
     p, nb, hdr = eng.build_index_partition_device(0)
     d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
     o = np.argsort(d["leaf_son"], kind="stable")
-    assert d["num_data"] == total and np.array_equal(d["leaf_pt"][o], vde[ids].reshape(total, 6))
+    assert d["num_data"] == total and np.array_equal(d["leaf_son"][o], np.arange(total))
+    assert np.array_equal(d["leaf_pt"][o], vde[ids].reshape(total, 6))
+    eng.close()
+
+
+@pytest.mark.parametrize("e,p", [(2, 3), (8, 2)])
+def test_pair_major_power_law_partitions(oracle, e, p):
+    """Power-law graph (hubs of several hundred entries: hub pairs spanning many units and many leaves), arbitrary order
+    and partition: per partition the leaf entries are exactly its paths."""
+    from gnnpe_amd import binding
+    g = synth.powerlaw_graph(3000, 20000, exponent=2.1, max_degree=700, n_labels=6, seed=3)
+    assert np.diff(g["offsets"].astype(np.int64)).max() > 200
+    rng = np.random.default_rng(e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    assert total == len(ref)
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert d["num_data"] == len(mine) and np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), 3 * e))
     eng.close()
 
 
