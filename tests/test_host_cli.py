@@ -127,3 +127,35 @@ def test_prep_tool_writes_the_layout_the_cli_expects(tmp_path):
         assert all(os.path.isdir(tmp_path / variant / "partitions" / f"partition-{i}") for i in range(3))
         sizes = np.bincount(part, minlength=3)
         assert sizes.min() >= 60  # balanced within reason
+
+
+def test_prep_partitioner_balance_and_cut():
+    """The partitioner as a partitioner (the reference calls METIS for this, gnnpe.py:66-69): on a planted-partition
+    graph with shuffled ids the refined partition is balanced and cuts far fewer edges than id blocks or plain BFS
+    regions -- close to the planted cut."""
+    from gnnpe_amd import prep
+    rng = np.random.default_rng(5)
+    n, p, k_in, k_out = 4000, 4, 12, 1
+    planted = rng.permutation(n) % p
+    eu, ev = [], []
+    for c in range(p):  # dense inside the communities, sparse between them
+        mem = np.flatnonzero(planted == c)
+        a = rng.choice(mem, size=len(mem) * k_in // 2)
+        b = rng.choice(mem, size=len(mem) * k_in // 2)
+        eu.append(a), ev.append(b)
+    eu.append(rng.integers(0, n, n * k_out // 2)), ev.append(rng.integers(0, n, n * k_out // 2))
+    eu, ev = np.concatenate(eu), np.concatenate(ev)
+    keep = eu != ev
+    lo, hi = np.minimum(eu, ev)[keep], np.maximum(eu, ev)[keep]
+    keys = np.unique(lo.astype(np.int64) * n + hi)
+    offs, nbrs = synth._csr_from_edges(n, keys // n, keys % n)
+    cut_planted = prep.edge_cut(offs, nbrs, planted)
+    cut_blocks = prep.edge_cut(offs, nbrs, synth.block_membership(n, p).astype(np.int64))
+    bfs = prep.bfs_partition(offs, nbrs, p)
+    cut_bfs = prep.edge_cut(offs, nbrs, bfs.astype(np.int64))
+    lp = prep.refine_lp(offs, nbrs, bfs, p)
+    cut_lp = prep.edge_cut(offs, nbrs, lp.astype(np.int64))
+    sizes = np.bincount(lp, minlength=p)
+    assert sizes.max() <= int(np.ceil(1.03 * n / p)) and sizes.min() >= 0.85 * n / p
+    assert cut_lp <= cut_bfs and cut_lp < 0.5 * cut_blocks
+    assert cut_lp <= 2.0 * cut_planted, (cut_planted, cut_lp, cut_bfs, cut_blocks)
