@@ -464,8 +464,8 @@ def main():
                                   next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
                                   tuple_array_build_ms=min(ib_tuple),
                                   first_call_ms=ib[0],
-                                  first_call_note="the first call allocates the image and the sort buffers (grow-only, ~25 GB of hipMalloc) "
-                                                  "and loads the kernels; later calls only enqueue kernels",
+                                  first_call_note="the first call allocates the grow-only buffers (the 22 GB image, pair records) and loads "
+                                                  "the kernels; later calls only enqueue kernels",
                                   reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
     # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps

@@ -1,12 +1,13 @@
 // gnnpe_fill_ranked.hip.h -- the enumeration (R2 count + emit, R5 embeddings; custom.h:52-92, 546-572) at l = 2.
 //
-// Layout idea: every adjacency row of degree <= 64 is stored a second time as 8+8e-byte records {id, id-position,
-// vde} SORTED BY RANK (k_rows_rank).  The neighbours c of b with rank[c] > rank[s] are then exactly the records after
-// s's own position: one contiguous suffix, no rank stream, nothing read and thrown away.  The output order inside a
-// pair is ascending id, so every (s, b) pair also carries G = the 64-bit set of id-positions with greater rank: a kept
-// record with id-position ip lands at slot popcount(G & ((1 << ip) - 1)); the pair's count is popcount(G), so the
-// count pass scans no candidates either.  The pair record also carries vde[b], so the emit kernel has no dependent
-// gather: start record -> pair records -> neighbour records -> stores.
+// Layout idea: every adjacency row of degree <= 64 is stored a second time as a ROW BLOCK on a 128-byte boundary:
+// header vde[b], then one record per neighbour {id | id-position, vde} (4+8e bytes; 8+8e for graphs beyond 2^26
+// vertices) in DESCENDING RANK order (k_rows_rank).  The neighbours c of b with rank[c] > rank[s] are then exactly the
+// block's first cnt records: every read of the emit kernel starts on a line boundary, no rank stream, nothing read and
+// thrown away but the tail of the last line.  The output order inside a pair is ascending id, so every (s, b) pair also
+// carries G = the 64-bit set of id-positions with greater rank: a kept record with id-position ip lands at slot
+// popcount(G & ((1 << ip) - 1)); the pair's count is popcount(G), so the count pass scans no candidates either.  The
+// emit kernel has no dependent gather: start record -> pair records -> row block (header + records) -> stores.
 //
 // Rows longer than 64 ("hub" rows; Test/data_graph.graph has one of degree 168) keep id order: their records are
 // {id, rank, vde}, their pair counts come from a per-row sort of the ranks (hipCUB segmented sort, hubs only) and the
