@@ -92,6 +92,7 @@ struct gnnpe_ctx {
     uint32_t n_rows = 0;        // rows held in storage order (owned rows; halo rows come after)
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
     gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, srec;
+    gnnpe::DevBuf nbr_label;  // label of every OWNED adjacency entry (what gen_vde sums over): built with the rows
     // rows longer than 64 entries ("hub" rows of the l=2 enumeration): ids and adjacency ranges; graph-only, rebuilt
     // whenever rows are loaded / appended / dropped
     gnnpe::DevBuf hub_rows, hub_beg, hub_end;

@@ -325,8 +325,13 @@ int gnnpe_load_csr(gnnpe_ctx *c, uint32_t n, const uint32_t *offs, const uint32_
     c->n_held = n;
     c->nbr_used = c->nbr_owned = m2;
     c->nbr_cap = c->nbrs.bytes / 4;
-    // reverse positions and the hub list are part of the graph structure (they depend on the graph only)
-    if ((rc = finish_rows(c, n, nullptr))) return rc;
+    // the neighbours' labels, reverse positions and the hub list are part of the graph structure
+    if ((rc = c->nbr_label.reserve((m2 + 1) * 4))) return rc;
+    if ((rc = finish_rows(c, n, nullptr))) return rc;  // validates the neighbour ids first
+    if (m2)
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(m2)), dim3(kBlock), 0, c->stream, m2, c->nbrs.as<uint32_t>(),
+                           c->labels.as<uint32_t>(), c->nbr_label.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
     c->have_graph = true;
     c->slab_begin = 0;  // a new graph starts with the whole order as its slab (no stale slab)
     c->slab_end = n;
@@ -378,7 +383,12 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
     c->n_held = n_rows;
     c->nbr_used = c->nbr_owned = used;
     c->nbr_cap = c->nbrs.bytes / 4;
-    if ((rc = finish_rows(c, n_rows, c->rows.as<uint32_t>()))) return rc;
+    if ((rc = c->nbr_label.reserve((used + 1) * 4))) return rc;
+    if ((rc = finish_rows(c, n_rows, c->rows.as<uint32_t>()))) return rc;  // validates the neighbour ids first
+    if (used)
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(used)), dim3(kBlock), 0, c->stream, used, c->nbrs.as<uint32_t>(),
+                           c->labels.as<uint32_t>(), c->nbr_label.as<uint32_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
     c->have_graph = true;
     c->slab_begin = 0;
     c->slab_end = n;
@@ -508,7 +518,7 @@ static int run_vde(gnnpe_ctx *c)
         const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
         dim3 grid((nr + 255) / 256), block(256);
 #define GNNPE_VDE_ARGS                                                                                   \
-    nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),           \
+    nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbr_label.as<uint32_t>(),      \
         c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>()
         switch (e) {
         case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;

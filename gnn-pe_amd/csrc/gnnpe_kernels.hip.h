@@ -67,9 +67,10 @@ __global__ void k_slab_degrees(uint32_t len, uint32_t slab_begin, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// R4 gen_vde (custom.h:513-544).  One thread per held row; the block's adjacency range is contiguous
-// in the neighbour buffer, so it is streamed once with coalesced loads, turned into neighbour LABELS
-// in LDS, and every thread then adds its own row's features in ascending-neighbour order -- the same
+// R4 gen_vde (custom.h:513-544).  One thread per owned row; the block's adjacency range is contiguous, so the
+// neighbours' LABELS -- stored next to the neighbour ids when the rows are loaded: graph structure, labels come with
+// the graph file -- are streamed once with coalesced loads into LDS, and every thread then adds its own row's
+// features in ascending-neighbour order -- the same
 // operation order as the reference loop (:527-534), hence bit-identical fp64 results.
 // The label table (|Sigma| x e doubles) also sits in LDS when it fits.
 // ------------------------------------------------------------------------------------------------
@@ -80,7 +81,7 @@ template <int E>
 __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__restrict__ rows,
                                              const uint32_t *__restrict__ adj_start,
                                              const uint32_t *__restrict__ adj_deg,
-                                             const uint32_t *__restrict__ nbrs,
+                                             const uint32_t *__restrict__ nbr_label,
                                              const uint32_t *__restrict__ labels,
                                              const double *__restrict__ xtab, uint32_t n_labels, uint32_t e_rt,
                                              double *__restrict__ nx, double *__restrict__ vde)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
     __syncthreads();
     for (uint32_t c0 = q_begin; c0 < q_end; c0 += kVdeStage) {
         const uint32_t c1 = min(c0 + (uint32_t)kVdeStage, q_end);
-        for (uint32_t q = c0 + threadIdx.x; q < c1; q += blockDim.x) s_lab[q - c0] = labels[nbrs[q]];
+        for (uint32_t q = c0 + threadIdx.x; q < c1; q += blockDim.x) s_lab[q - c0] = nbr_label[q];
         __syncthreads();
         const uint32_t lo = max(my_b, c0), hi = min(my_e, c1);
         for (uint32_t q = lo; q < hi; q++) {
