@@ -37,6 +37,7 @@ from oracle import ref_main_path  # noqa: E402
 OUT = os.path.join(HERE, "large_index")
 QUERY = os.path.join(OUT, "query.graph")
 N, M = 70_000, 700_000
+P = int(os.environ.get("GNNPE_LARGE_INDEX_P", "1"))  # partitions; p = 4 is a size the reference's own heap survives
 
 
 def make_query(g, seed=7):
@@ -68,14 +69,14 @@ def make_query(g, seed=7):
 def dataset(wd, g):
     gp = os.path.join(wd, "g.graph")
     synth.write_graph_file(gp, g)
-    synth.make_dataset_dir(wd, 1)
-    synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), np.zeros(g["n"], np.uint32))
+    synth.make_dataset_dir(wd, P)
+    synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), synth.block_membership(g["n"], P))
     return gp
 
 
 def online(wd, gp):
     t0 = time.time()
-    r = subprocess.run([ref_main_path(), "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", "1"], capture_output=True, text=True)
+    r = subprocess.run([ref_main_path(), "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", str(P)], capture_output=True, text=True)
     m = re.search(r"Answer Number: (\d+)", r.stdout)
     return dict(returncode=r.returncode, answer_number=int(m.group(1)) if m else None, seconds=round(time.time() - t0, 1),
                 stdout_tail=r.stdout[-300:], stderr_tail=r.stderr[-300:])
@@ -91,33 +92,35 @@ def main():
         if part == "A":
             make_query(g)
             t0 = time.time()
-            subprocess.check_call([ref_main_path(), "-f", wd + "/", "-d", gp, "-m", "offline", "-p", "1"], stdout=subprocess.DEVNULL)
+            subprocess.check_call([ref_main_path(), "-f", wd + "/", "-d", gp, "-m", "offline", "-p", str(P)], stdout=subprocess.DEVNULL)
             off_s = round(time.time() - t0, 1)
             res = online(wd, gp)
-            hdr = np.fromfile(idx, np.int32, 6)
+            hdr = np.fromfile(idx, np.int32, 6)  # partition 0
             res.update(offline_seconds=off_s, paths=int(open(os.path.join(wd, "gnn-pe", "all_paths.txt")).readline()),
                        index_bytes=os.path.getsize(idx), node_blocks=int(hdr[1]), what="reference offline + its own insert-built R*-tree")
-            json.dump(res, open(os.path.join(OUT, "reference.json"), "w"), indent=1)
+            res["partitions"] = P
+            json.dump(res, open(os.path.join(OUT, "reference.json" if P == 1 else f"reference_p{P}.json"), "w"), indent=1)
         else:
             cli = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
             t0 = time.time()
-            subprocess.check_call([cli, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", "1", "--index"], stdout=subprocess.DEVNULL)
+            subprocess.check_call([cli, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", str(P), "--index"], stdout=subprocess.DEVNULL)
             off_s = round(time.time() - t0, 2)
             res = online(wd, gp)
             hdr = np.fromfile(idx, np.int32, 6)
             res.update(offline_seconds=off_s, index_bytes=os.path.getsize(idx), node_blocks=int(hdr[1]),
                        what="gnnpe_main -m offline --index (bulk-loaded index.dat), consumed by the untouched reference online binary")
-            ref = json.load(open(os.path.join(OUT, "reference.json")))
+            ref = json.load(open(os.path.join(OUT, "reference.json" if P == 1 else f"reference_p{P}.json")))
+            res["partitions"] = P
             res["reference_answer_number"] = ref["answer_number"]  # None: the reference's own tree overflows its heap
             # second opinion where the reference has none: this engine's own online side (filter + refinement on the GPU,
             # the reference's semantics; frozen round-1 code)
-            r2 = subprocess.run([cli, "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", "1"], capture_output=True, text=True)
+            r2 = subprocess.run([cli, "-f", wd + "/", "-d", gp, "-q", QUERY, "-m", "online", "-p", str(P)], capture_output=True, text=True)
             m2 = re.search(r"Answer Number: (\d+)", r2.stdout)
             res["gnnpe_main_online_answer_number"] = int(m2.group(1)) if m2 else None
             res["matches_reference"] = (res["returncode"] == 0 and res["answer_number"] is not None and
                                         res["answer_number"] == (ref["answer_number"] if ref["answer_number"] is not None
                                                                  else res["gnnpe_main_online_answer_number"]))
-            json.dump(res, open(os.path.join(os.environ.get("GNNPE_LARGE_INDEX_OUT", OUT), "ours.json"), "w"), indent=1)
+            json.dump(res, open(os.path.join(os.environ.get("GNNPE_LARGE_INDEX_OUT", OUT), "ours.json" if P == 1 else f"ours_p{P}.json"), "w"), indent=1)
         print(json.dumps(res))
 
 
