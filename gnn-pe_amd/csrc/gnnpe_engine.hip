@@ -959,8 +959,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     } while (0)
 #define GNNPE_L(EE)                                                                                                     \
     do {                                                                                                                \
-        if (packed) GNNPE_LK((k_fill_ranked<EE, true, FillBatch<EE>::rows>));                                           \
-        else GNNPE_LK((k_fill_ranked<EE, false, FillBatch<EE>::rows>));                                                 \
+        if (packed) GNNPE_LK((k_fill_ranked<EE, true, kFillRows>));                                                     \
+        else GNNPE_LK((k_fill_ranked<EE, false, kFillRows>));                                                           \
     } while (0)
         // pde_label is gathered from the emitted ids; without an id output of the caller's they go to scratch
         if (d_pdl && !d_vids) {

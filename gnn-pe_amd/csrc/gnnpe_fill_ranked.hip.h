@@ -212,7 +212,10 @@ __global__ __launch_bounds__(256) void k_hub_pairs(uint32_t n_hub, const uint32_
 // Measured (config 3, profiles/r02*): the launch moves what the fabric can move for this read/write mix (20.4 GB at
 // 5.0 TB/s before the aligned blocks); waves per SIMD beyond 5 change nothing, spilling to reach 8 costs 6-25 %.
 // ------------------------------------------------------------------------------------------------------------------
-template <int E> struct FillBatch { static constexpr int rows = E <= 2 ? 128 : 64; };
+// rows staged per wave between flushes.  Same-process A/B at config 3 (scripts/fill_ab.py: same records, same output
+// buffers): 64 rows 3.440 ms, 128 rows 3.466, 192 rows 3.462; forcing 8 waves per SIMD (64 VGPRs, spills) 3.598; plain
+// instead of non-temporal pde stores 3.748; grids of 2x / 4x / 16x the resident workgroups 3.458 / 3.451 / 3.440.
+constexpr int kFillRows = 64;
 
 struct __attribute__((packed, aligned(4))) IdRow {
     uint32_t s, b, c;
