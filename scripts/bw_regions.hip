@@ -19,7 +19,7 @@ __global__ void k_read(const f4 *src, size_t n, float *sink)
 int main(int argc, char **argv)
 {
     const int nb = argc > 1 ? atoi(argv[1]) : 16;
-    const size_t bytes = (size_t)9600 << 20, n = bytes / 16;
+    const size_t bytes = (size_t)(argc > 2 ? atoi(argv[2]) : 9600) << 20, n = bytes / 16;  // MiB per buffer
     std::vector<f4 *> bufs;
     float *sink;
     hipMalloc(&sink, 4);
@@ -36,7 +36,7 @@ int main(int argc, char **argv)
         printf("%s GB/s per buffer:", pass ? "read " : "write");
         for (size_t k = 0; k < bufs.size(); k++) {
             float best = 1e9f;
-            for (int rep = 0; rep < 3; rep++) {
+            for (int rep = 0; rep < 5; rep++) {
                 hipEventRecord(e0, 0);
                 if (pass) hipLaunchKernelGGL(k_read, dim3(8192), dim3(256), 0, 0, bufs[k], n, sink);
                 else hipLaunchKernelGGL(k_write, dim3(8192), dim3(256), 0, 0, bufs[k], n);
