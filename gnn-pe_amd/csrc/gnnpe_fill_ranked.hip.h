@@ -106,8 +106,18 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             rp = revpos[st + lane];
         }
         if (lane < (unsigned)E) reinterpret_cast<double *>(base)[lane] = vinfo[(uint64_t)b * S + lane];  // header
-        uint64_t G = 0;
-        for (uint32_t i = 0; i < d; i++) G |= (uint64_t)(rl32(r, (int)i) > r ? 1u : 0u) << i;
+        // G of lane i = the lanes ranked after u_i: one wave-wide compare against u_i's rank, handed to lane i (idle
+        // lanes hold rank 0 and never rank after anything).  The kernel is bound by its random traffic, not by this loop
+        // (scripts/count_ab.py: the gathers and the pair scatter are 0.3 of its 0.75-0.85 ms; 2 or 4 rows in flight per
+        // wave change nothing).
+        const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        uint32_t Glo = 0, Ghi = 0;
+        for (uint32_t i = 0; i < du; i++) {
+            const uint64_t m = __ballot(r > rl32(r, (int)i));
+            Glo = writelane32((uint32_t)m, i, Glo);
+            if (du > 32) Ghi = writelane32((uint32_t)(m >> 32), i, Ghi);
+        }
+        const uint64_t G = ((uint64_t)Ghi << 32) | Glo;
         if (lane < d) {
             const uint32_t cnt = (uint32_t)__popcll(G);
             Rec rec;

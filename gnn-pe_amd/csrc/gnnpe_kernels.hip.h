@@ -193,6 +193,13 @@ struct FillParams {
 constexpr uint64_t kNoOff = ~0ull;
 
 __device__ __forceinline__ uint32_t rl32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// v_writelane_b32: `old` with lane `l` (wave-uniform) replaced by the wave-uniform `v`.  This clang has no builtin for it;
+// the LLVM intrinsic is bound by name.
+extern "C" __device__ int gnnpe_llvm_writelane(int v, int l, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t writelane32(uint32_t v, uint32_t l, uint32_t old)
+{
+    return (uint32_t)gnnpe_llvm_writelane((int)v, (int)l, (int)old);
+}
 
 // revpos[q] for adjacency entry q = (b -> u): position of b inside N(u), or kNoEdge when row u is not
 // an OWNED row of this device (only owned rows start paths here).  Depends on the graph only -- not on
