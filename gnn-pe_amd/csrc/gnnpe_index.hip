@@ -609,43 +609,43 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int D = 3 * E;
-    constexpr int kWin = kBlockLen / 4 + 4;
     constexpr int kEnt = 4 * D + 1;
+    // LDS per wave decides the waves per SIMD here (24 VGPRs): the window holds the header and the entries only (the
+    // block's zero tail is produced by the stores), the strip one pair per possible entry plus the one that continues
+    // into the next leaf.  E = 2: 4.9 KB per wave = 8 waves per SIMD (6 with a full 4 KiB window and 64-pair strips:
+    // 7.1 -> 6.x ms, scripts/index_ab.py).
+    constexpr int kCap = (kBlockLen - 5) / (16 * D + 4) - 2 < 64 ? (kBlockLen - 5) / (16 * D + 4) - 2 : 64;  // = F (build_image)
+    constexpr int kWin = (2 + kCap * kEnt + 4 + 3) / 4 * 4;  // dwords, a multiple of 4; the last 4 feed the shifted reads
+    constexpr int kStrip = kCap + 1 < 64 ? (kCap + 1 + 7) / 8 * 8 : 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
-    __shared__ uint32_t s_pp[kLeafWaves][64], s_s[kLeafWaves][64], s_blk[kLeafWaves][64], s_first[kLeafWaves][64];
-    __shared__ uint64_t s_G[kLeafWaves][64], s_son[kLeafWaves][64];
+    __shared__ uint32_t s_s[kLeafWaves][kStrip], s_blk[kLeafWaves][kStrip], s_first[kLeafWaves][kStrip];
+    __shared__ uint64_t s_G[kLeafWaves][kStrip], s_son[kLeafWaves][kStrip];
+    __shared__ uint8_t s_pp[kLeafWaves][kStrip];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *w = s_win[wv];
-    const uint64_t stride = (uint64_t)gridDim.x * kLeafWaves;
     const uint64_t pbase = pref[r0];
-    // Software pipeline over the wave's leaves j, j + stride, ...: the strip of the NEXT leaf (its pairs' first points and
-    // records) is loaded while the current leaf is assembled, and `first` is read one leaf further ahead through the
-    // scalar cache (j is wave-uniform), so a leaf costs one dependent memory round trip (its records) instead of three.
-    uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
-    auto first_of = [&](uint64_t jj) -> uint64_t { return jj < n_leaves ? (uint64_t)first[jj] : r1; };
-    auto load_strip = [&](uint64_t f, uint64_t *rel, PairX *x) {
-        const uint64_t kk = f + lane;
-        *rel = ~0ull;
-        x->s = x->b = x->block = x->cnt = 0;
-        x->G = x->son0 = 0;
-        if (kk < r1) {
-            *rel = pref[kk] - pbase;
-            *x = px[kk];
-        }
-    };
-    uint64_t f_next = first_of(j + stride), rel_cur;
-    PairX x_cur;
-    load_strip(first_of(j), &rel_cur, &x_cur);
-    for (; j < n_leaves; j += stride) {
+    // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
+    // sorted pairs, and the block scheduler balances the tail.  Same-process A/B at config 3 (scripts/index_ab.py):
+    // 2048 resident-sized blocks walking strided leaves with the next leaf's strip prefetched 8.34 ms, 24576 blocks 7.42,
+    // one leaf per wave 7.11.
+    const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
+    if (j < n_leaves) {
         const uint64_t g0 = j * F;
         const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - g0);
-        const uint64_t f_next2 = first_of(j + 2 * stride);
-        uint64_t rel_nxt;
-        PairX x_nxt;
-        load_strip(f_next, &rel_nxt, &x_nxt);
+        // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
+        const uint64_t f_end = j + 1 < n_leaves ? (uint64_t)first[j + 1] : r1;
+        const uint64_t kk = (uint64_t)first[j] + lane;
+        uint64_t rel_cur = ~0ull;
+        PairX x_cur;
+        x_cur.s = x_cur.b = x_cur.block = x_cur.cnt = 0;
+        x_cur.G = x_cur.son0 = 0;
+        if (kk < r1 && kk <= f_end) {
+            rel_cur = pref[kk] - pbase;
+            x_cur = px[kk];
+        }
         // the wave's strip of pairs
-        uint32_t pp = 0xFFFFFFFFu;
-        if (rel_cur < g0 + ne) {
+        uint32_t pp = 0xFFu;
+        if (rel_cur < g0 + ne && lane < kStrip) {
             pp = (uint32_t)(rel_cur >= g0 ? rel_cur - g0 : 0u);  // first entry of the pair inside this leaf
             s_s[wv][lane] = x_cur.s;
             s_blk[wv][lane] = x_cur.block;
@@ -655,24 +655,21 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
             s_son[wv][lane] = ((x_cur.son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
         }
-        s_pp[wv][lane] = pp;
-        rel_cur = rel_nxt;
-        x_cur = x_nxt;
-        f_next = f_next2;
+        if (lane < kStrip) s_pp[wv][lane] = (uint8_t)pp;
         if (lane == 0) {
             w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
             w[1] = ne;
         }
-        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero tail
+        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero the window's tail
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if ((uint32_t)lane < ne) {
-            uint32_t a = 0, bnd = 64;  // largest a with s_pp[a] <= lane (unused slots hold 0xFFFFFFFF)
+            uint32_t a = 0, bnd = kStrip;  // largest a with s_pp[a] <= lane (unused slots hold 0xFF)
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const uint32_t mid = (a + bnd) >> 1;
-                if (s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
+                if ((uint32_t)s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
             }
             const uint64_t sw = s_son[wv][a];
             const uint32_t r = (uint32_t)lane - s_pp[wv][a] + (uint32_t)(sw & 0xFFu);  // point inside the unit
@@ -723,37 +720,48 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < D) {  // node MBR for the parent level: lane k scans dimension k of the assembled entries
+        // node MBR for the parent level: kMbrParts lanes per dimension, each scanning every kMbrParts-th assembled entry,
+        // then a butterfly over the dimension's lanes (one lane per dimension walking all 38 entries was 0.6 of the
+        // kernel's time)
+        constexpr int kMbrParts = D * 16 <= 64 ? 16 : D * 8 <= 64 ? 8 : D * 4 <= 64 ? 4 : 2;
+        static_assert(D * kMbrParts <= 64, "embedding width too large for the leaf kernel's MBR lanes");
+        if (lane < D * kMbrParts) {
+            const int k = lane / kMbrParts, part = lane % kMbrParts;
             double lo = 1e300, hi = -1e300;
-#pragma unroll 8
-            for (uint32_t i = 0; i < ne; i++) {
-                const uint32_t *q = w + 2 + i * kEnt + 4 * lane;
+            for (uint32_t i = (uint32_t)part; i < ne; i += kMbrParts) {
+                const uint32_t *q = w + 2 + i * kEnt + 4 * k;
                 const double x = __longlong_as_double((long long)(((uint64_t)q[1] << 32) | q[0]));
                 lo = fmin(lo, x);
                 hi = fmax(hi, x);
             }
-            node_mbr[(j * D + lane) * 2] = lo;
-            node_mbr[(j * D + lane) * 2 + 1] = hi;
+#pragma unroll
+            for (int m = 1; m < kMbrParts; m <<= 1) {
+                lo = fmin(lo, __shfl_xor(lo, m));
+                hi = fmax(hi, __shfl_xor(hi, m));
+            }
+            if (part == 0) {
+                node_mbr[(j * D + k) * 2] = lo;
+                node_mbr[(j * D + k) * 2 + 1] = hi;
+            }
         }
         uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
 #pragma unroll
         for (int rr = 0; rr < kBlockLen / 16 / 64; rr++) {
             const int c = lane + 64 * rr;
-            const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
-            const uint32_t nx = w[4 * c + 4];
-            uint4 o;
-            o.x = (lo4.x >> 24) | (lo4.y << 8);
-            o.y = (lo4.y >> 24) | (lo4.z << 8);
-            o.z = (lo4.z >> 24) | (lo4.w << 8);
-            o.w = (lo4.w >> 24) | (nx << 8);
+            uint4 o = {0u, 0u, 0u, 0u};  // beyond the window: the block's zero tail
+            if (4 * c + 4 < kWin) {
+                const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
+                const uint32_t nx = w[4 * c + 4];
+                o.x = (lo4.x >> 24) | (lo4.y << 8);
+                o.y = (lo4.y >> 24) | (lo4.z << 8);
+                o.z = (lo4.z >> 24) | (lo4.w << 8);
+                o.w = (lo4.w >> 24) | (nx << 8);
+            }
             __builtin_nontemporal_store(o.x, &dst[c].x);
             __builtin_nontemporal_store(o.y, &dst[c].y);
             __builtin_nontemporal_store(o.z, &dst[c].z);
             __builtin_nontemporal_store(o.w, &dst[c].w);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -1290,7 +1298,8 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(nl)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
                        c->px_first.as<uint32_t>());
     const bool packed = c->n <= (1u << kPackedIdBits);
-    const uint32_t g = (uint32_t)std::min<uint64_t>(256 * 8, (nl + kLeafWaves - 1) / kLeafWaves);
+    GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
+    const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
 #define GNNPE_PXL(EE, PK)                                                                                               \
     hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, F, r0, r1,    \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairX>(), c->rrecs.as<char>(), \

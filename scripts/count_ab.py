@@ -1,4 +1,6 @@
-"""Same-process A/B of the count phase (k_rows_rank + scan + start records) at config 3: env knobs read per call.
+"""Same-process timing of the count phase (k_rows_rank + scan + start records) at config 3.  The cases are environment
+settings read per call; the knobs this was written for (rows in flight per wave, grid, knock-outs of the gathers / pair
+scatter / record stores) were temporary and are gone from the library -- DESIGN.md section 3 has the results.
     python scripts/count_ab.py "GNNPE_ROWS_ILP=1" "GNNPE_ROWS_ILP=2" "GNNPE_ROWS_ILP=4,GNNPE_ROWS_GRID=2048" """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
