@@ -27,6 +27,8 @@ torch.distributed supplies the collectives (backend "nccl" = RCCL on GPUs, "gloo
 tests); the engine behind `eng` is the C-ABI library (`binding.Engine`).  Tests substitute an
 engine with the same methods to exercise this exchange logic on CPU.
 """
+import threading
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -132,15 +134,83 @@ def owned_rows(g, sorted_nodes, bounds, r):
     return rows, roff, rnbr
 
 
+class ThreadRanks:
+    """In-process transport for R logical ranks that share ONE device: every rank is a thread of the same process with
+    its own engine context and HIP stream, and a collective is device-to-device copies between the ranks' tensors
+    around two thread barriers (the Python analogue of `gnnpe_main --gpus R --same-device --transport copy`).  It
+    exists for single-GPU boxes, where RCCL refuses duplicate devices and a GPU box admits only a few processes per
+    card: tests and debugging runs drive SlabBuild's exchange code with 8 ranks in one process.  Not a product path --
+    with one GPU per rank the collectives are RCCL (`torch.distributed`, backend "nccl")."""
+
+    def __init__(self, world, timeout=600.0):
+        self.world, self.timeout = int(world), float(timeout)
+        self._barrier = threading.Barrier(self.world)
+        self._slots = [None] * self.world
+
+    def comm(self, rank):
+        return _ThreadComm(self, int(rank))
+
+    def abort(self):
+        """Called by a rank that failed: the peers' barriers raise instead of waiting for it forever."""
+        self._barrier.abort()
+
+
+class _ThreadComm:
+    backend = "threads"
+
+    def __init__(self, ranks, rank):
+        self.g, self.rank, self.world = ranks, rank, ranks.world
+
+    def barrier(self):
+        self.g._barrier.wait(self.g.timeout)
+
+    @staticmethod
+    def _sync(t):
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+
+    def _publish(self, inp, splits):
+        self._sync(inp)  # the engine wrote `inp` on this thread's stream; peers read it on theirs
+        self.g._slots[self.rank] = (inp, np.concatenate([[0], np.cumsum(splits)]).astype(np.int64))
+        self.barrier()
+
+    def _retire(self, out):
+        self._sync(out)
+        self.barrier()  # nobody reuses its send buffer before every peer has read it
+        self.g._slots[self.rank] = None
+
+    def all_to_all_single(self, out, inp, out_splits, in_splits):
+        self._publish(inp, in_splits)
+        o = 0
+        for p in range(self.world):
+            src, offs = self.g._slots[p]
+            k = int(offs[self.rank + 1] - offs[self.rank])
+            assert k == int(out_splits[p]), (self.rank, p, k, out_splits[p])
+            if k:
+                out[o:o + k].copy_(src[int(offs[self.rank]):int(offs[self.rank]) + k])
+            o += k
+        self._retire(out)
+
+    def all_gather_into_tensor(self, out, inp):
+        self._publish(inp, [inp.numel()])
+        k = inp.numel()
+        for p in range(self.world):
+            out[p * k:(p + 1) * k].copy_(self.g._slots[p][0].reshape(-1))
+        self._retire(out)
+
+
 class SlabBuild:
     """Per-rank state of the distributed offline build.  `eng` already holds this rank's rows
     (load_rows), the replicated order (set_order), slab (set_slab) and label table."""
 
-    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None, l=2):
+    def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None, l=2,
+                 comm=None):
         """nbr_capacity: most neighbour entries this rank can RECEIVE (<= 2m); owned_entries: size
         of its own rows -- every peer may ask for all of them, so the send buffer holds
-        (world-1) x owned_entries.  l: edges per path (2, or 3 = one more halo hop)."""
+        (world-1) x owned_entries.  l: edges per path (2, or 3 = one more halo hop).  comm: a ThreadRanks.comm(rank)
+        when the ranks are threads of one process sharing a device; None = torch.distributed."""
         self.eng, self.n, self.e, self.l = eng, int(n), int(e), int(l)
+        self.comm = comm
         self.bounds = np.ascontiguousarray(bounds, np.uint32)
         self.rank, self.world, self.device, self.group = rank, world, device, group
         i32 = dict(dtype=torch.int32, device=device)
@@ -178,6 +248,8 @@ class SlabBuild:
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def _a2a(self, out, inp, out_splits, in_splits):
+        if self.comm is not None:
+            return self.comm.all_to_all_single(out, inp, out_splits, in_splits)
         if self._staged(out):
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
@@ -187,6 +259,8 @@ class SlabBuild:
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
 
     def _allgather(self, out_flat, inp_flat):
+        if self.comm is not None:
+            return self.comm.all_gather_into_tensor(out_flat, inp_flat)
         if self._staged(out_flat):
             o = torch.empty(out_flat.shape, dtype=out_flat.dtype)
             dist.all_gather_into_tensor(o, inp_flat.cpu(), group=self.group)
@@ -312,10 +386,13 @@ class SlabBuild:
         if self.world > 1:
             # union of the ranks' bitmaps: all-gather + OR (RCCL/NCCL reject BOR/BAND/BXOR, so no all-reduce)
             t = torch.from_numpy(np.ascontiguousarray(bm).view(np.int32)).reshape(-1)
-            if dist.get_backend(self.group) != "gloo":
+            if self.comm is None and dist.get_backend(self.group) != "gloo":
                 t = t.to(self.device)
             allb = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(allb.view(-1), t, group=self.group)
+            if self.comm is not None:
+                self.comm.all_gather_into_tensor(allb.view(-1), t)
+            else:
+                dist.all_gather_into_tensor(allb.view(-1), t, group=self.group)
             u = allb[0]
             for r in range(1, self.world):
                 u = torch.bitwise_or(u, allb[r])

@@ -7,12 +7,19 @@ its slab's rows, installs the halo through dist.SlabBuild (the production exchan
 (gnnpe_rows_checksum_device, first_id = its global id base, so the ranks' checksums ADD to the single-rank one) and
 the outcome of the size-independent properties.
 
-Ranks share device 0 over gloo when GNNPE_BENCH_SAME_DEVICE=1 (single-GPU box); otherwise one GPU per rank over RCCL.
+Three ways to run R ranks:
+  --threads R                      R ranks as threads of THIS process sharing device 0 (dist.ThreadRanks: device copies
+                                   around thread barriers).  What the single-GPU box uses: a GPU box admits only a few
+                                   processes per card, 8 rank processes are killed by its process guard.
+  torchrun + GNNPE_BENCH_SAME_DEVICE=1   rank processes sharing device 0, collectives staged over gloo (<= 4 ranks).
+  torchrun                         one GPU per rank over RCCL.
 """
 import argparse
 import json
 import os
 import sys
+import threading
+import traceback
 
 import numpy as np
 import torch
@@ -22,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import gnnpe_amd  # noqa: E402,F401
 from gnnpe_amd import binding, synth  # noqa: E402
-from gnnpe_amd.dist import SlabBuild, owned_rows, plan_slabs  # noqa: E402
+from gnnpe_amd.dist import SlabBuild, ThreadRanks, owned_rows, plan_slabs  # noqa: E402
 
 M64 = (1 << 64) - 1
 
@@ -75,7 +82,34 @@ def main():
     ap.add_argument("--sample", type=int, default=0, help="l=3: rows per rank to emit and checksum (0 = all)")
     ap.add_argument("--ranges", default=None, help="world 1: JSON list of [begin, end) global id ranges to checksum")
     ap.add_argument("--weights", type=str, default="1,0,0", help="w_paths,w_owned,w_held of dist.plan_slabs")
+    ap.add_argument("--threads", type=int, default=0, help="run this many ranks as threads of one process on device 0")
     args = ap.parse_args()
+
+    z = np.load(args.graph)
+    g = dict(n=len(z["labels"]), offsets=z["offsets"], nbrs=z["nbrs"], labels=z["labels"])
+
+    if args.threads > 1:
+        world = args.threads
+        tr = ThreadRanks(world, timeout=1800.0)
+        errors = []
+
+        def body(rank):
+            try:
+                run_rank(args, g, rank, world, 0, "threads", tr.comm(rank))
+            except BaseException:  # noqa: BLE001 -- any failure must release the peers' barriers
+                errors.append((rank, traceback.format_exc()))
+                tr.abort()
+
+        ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errors:
+            for r, tb in errors:
+                sys.stderr.write(f"rank {r}:\n{tb}\n")
+            sys.exit(1)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -83,19 +117,24 @@ def main():
     same = os.environ.get("GNNPE_BENCH_SAME_DEVICE") == "1"
     if same:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if same else "nccl"
+        torch.cuda.set_device(local_rank)
         if same:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    run_rank(args, g, rank, world, local_rank, backend, None)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
-    z = np.load(args.graph)
-    g = dict(n=len(z["labels"]), offsets=z["offsets"], nbrs=z["nbrs"], labels=z["labels"])
+
+def run_rank(args, g, rank, world, local_rank, backend, comm):
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     n, L, e = g["n"], args.l + 1, args.e
     sn = synth.degree_order(g["offsets"])
     mem = synth.block_membership(n, max(world, 1))
@@ -115,7 +154,8 @@ def main():
     eng.set_order(sn, mem, max(world, 1))
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(args.labels, e))
-    sb = SlabBuild(eng, n, e, bounds, rank, world, dev, nbr_capacity=cap, owned_entries=owned_entries, l=args.l)
+    sb = SlabBuild(eng, n, e, bounds, rank, world, dev, nbr_capacity=cap, owned_entries=owned_entries, l=args.l,
+                   comm=comm)
     total, base = sb.step()
     res = dict(rank=rank, world=world, backend=backend, total=int(total), base=int(base), global_total=int(sb.global_total),
                slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats), owned_entries=int(owned_entries))
@@ -159,9 +199,8 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
         json.dump(res, f)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
     eng.close()
 
 

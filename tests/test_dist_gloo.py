@@ -134,3 +134,55 @@ def test_plan_slabs_balances_and_covers():
     for k in (0, len(rows) // 2, len(rows) - 1):
         v = int(rows[k])
         assert np.array_equal(rnbr[int(roff[k]):int(roff[k + 1])], g["nbrs"][offs[v]:offs[v + 1]])
+
+
+@pytest.mark.parametrize("world,l", [(8, 2), (3, 3)])
+def test_slab_build_over_thread_ranks(oracle, world, l):
+    """dist.ThreadRanks: the ranks as threads of one process (what the single-GPU box uses for 8 slab ranks) run
+    the same exchange code and produce the single-rank output."""
+    import sys
+    import threading
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_engine import FakeEngine
+    from gnnpe_amd.dist import ThreadRanks
+    g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    bounds = plan_slabs(g["offsets"], sn, world)
+    tr = ThreadRanks(world, timeout=120.0)
+    L = l + 1
+    res, errors = [None] * world, []
+
+    def body(rank):
+        try:
+            rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
+            eng = FakeEngine(oracle, g["n"], g["labels"], rows, roff, rnbr, sn, 2)
+            eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
+            sb = SlabBuild(eng, g["n"], 2, bounds, rank, world, torch.device("cpu"), nbr_capacity=2 * g["m"],
+                           owned_entries=int(roff[-1]), l=l, comm=tr.comm(rank))
+            total, base = sb.step()
+            ids = torch.zeros((max(total, 1), L), dtype=torch.int32)
+            pde = torch.zeros((max(total, 1), 2 * L), dtype=torch.float64)
+            assert sb.step(ids, pde) == (total, base)
+            out = dict(total=total, base=base, global_total=sb.global_total, ids=ids[:total].numpy(), pde=pde[:total].numpy())
+            if l == 2:
+                eng.set_degrees(np.diff(g["offsets"].astype(np.int64)))
+                out["filter"] = sb.filter(_query_plan(g))
+            res[rank] = out
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((rank, repr(ex)))
+            tr.abort()
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    ref_ids = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, L)
+    x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    assert [p["base"] for p in res] == list(np.cumsum([0] + [p["total"] for p in res[:-1]]))
+    assert all(p["global_total"] == len(ref_ids) for p in res)
+    assert np.array_equal(np.concatenate([p["ids"] for p in res]).astype(np.uint32), ref_ids)
+    assert np.array_equal(np.concatenate([p["pde"] for p in res]), vde[ref_ids].reshape(len(ref_ids), 2 * L))
+    if l == 2:
+        assert all(np.array_equal(res[0]["filter"], p["filter"]) for p in res[1:])
