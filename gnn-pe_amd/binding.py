@@ -71,6 +71,14 @@ SIGNATURES = {
                                                C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_f64p),
                                                C.POINTER(_f64p)]),
     "gnnpe_host_write_paths_header": (C.c_int, [_vp, C.c_uint32, C.c_uint64]),
+    "gnnpe_host_load_partition_sidecar": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, _u32p, _u32p, _u64p, _u32p,
+                                                    _u32p, C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p),
+                                                    C.POINTER(_u32p), C.POINTER(_f64p), C.POINTER(_f64p)]),
+    "gnnpe_aux_index_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), C.POINTER(_vp),
+                                         C.POINTER(_vp), _u32p, _u32p]),
+    "gnnpe_build_aux_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
+    "gnnpe_host_load_aux_index": (C.c_int, [C.c_char_p, _u32p, _u32p, _u32p, C.POINTER(_f64p), C.POINTER(_u32p),
+                                            C.POINTER(_f64p)]),
     "gnnpe_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
     "gnnpe_pinned_free": (None, [_vp]),
     "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
@@ -230,6 +238,46 @@ def host_load_path_sidecar(paths_bin, vde_bin, labels, degrees):
     for name, ptr, w in (("vids", pv, Lv), ("labels", pl, Lv), ("degrees", pd, Lv), ("pde", pp, D), ("pde_label", px, D)):
         out[name] = np.ctypeslib.as_array(ptr, shape=(max(n * w, 1),)).copy()[: n * w].reshape(n, w)
         lib.gnnpe_host_free(ptr)
+    return out
+
+
+def host_load_partition_sidecar(paths_bin, vde_bin, partition_paths_txt, labels, degrees):
+    """SURVEY 8(f)3: the partition's copy of the paths (Partition::Partition, custom.h:205-216) from the sidecars and the
+    partition's partition_paths.txt: gen_pde's arrays for its rows only, plus the global path ids."""
+    lib = load()
+    lab, deg = _np(labels, np.uint32), _np(degrees, np.uint32)
+    P, L, e = C.c_uint64(), C.c_uint32(), C.c_uint32()
+    pi, pv, pl, pd = _u32p(), _u32p(), _u32p(), _u32p()
+    pp, px = _f64p(), _f64p()
+    rc = lib.gnnpe_host_load_partition_sidecar(paths_bin.encode(), vde_bin.encode(), partition_paths_txt.encode(), len(lab),
+                                               _ptr(lab, _u32p), _ptr(deg, _u32p), C.byref(P), C.byref(L), C.byref(e),
+                                               C.byref(pi), C.byref(pv), C.byref(pl), C.byref(pd), C.byref(pp), C.byref(px))
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    n, Lv, D = P.value, L.value, L.value * e.value
+    out = {}
+    for name, ptr, w in (("path_ids", pi, 1), ("vids", pv, Lv), ("labels", pl, Lv), ("degrees", pd, Lv), ("pde", pp, D),
+                         ("pde_label", px, D)):
+        out[name] = np.ctypeslib.as_array(ptr, shape=(max(n * w, 1),)).copy()[: n * w].reshape(n, w)
+        lib.gnnpe_host_free(ptr)
+    out["path_ids"] = out["path_ids"].reshape(-1)
+    return out
+
+
+def host_load_aux_index(path):
+    """SURVEY 8(f)3: aux_index.bin -> what Partition::build_auxiliary_index (custom.h:268-364) computes, by node block id."""
+    lib = load()
+    N, L, D = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    pk, pd, pm = _f64p(), _u32p(), _f64p()
+    rc = lib.gnnpe_host_load_aux_index(path.encode(), C.byref(N), C.byref(L), C.byref(D), C.byref(pk), C.byref(pd), C.byref(pm))
+    if rc:
+        raise GnnpeError(lib.gnnpe_last_error().decode())
+    n = N.value
+    out = dict(L=L.value, D=D.value)
+    for name, ptr, w in (("key", pk, 1), ("degrees", pd, L.value), ("label_mbr", pm, 2 * D.value)):
+        out[name] = np.ctypeslib.as_array(ptr, shape=(max(n * w, 1),)).copy()[: n * w].reshape(n, w)
+        lib.gnnpe_host_free(ptr)
+    out["key"] = out["key"].reshape(-1)
     return out
 
 
@@ -471,6 +519,21 @@ class Engine:
 
     def build_index(self, pid, path):
         self._ck(self.lib.gnnpe_build_index(self.ctx, int(pid), path.encode()))
+
+    def aux_index_device(self, dev_image, nbytes, cnt, L, dev_tuples):
+        """Partition::build_auxiliary_index (custom.h:268-364) over an index.dat image in device memory; dev_tuples =
+        the partition's paths [cnt x L] in partition order.  Returns host copies: key[N], degrees[N x L], label_mbr[N x 2D]."""
+        k, d, m = _vp(), _vp(), _vp()
+        N, D = C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.gnnpe_aux_index_device(self.ctx, _dev(dev_image), int(nbytes), int(cnt), int(L), _dev(dev_tuples),
+                                                 C.byref(k), C.byref(d), C.byref(m), C.byref(N), C.byref(D)))
+        n, dim = N.value, D.value
+        return dict(key=self.copy_to_host(k.value, n * 8).view(np.float64),
+                    degrees=self.copy_to_host(d.value, n * L * 4).view(np.uint32).reshape(n, L),
+                    label_mbr=self.copy_to_host(m.value, n * 2 * dim * 8).view(np.float64).reshape(n, 2 * dim), L=int(L), D=dim)
+
+    def build_aux_index(self, pid, path):
+        self._ck(self.lib.gnnpe_build_aux_index(self.ctx, int(pid), path.encode()))
 
     def copy_to_host(self, dev_ptr, nbytes):
         out = np.zeros(nbytes, np.uint8)

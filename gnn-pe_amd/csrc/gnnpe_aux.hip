@@ -1,0 +1,224 @@
+// gnnpe_aux.hip -- SURVEY 8(f) row 3, second half: the auxiliary index the online side keeps next to every R-tree
+// (Partition::build_auxiliary_index, GNN-PE/include/custom.h:268-364; struct Auxiliary_Index custom.h:152-165).
+//
+// Per node block of a partition's index.dat, indexed by block id:
+//   degrees[j]    = max over the paths below the node of the degree of their j-th vertex          (custom.h:276-291, 331-344)
+//   label_mbr     = min / max over those paths of pde_label, laid out lo0, hi0, lo1, hi1, ...     (custom.h:293-311, 346-360)
+//   key           = 0 - hi_0 - hi_1 - ... - hi_{D-1} of the node's entry in its PARENT, subtracted in that order
+//                   (custom.h:324-328); the root has no parent and keeps 0 (custom.h:159)
+// The reference computes it on every start of `-m online` by a recursive walk that re-reads every block from the file
+// (one `new RTNode` per node).  Here it is a bottom-up pass over the image on the device: one wave per node block, one
+// launch per tree level.  It reads the TREE from the image alone (level byte, entry count, entries: rtnode.cpp:1099-1117,
+// entry.cpp:127-136), so it serves the bulk-loaded images of gnnpe_index.hip and an index.dat the reference's own
+// insert loop wrote alike -- which is how the tests pin it: the same file through the compiled reference and through
+// this pass must give the same arrays, bit for bit.
+#include "gnnpe_common.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace gnnpe {
+
+constexpr uint32_t kAuxBlockLen = 4096;  // blk_file.cpp:38: the only block length the reference writes
+
+__device__ __forceinline__ int32_t ld_i32(const char *p)
+{
+    int32_t v;
+    __builtin_memcpy(&v, p, 4);  // entries start at byte 5 of a block: nothing in them is aligned
+    return v;
+}
+__device__ __forceinline__ double ld_f64(const char *p)
+{
+    double v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+
+// err[0] = first problem seen (0 none, 1 leaf son outside the partition's paths, 2 child block id outside the file,
+// 3 vertex id outside the graph, 4 entry count beyond the block), err[1] = the block it was seen in
+__device__ __forceinline__ void aux_fail(uint32_t *err, uint32_t code, uint32_t blk)
+{
+    if (atomicCAS(&err[0], 0u, code) == 0u) err[1] = blk;
+}
+
+// One wave per node block; blocks of another level return after reading their first bytes.
+//   level 0: entry -> son = index of a path of the partition -> its vertices -> their degrees and label features
+//   level k: entry -> son = child block (already done: the launches go bottom-up) -> the child's arrays; the entry's
+//            upper bounds give the child's key
+__global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ image, uint32_t n_nodes, int level, uint32_t D,
+                                                   uint32_t L, uint32_t e, uint64_t cnt, const uint32_t *__restrict__ tuples,
+                                                   uint32_t n, const uint32_t *__restrict__ degree,
+                                                   const double *__restrict__ x, double *__restrict__ key,
+                                                   uint32_t *__restrict__ adeg, double *__restrict__ ambr,
+                                                   uint32_t *__restrict__ err)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
+    for (uint64_t b = w0; b < n_nodes; b += nw) {
+        const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;  // block 0 of the file is the header (blk_file.cpp:110)
+        if ((int)blk[0] != level) continue;
+        const int32_t ne_raw = ld_i32(blk + 1);
+        if (ne_raw < 0 || (uint32_t)ne_raw > cap) {
+            if (lane == 0) aux_fail(err, 4u, (uint32_t)b);
+            continue;
+        }
+        const uint32_t ne = (uint32_t)ne_raw;
+        // per-lane partial results over the entries lane, lane + 64, ... (cap <= 64 whenever D >= 4)
+        for (uint32_t j = 0; j < L; j++) {
+            uint32_t dmax = 0;
+            for (uint32_t t = lane; t < ne; t += 64) {
+                const uint32_t son = (uint32_t)ld_i32(blk + 5 + (uint64_t)t * esz + 16 * D);
+                uint32_t d = 0;
+                if (level == 0) {
+                    if (son >= cnt) {
+                        aux_fail(err, 1u, (uint32_t)b);
+                        continue;
+                    }
+                    const uint32_t v = tuples[(uint64_t)son * L + j];
+                    if (v >= n) {
+                        aux_fail(err, 3u, (uint32_t)b);
+                        continue;
+                    }
+                    d = degree[v];
+                } else {
+                    if (son >= n_nodes) {
+                        aux_fail(err, 2u, (uint32_t)b);
+                        continue;
+                    }
+                    d = adeg[(uint64_t)son * L + j];
+                }
+                dmax = max(dmax, d);
+            }
+            dmax = wave_max_u32(dmax);
+            if (lane == 0) adeg[b * L + j] = dmax;
+        }
+        for (uint32_t k = 0; k < D; k++) {
+            double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+            for (uint32_t t = lane; t < ne; t += 64) {
+                const uint32_t son = (uint32_t)ld_i32(blk + 5 + (uint64_t)t * esz + 16 * D);
+                if (level == 0) {
+                    if (son >= cnt) continue;
+                    const uint32_t v = tuples[(uint64_t)son * L + k / e];
+                    if (v >= n) continue;
+                    const double pl = x[(uint64_t)v * e + k % e];  // pde_label (custom.h:561-567): x of the path's vertices
+                    lo = fmin(lo, pl);
+                    hi = fmax(hi, pl);
+                } else {
+                    if (son >= n_nodes) continue;
+                    lo = fmin(lo, ambr[((uint64_t)son * D + k) * 2]);
+                    hi = fmax(hi, ambr[((uint64_t)son * D + k) * 2 + 1]);
+                }
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) {
+                // a node without entries (the empty tree's root leaf) keeps the constructor's zeros (custom.h:159-164)
+                ambr[(b * D + k) * 2] = ne ? lo : 0.0;
+                ambr[(b * D + k) * 2 + 1] = ne ? hi : 0.0;
+            }
+        }
+        if (level > 0) {
+            for (uint32_t t = lane; t < ne; t += 64) {
+                const char *ent = blk + 5 + (uint64_t)t * esz;
+                const uint32_t son = (uint32_t)ld_i32(ent + 16 * D);
+                if (son >= n_nodes) continue;
+                double kv = 0.0;
+                for (uint32_t k = 0; k < D; k++) kv -= ld_f64(ent + (2 * k + 1) * 8);  // custom.h:324-328, same order
+                key[son] = kv;
+            }
+        }
+    }
+}
+
+}  // namespace gnnpe
+
+using namespace gnnpe;
+
+extern "C" {
+
+int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes, uint64_t cnt, uint32_t L,
+                           const void *dev_tuples, void **dev_key, void **dev_degrees, void **dev_label_mbr,
+                           uint32_t *n_nodes_out, uint32_t *dim_out)
+{
+    GNNPE_REQUIRE(c && dev_image && dev_key && dev_degrees && dev_label_mbr && n_nodes_out, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->have_graph && c->have_table && c->have_vde, GNNPE_ERR_ARG,
+                  "gnnpe_aux_index_device: need the graph, the label table and gnnpe_vde (label features x)");
+    GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
+                  "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
+    GNNPE_REQUIRE(L >= 1 && (cnt == 0 || dev_tuples), GNNPE_ERR_ARG, "null path tuples");
+    GNNPE_REQUIRE(nbytes >= 2 * (uint64_t)kAuxBlockLen && nbytes % kAuxBlockLen == 0, GNNPE_ERR_ARG,
+                  "index image of %llu bytes is not a whole number (>= 2) of %u-byte blocks", (unsigned long long)nbytes, kAuxBlockLen);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    // header block: blocklength, number of node blocks (blk_file.cpp:38-39), then dimension ... root (rtree.cpp:341-362)
+    char h[32];
+    GNNPE_HIP_TRY(hipMemcpyAsync(h, dev_image, 32, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    int32_t blen, nblk, dim, root;
+    memcpy(&blen, h, 4);
+    memcpy(&nblk, h + 4, 4);
+    memcpy(&dim, h + 8, 4);
+    memcpy(&root, h + 25, 4);
+    GNNPE_REQUIRE(blen == (int32_t)kAuxBlockLen, GNNPE_ERR_ARG, "index image: block length %d, expected %u", blen, kAuxBlockLen);
+    GNNPE_REQUIRE(nblk >= 1 && ((uint64_t)nblk + 1) * kAuxBlockLen <= nbytes, GNNPE_ERR_ARG,
+                  "index image: header counts %d node blocks, the image holds %llu", nblk,
+                  (unsigned long long)(nbytes / kAuxBlockLen - 1));
+    GNNPE_REQUIRE(dim == (int32_t)(L * c->e), GNNPE_ERR_ARG, "index image: dimension %d, paths of %u vertices x e = %u give %u", dim, L,
+                  c->e, L * c->e);
+    GNNPE_REQUIRE(root >= 0 && root < nblk, GNNPE_ERR_ARG, "index image: root block %d outside [0, %d)", root, nblk);
+    const uint32_t D = (uint32_t)dim, N = (uint32_t)nblk;
+    char root_level = 0;
+    GNNPE_HIP_TRY(hipMemcpyAsync(&root_level, (const char *)dev_image + ((uint64_t)root + 1) * kAuxBlockLen, 1,
+                                 hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    GNNPE_REQUIRE(root_level >= 0 && root_level < 32, GNNPE_ERR_ARG, "index image: root level %d", (int)root_level);
+
+    int rc;
+    if ((rc = c->aux_key.reserve(((size_t)N + 1) * 8)) || (rc = c->aux_deg.reserve(((size_t)N * L + 1) * 4)) ||
+        (rc = c->aux_mbr.reserve(((size_t)N * 2 * D + 1) * 8)))
+        return rc;
+    GNNPE_HIP_TRY(hipMemsetAsync(c->aux_key.p, 0, (size_t)N * 8, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->aux_deg.p, 0, (size_t)N * L * 4, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(c->aux_mbr.p, 0, (size_t)N * 2 * D * 8, c->stream));
+    uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2407 of the context's small buffer
+    GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 8, c->stream));
+    const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
+    for (int level = 0; level <= (int)root_level; level++)
+        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, level, D,
+                           L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, deg, c->x.as<double>(), c->aux_key.as<double>(),
+                           c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);
+    GNNPE_HIP_TRY(hipGetLastError());
+    uint32_t err[2] = {0, 0};
+    GNNPE_HIP_TRY(hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    static const char *const what[] = {"", "a leaf entry points outside the partition's paths", "a child block id lies outside the file",
+                                       "a path holds a vertex id outside the graph", "an entry count exceeds the block's capacity"};
+    GNNPE_REQUIRE(err[0] == 0, GNNPE_ERR_ARG, "index image, node block %u: %s", err[1], what[std::min(err[0], 4u)]);
+    *dev_key = c->aux_key.p;
+    *dev_degrees = c->aux_deg.p;
+    *dev_label_mbr = c->aux_mbr.p;
+    *n_nodes_out = N;
+    if (dim_out) *dim_out = D;
+    return GNNPE_OK;
+}
+
+}  // extern "C"

@@ -148,6 +148,11 @@ struct gnnpe_ctx {
     uint64_t rblock_units = 0;
     bool rblock_valid = false;
     uint32_t rblock_e = 0;
+    gnnpe::DevBuf aux_key, aux_deg, aux_mbr;  // auxiliary index of the last gnnpe_aux_index_device call (gnnpe_aux.hip)
+    // which partition's image index_image holds (set by gnnpe_build_index_partition_device, cleared by the other builds)
+    bool img_valid = false;
+    uint32_t img_pid = 0;
+    uint64_t img_gen = 0, img_bytes = 0;
     gnnpe::DevBuf pge_pg, pge_plg;  // GNN-PGE path groups (n x 4e doubles each)
     bool have_pge = false;
 

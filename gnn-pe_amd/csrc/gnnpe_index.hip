@@ -896,6 +896,7 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     const uint64_t n_nodes = plan_levels(cnt, F, level_n);
     GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
     const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
+    c->img_valid = false;  // the image buffer is about to hold something else
     if ((rc = c->index_image.reserve(image_bytes))) return rc;
     char *image = c->index_image.as<char>();
     GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
@@ -1386,13 +1387,24 @@ int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_im
                   "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
     GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
-    if (pair_major_ok(c)) return build_partition_image(c, pid, dev_image, nbytes, hdr_out);
-    // hub rows, l = 3 or the generic enumeration: the partition's tuples, then the tuple-array build
-    DevBuf mine;
-    uint64_t cnt = 0;
-    int rc = collect_partition_tuples(c, pid, mine, &cnt);
-    if (!rc) rc = gnnpe_build_index_device(c, cnt, c->l + 1, mine.p, dev_image, nbytes, hdr_out);
-    (void)hipStreamSynchronize(c->stream);
+    int rc;
+    c->img_valid = false;
+    if (pair_major_ok(c)) {
+        rc = build_partition_image(c, pid, dev_image, nbytes, hdr_out);
+    } else {
+        // l = 3 or the generic enumeration: the partition's tuples, then the tuple-array build
+        DevBuf mine;
+        uint64_t cnt = 0;
+        rc = collect_partition_tuples(c, pid, mine, &cnt);
+        if (!rc) rc = gnnpe_build_index_device(c, cnt, c->l + 1, mine.p, dev_image, nbytes, hdr_out);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (!rc && *dev_image == c->index_image.p) {  // remembered for gnnpe_build_aux_index
+        c->img_valid = true;
+        c->img_pid = pid;
+        c->img_gen = c->count_gen;
+        c->img_bytes = *nbytes;
+    }
     return rc;
 }
 
@@ -1405,6 +1417,50 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
     if (!rc) rc = write_device_image(c, (const char *)image, nbytes, path);
     (void)hipStreamSynchronize(c->stream);
     return rc;
+}
+
+// aux_index.bin: magic "GNNPEAUX", uint32 version = 1, uint32 L, uint32 D, uint32 reserved, uint64 n_nodes, then
+// key[n_nodes] (double), degrees[n_nodes x L] (uint32), label_mbr[n_nodes x 2D] (double), all indexed by node block id
+int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
+{
+    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
+                  "gnnpe_build_aux_index: need gnnpe_vde and gnnpe_count_paths first");
+    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    void *image = c->index_image.p;
+    uint64_t nbytes = c->img_bytes;
+    if (!(c->img_valid && c->img_pid == pid && c->img_gen == c->count_gen) &&
+        (rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr)))
+        return rc;
+    DevBuf mine;
+    uint64_t cnt = 0;
+    if ((rc = collect_partition_tuples(c, pid, mine, &cnt))) return rc;
+    void *d_key = nullptr, *d_deg = nullptr, *d_mbr = nullptr;
+    uint32_t N = 0, D = 0;
+    const uint32_t L = c->l + 1;
+    if ((rc = gnnpe_aux_index_device(c, image, nbytes, cnt, L, mine.p, &d_key, &d_deg, &d_mbr, &N, &D))) return rc;
+    std::vector<char> host((size_t)N * (8 + 4 * (size_t)L + 16 * (size_t)D));
+    char *hk = host.data(), *hd = hk + (size_t)N * 8, *hm = hd + (size_t)N * L * 4;
+    GNNPE_HIP_TRY(hipMemcpyAsync(hk, d_key, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(hd, d_deg, (size_t)N * L * 4, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(hm, d_mbr, (size_t)N * 2 * D * 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        set_error("cannot open %s for writing", path);
+        return GNNPE_ERR_IO;
+    }
+    const uint32_t h32[4] = {1u, L, D, 0u};
+    const uint64_t n64 = N;
+    const bool ok = fwrite("GNNPEAUX", 1, 8, f) == 8 && fwrite(h32, 4, 4, f) == 4 && fwrite(&n64, 8, 1, f) == 1 &&
+                    fwrite(host.data(), 1, host.size(), f) == host.size();
+    if (fclose(f) != 0 || !ok) {
+        set_error("%s: write failed", path);
+        return GNNPE_ERR_IO;
+    }
+    return GNNPE_OK;
 }
 
 }  // extern "C"

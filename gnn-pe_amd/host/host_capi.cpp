@@ -157,9 +157,11 @@ int gnnpe_host_write_paths_header(void *file, uint32_t L, uint64_t n_paths)
     return 0;
 }
 
-int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uint32_t n, const uint32_t *labels,
-                                 const uint32_t *degrees, uint64_t *n_paths, uint32_t *L_out, uint32_t *e_out, uint32_t **vids,
-                                 uint32_t **plabels, uint32_t **pdegrees, double **pde, double **pde_label)
+// gen_pde's arrays for all paths of paths.bin (sel == nullptr) or for the rows sel[0..n_sel) of it, in that order
+static int load_path_rows(const char *paths_bin, const char *vde_bin, uint32_t n, const uint32_t *labels,
+                          const uint32_t *degrees, const uint32_t *sel, uint64_t n_sel, uint64_t *n_paths, uint32_t *L_out,
+                          uint32_t *e_out, uint32_t **vids, uint32_t **plabels, uint32_t **pdegrees, double **pde,
+                          double **pde_label)
 {
     if (!paths_bin || !vde_bin || !labels || !degrees || !n_paths || !L_out || !e_out || !vids || !plabels || !pdegrees || !pde ||
         !pde_label) {
@@ -205,16 +207,23 @@ int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uin
         return GNNPE_ERR_ARG;
     }
     uint32_t version, L;
-    uint64_t P;
+    uint64_t P_file;
     memcpy(&version, map + 8, 4);
     memcpy(&L, map + 12, 4);
-    memcpy(&P, map + 16, 8);
-    if (version != 1 || L < 1 || L > 16 || (uint64_t)st.st_size != 24 + P * L * 4) {
+    memcpy(&P_file, map + 16, 8);
+    if (version != 1 || L < 1 || L > 16 || (uint64_t)st.st_size != 24 + P_file * L * 4) {
         munmap(map, (size_t)st.st_size);
-        gnnpe::set_error("%s: bad header (version %u, L %u, %llu paths, %lld bytes)", paths_bin, version, L, (unsigned long long)P,
-                         (long long)st.st_size);
+        gnnpe::set_error("%s: bad header (version %u, L %u, %llu paths, %lld bytes)", paths_bin, version, L,
+                         (unsigned long long)P_file, (long long)st.st_size);
         return GNNPE_ERR_ARG;
     }
+    const uint64_t P = sel ? n_sel : P_file;
+    for (uint64_t i = 0; sel && i < n_sel; i++)
+        if (sel[i] >= P_file) {
+            munmap(map, (size_t)st.st_size);
+            gnnpe::set_error("path id %u of the partition >= the %llu paths of %s", sel[i], (unsigned long long)P_file, paths_bin);
+            return GNNPE_ERR_ARG;
+        }
     const uint32_t *src = reinterpret_cast<const uint32_t *>(map + 24);
     const size_t D = (size_t)L * e;
     uint32_t *o_v = (uint32_t *)malloc((P * L + 1) * 4), *o_l = (uint32_t *)malloc((P * L + 1) * 4), *o_d = (uint32_t *)malloc((P * L + 1) * 4);
@@ -232,7 +241,7 @@ int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uin
         const uint64_t a = P * t / nt, b = P * (t + 1) / nt;
         for (uint64_t i = a; i < b; i++)
             for (uint32_t j = 0; j < L; j++) {
-                const uint32_t v = src[i * L + j];
+                const uint32_t v = src[(sel ? (uint64_t)sel[i] : i) * L + j];
                 if (v >= n) {
                     bad[t] = v;
                     return;
@@ -264,6 +273,131 @@ int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uin
     *pdegrees = o_d;
     *pde = o_p;
     *pde_label = o_x;
+    return 0;
+}
+
+int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uint32_t n, const uint32_t *labels,
+                                 const uint32_t *degrees, uint64_t *n_paths, uint32_t *L_out, uint32_t *e_out, uint32_t **vids,
+                                 uint32_t **plabels, uint32_t **pdegrees, double **pde, double **pde_label)
+{
+    return load_path_rows(paths_bin, vde_bin, n, labels, degrees, nullptr, 0, n_paths, L_out, e_out, vids, plabels, pdegrees, pde,
+                          pde_label);
+}
+
+// partition_paths.txt (main.cpp:98-108): "<count>\n", then one global path id per line
+static int read_partition_ids(const char *path, std::vector<uint32_t> &ids)
+{
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) {
+        if (fd >= 0) close(fd);
+        gnnpe::set_error("cannot open %s", path);
+        return GNNPE_ERR_IO;
+    }
+    const char *map = st.st_size ? (const char *)mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : (const char *)MAP_FAILED;
+    close(fd);
+    if (map == MAP_FAILED) {
+        gnnpe::set_error("%s: empty or unreadable", path);
+        return GNNPE_ERR_IO;
+    }
+    const char *q = map, *end = map + st.st_size;
+    auto next = [&](uint64_t &v) {
+        while (q < end && (*q == ' ' || *q == '\n' || *q == '\r' || *q == '\t')) q++;
+        if (q >= end || *q < '0' || *q > '9') return false;
+        v = 0;
+        while (q < end && *q >= '0' && *q <= '9') v = v * 10 + (uint64_t)(*q++ - '0');
+        return true;
+    };
+    uint64_t cnt = 0, v = 0;
+    bool ok = next(cnt);
+    if (ok) {
+        ids.resize(cnt);
+        for (uint64_t i = 0; i < cnt && ok; i++) {
+            ok = next(v) && v <= 0xFFFFFFFFull;
+            ids[i] = (uint32_t)v;
+        }
+    }
+    munmap((void *)map, (size_t)st.st_size);
+    if (!ok) {
+        gnnpe::set_error("%s: not a partition_paths.txt (count, then that many path ids)", path);
+        return GNNPE_ERR_ARG;
+    }
+    return 0;
+}
+
+int gnnpe_host_load_partition_sidecar(const char *paths_bin, const char *vde_bin, const char *partition_paths_txt, uint32_t n,
+                                      const uint32_t *labels, const uint32_t *degrees, uint64_t *n_paths, uint32_t *L_out,
+                                      uint32_t *e_out, uint32_t **path_ids, uint32_t **vids, uint32_t **plabels,
+                                      uint32_t **pdegrees, double **pde, double **pde_label)
+{
+    if (!partition_paths_txt || !path_ids) {
+        gnnpe::set_error("gnnpe_host_load_partition_sidecar: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    *path_ids = nullptr;
+    std::vector<uint32_t> ids;
+    int rc = read_partition_ids(partition_paths_txt, ids);
+    if (rc) return rc;
+    static const uint32_t none = 0;
+    rc = load_path_rows(paths_bin, vde_bin, n, labels, degrees, ids.empty() ? &none : ids.data(), ids.size(), n_paths, L_out, e_out,
+                        vids, plabels, pdegrees, pde, pde_label);
+    if (rc) return rc;
+    uint32_t *o = (uint32_t *)malloc((ids.size() + 1) * 4);
+    if (!o) {
+        free(*vids); free(*plabels); free(*pdegrees); free(*pde); free(*pde_label);
+        *vids = *plabels = *pdegrees = nullptr;
+        *pde = *pde_label = nullptr;
+        gnnpe::set_error("gnnpe_host_load_partition_sidecar: out of memory");
+        return GNNPE_ERR_ARG;
+    }
+    if (!ids.empty()) memcpy(o, ids.data(), ids.size() * 4);
+    *path_ids = o;
+    return 0;
+}
+
+// aux_index.bin (written by gnnpe_build_aux_index): what Partition::build_auxiliary_index (custom.h:268-364) computes
+int gnnpe_host_load_aux_index(const char *path, uint32_t *n_nodes, uint32_t *L_out, uint32_t *D_out, double **key,
+                              uint32_t **degrees, double **label_mbr)
+{
+    if (!path || !n_nodes || !L_out || !D_out || !key || !degrees || !label_mbr) {
+        gnnpe::set_error("gnnpe_host_load_aux_index: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    *key = *label_mbr = nullptr;
+    *degrees = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        gnnpe::set_error("cannot open %s", path);
+        return GNNPE_ERR_IO;
+    }
+    char magic[8];
+    uint32_t h[4] = {0, 0, 0, 0};
+    uint64_t N = 0;
+    struct stat st;
+    const bool hdr_ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "GNNPEAUX", 8) == 0 && fread(h, 4, 4, f) == 4 &&
+                        fread(&N, 8, 1, f) == 1 && fstat(fileno(f), &st) == 0;
+    const uint64_t L = h[1], D = h[2];
+    if (!hdr_ok || h[0] != 1 || L < 1 || L > 16 || D < 1 || D > 512 || N > 0x7FFFFFFFull ||
+        (uint64_t)st.st_size != 32 + N * (8 + 4 * L + 16 * D)) {
+        fclose(f);
+        gnnpe::set_error("%s: not an aux_index.bin (version %u, L %u, D %u, %llu nodes)", path, h[0], h[1], h[2], (unsigned long long)N);
+        return GNNPE_ERR_ARG;
+    }
+    double *k = (double *)malloc((N + 1) * 8), *m = (double *)malloc((N * 2 * D + 1) * 8);
+    uint32_t *d = (uint32_t *)malloc((N * L + 1) * 4);
+    const bool ok = k && m && d && fread(k, 8, N, f) == N && fread(d, 4, N * L, f) == N * L && fread(m, 8, N * 2 * D, f) == N * 2 * D;
+    fclose(f);
+    if (!ok) {
+        free(k); free(m); free(d);
+        gnnpe::set_error("%s: truncated or out of memory", path);
+        return GNNPE_ERR_IO;
+    }
+    *n_nodes = (uint32_t)N;
+    *L_out = (uint32_t)L;
+    *D_out = (uint32_t)D;
+    *key = k;
+    *degrees = d;
+    *label_mbr = m;
     return 0;
 }
 

@@ -442,6 +442,10 @@ int main(int argc, char **argv)
             const std::string ip = partitions_path + "partition-" + std::to_string(pid) + "/index.dat";
             check(gnnpe_build_index(ctx, pid, ip.c_str()), "build_index");
             warn_if_index_too_large_for_reference(ip);
+            if (o.sidecars) {  // the tree's auxiliary index (custom.h:268-364), which the online side rebuilds on every start
+                const std::string ap = partitions_path + "partition-" + std::to_string(pid) + "/aux_index.bin";
+                check(gnnpe_build_aux_index(ctx, pid, ap.c_str()), "build_aux_index");
+            }
         }
         t_index = secs(i0, Clock::now());
     }

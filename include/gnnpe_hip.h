@@ -281,6 +281,35 @@ int gnnpe_host_load_path_sidecar(const char *paths_bin, const char *vde_bin, uin
                                  uint32_t **path_labels, uint32_t **path_degrees, double **pde, double **pde_label);
 int gnnpe_host_write_paths_header(void *file, uint32_t L, uint64_t n_paths);
 
+/* The partition's copy of the paths -- the loop of Partition::Partition (custom.h:205-216: `paths.push_back(
+ * data_paths[path_id])` for every id of partition_paths.txt): the same arrays as gnnpe_host_load_path_sidecar, but
+ * only the rows of one partition, in the order of its partition_paths.txt (`path_ids`, also returned), i.e. indexed by
+ * what the leaf entries of that partition's index.dat carry in `son` (custom.h:243). */
+int gnnpe_host_load_partition_sidecar(const char *paths_bin, const char *vde_bin, const char *partition_paths_txt, uint32_t n,
+                                      const uint32_t *labels, const uint32_t *degrees, uint64_t *n_paths, uint32_t *L,
+                                      uint32_t *e, uint32_t **path_ids, uint32_t **vids, uint32_t **path_labels,
+                                      uint32_t **path_degrees, double **pde, double **pde_label);
+
+/* The auxiliary index of a partition's R-tree -- Partition::build_auxiliary_index (custom.h:268-364), which the
+ * reference recomputes on every start of `-m online` by walking the tree block by block: per node block id,
+ * degrees[L] (largest degree per path position below the node), label_mbr[2D] (lo0, hi0, lo1, hi1, ... of pde_label
+ * below the node) and key = 0 - hi_0 - ... - hi_{D-1} of the node's entry in its parent (0 for the root).
+ * gnnpe_aux_index_device: bottom-up pass over ANY index.dat image in device memory (bulk-loaded here or written by the
+ * reference's insert loop); dev_tuples = the partition's paths, [cnt x L] uint32 vertex ids in partition order (what
+ * the leaf entries' `son` index).  Needs the graph, the label table and gnnpe_vde in the context.  Outputs are
+ * context-owned device arrays (valid until the next call): key double[n_nodes], degrees uint32[n_nodes x L], label_mbr
+ * double[n_nodes x 2D]. */
+int gnnpe_aux_index_device(gnnpe_ctx *ctx, const void *dev_image, uint64_t nbytes, uint64_t cnt, uint32_t L,
+                           const void *dev_tuples, void **dev_key, void **dev_degrees, void **dev_label_mbr,
+                           uint32_t *n_nodes, uint32_t *dim);
+/* Partition pid of the current count: its index image (the one gnnpe_build_index just built, or a fresh build), its
+ * auxiliary index, written to `path` as aux_index.bin: magic "GNNPEAUX", uint32 version = 1, L, D, reserved, uint64
+ * n_nodes, then key, degrees, label_mbr as above.  `gnnpe_main --index --sidecars` leaves one next to every index.dat. */
+int gnnpe_build_aux_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
+/* Host-side reader of aux_index.bin: malloc'ed arrays (gnnpe_host_free).  No GPU. */
+int gnnpe_host_load_aux_index(const char *path, uint32_t *n_nodes, uint32_t *L, uint32_t *D, double **key, uint32_t **degrees,
+                              double **label_mbr);
+
 /* ---- introspection for bench / tests ------------------------------------------------------------ */
 /* Name of the kernel instantiation that dominates the fill (for matching rocprofv3 rows). */
 const char *gnnpe_fill_kernel_name(void);

@@ -274,6 +274,51 @@ class Oracle:
         out.update(leaf_son=son, leaf_pt=pt, height=h.value)
         return out
 
+    # Partition::build_auxiliary_index, custom.h:268-364 (numpy restatement; struct Auxiliary_Index
+    # custom.h:152-165).  Pinned by tests/golden/aux_index/ (dumps of the compiled reference's own constructor).
+    def aux_index(self, img, L, path_degrees, path_pde_label):
+        """img: bytes of an index.dat; path_degrees [n x L], path_pde_label [n x D]: the partition's paths in partition
+        order (what a leaf entry's `son` indexes, custom.h:243,274).  The same recursive walk from the root as the
+        reference: leaves reduce their paths (custom.h:270-313), inner nodes recurse into every child first, set the
+        child's key from the entry's upper bounds (custom.h:319-328) and reduce the children (custom.h:330-360).
+        Returns key [N], degrees [N x L] uint32, label_mbr [N x 2D] (lo0, hi0, lo1, hi1, ...), by node block id."""
+        img = bytes(img)
+        nblk = int(np.frombuffer(img, np.int32, 1, 4)[0])
+        dim = int(np.frombuffer(img, np.int32, 1, 8)[0])
+        root = int(np.frombuffer(img, np.int32, 1, 25)[0])
+        esz = 16 * dim + 4
+        key = np.zeros(nblk)                       # Auxiliary_Index(): key 0, degrees 0, label_mbr 0 (custom.h:159-164)
+        deg = np.zeros((nblk, L), np.uint32)
+        mbr = np.zeros((nblk, 2 * dim))
+        path_degrees = np.asarray(path_degrees)
+        path_pde_label = np.asarray(path_pde_label)
+
+        def walk(b):
+            base = (b + 1) * 4096                  # blk_file.cpp:110
+            level = int(np.frombuffer(img, np.int8, 1, base)[0])
+            ne = int(np.frombuffer(img, np.int32, 1, base + 1)[0])
+            if ne == 0:
+                return
+            ent = np.frombuffer(img, np.uint8, ne * esz, base + 5).reshape(ne, esz)
+            son = ent[:, 16 * dim:].copy().view(np.int32).reshape(-1)
+            if level == 0:
+                d, lo, hi = path_degrees[son], path_pde_label[son], path_pde_label[son]
+            else:
+                bounces = ent[:, :16 * dim].copy().view(np.float64).reshape(ne, 2 * dim)
+                for i, c in enumerate(son):
+                    walk(int(c))
+                    k = 0.0
+                    for j in range(dim):            # custom.h:324-328: subtracted one by one, in this order
+                        k -= float(bounces[i, 2 * j + 1])
+                    key[c] = k
+                d, lo, hi = deg[son], mbr[son, 0::2], mbr[son, 1::2]
+            deg[b] = d.max(axis=0)
+            mbr[b, 0::2] = lo.min(axis=0)
+            mbr[b, 1::2] = hi.max(axis=0)
+
+        walk(root)
+        return key, deg, mbr
+
     # GNN-PGE offline (GNN-PGE/src/main.cpp:91-195)
     def pge_groups(self, offs, nbrs, e, x, vde):
         n = len(offs) - 1

@@ -8,6 +8,11 @@
 //
 // usage: ref_online <dataset dir/> <data.graph> <query.graph> <p> dump   <out.bin>
 //        ref_online <dataset dir/> <data.graph> <query.graph> <p> refine <candidates.bin>
+//        ref_online <dataset dir/> <data.graph> <query.graph> <p> aux    <out.bin>
+//   aux out.bin    : what the reference's Partition constructor leaves behind (custom.h:205-266, 268-364), per partition:
+//                    uint32 n_paths, n_nodes, L, D; the partition's paths (vids[L] labels[L] degrees[L] uint32,
+//                    pde[D] pde_label[D] double, each); then per node block id: key (double), degrees[L] (uint32),
+//                    label_mbr[2D] (double).  Uses the index.dat found in the partition directory (or inserts one).
 //   out.bin        : uint32 n_query_vertices, n_query_paths, L, e; per query path: vids[L] labels[L] degrees[L]
 //                    (uint32), pde[eL] pde_label[eL] (double); then per query vertex: uint32 count, ids ascending
 //   candidates.bin : uint32 n_query_vertices; per query vertex: uint32 count, ids
@@ -77,6 +82,29 @@ int main(int argc, char **argv)
     for (ui i = 0; i < partition_num; i++) {
         Partition partition(data_paths, partitions_path + "partition-" + to_string(i) + "/");
         partitions.push_back(partition);
+    }
+    if (mode == "aux") {  // the Partition constructor's outputs, nothing else
+        FILE *fa = fopen(argv[6], "wb");
+        if (!fa) return 3;
+        for (ui pid = 0; pid < partition_num; pid++) {
+            const Partition &P = partitions[pid];
+            const uint32_t hdr[4] = {(uint32_t)P.paths.size(), (uint32_t)P.node_num, path_length, pde_dim};
+            fwrite(hdr, 4, 4, fa);
+            for (const auto &q : P.paths) {
+                fwrite(q.vids.data(), 4, path_length, fa);
+                fwrite(q.labels.data(), 4, path_length, fa);
+                fwrite(q.degrees.data(), 4, path_length, fa);
+                fwrite(q.pde.data(), 8, pde_dim, fa);
+                fwrite(q.pde_label.data(), 8, pde_dim, fa);
+            }
+            for (ui k = 0; k < P.node_num; k++) {
+                fwrite(&P.auxiliary_index[k].key, 8, 1, fa);
+                fwrite(P.auxiliary_index[k].degrees.data(), 4, path_length, fa);
+                fwrite(P.auxiliary_index[k].label_mbr.data(), 8, 2 * pde_dim, fa);
+            }
+        }
+        fclose(fa);
+        return 0;
     }
     // main.cpp:139-151
     vector<vector<ui>> all_paths;
