@@ -83,65 +83,68 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
             continue;
         }
         const uint32_t ne = (uint32_t)ne_raw;
-        // per-lane partial results over the entries lane, lane + 64, ... (cap <= 64 whenever D >= 4)
-        for (uint32_t j = 0; j < L; j++) {
-            uint32_t dmax = 0;
-            for (uint32_t t = lane; t < ne; t += 64) {
-                const uint32_t son = (uint32_t)ld_i32(blk + 5 + (uint64_t)t * esz + 16 * D);
-                uint32_t d = 0;
-                if (level == 0) {
-                    if (son >= cnt) {
-                        aux_fail(err, 1u, (uint32_t)b);
-                        continue;
-                    }
-                    const uint32_t v = tuples[(uint64_t)son * L + j];
-                    if (v >= n) {
-                        aux_fail(err, 3u, (uint32_t)b);
-                        continue;
-                    }
-                    d = degree[v];
-                } else {
-                    if (son >= n_nodes) {
-                        aux_fail(err, 2u, (uint32_t)b);
-                        continue;
-                    }
-                    d = adeg[(uint64_t)son * L + j];
-                }
-                dmax = max(dmax, d);
-            }
-            dmax = wave_max_u32(dmax);
-            if (lane == 0) adeg[b * L + j] = dmax;
-        }
-        for (uint32_t k = 0; k < D; k++) {
-            double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
-            for (uint32_t t = lane; t < ne; t += 64) {
-                const uint32_t son = (uint32_t)ld_i32(blk + 5 + (uint64_t)t * esz + 16 * D);
-                if (level == 0) {
-                    if (son >= cnt) continue;
-                    const uint32_t v = tuples[(uint64_t)son * L + k / e];
-                    if (v >= n) continue;
-                    const double pl = x[(uint64_t)v * e + k % e];  // pde_label (custom.h:561-567): x of the path's vertices
-                    lo = fmin(lo, pl);
-                    hi = fmax(hi, pl);
-                } else {
-                    if (son >= n_nodes) continue;
-                    lo = fmin(lo, ambr[((uint64_t)son * D + k) * 2]);
-                    hi = fmax(hi, ambr[((uint64_t)son * D + k) * 2 + 1]);
+        // One entry per lane; a node holds more than 64 entries only when D <= 3 (cap = 4091 / (16 D + 4)), then the
+        // chunks of 64 are combined through lane 0's own earlier stores.  `son` is read once per entry, a path's vertex
+        // once per position: degrees[j] and the e label-feature dimensions of position j come from the same gather.
+        // (a node without entries -- the empty tree's root leaf -- keeps the constructor's zeros, custom.h:159-164: the
+        // arrays were cleared before the first launch)
+        for (uint32_t t0 = 0; t0 < ne; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool ok = t < ne;
+            const char *ent = blk + 5 + (uint64_t)t * esz;
+            uint32_t son = 0;
+            if (ok) {
+                son = (uint32_t)ld_i32(ent + 16 * D);
+                if (level == 0 ? son >= cnt : son >= n_nodes) {
+                    aux_fail(err, level == 0 ? 1u : 2u, (uint32_t)b);
+                    ok = false;
                 }
             }
-            lo = wave_min(lo);
-            hi = wave_max(hi);
-            if (lane == 0) {
-                // a node without entries (the empty tree's root leaf) keeps the constructor's zeros (custom.h:159-164)
-                ambr[(b * D + k) * 2] = ne ? lo : 0.0;
-                ambr[(b * D + k) * 2 + 1] = ne ? hi : 0.0;
+            for (uint32_t j = 0; j < L; j++) {
+                uint32_t d = 0, v = 0;
+                bool okv = ok;
+                if (ok) {
+                    if (level == 0) {
+                        v = tuples[(uint64_t)son * L + j];
+                        if (v >= n) {
+                            aux_fail(err, 3u, (uint32_t)b);
+                            okv = false;
+                        } else {
+                            d = degree[v];
+                        }
+                    } else {
+                        d = adeg[(uint64_t)son * L + j];
+                    }
+                }
+                uint32_t dmax = wave_max_u32(d);
+                if (lane == 0) {
+                    if (t0) dmax = max(dmax, adeg[b * L + j]);
+                    adeg[b * L + j] = dmax;
+                }
+                for (uint32_t kk = 0; kk < e; kk++) {
+                    const uint32_t k = j * e + kk;
+                    double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+                    if (okv) {
+                        if (level == 0) {
+                            lo = hi = x[(uint64_t)v * e + kk];  // pde_label (custom.h:561-567): x of the path's vertices
+                        } else {
+                            lo = ambr[((uint64_t)son * D + k) * 2];
+                            hi = ambr[((uint64_t)son * D + k) * 2 + 1];
+                        }
+                    }
+                    lo = wave_min(lo);
+                    hi = wave_max(hi);
+                    if (lane == 0) {
+                        if (t0) {
+                            lo = fmin(lo, ambr[(b * D + k) * 2]);
+                            hi = fmax(hi, ambr[(b * D + k) * 2 + 1]);
+                        }
+                        ambr[(b * D + k) * 2] = lo;
+                        ambr[(b * D + k) * 2 + 1] = hi;
+                    }
+                }
             }
-        }
-        if (level > 0) {
-            for (uint32_t t = lane; t < ne; t += 64) {
-                const char *ent = blk + 5 + (uint64_t)t * esz;
-                const uint32_t son = (uint32_t)ld_i32(ent + 16 * D);
-                if (son >= n_nodes) continue;
+            if (level > 0 && ok) {
                 double kv = 0.0;
                 for (uint32_t k = 0; k < D; k++) kv -= ld_f64(ent + (2 * k + 1) * 8);  // custom.h:324-328, same order
                 key[son] = kv;

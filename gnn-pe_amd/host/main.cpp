@@ -437,6 +437,14 @@ int main(int argc, char **argv)
             check(gnnpe_set_slab(ctx, 0, g.n), "set_slab(all)");
             check(gnnpe_count_paths(ctx, o.path_length, nullptr, &t), "count_paths(all)");
         }
+        if (o.partition_num > 1 && !o.sidecars) {  // all images first, then the files side by side
+            std::vector<std::string> ips;
+            std::vector<const char *> ipp;
+            for (uint32_t pid = 0; pid < o.partition_num; pid++) ips.push_back(partitions_path + "partition-" + std::to_string(pid) + "/index.dat");
+            for (auto &ip : ips) ipp.push_back(ip.c_str());
+            check(gnnpe_build_index_files(ctx, o.partition_num, ipp.data()), "build_index_files");
+            for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
+        } else
         for (uint32_t pid = 0; pid < o.partition_num; pid++)
         {
             const std::string ip = partitions_path + "partition-" + std::to_string(pid) + "/index.dat";
