@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--no-index", action="store_true", help="skip the index-build, online-filter and end-to-end legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
-    ap.add_argument("--placements", type=int, default=3,
+    ap.add_argument("--placements", type=int, default=5,
                     help="candidate allocations of the output buffers; the one the emit kernel writes fastest is kept (1 = take what comes)")
     ap.add_argument("--equal-paths", action="store_true",
                     help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
@@ -325,7 +325,7 @@ def main():
     # Where the 12 GB of output land matters on this hardware: a fresh 9.6 GB allocation streams at either ~5.0 or
     # ~5.7 TB/s (scripts/bw_regions.hip: per-allocation write bandwidth, no pattern between processes), and the emit
     # kernel follows (3.4 vs 4.0 ms into the same records, scripts/fill_alloc_probe*.py).  A deployment allocates its
-    # output pool once, so the bench does what it would do: a few candidate allocations, one untimed fill into each,
+    # output pool once, so the bench does what it would do: five candidate allocations, one untimed fill into each,
     # the fastest kept, the others freed.  (A plain streaming write as the probe was tried: it does not predict the
     # emit kernel's time well enough.)  All candidate times are reported; nothing in the timed region changes.
     def alloc_outputs():

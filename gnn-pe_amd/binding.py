@@ -88,7 +88,7 @@ SIGNATURES = {
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                            C.POINTER(C.c_int32)]),
     "gnnpe_build_index": (C.c_int, [_vp, C.c_uint32, C.c_char_p]),
-    "gnnpe_build_index_files": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_char_p)]),
+    "gnnpe_build_index_files": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     "gnnpe_build_index_partition_device": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), _u64p, C.POINTER(C.c_int32)]),
     "gnnpe_build_box_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                                C.POINTER(C.c_int32)]),
@@ -521,10 +521,11 @@ class Engine:
     def build_index(self, pid, path):
         self._ck(self.lib.gnnpe_build_index(self.ctx, int(pid), path.encode()))
 
-    def build_index_files(self, paths):
-        """index.dat of partitions 0..len(paths)-1, written side by side."""
+    def build_index_files(self, paths, aux_paths=None):
+        """index.dat (and optionally aux_index.bin) of partitions 0..len(paths)-1, the index files written side by side."""
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
-        self._ck(self.lib.gnnpe_build_index_files(self.ctx, len(paths), arr))
+        aux = None if aux_paths is None else (C.c_char_p * len(aux_paths))(*[p.encode() for p in aux_paths])
+        self._ck(self.lib.gnnpe_build_index_files(self.ctx, len(paths), arr, aux))
 
     def aux_index_device(self, dev_image, nbytes, cnt, L, dev_tuples):
         """Partition::build_auxiliary_index (custom.h:268-364) over an index.dat image in device memory; dev_tuples =

@@ -1532,49 +1532,12 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
     return rc;
 }
 
-int gnnpe_build_index_files(gnnpe_ctx *c, uint32_t n_parts, const char *const *paths)
+// auxiliary index of partition pid over `image` (an index.dat image of that partition on the device) -> aux_index.bin:
+// magic "GNNPEAUX", uint32 version = 1, uint32 L, uint32 D, uint32 reserved, uint64 n_nodes, then key[n_nodes] (double),
+// degrees[n_nodes x L] (uint32), label_mbr[n_nodes x 2D] (double), all indexed by node block id
+static int aux_to_file(gnnpe_ctx *c, uint32_t pid, const void *image, uint64_t nbytes, const char *path)
 {
-    GNNPE_REQUIRE(c && paths && n_parts >= 1 && n_parts <= c->p, GNNPE_ERR_ARG, "gnnpe_build_index_files: bad argument");
-    for (uint32_t pid = 0; pid < n_parts; pid++) GNNPE_REQUIRE(paths[pid], GNNPE_ERR_ARG, "null path for partition %u", pid);
-    if (n_parts == 1) return gnnpe_build_index(c, 0, paths[0]);
-    GNNPE_HIP_TRY(hipSetDevice(c->device));
-    // every partition's image is built first (milliseconds) and kept, then the files are written side by side
-    std::vector<DevBuf> keep(n_parts);
-    std::vector<const char *> images(n_parts);
-    std::vector<uint64_t> sizes(n_parts);
-    int rc = GNNPE_OK;
-    for (uint32_t pid = 0; pid < n_parts && !rc; pid++) {
-        void *image = nullptr;
-        uint64_t nbytes = 0;
-        if ((rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr))) break;
-        if ((rc = keep[pid].reserve(nbytes))) break;
-        GNNPE_HIP_TRY(hipMemcpyAsync(keep[pid].p, image, nbytes, hipMemcpyDeviceToDevice, c->stream));
-        images[pid] = keep[pid].as<char>();
-        sizes[pid] = nbytes;
-    }
-    if (!rc) {
-        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-        rc = write_device_images(c, n_parts, images.data(), sizes.data(), paths);
-    }
-    (void)hipStreamSynchronize(c->stream);
-    return rc;
-}
-
-// aux_index.bin: magic "GNNPEAUX", uint32 version = 1, uint32 L, uint32 D, uint32 reserved, uint64 n_nodes, then
-// key[n_nodes] (double), degrees[n_nodes x L] (uint32), label_mbr[n_nodes x 2D] (double), all indexed by node block id
-int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
-{
-    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
-    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
-                  "gnnpe_build_aux_index: need gnnpe_vde and gnnpe_count_paths first");
-    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
-    GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc;
-    void *image = c->index_image.p;
-    uint64_t nbytes = c->img_bytes;
-    if (!(c->img_valid && c->img_pid == pid && c->img_gen == c->count_gen) &&
-        (rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr)))
-        return rc;
     DevBuf mine;
     uint64_t cnt = 0;
     if ((rc = collect_partition_tuples(c, pid, mine, &cnt))) return rc;
@@ -1602,6 +1565,55 @@ int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
         return GNNPE_ERR_IO;
     }
     return GNNPE_OK;
+}
+
+int gnnpe_build_index_files(gnnpe_ctx *c, uint32_t n_parts, const char *const *paths, const char *const *aux_paths)
+{
+    GNNPE_REQUIRE(c && paths && n_parts >= 1 && n_parts <= c->p, GNNPE_ERR_ARG, "gnnpe_build_index_files: bad argument");
+    for (uint32_t pid = 0; pid < n_parts; pid++)
+        GNNPE_REQUIRE(paths[pid] && (!aux_paths || aux_paths[pid]), GNNPE_ERR_ARG, "null path for partition %u", pid);
+    int rc = GNNPE_OK;
+    if (n_parts == 1) {
+        if ((rc = gnnpe_build_index(c, 0, paths[0]))) return rc;
+        return aux_paths ? gnnpe_build_aux_index(c, 0, aux_paths[0]) : GNNPE_OK;
+    }
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    // every partition's image is built first (milliseconds) and kept, then the files are written side by side
+    std::vector<DevBuf> keep(n_parts);
+    std::vector<const char *> images(n_parts);
+    std::vector<uint64_t> sizes(n_parts);
+    for (uint32_t pid = 0; pid < n_parts && !rc; pid++) {
+        void *image = nullptr;
+        uint64_t nbytes = 0;
+        if ((rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr))) break;
+        if ((rc = keep[pid].reserve(nbytes))) break;
+        GNNPE_HIP_TRY(hipMemcpyAsync(keep[pid].p, image, nbytes, hipMemcpyDeviceToDevice, c->stream));
+        images[pid] = keep[pid].as<char>();
+        sizes[pid] = nbytes;
+        if (aux_paths) rc = aux_to_file(c, pid, image, nbytes, aux_paths[pid]);
+    }
+    if (!rc) {
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = write_device_images(c, n_parts, images.data(), sizes.data(), paths);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
+{
+    GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
+    GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
+                  "gnnpe_build_aux_index: need gnnpe_vde and gnnpe_count_paths first");
+    GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    void *image = c->index_image.p;
+    uint64_t nbytes = c->img_bytes;
+    if (!(c->img_valid && c->img_pid == pid && c->img_gen == c->count_gen) &&
+        (rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr)))
+        return rc;
+    return aux_to_file(c, pid, image, nbytes, path);
 }
 
 }  // extern "C"

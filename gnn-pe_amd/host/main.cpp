@@ -437,24 +437,20 @@ int main(int argc, char **argv)
             check(gnnpe_set_slab(ctx, 0, g.n), "set_slab(all)");
             check(gnnpe_count_paths(ctx, o.path_length, nullptr, &t), "count_paths(all)");
         }
-        if (o.partition_num > 1 && !o.sidecars) {  // all images first, then the files side by side
-            std::vector<std::string> ips;
-            std::vector<const char *> ipp;
-            for (uint32_t pid = 0; pid < o.partition_num; pid++) ips.push_back(partitions_path + "partition-" + std::to_string(pid) + "/index.dat");
-            for (auto &ip : ips) ipp.push_back(ip.c_str());
-            check(gnnpe_build_index_files(ctx, o.partition_num, ipp.data()), "build_index_files");
-            for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
-        } else
-        for (uint32_t pid = 0; pid < o.partition_num; pid++)
-        {
-            const std::string ip = partitions_path + "partition-" + std::to_string(pid) + "/index.dat";
-            check(gnnpe_build_index(ctx, pid, ip.c_str()), "build_index");
-            warn_if_index_too_large_for_reference(ip);
-            if (o.sidecars) {  // the tree's auxiliary index (custom.h:268-364), which the online side rebuilds on every start
-                const std::string ap = partitions_path + "partition-" + std::to_string(pid) + "/aux_index.bin";
-                check(gnnpe_build_aux_index(ctx, pid, ap.c_str()), "build_aux_index");
-            }
+        // every partition's image first, then the files side by side; with --sidecars also the trees' auxiliary index
+        // (custom.h:268-364), which the online side otherwise rebuilds on every start
+        std::vector<std::string> ips, aps;
+        std::vector<const char *> ipp, app;
+        for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+            ips.push_back(partitions_path + "partition-" + std::to_string(pid) + "/index.dat");
+            aps.push_back(partitions_path + "partition-" + std::to_string(pid) + "/aux_index.bin");
         }
+        for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+            ipp.push_back(ips[pid].c_str());
+            app.push_back(aps[pid].c_str());
+        }
+        check(gnnpe_build_index_files(ctx, o.partition_num, ipp.data(), o.sidecars ? app.data() : nullptr), "build_index_files");
+        for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
         t_index = secs(i0, Clock::now());
     }
     for (auto &d : devs) gnnpe_destroy(d.ctx);

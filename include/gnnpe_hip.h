@@ -216,8 +216,9 @@ int gnnpe_build_index_partition_device(gnnpe_ctx *ctx, uint32_t pid, void **dev_
 int gnnpe_build_index(gnnpe_ctx *ctx, uint32_t pid, const char *path);
 /* index.dat of partitions 0..n_parts-1, all at once: every image is built on the device first, then the files are
  * written side by side (one writer thread per file: buffered writes to one file serialise, writes to different files do
- * not).  Same files as n_parts calls of gnnpe_build_index. */
-int gnnpe_build_index_files(gnnpe_ctx *ctx, uint32_t n_parts, const char *const *paths);
+ * not).  Same files as n_parts calls of gnnpe_build_index; aux_paths (or NULL): where to leave every partition's
+ * auxiliary index (gnnpe_build_aux_index below). */
+int gnnpe_build_index_files(gnnpe_ctx *ctx, uint32_t n_parts, const char *const *paths, const char *const *aux_paths);
 
 /* Pieces for callers that assemble a partition's tuples themselves (multi-GPU host: the tuples of partition pid come
  * from every rank): rows of dev_rows (k x L uint32 selected by the global ids dev_sel[i] - sel_base) -> dev_out; and a
