@@ -128,3 +128,22 @@ def test_driver_answers_a_query_across_ranks(tmp_path, world):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert int(re.search(r"Answer Number: (\d+)", r.stdout).group(1)) == 45426
+
+
+def test_bench_multi_rank_flow_on_one_device(tmp_path):
+    """bench.py's N > 1 path (slab planning, load_rows, halo install, per-step vde all-gather / count all-gather / fill,
+    the closed-form sanity check, max-over-ranks timing) with two ranks sharing device 0 over gloo
+    (GNNPE_BENCH_SAME_DEVICE=1: the explicit debugging mode; the driver's own runs use RCCL, one GPU per rank)."""
+    import json
+    env = dict(os.environ, GNNPE_BENCH_SAME_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--vertices", "200000", "--edges", "2000000", "--placements", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2" and d["scaling"] == "strong"
+    assert d["config"]["paths"] == synth.expected_paths_l2(synth.gnm_graph(200_000, 2_000_000)["offsets"])
+    assert d["value"] > 0 and d["halo"]["halo_rows"] > 0 and "halo_install_ms" in d["phases_ms"]["one_time"]
+    assert d["cpu_baseline"] is None and "gloo" in d["config"]["collectives"]
