@@ -353,7 +353,7 @@ def main():
     def one_step(timed):
         if world > 1:
             sb.exchange_vde()
-            t = sb.count()
+            t = sb.count_begin()  # the all-gather of the ranks' totals runs beside the fill; collected below
         else:
             eng.vde(want=False)
             t = sb._count_single()
@@ -362,6 +362,8 @@ def main():
         ev0.record()
         eng.fill_paths_device(0, t, out_ids, out_pde, None)
         ev1.record()
+        if world > 1:
+            sb.count_end()
         if timed:
             fill_ms.append((ev0, ev1))
         return t

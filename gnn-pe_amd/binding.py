@@ -56,6 +56,7 @@ SIGNATURES = {
     "gnnpe_vde_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "gnnpe_vde_pack_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "gnnpe_vde_unpack_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "gnnpe_vde_unpack_all": (C.c_int, [_vp, C.c_uint32, _u32p, C.c_uint32, C.c_uint32, _vp]),
     "gnnpe_count_paths": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
     "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
     "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
@@ -389,6 +390,10 @@ class Engine:
         self._ck(self.lib.gnnpe_vde_unpack_slab(self.ctx, begin, end, _dev(dev_buf)))
 
     # R2: dfs + VectorHash (custom.h:52-92), count half
+    def vde_unpack_all(self, bounds, stride, skip_rank, dev_buf):
+        b = _np(bounds, np.uint32)
+        self._ck(self.lib.gnnpe_vde_unpack_all(self.ctx, len(b) - 1, _ptr(b, _u32p), int(stride), int(skip_rank), _dev(dev_buf)))
+
     def count_paths(self, l=2, per_start=False):
         tot = C.c_uint64()
         ps = np.zeros(self.slab[1] - self.slab[0], np.uint64) if per_start else None

@@ -587,6 +587,30 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
     return GNNPE_OK;
 }
 
+int gnnpe_vde_unpack_all(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds, uint32_t stride, uint32_t skip_rank,
+                         const void *dev_buf)
+{
+    GNNPE_REQUIRE(c && c->have_vde && c->have_order && dev_buf && bounds && n_ranks >= 1, GNNPE_ERR_ARG,
+                  "gnnpe_vde_unpack_all: bad state");
+    GNNPE_REQUIRE(bounds[0] == 0 && bounds[n_ranks] == c->n, GNNPE_ERR_ARG, "slab bounds must run from 0 to n");
+    for (uint32_t r = 0; r < n_ranks; r++)
+        GNNPE_REQUIRE(bounds[r] <= bounds[r + 1] && bounds[r + 1] - bounds[r] <= stride, GNNPE_ERR_ARG,
+                      "slab %u: [%u, %u) does not fit rows of stride %u", r, bounds[r], bounds[r + 1], stride);
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->slab_bounds.reserve(((size_t)n_ranks + 1) * 4))) return rc;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->slab_bounds.p, bounds, ((size_t)n_ranks + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->n)
+        hipLaunchKernelGGL(k_vde_unpack_all, dim3(grid_for((uint64_t)c->n * c->e)), dim3(kBlock), 0, c->stream, c->n, c->e, n_ranks,
+                           c->slab_bounds.as<uint32_t>(), stride, skip_rank, c->sorted.as<uint32_t>(), (const double *)dev_buf,
+                           c->vde.as<double>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->nbr_vde_valid = false;
+    c->ranked_vde_valid = false;
+    c->vkey_valid = false;
+    return GNNPE_OK;
+}
+
 // ---- R2 / R5: enumeration ---------------------------------------------------------------------------
 //   4 ranked     one wave per start vertex over rank-sorted neighbour records, hub rows (degree > 64) streamed in id
 //                order by the same kernel (gnnpe_fill_ranked.hip.h)                                        default

@@ -169,6 +169,25 @@ __global__ void k_vde_unpack(uint32_t begin, uint32_t end, uint32_t e, const uin
     }
 }
 
+// every rank's slab of an all-gathered table [n_ranks][stride rows][e] back into the vde table, one launch: position p
+// of the processing order belongs to the slab r with bounds[r] <= p < bounds[r + 1] (bounds: n_ranks + 1 device words)
+__global__ void k_vde_unpack_all(uint32_t n, uint32_t e, uint32_t n_ranks, const uint32_t *__restrict__ bounds,
+                                 uint32_t stride, uint32_t skip_rank, const uint32_t *__restrict__ sorted,
+                                 const double *__restrict__ buf, double *__restrict__ vde)
+{
+    const uint64_t tot = (uint64_t)n * e;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = (uint32_t)(i / e), k = (uint32_t)(i % e);
+        uint32_t lo = 0, hi = n_ranks;  // largest r with bounds[r] <= p
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (bounds[mid] <= p) lo = mid; else hi = mid;
+        }
+        if (lo == skip_rank) continue;
+        vde[(uint64_t)sorted[p] * e + k] = buf[((uint64_t)lo * stride + (p - bounds[lo])) * e + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared pieces of the enumeration kernels (gnnpe_fill_*.hip.h)
 // ------------------------------------------------------------------------------------------------

@@ -18,7 +18,8 @@ Each rank holds the adjacency rows of its own start vertices.  Two kinds of work
       the CSR of a single-GPU run (one rule for N = 1 and N > 1).
   per step:
       1. vde            -- local rows, then an all-gather of the vde rows (n x e doubles in total),
-      2. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base,
+      2. count + scan   -- local; an all-gather of one uint64 per rank gives the global path-id base (started right
+                           after the count, collected after the fill is enqueued: the fill needs the local total only),
       3. fill           -- local, into caller-provided device buffers.
 There is no reduction across ranks anywhere on the offline side; the online filter (`filter`) takes the union
 of the ranks' candidate bitmaps (all-gather + OR: RCCL has no bitwise reductions).
@@ -349,18 +350,39 @@ class SlabBuild:
         eng.vde(want=False)
         eng.vde_pack_slab(int(b[self.rank]), int(b[self.rank + 1]), self.vde_send)
         self._allgather(self.vde_all.view(-1), self.vde_send.view(-1))
+        if hasattr(eng, "vde_unpack_all"):  # one launch for all the peers' slabs
+            eng.vde_unpack_all(b, max(self.maxlen, 1), self.rank, self.vde_all)
+            return
         for r in range(R):
             if r != self.rank and b[r + 1] > b[r]:
                 eng.vde_unpack_slab(int(b[r]), int(b[r + 1]), self.vde_all[r])
 
-    def count(self):
+    def count_begin(self):
+        """Local count, and the all-gather of the ranks' totals STARTED: the fill only needs the local total, so over
+        RCCL the collective (and its host round trip) runs beside the fill kernel; count_end() collects it."""
         total = self.eng.count_paths(self.l)
-        mine = torch.tensor([total], dtype=torch.int64, device=self.device)
-        self._allgather(self.tot_all, mine)
-        tots = [int(x) for x in self.tot_all.tolist()]
         self.local_total = total
+        self._tot_mine = torch.tensor([total], dtype=torch.int64, device=self.device)
+        self._tot_work = None
+        if self.comm is None and not self._staged(self.tot_all):
+            self._tot_work = dist.all_gather_into_tensor(self.tot_all, self._tot_mine, group=self.group, async_op=True)
+        else:
+            self._allgather(self.tot_all, self._tot_mine)
+        return total
+
+    def count_end(self):
+        """Global path-id base of this rank's rows and the global total, from the all-gather count_begin() started."""
+        if self._tot_work is not None:
+            self._tot_work.wait()
+            self._tot_work = None
+        tots = [int(x) for x in self.tot_all.tolist()]
         self.base = sum(tots[:self.rank])
         self.global_total = sum(tots)
+        return self.base
+
+    def count(self):
+        total = self.count_begin()
+        self.count_end()
         return total
 
     def step(self, out_ids=None, out_pde=None, out_pde_label=None):
@@ -372,9 +394,11 @@ class SlabBuild:
             self.exchange_vde()
         else:
             self.eng.vde(want=False)
-        total = self.count() if self.world > 1 else self._count_single()
+        total = self.count_begin() if self.world > 1 else self._count_single()
         if out_ids is not None or out_pde is not None or out_pde_label is not None:
             self.eng.fill_paths_device(0, total, out_ids, out_pde, out_pde_label)
+        if self.world > 1:
+            self.count_end()
         return total, self.base
 
     def filter(self, plan, eps=1e-6):

@@ -151,6 +151,11 @@ int gnnpe_vde_device_ptr(gnnpe_ctx *ctx, void **dev_vde, void **dev_x);
  * processing order -- the all-gather payload (x needs no exchange: labels are replicated). */
 int gnnpe_vde_pack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, void *dev_buf);
 int gnnpe_vde_unpack_slab(gnnpe_ctx *ctx, uint32_t begin, uint32_t end, const void *dev_buf);
+/* The same for every rank's slab at once, from the all-gathered buffer [n_ranks][stride rows][e] (stride = the longest
+ * slab; bounds[n_ranks + 1] host words, the slabs' first positions): one launch per step instead of n_ranks - 1.  The
+ * rows of skip_rank (this rank's own: already in the table) are left alone; pass n_ranks to scatter all. */
+int gnnpe_vde_unpack_all(gnnpe_ctx *ctx, uint32_t n_ranks, const uint32_t *bounds, uint32_t stride, uint32_t skip_rank,
+                         const void *dev_buf);
 
 /* ---- R2: path enumeration (dfs + VectorHash, custom.h:52-92; driver loop main.cpp:87-96) ------- */
 /* Counts the paths of the context's slab with l edges (l+1 vertices).  l=2 is the reference's path (it
