@@ -8,7 +8,7 @@
 //
 // usage: ref_online <dataset dir/> <data.graph> <query.graph> <p> dump   <out.bin>
 //        ref_online <dataset dir/> <data.graph> <query.graph> <p> refine <candidates.bin>
-//        ref_online <dataset dir/> <data.graph> <query.graph> <p> aux    <out.bin>
+//        ref_online <dataset dir/> <data.graph> <query.graph> <p> aux    <out.bin> [e]
 //   aux out.bin    : what the reference's Partition constructor leaves behind (custom.h:205-266, 268-364), per partition:
 //                    uint32 n_paths, n_nodes, L, D; the partition's paths (vids[L] labels[L] degrees[L] uint32,
 //                    pde[D] pde_label[D] double, each); then per node block id: key (double), degrees[L] (uint32),
@@ -44,6 +44,7 @@ int main(int argc, char **argv)
     }
     const string dataset_path = argv[1], mode = argv[5];
     partition_num = (ui)atoi(argv[4]);
+    if (argc > 7) vde_dim = (ui)atoi(argv[7]);  // optional embedding width (main.cpp:53 `-e`; default 2, custom.h:45)
     path_length = 3;  // main.cpp:58 with the only working -l 2
     pde_dim = vde_dim * path_length;
     MAX_LIMIT = UINT_MAX;

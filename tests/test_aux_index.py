@@ -25,9 +25,12 @@ sys.path.insert(0, GOLDEN)
 from make_golden_aux import QUERY, read_aux_dump  # noqa: E402  (parser of the harness dump: test infrastructure)
 
 
-def _golden(pid):
-    img = gzip.open(os.path.join(AUX, f"partition-{pid}.index.dat.gz"), "rb").read()
-    return img, np.load(os.path.join(AUX, f"partition-{pid}.npz"))
+def _golden(pid, prefix=""):
+    img = gzip.open(os.path.join(AUX, f"{prefix}partition-{pid}.index.dat.gz"), "rb").read()
+    return img, np.load(os.path.join(AUX, f"{prefix}partition-{pid}.npz"))
+
+
+WIDTHS = [("", 2), ("e1-", 1)]  # fixture prefix, embedding width (e1-: nodes of up to 76 entries)
 
 
 def _bits(a):
@@ -46,13 +49,16 @@ def _graph(oracle):
     return dict(offsets=offs, nbrs=nbrs, labels=labels, n=meta["n"]), sn, mem
 
 
+@pytest.mark.parametrize("prefix,e", WIDTHS)
 @pytest.mark.parametrize("pid", [0, 1])
-def test_oracle_aux_index_matches_the_reference_constructor(oracle, pid):
-    img, z = _golden(pid)
+def test_oracle_aux_index_matches_the_reference_constructor(oracle, pid, prefix, e):
+    img, z = _golden(pid, prefix)
     key, deg, mbr = oracle.aux_index(img, 3, z["degrees"], z["pde_label"])
     _same(dict(key=key, degrees=deg, label_mbr=mbr), z, f"partition {pid}")
     # the fixture exercises what it should: a tree of height >= 2, non-trivial keys, one root with key 0
     assert len(key) > 100 and (key == 0).sum() == 1 and (key < 0).sum() == len(key) - 1
+    ne = [struct.unpack_from("<i", img, (b + 1) * 4096 + 1)[0] for b in range(len(key))]
+    assert max(ne) > 64 if e == 1 else max(ne) <= 64
 
 
 def _write_sidecars(tmp_path, oracle, g, sn):
@@ -120,13 +126,14 @@ def _engine(g, sn, mem, p, e=2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prefix,e", WIDTHS)
 @pytest.mark.parametrize("pid", [0, 1])
-def test_hip_aux_of_the_reference_tree_matches_the_reference(oracle, pid):
+def test_hip_aux_of_the_reference_tree_matches_the_reference(oracle, pid, prefix, e):
     """The HIP pass over the index.dat the reference's insert loop wrote = the reference's own auxiliary index."""
     import torch
     g, sn, mem = _graph(oracle)
-    eng = _engine(g, sn, mem, 2)
-    img, z = _golden(pid)
+    eng = _engine(g, sn, mem, 2, e)
+    img, z = _golden(pid, prefix)
     dev = torch.device("cuda:0")
     d_img = torch.from_numpy(np.frombuffer(img, np.uint8).copy()).to(dev)
     d_tup = torch.from_numpy(np.ascontiguousarray(z["vids"]).view(np.int32)).to(dev)
@@ -136,7 +143,8 @@ def test_hip_aux_of_the_reference_tree_matches_the_reference(oracle, pid):
     bad = np.frombuffer(img, np.uint8).copy()
     nblk = struct.unpack_from("<i", img, 4)[0]
     leaf = next(b for b in range(nblk) if img[(b + 1) * 4096] == 0)
-    bad[(leaf + 1) * 4096 + 5 + 96:(leaf + 1) * 4096 + 5 + 100] = np.frombuffer(struct.pack("<i", 1 << 30), np.uint8)
+    D = 3 * e
+    bad[(leaf + 1) * 4096 + 5 + 16 * D:(leaf + 1) * 4096 + 5 + 16 * D + 4] = np.frombuffer(struct.pack("<i", 1 << 30), np.uint8)
     with pytest.raises(binding.GnnpeError, match="outside the partition"):
         eng.aux_index_device(torch.from_numpy(bad).to(dev), len(img), len(z["vids"]), 3, d_tup)
     eng.close()

@@ -1,7 +1,8 @@
 """Randomised differential test: many small random graphs (G(n,m) and power-law, isolated vertices, hubs above the
 64-neighbour limit of the ranked variant), arbitrary processing orders and partitions, every embedding width with and
 without a specialised kernel, l = 2 (every enumeration variant) and l = 3, random chunk boundaries -- engine through
-the C-ABI against the oracle, bit for bit (ids, partitions, vde, pde, pde_label, rendered text, index contents)."""
+the C-ABI against the oracle, bit for bit (ids, partitions, vde, pde, pde_label, rendered text, index contents, the
+index's auxiliary arrays)."""
 import numpy as np
 import pytest
 
@@ -88,10 +89,18 @@ def test_random_case_matches_the_oracle(oracle, seed):
             for pid in range(p):
                 mine = want[mem[want[:, 0]] == pid]
                 img, nbytes, hdr = eng.build_index_partition_device(pid)
+                # the tree's auxiliary index (custom.h:268-364) against the oracle's walk of the same image
+                raw = eng.copy_to_host(img, nbytes).tobytes()
+                tup = torch.from_numpy(np.ascontiguousarray(mine).view(np.int32)).to(dev) if len(mine) else None
+                aux = eng.aux_index_device(img, nbytes, len(mine), L, tup)
+                deg = np.diff(g["offsets"].astype(np.int64)).astype(np.uint32)
+                key, adeg, ambr = oracle.aux_index(raw, L, deg[mine].reshape(len(mine), L), ox[mine].reshape(len(mine), L * e))
+                assert np.array_equal(aux["key"].view(np.uint64), key.view(np.uint64)), (l, pid)
+                assert np.array_equal(aux["degrees"], adeg) and np.array_equal(aux["label_mbr"].view(np.uint64), ambr.view(np.uint64))
                 if len(mine) == 0:  # the reference's own empty tree: one empty leaf that is the root (rtree.cpp:11-32)
                     assert nbytes == 2 * 4096 and hdr == [4096, 1, L * e, 0, 1, 0, 1, 0]
                     continue
-                d = oracle.index_validate(eng.copy_to_host(img, nbytes).tobytes())
+                d = oracle.index_validate(raw)
                 assert d["num_data"] == len(mine), (l, pid)
                 order = np.argsort(d["leaf_son"], kind="stable")
                 assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
