@@ -83,10 +83,19 @@ def main():
     ap.add_argument("--ranges", default=None, help="world 1: JSON list of [begin, end) global id ranges to checksum")
     ap.add_argument("--weights", type=str, default="1,0,0", help="w_paths,w_owned,w_held of dist.plan_slabs")
     ap.add_argument("--threads", type=int, default=0, help="run this many ranks as threads of one process on device 0")
+    ap.add_argument("--oracle", type=int, default=0,
+                    help="l=2: compare every emitted id and double with the oracle's all-core pass (needs ~15 GB of host memory per 2e8 paths)")
     args = ap.parse_args()
 
     z = np.load(args.graph)
     g = dict(n=len(z["labels"]), offsets=z["offsets"], nbrs=z["nbrs"], labels=z["labels"])
+
+    args.oracle_rows = None
+    if args.oracle and args.l == 2:
+        from oracle import Oracle
+        sn0 = synth.degree_order(g["offsets"])
+        P, ovde, so, oids, opde = Oracle().offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn0, args.e)
+        args.oracle_rows = (P, oids, opde)
 
     if args.threads > 1:
         world = args.threads
@@ -187,6 +196,15 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
             _, _, vde_ref = ref.vde()
             ref.close()
             res["props"] = l2_properties(g, sn, dev, ids[:emit], pde[:emit], vde_ref, int(bounds[rank]), int(bounds[rank + 1]))
+            if args.oracle_rows is not None:  # this rank's rows = rows [base, base + total) of the single-rank output, bit for bit
+                P, oids, opde = args.oracle_rows
+                ok = int(sb.global_total) == P
+                CH = 1 << 24
+                for a in range(0, emit, CH):
+                    b = min(emit, a + CH)
+                    ok = ok and np.array_equal(ids[a:b].cpu().numpy().view(np.uint32), oids[base + a:base + b])
+                    ok = ok and np.array_equal(pde[a:b].cpu().numpy().view(np.uint64), opde[base + a:base + b].view(np.uint64))
+                res["oracle_exact"] = bool(ok)
             res["middle_sum"] = int(ids[:emit, 1].to(torch.int64).sum())
         else:
             buf = torch.empty((chunk, L), dtype=torch.int32, device=dev)

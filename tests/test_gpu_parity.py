@@ -256,6 +256,44 @@ def test_config3_1m_10m_properties():
     eng.close()
 
 
+def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
+    """BASELINE config 3 at full size, bit for bit: all 2.0e8 path rows and all 1.2e9 embedding doubles against the
+    oracle's all-core pass (oracle.offline_parallel: the closed form over every host core, itself pinned to the
+    sequential restatement and through it to the compiled reference in tests/test_oracle_golden.py).  Needs ~30 GB of
+    host memory for the two 12 GB result sets; skipped on a smaller box."""
+    import torch
+    from gnnpe_amd import binding, synth
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable:"):
+            avail = int(line.split()[1]) >> 20
+    if avail < 40:
+        pytest.skip(f"{avail} GiB of host memory available, 40 needed")
+    g = synth.gnm_graph(1_000_000, 10_000_000)
+    sn = synth.degree_order(g["offsets"])
+    P, ovde, so, oids, opde = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
+    assert P == synth.expected_paths_l2(g["offsets"])
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(64, 2))
+    x, nx, vde = eng.vde()
+    assert np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
+    total, per_start = eng.count_paths(2, per_start=True)
+    assert total == P and np.array_equal(np.cumsum(per_start), so[1:].astype(np.int64))
+    dev = torch.device("cuda:0")
+    CH = 1 << 25  # rows per chunk: 0.4 GB of ids + 1.6 GB of pde on the device, compared on the host
+    ids = torch.empty((CH, 3), dtype=torch.int32, device=dev)
+    pde = torch.empty((CH, 6), dtype=torch.float64, device=dev)
+    for a in range(0, total, CH):
+        b = min(total, a + CH)
+        eng.fill_paths_device(a, b, ids, pde, None)
+        eng.sync()
+        assert np.array_equal(ids[:b - a].cpu().numpy().view(np.uint32), oids[a:b]), a
+        assert np.array_equal(pde[:b - a].cpu().numpy().view(np.uint64), opde[a:b].view(np.uint64)), a
+    eng.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle, variant):
     """The multi-GPU path driven by hand on one device: two contexts own the two halves of the
