@@ -240,3 +240,36 @@ def test_reference_online_consumes_pair_major_index(tmp_path):
         out = subprocess.check_output([ref_main_path(), "-f", d + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
         ans.append(int(re.search(r"Answer Number: (\d+)", out).group(1)))
     assert ans[0] == ans[1]
+
+
+@pytest.mark.parametrize("n,m,p", [(100_000, 1_000_000, 4), (1_000_000, 10_000_000, 8)])
+def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
+    """BASELINE config 2 (100K / 1M, 2.0e7 paths, p = 4) and configs 3 / 4 (1M / 10M, 2.0e8 paths, p = 8: 22 GB of
+    index.dat): every partition's image passes the oracle's validator of the consumer's constraints, holds every path
+    of the partition exactly once with son = its index inside the partition, and lo = hi = its pde row, bit for bit
+    (paths and vde from the oracle's all-core pass)."""
+    from gnnpe_amd import binding
+    if n >= 1_000_000:
+        avail = [int(ln.split()[1]) >> 20 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+        if avail < 64:
+            pytest.skip(f"{avail} GiB of host memory available, 64 needed")
+    g = synth.gnm_graph(n, m)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(g["n"], p)
+    eng = _engine(binding, g, sn, mem, p, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    P, ovde, so, ref, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
+    assert total == P and np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
+    seen = 0
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["dim"] == 6 and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order].view(np.uint64), ovde[mine].reshape(len(mine), 6).view(np.uint64))
+        seen += len(mine)
+    assert seen == total
+    eng.close()
