@@ -269,8 +269,12 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
                 IdRow *dst = reinterpret_cast<IdRow *>(P.out_ids) + o;
 #pragma unroll 1
                 for (uint32_t g = lane; g < nr; g += 64) {
-                    IdRow t = {s, sb[sa[r0 + g]], sid[r0 + g]};
-                    dst[g] = t;
+                    // non-temporal like the pde rows: same-process A/B at config 3 (scripts/fill_exp.py, same records and
+                    // buffers) 3.40 -> 3.30 ms; sc1 / sc0 sc1 instead 3.45; any policy but nt for the pde rows 3.6-3.9
+                    uint32_t *q = reinterpret_cast<uint32_t *>(&dst[g]);
+                    __builtin_nontemporal_store(s, q);
+                    __builtin_nontemporal_store(sb[sa[r0 + g]], q + 1);
+                    __builtin_nontemporal_store(sid[r0 + g], q + 2);
                 }
             }
             if (want_pde) {
@@ -309,8 +313,13 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
         bk = 0;
         const uint32_t k = k0 + lane;
         if (k < sr.ds) {
-            pr = pairs[sr.e0 + k];
-            bk = P.nbrs[sr.a_s + k];  // the k-th neighbour of s is the pair's middle vertex
+            // read once, never again: non-temporal (same-process A/B at config 3: 3.085 -> 3.036 ms; the RECORD loads must
+            // stay cached -- a pair's header and first records share lines across load instructions: 4.02 -> 4.37 ms)
+            const uint32_t *pq = reinterpret_cast<const uint32_t *>(&pairs[sr.e0 + k]);
+            pr.block = __builtin_nontemporal_load(pq);
+            pr.cnt = __builtin_nontemporal_load(pq + 1);
+            pr.G = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pq + 2));
+            bk = __builtin_nontemporal_load(&P.nbrs[sr.a_s + k]);  // the k-th neighbour of s is the pair's middle vertex
         }
     };
 

@@ -15,7 +15,7 @@ eng = binding.Engine(0, stream=stream.cuda_stream)
 eng.load_csr(g["offsets"], g["nbrs"], g["labels"]); eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
 eng.set_label_table(binding.host_label_table(64, 2)); eng.vde(want=False)
 want = synth.expected_paths_l2(g["offsets"])
-KEYS = ["GNNPE_ROWS_ILP", "GNNPE_ROWS_GRID", "GNNPE_ROWS_KNOCK"]
+KEYS = ["GNNPE_ROWS_ILP", "GNNPE_ROWS_GRID", "GNNPE_ROWS_KNOCK", "GNNPE_ROWS_EXP"]
 for rnd in range(3):
     for case in cases:
         for k in KEYS: os.environ.pop(k, None)
