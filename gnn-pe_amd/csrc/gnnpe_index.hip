@@ -695,7 +695,16 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
                 son = (uint32_t)(sw >> 8) + r;
             } else {
-                const Rec rec = reinterpret_cast<const Rec *>(blk + 8 * E)[r];
+                // read once by this leaf: non-temporal (same-process A/B at config 3, scripts/index_ab.py: 6.80 -> 6.63 ms per
+                // further partition; the sorted pair rows, shared with the neighbouring leaves, must stay cached: 6.98)
+                Rec rec;
+                {
+                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E) + (uint64_t)r * (sizeof(Rec) / 4);
+                    uint32_t wq[sizeof(Rec) / 4];
+#pragma unroll
+                    for (int z = 0; z < (int)(sizeof(Rec) / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);
+                    __builtin_memcpy(&rec, wq, sizeof(Rec));
+                }
                 uint32_t ip;
                 if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
 #pragma unroll

@@ -14,7 +14,7 @@ eng = binding.Engine(0, stream=stream.cuda_stream)
 eng.load_csr(g["offsets"], g["nbrs"], g["labels"]); eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
 eng.set_label_table(binding.host_label_table(64, 2)); eng.vde(want=False)
 eng.count_paths(2)
-KEYS = ["GNNPE_LEAF_STRIP_ALL", "GNNPE_LEAF_DYNLDS", "GNNPE_LEAF_GRID", "GNNPE_LEAF_KNOCK"]
+KEYS = ["GNNPE_LEAF_STRIP_ALL", "GNNPE_LEAF_DYNLDS", "GNNPE_LEAF_GRID", "GNNPE_LEAF_KNOCK", "GNNPE_LEAF_EXP"]
 sums = {}
 for rnd in range(3):
     for case in cases:
