@@ -309,7 +309,7 @@ static int read_partition_ids(const char *path, std::vector<uint32_t> &ids)
         return true;
     };
     uint64_t cnt = 0, v = 0;
-    bool ok = next(cnt);
+    bool ok = next(cnt) && cnt <= (uint64_t)st.st_size;  // every id takes at least a digit and a newline
     if (ok) {
         ids.resize(cnt);
         for (uint64_t i = 0; i < cnt && ok; i++) {
