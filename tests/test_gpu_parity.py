@@ -294,6 +294,65 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
     eng.close()
 
 
+def test_graph_beyond_2_26_vertices_takes_the_wide_records(oracle):
+    """Vertex ids above 2^26 no longer fit the packed records (the id-position rides in the id's top 6 bits), so such a
+    graph runs the wide-record instantiations of the count, emit and leaf kernels.  67 M vertices, almost all isolated,
+    a small connected part spread over the whole id range (first ids, last ids, random ones): ids, vde, pde and the
+    index image against the oracle, bit for bit."""
+    import torch
+    from gnnpe_amd import binding, synth
+    avail = [int(ln.split()[1]) >> 20 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+    if avail < 32:
+        pytest.skip(f"{avail} GiB of host memory available, 32 needed")
+    n = (1 << 26) + 4099
+    rng = np.random.default_rng(26)
+    verts = np.unique(np.concatenate([rng.integers(0, n, 1500), np.arange(n - 60, n), np.arange(0, 60)])).astype(np.int64)
+    a, b = verts[rng.integers(0, len(verts), 9000)], verts[rng.integers(0, len(verts), 9000)]
+    keep = a != b
+    eu, ev = np.minimum(a[keep], b[keep]), np.maximum(a[keep], b[keep])
+    uniq = np.unique(eu * n + ev)
+    eu, ev = uniq // n, uniq % n
+    offs, nbrs = synth._csr_from_edges(n, eu, ev)
+    labels = rng.integers(0, 5, n).astype(np.uint32)
+    assert int(nbrs.max()) > (1 << 26) and np.diff(offs.astype(np.int64)).max() <= 64
+    sn = np.arange(n, dtype=np.uint32)[::-1].copy()  # any processing order is valid; this one costs no sort
+    mem = np.zeros(n, np.uint32)
+    want = oracle.enumerate_closed(offs, nbrs, sn, 3)
+    # gen_vde (custom.h:513-544) from the oracle's label table: the oracle's own gen_vde re-seeds a Mersenne twister per
+    # vertex like the reference (minutes at 67 M vertices); x = table[label], nx = the neighbours' x added one by one in
+    # ascending order from 0.0, vde = x + nx -- the same operations in the same order
+    table = oracle.label_table(5, 2)
+    ox = table[labels]
+    onx = np.zeros_like(ox)
+    o64 = offs.astype(np.int64)
+    for v in np.nonzero(np.diff(o64))[0]:
+        acc = np.zeros(2)
+        for u in nbrs[o64[v]:o64[v + 1]]:
+            acc = acc + ox[u]
+        onx[v] = acc
+    ovde = ox + onx
+    eng = binding.Engine(0)
+    eng.load_csr(offs, nbrs, labels)
+    eng.set_order(sn, mem, 1)
+    eng.set_label_table(binding.host_label_table(5, 2))
+    x, nx, vde = eng.vde()
+    assert np.array_equal(vde.view(np.uint64), ovde.view(np.uint64)) and np.array_equal(nx.view(np.uint64), onx.view(np.uint64))
+    total = eng.count_paths(2)
+    assert total == len(want) > 10000
+    ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
+    assert np.array_equal(ids, want)
+    assert np.array_equal(pde.view(np.uint64), ovde[want].reshape(len(want), 6).view(np.uint64))
+    assert np.array_equal(pdl.view(np.uint64), ox[want].reshape(len(want), 6).view(np.uint64))
+    cuts = [0, 1, total // 3, total - 1, total]  # chunked emission
+    assert np.array_equal(np.concatenate([eng.fill_paths(a_, b_, pde=False)[0] for a_, b_ in zip(cuts[:-1], cuts[1:])]), want)
+    img, nbytes, hdr = eng.build_index_partition_device(0)  # pair-major build over the wide records
+    d = oracle.index_validate(eng.copy_to_host(img, nbytes).tobytes())
+    order = np.argsort(d["leaf_son"], kind="stable")
+    assert d["num_data"] == total and np.array_equal(d["leaf_son"][order], np.arange(total))
+    assert np.array_equal(d["leaf_pt"][order].view(np.uint64), ovde[want].reshape(total, 6).view(np.uint64))
+    eng.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle, variant):
     """The multi-GPU path driven by hand on one device: two contexts own the two halves of the
