@@ -353,6 +353,53 @@ def test_graph_beyond_2_26_vertices_takes_the_wide_records(oracle):
     eng.close()
 
 
+def test_l2_beyond_2_32_paths(oracle):
+    """More 3-vertex paths than the reference's 32-bit path ids can number (G(1.5 M, 60 M): 4.8e9 paths, rows of ~80
+    neighbours: a mix of ordinary and hub rows): the count, every start's count and offset against the oracle's all-core
+    pass, and emitted chunks around 2^32, at the very end and in between against the closed form of the covered starts."""
+    import torch
+    from gnnpe_amd import binding, synth
+    g = synth.gnm_graph(1_500_000, 60_000_000, n_labels=8, seed=11)
+    n, offs, nbrs = g["n"], g["offsets"].astype(np.int64), g["nbrs"]
+    sn = synth.degree_order(g["offsets"])
+    P, ovde, so, _, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2, want=False)
+    assert P == synth.expected_paths_l2(g["offsets"]) > (1 << 32)
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, np.zeros(n, np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(8, 2))
+    x, nx, vde = eng.vde()
+    assert np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
+    total, per_start = eng.count_paths(2, per_start=True)
+    assert total == P and np.array_equal(np.cumsum(per_start.astype(np.uint64)), so[1:])
+    rank = np.empty(n, np.int64)
+    rank[sn] = np.arange(n)
+    so64 = so.astype(np.int64)
+
+    def rows_of(i):  # closed form of start i (SURVEY 8(a) R2)
+        s = int(sn[i])
+        out = []
+        for b in nbrs[offs[s]:offs[s + 1]]:
+            cs = nbrs[offs[b]:offs[b + 1]]
+            cs = cs[rank[cs] > i]
+            out.append(np.stack([np.full(len(cs), s, np.uint32), np.full(len(cs), b, np.uint32), cs], axis=1))
+        return np.concatenate(out) if out else np.zeros((0, 3), np.uint32)
+
+    dev = torch.device("cuda:0")
+    for a, b in (((1 << 32) - 3000, (1 << 32) + 3000), (P - 5000, P), (3 * P // 4, 3 * P // 4 + 4000), (0, 2000)):
+        ids = torch.empty((b - a, 3), dtype=torch.int32, device=dev)
+        pde = torch.empty((b - a, 6), dtype=torch.float64, device=dev)
+        eng.fill_paths_device(a, b, ids, pde, None)
+        eng.sync()
+        i0 = int(np.searchsorted(so64, a, side="right")) - 1
+        i1 = int(np.searchsorted(so64, b - 1, side="right")) - 1
+        want = np.concatenate([rows_of(i) for i in range(i0, i1 + 1)])[a - so64[i0]:b - so64[i0]]
+        got = ids.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), (a, b)
+        assert np.array_equal(pde.cpu().numpy().view(np.uint64), ovde[want].reshape(len(want), 6).view(np.uint64)), (a, b)
+    eng.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle, variant):
     """The multi-GPU path driven by hand on one device: two contexts own the two halves of the
