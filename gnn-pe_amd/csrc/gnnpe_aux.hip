@@ -33,24 +33,50 @@ __device__ __forceinline__ double ld_f64(const char *p)
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-__device__ __forceinline__ double wave_min(double v)
+// Wave-wide reductions on the VALU's data-parallel primitives (DPP: quad permutes, row mirrors, row broadcasts -- gfx9
+// family), result broadcast from lane 63.  The first version used __shfl_xor butterflies = ds_bpermute through the LDS
+// crossbar: 162 of them per leaf (27 dwords x 6 steps) made the LDS pipe of every CU the pass's bottleneck.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+#define GNNPE_DPP_REDUCE(T, DPP, OP)                                            \
+    v = OP(v, DPP<0xB1, 0xF>(v));   /* quad_perm [1,0,3,2] */                   \
+    v = OP(v, DPP<0x4E, 0xF>(v));   /* quad_perm [2,3,0,1] */                   \
+    v = OP(v, DPP<0x141, 0xF>(v));  /* row_half_mirror */                       \
+    v = OP(v, DPP<0x140, 0xF>(v));  /* row_mirror: every row of 16 is reduced */ \
+    v = OP(v, DPP<0x142, 0xA>(v));  /* row_bcast15 into rows 1 and 3 */         \
+    v = OP(v, DPP<0x143, 0xC>(v));  /* row_bcast31 into rows 2 and 3: lane 63 holds the wave's result */
+__device__ __forceinline__ double lane63(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double dpp_min_f64(double v)  // result in lane 63
+{
+    GNNPE_DPP_REDUCE(double, dpp_f64, fmin)
     return v;
 }
-__device__ __forceinline__ double wave_max(double v)
+__device__ __forceinline__ double dpp_max_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    GNNPE_DPP_REDUCE(double, dpp_f64, fmax)
     return v;
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    GNNPE_DPP_REDUCE(uint32_t, dpp_u32, max)
     return v;
 }
+__device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64(v)); }
+__device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }
 
 // err[0] = first problem seen (0 none, 1 leaf son outside the partition's paths, 2 child block id outside the file,
 // 3 vertex id outside the graph, 4 entry count beyond the block), err[1] = the block it was seen in
@@ -59,14 +85,23 @@ __device__ __forceinline__ void aux_fail(uint32_t *err, uint32_t code, uint32_t 
     if (atomicCAS(&err[0], 0u, code) == 0u) err[1] = blk;
 }
 
+// {degree, label} of every vertex side by side: one 8-byte gather per path vertex instead of two 4-byte ones (the leaf
+// level issues 1.2e9 of them at config 3 and is bound by their number)
+__global__ void k_aux_pack_vertex(uint32_t n, const uint32_t *__restrict__ degree, const uint32_t *__restrict__ labels,
+                                  uint64_t *__restrict__ vdl)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
+        vdl[v] = (uint64_t)degree[v] | ((uint64_t)labels[v] << 32);
+}
+
 // One wave per node block; blocks of another level return after reading their first bytes.
 //   level 0: entry -> son = index of a path of the partition -> its vertices -> their degrees and label features
 //   level k: entry -> son = child block (already done: the launches go bottom-up) -> the child's arrays; the entry's
 //            upper bounds give the child's key
 __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ image, uint32_t n_nodes, int level, uint32_t D,
                                                    uint32_t L, uint32_t e, uint64_t cnt, const uint32_t *__restrict__ tuples,
-                                                   uint32_t n, const uint32_t *__restrict__ degree,
-                                                   const double *__restrict__ x, double *__restrict__ key,
+                                                   uint32_t n, const uint64_t *__restrict__ vdl,
+                                                   const double *__restrict__ xtab, double *__restrict__ key,
                                                    uint32_t *__restrict__ adeg, double *__restrict__ ambr,
                                                    uint32_t *__restrict__ err)
 {
@@ -101,16 +136,18 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                 }
             }
             for (uint32_t j = 0; j < L; j++) {
-                uint32_t d = 0, v = 0;
+                uint32_t d = 0, lab = 0;
                 bool okv = ok;
                 if (ok) {
                     if (level == 0) {
-                        v = tuples[(uint64_t)son * L + j];
+                        const uint32_t v = tuples[(uint64_t)son * L + j];
                         if (v >= n) {
                             aux_fail(err, 3u, (uint32_t)b);
                             okv = false;
                         } else {
-                            d = degree[v];
+                            const uint64_t w = vdl[v];  // {degree, label}: an 8 MB table, unlike the n x e table of x rows
+                            d = (uint32_t)w;
+                            lab = (uint32_t)(w >> 32);
                         }
                     } else {
                         d = adeg[(uint64_t)son * L + j];
@@ -126,7 +163,9 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                     double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
                     if (okv) {
                         if (level == 0) {
-                            lo = hi = x[(uint64_t)v * e + kk];  // pde_label (custom.h:561-567): x of the path's vertices
+                            // pde_label (custom.h:561-567) = x of the path's vertices = the label's row of the table
+                            // (gen_vde_x, custom.h:492-511): a 1 KB table instead of a random 8-byte gather per dimension
+                            lo = hi = xtab[(uint64_t)lab * e + kk];
                         } else {
                             lo = ambr[((uint64_t)son * D + k) * 2];
                             hi = ambr[((uint64_t)son * D + k) * 2 + 1];
@@ -149,6 +188,88 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                 for (uint32_t k = 0; k < D; k++) kv -= ld_f64(ent + (2 * k + 1) * 8);  // custom.h:324-328, same order
                 key[son] = kv;
             }
+        }
+    }
+}
+
+// The leaf level again, for compile-time path length and embedding width (what gnnpe_count_paths produces: L = 3 or 4,
+// e with a specialised emit kernel).  The generic kernel above walks a leaf as twelve dependent steps -- header, entry
+// count, son, then per path position vertex -> degree / label -> feature row -> a wave-wide reduction -- and a leaf cost a
+// resident wave ~18 us (5.3 M leaves: 11.7 of the pass's 14.4 ms at config 3).  Here the header is one load, the vertices
+// of all positions are fetched together, then their {degree, label} words, and the L + 2 L e reductions are unrolled
+// side by side on DPP.  Measured at config 3 (bench.py index_build.aux_index_ms): 14.4 -> 13.4 (label table instead of x
+// gathers) -> 12.7 (this kernel) -> 11.7 (one gather per vertex) -> 10.3 ms (DPP instead of ds_bpermute); staging the
+// block through LDS with coalesced loads changed nothing (10.4).
+template <int LC, int EC>
+__global__ __launch_bounds__(256) void k_aux_leaves(const char *__restrict__ image, uint32_t n_nodes, uint64_t cnt,
+                                                    const uint32_t *__restrict__ tuples, uint32_t n,
+                                                    const uint64_t *__restrict__ vdl,
+                                                    const double *__restrict__ xtab, uint32_t *__restrict__ adeg,
+                                                    double *__restrict__ ambr, uint32_t *__restrict__ err)
+{
+    constexpr int D = LC * EC;
+    constexpr uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
+    static_assert(cap <= 64, "one entry per lane");
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t b = w0; b < n_nodes; b += nw) {
+        const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;
+        const uint64_t h = *reinterpret_cast<const uint64_t *>(blk);  // level (1 byte), entry count (4 bytes): blocks are 4 KiB aligned
+        if ((int)(int8_t)(h & 0xFFu) != 0) continue;
+        const uint32_t ne = (uint32_t)(h >> 8);
+        if (ne > cap) {
+            if (lane == 0) aux_fail(err, 4u, (uint32_t)b);
+            continue;
+        }
+        if (ne == 0) continue;  // the empty tree's root leaf keeps the constructor's zeros (custom.h:159-164)
+        bool ok = lane < ne;
+        uint32_t son = 0;
+        if (ok) {
+            son = (uint32_t)ld_i32(blk + 5 + (uint64_t)lane * esz + 16 * D);
+            if (son >= cnt) {
+                aux_fail(err, 1u, (uint32_t)b);
+                ok = false;
+            }
+        }
+        uint32_t v[LC], d[LC], lab[LC];
+#pragma unroll
+        for (int j = 0; j < LC; j++) v[j] = ok ? tuples[(uint64_t)son * LC + j] : 0u;
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            if (ok && v[j] >= n) {
+                aux_fail(err, 3u, (uint32_t)b);
+                ok = false;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LC; j++) {
+            const uint64_t w = ok ? vdl[v[j]] : 0ull;
+            d[j] = (uint32_t)w;
+            lab[j] = (uint32_t)(w >> 32);
+        }
+        double lo[D], hi[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double pl = ok ? xtab[(uint64_t)lab[k / EC] * EC + k % EC] : 0.0;  // pde_label (custom.h:561-567)
+            lo[k] = ok ? pl : __builtin_huge_val();
+            hi[k] = ok ? pl : -__builtin_huge_val();
+        }
+#pragma unroll
+        for (int j = 0; j < LC; j++) d[j] = dpp_max_u32(d[j]);
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            lo[k] = dpp_min_f64(lo[k]);
+            hi[k] = dpp_max_f64(hi[k]);
+        }
+        if (lane == 63) {  // the reductions end in the last lane
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                ambr[(b * D + k) * 2] = lo[k];
+                ambr[(b * D + k) * 2 + 1] = hi[k];
+            }
+#pragma unroll
+            for (int j = 0; j < LC; j++) adeg[b * LC + j] = d[j];
         }
     }
 }
@@ -205,10 +326,25 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2407 of the context's small buffer
     GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 8, c->stream));
     const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
-    for (int level = 0; level <= (int)root_level; level++)
+    if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8))) return rc;
+    if (c->n)
+        hipLaunchKernelGGL(k_aux_pack_vertex, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, deg, c->labels.as<uint32_t>(),
+                           c->aux_vdl.as<uint64_t>());
+    // the leaf level -- almost all of the nodes -- through the specialised kernel where there is one (D >= 4: one entry per lane)
+    int first_generic = 0;
+#define GNNPE_AUXL(LL, EE)                                                                                               \
+    if (first_generic == 0 && L == LL && c->e == EE) {                                                                   \
+        hipLaunchKernelGGL((k_aux_leaves<LL, EE>), dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream,           \
+                           (const char *)dev_image, N, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(),    \
+                           c->xtab.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);               \
+        first_generic = 1;                                                                                               \
+    }
+    GNNPE_AUXL(3, 2) GNNPE_AUXL(3, 3) GNNPE_AUXL(3, 4) GNNPE_AUXL(3, 8) GNNPE_AUXL(4, 1) GNNPE_AUXL(4, 2) GNNPE_AUXL(4, 3) GNNPE_AUXL(4, 4) GNNPE_AUXL(4, 8)
+#undef GNNPE_AUXL
+    for (int level = first_generic; level <= (int)root_level; level++)
         hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, level, D,
-                           L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, deg, c->x.as<double>(), c->aux_key.as<double>(),
-                           c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);
+                           L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
+                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);
     GNNPE_HIP_TRY(hipGetLastError());
     uint32_t err[2] = {0, 0};
     GNNPE_HIP_TRY(hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
