@@ -103,15 +103,24 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                                                    uint32_t n, const uint64_t *__restrict__ vdl,
                                                    const double *__restrict__ xtab, double *__restrict__ key,
                                                    uint32_t *__restrict__ adeg, double *__restrict__ ambr,
-                                                   uint32_t *__restrict__ err)
+                                                   uint32_t *__restrict__ err, uint32_t *__restrict__ upper,
+                                                   uint32_t *__restrict__ n_upper)
 {
+    // level 0 visits every block and lists the inner nodes it passes (a few per thousand blocks); the launches of the
+    // upper levels walk that list instead of the whole image (five launches over 5.4 M block headers were 2.5 ms of the
+    // pass at config 3)
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t w0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
-    for (uint64_t b = w0; b < n_nodes; b += nw) {
+    const uint64_t n_visit = level == 0 ? (uint64_t)n_nodes : (uint64_t)*n_upper;
+    for (uint64_t it = w0; it < n_visit; it += nw) {
+        const uint64_t b = level == 0 ? it : (uint64_t)upper[it];
         const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;  // block 0 of the file is the header (blk_file.cpp:110)
-        if ((int)blk[0] != level) continue;
+        if ((int)blk[0] != level) {
+            if (level == 0 && lane == 0) upper[atomicAdd(n_upper, 1u)] = (uint32_t)b;
+            continue;
+        }
         const int32_t ne_raw = ld_i32(blk + 1);
         if (ne_raw < 0 || (uint32_t)ne_raw > cap) {
             if (lane == 0) aux_fail(err, 4u, (uint32_t)b);
@@ -198,14 +207,15 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
 // resident wave ~18 us (5.3 M leaves: 11.7 of the pass's 14.4 ms at config 3).  Here the header is one load, the vertices
 // of all positions are fetched together, then their {degree, label} words, and the L + 2 L e reductions are unrolled
 // side by side on DPP.  Measured at config 3 (bench.py index_build.aux_index_ms): 14.4 -> 13.4 (label table instead of x
-// gathers) -> 12.7 (this kernel) -> 11.7 (one gather per vertex) -> 10.3 ms (DPP instead of ds_bpermute); staging the
-// block through LDS with coalesced loads changed nothing (10.4).
+// gathers) -> 12.7 (this kernel) -> 11.7 (one gather per vertex) -> 10.3 ms (DPP instead of ds_bpermute) -> 8.2 (upper
+// levels from a list); staging the block through LDS with coalesced loads changed nothing (10.4).
 template <int LC, int EC>
 __global__ __launch_bounds__(256) void k_aux_leaves(const char *__restrict__ image, uint32_t n_nodes, uint64_t cnt,
                                                     const uint32_t *__restrict__ tuples, uint32_t n,
                                                     const uint64_t *__restrict__ vdl,
                                                     const double *__restrict__ xtab, uint32_t *__restrict__ adeg,
-                                                    double *__restrict__ ambr, uint32_t *__restrict__ err)
+                                                    double *__restrict__ ambr, uint32_t *__restrict__ err,
+                                                    uint32_t *__restrict__ upper, uint32_t *__restrict__ n_upper)
 {
     constexpr int D = LC * EC;
     constexpr uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
@@ -216,7 +226,10 @@ __global__ __launch_bounds__(256) void k_aux_leaves(const char *__restrict__ ima
     for (uint64_t b = w0; b < n_nodes; b += nw) {
         const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;
         const uint64_t h = *reinterpret_cast<const uint64_t *>(blk);  // level (1 byte), entry count (4 bytes): blocks are 4 KiB aligned
-        if ((int)(int8_t)(h & 0xFFu) != 0) continue;
+        if ((int)(int8_t)(h & 0xFFu) != 0) {  // an inner node: listed for the launches of the upper levels
+            if (lane == 0) upper[atomicAdd(n_upper, 1u)] = (uint32_t)b;
+            continue;
+        }
         const uint32_t ne = (uint32_t)(h >> 8);
         if (ne > cap) {
             if (lane == 0) aux_fail(err, 4u, (uint32_t)b);
@@ -323,8 +336,10 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     GNNPE_HIP_TRY(hipMemsetAsync(c->aux_key.p, 0, (size_t)N * 8, c->stream));
     GNNPE_HIP_TRY(hipMemsetAsync(c->aux_deg.p, 0, (size_t)N * L * 4, c->stream));
     GNNPE_HIP_TRY(hipMemsetAsync(c->aux_mbr.p, 0, (size_t)N * 2 * D * 8, c->stream));
-    uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2407 of the context's small buffer
-    GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 8, c->stream));
+    uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2411 of the context's small buffer: error code, block, list length
+    uint32_t *d_nup = d_err + 2;
+    GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 12, c->stream));
+    if ((rc = c->aux_upper.reserve(((size_t)N + 1) * 4))) return rc;
     const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
     if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8))) return rc;
     if (c->n)
@@ -336,7 +351,8 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     if (first_generic == 0 && L == LL && c->e == EE) {                                                                   \
         hipLaunchKernelGGL((k_aux_leaves<LL, EE>), dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream,           \
                            (const char *)dev_image, N, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(),    \
-                           c->xtab.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);               \
+                           c->xtab.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,                \
+                           c->aux_upper.as<uint32_t>(), d_nup);                                                          \
         first_generic = 1;                                                                                               \
     }
     GNNPE_AUXL(3, 2) GNNPE_AUXL(3, 3) GNNPE_AUXL(3, 4) GNNPE_AUXL(3, 8) GNNPE_AUXL(4, 1) GNNPE_AUXL(4, 2) GNNPE_AUXL(4, 3) GNNPE_AUXL(4, 4) GNNPE_AUXL(4, 8)
@@ -344,7 +360,8 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     for (int level = first_generic; level <= (int)root_level; level++)
         hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, level, D,
                            L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
-                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err);
+                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
+                           c->aux_upper.as<uint32_t>(), d_nup);
     GNNPE_HIP_TRY(hipGetLastError());
     uint32_t err[2] = {0, 0};
     GNNPE_HIP_TRY(hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
