@@ -970,8 +970,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         }
 #undef GNNPE_L
     } else if (var == kVarRanked) {
-        // a resident grid: every wave walks its share of the start vertices (w, w + waves, ...), the next start's
-        // records in flight while the current one is emitted
+        // a resident grid: every wave walks its share of the start vertices (w, w + waves, ...): the waves in flight
+        // write one moving window of the output
         const StartRec *sr = c->srec.as<StartRec>();
         const bool packed = packed_ids(c);
 #define GNNPE_LK(KERN)                                                                                                  \
