@@ -245,8 +245,8 @@ def test_reference_online_consumes_pair_major_index(tmp_path):
 @pytest.mark.parametrize("n,m,p", [(100_000, 1_000_000, 4), (1_000_000, 10_000_000, 8)])
 def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
     """BASELINE config 2 (100K / 1M, 2.0e7 paths, p = 4) and configs 3 / 4 (1M / 10M, 2.0e8 paths, p = 8: 22 GB of
-    index.dat): every partition's image passes the oracle's validator of the consumer's constraints, holds every path
-    of the partition exactly once with son = its index inside the partition, and lo = hi = its pde row, bit for bit
+    index.dat): every partition's image (at the larger size: three of the eight, the header of the others) passes the oracle's
+    validator of the consumer's constraints, holds every path of the partition exactly once with son = its index inside the partition, and lo = hi = its pde row, bit for bit
     (paths and vde from the oracle's all-core pass)."""
     from gnnpe_amd import binding
     if n >= 1_000_000:
@@ -262,9 +262,14 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
     P, ovde, so, ref, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
     assert total == P and np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
     seen = 0
+    full = set(range(p)) if n < 1_000_000 else {0, p // 2, p - 1}  # 22 GB through the host validator takes a minute: three of eight
     for pid in range(p):
         mine = _partition_paths(ref, mem, pid)
         img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        if pid not in full:  # the other partitions: header only (entry count, node counts, file size)
+            assert hdr[3] == len(mine) and nbytes == (hdr[1] + 1) * 4096 and hdr[4] == -(-len(mine) // 38)
+            seen += len(mine)
+            continue
         d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
         assert d["dim"] == 6 and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
         order = np.argsort(d["leaf_son"], kind="stable")
