@@ -268,15 +268,20 @@ int main(int argc, char **argv)
     if (o.mode == "online" || o.mode == "filter") return run_filter(o);
     if (o.mode != "offline") return 0;  // the reference does nothing for other modes
 
-    // HIP start-up (0.1-0.2 s: runtime initialisation, context, code objects) runs beside the graph load
-    int early_ndev = -1;
-    gnnpe_ctx *early_ctx = nullptr;
-    std::thread *warm = nullptr;
-    if (o.gpus == 1)
-        warm = new std::thread([&early_ndev, &early_ctx] {
+    // HIP start-up (0.1-0.2 s: runtime initialisation, context, code objects) runs beside the graph load.  An error
+    // exit in between (die() -> exit()) must not tear the process down under that thread: it is joined first.
+    static int early_ndev = -1;
+    static gnnpe_ctx *early_ctx = nullptr;
+    static std::thread *warm = nullptr;
+    if (o.gpus == 1) {
+        warm = new std::thread([] {
             early_ndev = gnnpe_device_count();
             if (early_ndev > 0) early_ctx = gnnpe_create(0);
         });
+        atexit([] {
+            if (warm && warm->joinable()) warm->join();
+        });
+    }
 
     StaticGraph g;
     std::string err;
@@ -302,6 +307,7 @@ int main(int argc, char **argv)
     if (warm) {
         warm->join();
         delete warm;
+        warm = nullptr;
     }
     const int ndev = early_ndev >= 0 ? early_ndev : gnnpe_device_count();
     if (ndev <= 0) die("no HIP device: this tool has no CPU fallback");

@@ -65,7 +65,9 @@ def test_input_validation_fails_loudly(tmp_path):
     r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2", "-q", os.path.join(root, "nope.graph"))
     assert r.returncode == 255 and "Can not open the graph file" in r.stdout
     r = _run("-f", root, "-d", gp, "-m", "online", "-p", "2", "-q", gp)
-    assert (r.returncode == 1 and "no HIP device" in r.stderr) or (r.returncode == 0 and "Answer Number:" in r.stdout)
+    # (on a GPU box the 50-vertex data graph used as its own query is refused by the frozen refinement: 1..32 vertices)
+    assert (r.returncode == 1 and ("no HIP device" in r.stderr or "query graphs of 1..32 vertices" in r.stderr)) or \
+        (r.returncode == 0 and "Answer Number:" in r.stdout)
     # membership.txt missing / short / duplicate vertex / partition out of range
     os.rename(os.path.join(root, "gnn-pe", "membership.txt"), os.path.join(root, "gnn-pe", "m.bak"))
     r = _run("-f", root, "-d", gp, "-p", "2")
