@@ -492,15 +492,11 @@ def main():
         # the tree's auxiliary index (custom.h:268-364; the reference rebuilds it at every online start): device pass only
         aux_ms = []
         img, nbytes, hdr = eng.build_index_partition_device(0)
-        k_, d_, m_ = binding._vp(), binding._vp(), binding._vp()
-        nn_, dd_ = binding.C.c_uint32(), binding.C.c_uint32()
         for _ in range(3):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-            eng._ck(eng.lib.gnnpe_aux_index_device(eng.ctx, binding._dev(img), nbytes, total, L, binding._dev(out_ids),
-                                                   binding.C.byref(k_), binding.C.byref(d_), binding.C.byref(m_),
-                                                   binding.C.byref(nn_), binding.C.byref(dd_)))
+            eng.aux_index_device_ptrs(img, nbytes, total, L, out_ids)
             ev1.record()
             torch.cuda.synchronize()
             aux_ms.append(ev0.elapsed_time(ev1))

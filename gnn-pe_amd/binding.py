@@ -532,6 +532,15 @@ class Engine:
         aux = None if aux_paths is None else (C.c_char_p * len(aux_paths))(*[p.encode() for p in aux_paths])
         self._ck(self.lib.gnnpe_build_index_files(self.ctx, len(paths), arr, aux))
 
+    def aux_index_device_ptrs(self, dev_image, nbytes, cnt, L, dev_tuples):
+        """The same pass, results left on the device: (key ptr, degrees ptr, label_mbr ptr, n_nodes, D) -- context-owned
+        arrays, valid until the next call."""
+        k, d, m = _vp(), _vp(), _vp()
+        N, D = C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.gnnpe_aux_index_device(self.ctx, _dev(dev_image), int(nbytes), int(cnt), int(L), _dev(dev_tuples),
+                                                 C.byref(k), C.byref(d), C.byref(m), C.byref(N), C.byref(D)))
+        return k.value, d.value, m.value, N.value, D.value
+
     def aux_index_device(self, dev_image, nbytes, cnt, L, dev_tuples):
         """Partition::build_auxiliary_index (custom.h:268-364) over an index.dat image in device memory; dev_tuples =
         the partition's paths [cnt x L] in partition order.  Returns host copies: key[N], degrees[N x L], label_mbr[N x 2D]."""
