@@ -1,0 +1,24 @@
+#!/bin/bash
+# fabric-side counters of the count kernel (k_rows_rank) at config 3: one rocprofv3 --pmc pass per set over scripts/count_ab.py
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+i=0
+for set in "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rm -rf gpurun_out/rows_pmc_$i
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/rows_pmc_$i -- python3 scripts/count_ab.py "A=1" > gpurun_out/rows_pmc_$i.log 2>&1
+  python3 - "$i" <<'PY'
+import csv, glob, sys
+i = sys.argv[1]
+for f in glob.glob(f"gpurun_out/rows_pmc_{i}/*/*_counter_collection.csv"):
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_rows_rank" in r["Kernel_Name"]:
+            per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
+            per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    for c, v in sorted(per.items()):
+        vals = list(v.values())
+        print(f"{c:40s} mean {sum(vals)/len(vals):.5g} over {len(vals)} launches")
+PY
+done
