@@ -351,14 +351,14 @@ def main():
     fill_ms = []
 
     def one_step(timed):
+        ev0 = torch.cuda.Event(enable_timing=True)  # created before the count: nothing but the launch after its read-back
+        ev1 = torch.cuda.Event(enable_timing=True)
         if world > 1:
             sb.exchange_vde()
             t = sb.count_begin()  # the all-gather of the ranks' totals runs beside the fill; collected below
         else:
             eng.vde(want=False)
             t = sb._count_single()
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
         eng.fill_paths_device(0, t, out_ids, out_pde, None)
         ev1.record()
