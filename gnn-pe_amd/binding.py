@@ -60,6 +60,10 @@ SIGNATURES = {
     "gnnpe_count_paths": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
     "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
     "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    "gnnpe_count_paths_enqueue": (C.c_int, [_vp, C.c_uint32]),
+    "gnnpe_count_total": (C.c_int, [_vp, _u64p]),
+    "gnnpe_count_total_device": (C.c_int, [_vp, _vp]),
+    "gnnpe_fill_paths_capped_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "gnnpe_path_partitions_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "gnnpe_text_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_uint64, _u64p]),
     "gnnpe_text_ids": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p]),
@@ -401,6 +405,26 @@ class Engine:
         self.total = tot.value
         self.l = l
         return (tot.value, ps) if per_start else tot.value
+
+    def count_paths_enqueue(self, l=2):
+        """The count enqueued only (no read-back); count_total() fetches the number, count_total_device() copies it
+        to a device word a collective can send."""
+        self._ck(self.lib.gnnpe_count_paths_enqueue(self.ctx, l))
+        self.total = None
+        self.l = l
+
+    def count_total(self):
+        tot = C.c_uint64()
+        self._ck(self.lib.gnnpe_count_total(self.ctx, C.byref(tot)))
+        self.total = tot.value
+        return tot.value
+
+    def count_total_device(self, dev_u64):
+        self._ck(self.lib.gnnpe_count_total_device(self.ctx, _dev(dev_u64)))
+
+    def fill_paths_capped_device(self, cap_rows, dev_vids=None, dev_pde=None):
+        """Rows [0, min(total, cap_rows)) into buffers of cap_rows rows; the host never learns the total."""
+        self._ck(self.lib.gnnpe_fill_paths_capped_device(self.ctx, int(cap_rows), _dev(dev_vids), _dev(dev_pde)))
 
     # R2 + R5: emit half (gen_pde, custom.h:546-572)
     def fill_paths(self, begin=0, end=None, ids=True, pde=True, pde_label=False, L=None):

@@ -12,9 +12,12 @@
 
 #include "../../include/gnnpe_hip.h"
 
+struct gnnpe_ctx;
+
 namespace gnnpe {
 
 void set_error(const char *fmt, ...);
+int resolve_total(gnnpe_ctx *c);  // gnnpe_engine.hip: fetch the count's total if the last count was enqueue-only
 
 #define GNNPE_HIP_TRY(expr)                                                                       \
     do {                                                                                          \
@@ -128,6 +131,7 @@ struct gnnpe_ctx {
     uint32_t l = 0;
     uint64_t n_edges = 0;  // directed (start, middle) pairs of the slab
     uint64_t total_paths = 0;
+    bool total_known = false;  // false after gnnpe_count_paths_enqueue until gnnpe::resolve_total fetches eoff[n_edges]
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
     int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default), 1 = generic pair-wave
     bool slab_struct_valid = false;  // poffs / n_edges match the current graph, order and slab

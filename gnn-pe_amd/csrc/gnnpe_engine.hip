@@ -71,6 +71,19 @@ static int ensure_rank_arrays(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+// The count leaves its total on the device (eoff[n_edges]); gnnpe_count_paths_enqueue does not fetch it.  Everything
+// that needs the number on the host (range checks, the index build) resolves it here: one 8-byte read-back.
+int resolve_total(gnnpe_ctx *c)
+{
+    if (!c->counted || c->total_known) return GNNPE_OK;
+    uint64_t w = 0;
+    int rc = read_back_u64(c, c->eoff.as<uint64_t>() + c->n_edges, 8, &w);
+    if (rc) return rc;
+    c->total_paths = w;
+    c->total_known = true;
+    return GNNPE_OK;
+}
+
 // blocks of a kernel that fit one CU (occupancy query, once per instantiation)
 template <class K> static int blocks_per_cu(K kernel)
 {
@@ -764,7 +777,7 @@ static int ensure_slab_struct(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
+static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total, bool fetch_total)
 {
     GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
@@ -896,12 +909,18 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
                            c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
         GNNPE_HIP_TRY(hipGetLastError());
     }
-    if ((rc = read_back_u64(c, c->eoff.as<uint64_t>() + ne, 8, &w))) return rc;
-    c->total_paths = w;
     c->l = l;
     c->counted = true;
     c->count_gen++;
     c->counted_variant = var;
+    c->total_known = false;
+    c->total_paths = 0;
+    if (!fetch_total) return GNNPE_OK;  // enqueue-only: the total stays in eoff[ne] until somebody asks (resolve_total)
+    if ((rc = resolve_total(c))) {
+        c->counted = false;
+        return rc;
+    }
+    w = c->total_paths;
     // embeddings of the adjacency entries, when the vde table is already there (keeps it out of the fill)
     if (c->have_vde && (var == kVarPairWave || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
@@ -915,12 +934,52 @@ int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64
     return GNNPE_OK;
 }
 
+int gnnpe_count_paths(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total)
+{
+    return count_paths_impl(c, l, host_per_start, host_total, true);
+}
+
+int gnnpe_count_paths_enqueue(gnnpe_ctx *c, uint32_t l)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_REQUIRE(l == 2 && c->fill_variant == kVarRanked && fast_e(c->have_table ? c->e : 2), GNNPE_ERR_UNSUPPORTED,
+                  "gnnpe_count_paths_enqueue: l=2 with a specialised embedding width only (use gnnpe_count_paths)");
+    return count_paths_impl(c, l, nullptr, nullptr, false);
+}
+
+int gnnpe_count_total(gnnpe_ctx *c, uint64_t *host_total)
+{
+    GNNPE_REQUIRE(c && c->counted && host_total, GNNPE_ERR_ARG, "gnnpe_count_total: no count on this context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc = resolve_total(c);
+    if (rc) return rc;
+    *host_total = c->total_paths;
+    return GNNPE_OK;
+}
+
+int gnnpe_count_total_device(gnnpe_ctx *c, void *dev_u64)
+{
+    GNNPE_REQUIRE(c && c->counted && dev_u64, GNNPE_ERR_ARG, "gnnpe_count_total_device: no count on this context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    GNNPE_HIP_TRY(hipMemcpyAsync(dev_u64, c->eoff.as<uint64_t>() + c->n_edges, 8, hipMemcpyDeviceToDevice, c->stream));
+    return GNNPE_OK;
+}
+
+// capped: rows [0, min(total, end)) with the total read by nobody on the host -- the kernel clips against the start
+// records, which carry every start vertex' output range
 static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids, void *d_pde, void *d_pdl,
-                       void *d_part)
+                       void *d_part, bool capped = false)
 {
     GNNPE_REQUIRE(c && c->counted, GNNPE_ERR_ARG, "gnnpe_fill_paths: call gnnpe_count_paths first");
-    GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "path range [%llu,%llu) outside [0,%llu]",
-                  (unsigned long long)begin, (unsigned long long)end, (unsigned long long)c->total_paths);
+    if (capped) {
+        GNNPE_REQUIRE(begin == 0 && !d_pdl && !d_part && c->counted_variant == kVarRanked, GNNPE_ERR_UNSUPPORTED,
+                      "capped fill: ids and pde of the rank-sorted l=2 enumeration only");
+    } else {
+        int rc0 = resolve_total(c);
+        if (rc0) return rc0;
+        GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "path range [%llu,%llu) outside [0,%llu]",
+                      (unsigned long long)begin, (unsigned long long)end, (unsigned long long)c->total_paths);
+    }
     GNNPE_REQUIRE((!d_pde && !d_pdl) || c->have_vde, GNNPE_ERR_ARG, "gnnpe_fill_paths: embeddings requested before gnnpe_vde");
     if (begin == end) return GNNPE_OK;
     const int var = c->counted_variant;
@@ -1018,6 +1077,13 @@ int gnnpe_fill_paths_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *de
     return fill_device(c, begin, end, dev_vids, dev_pde, dev_pde_label, nullptr);
 }
 
+int gnnpe_fill_paths_capped_device(gnnpe_ctx *c, uint64_t cap_rows, void *dev_vids, void *dev_pde)
+{
+    GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    return fill_device(c, 0, cap_rows, dev_vids, dev_pde, nullptr, nullptr, true);
+}
+
 int gnnpe_path_partitions_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *dev_part)
 {
     GNNPE_REQUIRE(c && dev_part, GNNPE_ERR_ARG, "null argument");
@@ -1028,8 +1094,10 @@ int gnnpe_path_partitions_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, voi
 int gnnpe_fill_paths(gnnpe_ctx *c, uint64_t begin, uint64_t end, uint32_t *hv, double *hpde, double *hpdl)
 {
     GNNPE_REQUIRE(c && c->counted, GNNPE_ERR_ARG, "gnnpe_fill_paths: call gnnpe_count_paths first");
-    GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "bad path range");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc_t = resolve_total(c);
+    if (rc_t) return rc_t;
+    GNNPE_REQUIRE(begin <= end && end <= c->total_paths, GNNPE_ERR_ARG, "bad path range");
     const uint64_t cnt = end - begin;
     if (!cnt) return GNNPE_OK;
     const uint32_t e = c->have_table ? c->e : 2, L = c->l + 1, D = L * e;

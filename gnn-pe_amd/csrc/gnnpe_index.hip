@@ -1507,6 +1507,7 @@ int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_im
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
     GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
                   "gnnpe_build_index: need gnnpe_vde and gnnpe_count_paths first");
+    if (int rc_t = gnnpe::resolve_total(c)) return rc_t;  // the last count may have been enqueue-only
     GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -1614,6 +1615,7 @@ int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
     GNNPE_REQUIRE(c && path, GNNPE_ERR_ARG, "null argument");
     GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
                   "gnnpe_build_aux_index: need gnnpe_vde and gnnpe_count_paths first");
+    if (int rc_t = gnnpe::resolve_total(c)) return rc_t;  // the last count may have been enqueue-only
     GNNPE_REQUIRE(pid < c->p, GNNPE_ERR_ARG, "partition %u >= %u", pid, c->p);
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc;

@@ -205,13 +205,16 @@ class SlabBuild:
     (load_rows), the replicated order (set_order), slab (set_slab) and label table."""
 
     def __init__(self, eng, n, e, bounds, rank, world, device, nbr_capacity, owned_entries=None, group=None, l=2,
-                 comm=None):
+                 comm=None, force_collectives=False):
         """nbr_capacity: most neighbour entries this rank can RECEIVE (<= 2m); owned_entries: size
         of its own rows -- every peer may ask for all of them, so the send buffer holds
         (world-1) x owned_entries.  l: edges per path (2, or 3 = one more halo hop).  comm: a ThreadRanks.comm(rank)
-        when the ranks are threads of one process sharing a device; None = torch.distributed."""
+        when the ranks are threads of one process sharing a device; None = torch.distributed.
+        force_collectives: run the N > 1 step (halo plan, all-to-all-v, vde all-gather, all-gather of the totals) even
+        with world == 1 -- a 1-rank process group over RCCL executes the multi-GPU code on a single-GPU box."""
         self.eng, self.n, self.e, self.l = eng, int(n), int(e), int(l)
         self.comm = comm
+        self.dist_on = world > 1 or bool(force_collectives)
         self.bounds = np.ascontiguousarray(bounds, np.uint32)
         self.rank, self.world, self.device, self.group = rank, world, device, group
         i32 = dict(dtype=torch.int32, device=device)
@@ -357,6 +360,34 @@ class SlabBuild:
             if r != self.rank and b[r + 1] > b[r]:
                 eng.vde_unpack_slab(int(b[r]), int(b[r + 1]), self.vde_all[r])
 
+    def count_enqueue(self):
+        """The count and the all-gather of the ranks' totals ENQUEUED, nothing read back: the local total goes from the
+        engine's device word straight into the collective's send buffer.  For steps whose outputs were sized by an
+        earlier pass (fill_paths_capped_device clips on the device); count_end() collects the numbers afterwards."""
+        if not hasattr(self, "_tot_dev"):
+            self._tot_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.eng.count_paths_enqueue(self.l)
+        self.eng.count_total_device(self._tot_dev)
+        self._tot_mine = self._tot_dev
+        self._tot_work = None
+        if self.comm is None and not self._staged(self.tot_all):
+            self._tot_work = dist.all_gather_into_tensor(self.tot_all, self._tot_mine, group=self.group, async_op=True)
+        else:
+            self._allgather(self.tot_all, self._tot_mine)
+
+    def step_enqueue(self, out_ids, out_pde, cap_rows):
+        """One rank-step with no host round trip before the fill: vde [+ all-gather] -> count -> totals all-gather
+        (async) -> capped fill.  Returns nothing; count_end() afterwards yields base / totals (one synchronisation, after
+        everything is enqueued)."""
+        if self.dist_on:
+            if not self.halo_installed:
+                self.install_halo()
+            self.exchange_vde()
+        else:
+            self.eng.vde(want=False)
+        self.count_enqueue()
+        self.eng.fill_paths_capped_device(cap_rows, out_ids, out_pde)
+
     def count_begin(self):
         """Local count, and the all-gather of the ranks' totals STARTED: the fill only needs the local total, so over
         RCCL the collective (and its host round trip) runs beside the fill kernel; count_end() collects it."""
@@ -378,6 +409,7 @@ class SlabBuild:
         tots = [int(x) for x in self.tot_all.tolist()]
         self.base = sum(tots[:self.rank])
         self.global_total = sum(tots)
+        self.local_total = tots[self.rank]
         return self.base
 
     def count(self):
@@ -388,16 +420,16 @@ class SlabBuild:
     def step(self, out_ids=None, out_pde=None, out_pde_label=None):
         """One full pass of the hot path for this rank's slab; returns (local paths, global id base).  The halo rows
         are fetched by the first call (or an explicit install_halo) and stay resident."""
-        if self.world > 1:
+        if self.dist_on:
             if not self.halo_installed:
                 self.install_halo()
             self.exchange_vde()
         else:
             self.eng.vde(want=False)
-        total = self.count_begin() if self.world > 1 else self._count_single()
+        total = self.count_begin() if self.dist_on else self._count_single()
         if out_ids is not None or out_pde is not None or out_pde_label is not None:
             self.eng.fill_paths_device(0, total, out_ids, out_pde, out_pde_label)
-        if self.world > 1:
+        if self.dist_on:
             self.count_end()
         return total, self.base
 
@@ -407,7 +439,7 @@ class SlabBuild:
         candidate bitmaps are OR-ed across ranks -- the one reduction of the online side, the analogue of the union
         over partitions in main.cpp:165-171.  Returns the global bitmap [n_query_vertices x ceil(n/32)] uint32."""
         bm, _ = self.eng.filter_candidates(plan, eps)
-        if self.world > 1:
+        if self.dist_on:
             # union of the ranks' bitmaps: all-gather + OR (RCCL/NCCL reject BOR/BAND/BXOR, so no all-reduce)
             t = torch.from_numpy(np.ascontiguousarray(bm).view(np.int32)).reshape(-1)
             if self.comm is None and dist.get_backend(self.group) != "gloo":

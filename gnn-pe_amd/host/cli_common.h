@@ -31,6 +31,9 @@ struct Options {
     bool allow_large = false, timing = false, sidecars = false, write_index = false;
     bool same_device = false;  // testing aid: all --gpus contexts on device 0 (halo by device copies: RCCL needs distinct GPUs)
     std::string transport = "rccl";  // --gpus N > 1: "rccl" (ncclSend/ncclRecv over xGMI) or "copy" (device-to-device copies)
+    // --transport given explicitly: take the slab path (host/slab_offline.cpp) even with --gpus 1 -- a 1-rank communicator
+    // whose exchanges go through librccl (self ncclSend/ncclRecv), i.e. the N > 1 code on a single-GPU box
+    bool transport_explicit = false;
 };
 
 static const char *g_tool = "gnnpe_main";
@@ -84,6 +87,7 @@ inline Options parse_args(int argc, char **argv, const char *tool = "gnnpe_main"
             if (i + 1 >= argc) die(a + " needs a value");
             o.transport = argv[++i];
             if (o.transport != "rccl" && o.transport != "copy") die("--transport must be rccl or copy");
+            o.transport_explicit = true;
             continue;
         }
         if (a == "--allow-large") { o.allow_large = true; continue; }

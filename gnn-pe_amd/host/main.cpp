@@ -273,7 +273,8 @@ int main(int argc, char **argv)
     static int early_ndev = -1;
     static gnnpe_ctx *early_ctx = nullptr;
     static std::thread *warm = nullptr;
-    if (o.gpus == 1) {
+    const bool slab_path = o.gpus > 1 || o.transport_explicit;
+    if (!slab_path) {
         warm = new std::thread([] {
             early_ndev = gnnpe_device_count();
             if (early_ndev > 0) early_ctx = gnnpe_create(0);
@@ -314,9 +315,10 @@ int main(int argc, char **argv)
     if (o.gpus < 1 || (o.gpus > ndev && !o.same_device)) die("--gpus " + std::to_string(o.gpus) + " but " + std::to_string(ndev) + " device(s) present");
     std::vector<double> table((size_t)std::max<uint32_t>(g.labels_count, 1) * o.vde_dim);
     check(gnnpe_host_label_table(std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "label table");
-    if (o.gpus > 1) {
+    if (slab_path) {
         // the north-star split: one thread + one GPU per slab of the order, each with its own rows only, halo by
-        // all-to-all-v, concurrent emit and pwrite (host/slab_offline.cpp)
+        // all-to-all-v, concurrent emit and pwrite (host/slab_offline.cpp); `--gpus 1 --transport rccl` runs the same
+        // code as a 1-rank communicator
         if (o.sidecars) die("--sidecars is a single-GPU option");
         return slab::run_offline_slabs(o, g, sorted_nodes, membership, table, t_start, t_loaded);
     }

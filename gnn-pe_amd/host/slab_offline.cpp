@@ -25,6 +25,7 @@
 #include <deque>
 #include <mutex>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -43,20 +44,41 @@ using gnnpe_host::StaticGraph;
 
 namespace {
 
+// An error inside a rank thread must not exit() the process under its siblings (they may be inside HIP or RCCL calls:
+// that ends in SIGABRT, not in exit code 1).  Everything in this file reports by exception; the rank's entry function
+// records the first message, releases the barrier for the peers, aborts the communicators, and the main thread exits
+// non-zero after joining every rank.  (These two hide cli::die / cli::check inside this namespace on purpose.)
+struct RankError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+[[noreturn]] void die(const std::string &msg) { throw RankError(msg); }
+void check(int rc, const char *what)
+{
+    if (rc != 0) die(std::string(what) + ": " + gnnpe_last_error());
+}
+
 class Barrier {
 public:
     explicit Barrier(int n) : n_(n) {}
     void wait()
     {
         std::unique_lock<std::mutex> lk(mu_);
+        if (aborted_) throw RankError("stopped: another rank failed");
         const uint64_t gen = gen_;
         if (++count_ == n_) {
             count_ = 0;
             gen_++;
             cv_.notify_all();
         } else {
-            cv_.wait(lk, [&] { return gen_ != gen; });
+            cv_.wait(lk, [&] { return gen_ != gen || aborted_; });
+            if (gen_ == gen) throw RankError("stopped: another rank failed");
         }
+    }
+    void abort()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        aborted_ = true;
+        cv_.notify_all();
     }
 
 private:
@@ -64,14 +86,16 @@ private:
     std::condition_variable cv_;
     int n_, count_ = 0;
     uint64_t gen_ = 0;
+    bool aborted_ = false;
 };
 
-// librccl is loaded only when more than one device takes part: a single-GPU run never pays for it
+// librccl is loaded only by the slab path with the rccl transport: a plain single-GPU run never pays for it
 struct Rccl {
     void *lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -88,6 +112,7 @@ struct Rccl {
         GNNPE_SYM(GetUniqueId, "ncclGetUniqueId");
         GNNPE_SYM(CommInitRank, "ncclCommInitRank");
         GNNPE_SYM(CommDestroy, "ncclCommDestroy");
+        GNNPE_SYM(CommAbort, "ncclCommAbort");
         GNNPE_SYM(GroupStart, "ncclGroupStart");
         GNNPE_SYM(GroupEnd, "ncclGroupEnd");
         GNNPE_SYM(Send, "ncclSend");
@@ -98,7 +123,9 @@ struct Rccl {
 };
 
 // Collectives between the rank threads.  Device payloads move by RCCL (default) or by device-to-device copies; the
-// few host words (counts, sizes) are exchanged through shared memory.
+// few host words (counts, sizes) are exchanged through shared memory.  With RCCL a rank's piece for ITSELF takes the
+// same route as the pieces for its peers (ncclSend + ncclRecv to its own rank inside the group): one code path for
+// every N, so `--gpus 1 --transport rccl` on a single-GPU box executes exactly what runs between 8 GPUs.
 class Transport {
 public:
     Transport(int n, bool use_rccl) : n_(n), rccl_on_(use_rccl), bar_(n), pub_(n), words_((size_t)n * n, 0), comms_(n, nullptr)
@@ -122,7 +149,23 @@ public:
     void finish_rank(int r)
     {
         if (rccl_on_ && comms_[r]) rccl_.CommDestroy(comms_[r]);
+        comms_[r] = nullptr;
     }
+    // a rank failed: keep the first message, let the peers out of their barriers and out of RCCL
+    void fail(int r, const std::string &msg)
+    {
+        {
+            std::lock_guard<std::mutex> lk(fail_mu_);
+            if (!failed_) first_error_ = "rank " + std::to_string(r) + ": " + msg;
+            failed_ = true;
+        }
+        bar_.abort();
+        if (rccl_on_)
+            for (auto &cm : comms_)
+                if (cm) rccl_.CommAbort(cm);
+    }
+    bool failed() const { return failed_; }
+    const std::string &first_error() const { return first_error_; }
 
     // every rank contributes one word per peer; returns what the peers addressed to me: out[p] = word rank p gave for r
     std::vector<uint64_t> exchange_words(int r, const std::vector<uint64_t> &to_peer)
@@ -149,14 +192,13 @@ public:
         if (rccl_on_) {
             void *stream = nullptr;
             check(gnnpe_get_stream(ctx, &stream), "get_stream");
-            rccl_.GroupStart();
-            for (int p = 0; p < n_; p++) {
-                if (p == r) continue;
+            if (scount[r] != rcount[r]) die("all_to_all_v: a rank's piece for itself has two sizes");
+            nccl_ok(rccl_.GroupStart(), "ncclGroupStart");
+            for (int p = 0; p < n_; p++) {  // p == r included: the self piece is an RCCL send/recv pair like the others
                 if (scount[p]) nccl_ok(rccl_.Send((const char *)send + soff[p] * esize, scount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
                 if (rcount[p]) nccl_ok(rccl_.Recv((char *)recv + roff[p] * esize, rcount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
             }
             nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
-            if (scount[r]) check(gnnpe_copy_device(ctx, (char *)recv + roff[r] * esize, (const char *)send + soff[r] * esize, scount[r] * esize), "self copy");
             check(gnnpe_sync(ctx), "sync");
             return;
         }
@@ -182,14 +224,12 @@ public:
         if (rccl_on_) {
             void *stream = nullptr;
             check(gnnpe_get_stream(ctx, &stream), "get_stream");
-            rccl_.GroupStart();
-            for (int p = 0; p < n_; p++) {
-                if (p == r) continue;
+            nccl_ok(rccl_.GroupStart(), "ncclGroupStart");
+            for (int p = 0; p < n_; p++) {  // p == r included
                 if (counts[r]) nccl_ok(rccl_.Send(send, counts[r] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
                 if (counts[p]) nccl_ok(rccl_.Recv((char *)recv + off[p] * esize, counts[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
             }
             nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
-            if (counts[r]) check(gnnpe_copy_device(ctx, (char *)recv + off[r] * esize, send, counts[r] * esize), "self copy");
             check(gnnpe_sync(ctx), "sync");
             return;
         }
@@ -219,6 +259,9 @@ private:
     Rccl rccl_;
     ncclUniqueId uid_;
     std::vector<ncclComm_t> comms_;
+    std::mutex fail_mu_;
+    bool failed_ = false;
+    std::string first_error_;
 };
 
 struct DevMem {  // device buffer of one context
@@ -272,16 +315,21 @@ public:
     }
     void close()
     {
+        stop();
+        if (failed_) die("write error");
+    }
+    ~RankWriter() { stop(); }  // an exception on the rank thread unwinds through here: never leave the thread joinable
+
+private:
+    void stop()
+    {
         {
             std::unique_lock<std::mutex> lk(mu_);
             done_ = true;
             cv_.notify_all();
         }
-        th_.join();
-        if (failed_) die("write error");
+        if (th_.joinable()) th_.join();
     }
-
-private:
     struct Item {
         int k, fd;
         uint64_t offset;
@@ -625,6 +673,15 @@ void rank_main(int r, Shared &S)
     gnnpe_destroy(ctx);
 }
 
+void rank_entry(int r, Shared &S)
+{
+    try {
+        rank_main(r, S);
+    } catch (const std::exception &ex) {
+        S.tp->fail(r, ex.what());
+    }
+}
+
 }  // namespace
 
 int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<uint32_t> &sorted_nodes,
@@ -633,6 +690,7 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
 {
     const int R = o.gpus;
     const bool use_rccl = !o.same_device && o.transport != "copy";
+    try {
     Transport tp(R, use_rccl);
     Shared S;
     S.o = &o;
@@ -651,8 +709,12 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
     S.t_emit.assign(R, 0);
     S.t_index.assign(R, 0);
     std::vector<std::thread> th;
-    for (int r = 0; r < R; r++) th.emplace_back(rank_main, r, std::ref(S));
+    for (int r = 0; r < R; r++) th.emplace_back(rank_entry, r, std::ref(S));
     for (auto &t : th) t.join();
+    if (tp.failed()) {  // every rank thread has returned: a clean non-zero exit from the main thread
+        fprintf(stderr, "%s: %s\n", o.tool, tp.first_error().c_str());
+        return 1;
+    }
     if (S.all_fd >= 0 && close(S.all_fd) != 0) die("write error on all_paths.txt");
     for (int fd : S.part_fd)
         if (fd >= 0 && close(fd) != 0) die("write error on partition_paths.txt");
@@ -669,6 +731,10 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
                 (unsigned long long)S.P, R, use_rccl ? "rccl" : "copy", secs(t_start, t_loaded), mx(S.t_halo), mx(S.t_count), mx(S.t_emit),
                 mx(S.t_index), secs(t_start, Clock::now()), (unsigned long long)S.bytes_all, (unsigned long long)S.bytes_part,
                 (unsigned long long)g.offsets[g.n], per.c_str());
+    }
+    } catch (const std::exception &ex) {
+        fprintf(stderr, "%s: %s\n", o.tool, ex.what());
+        return 1;
     }
     return 0;
 }

@@ -165,6 +165,15 @@ int gnnpe_vde_unpack_all(gnnpe_ctx *ctx, uint32_t n_ranks, const uint32_t *bound
  * start is sorted_nodes[slab_begin+i]; *host_total = their sum.  Leaves the scanned offsets on the
  * device for gnnpe_fill_paths*. */
 int gnnpe_count_paths(gnnpe_ctx *ctx, uint32_t l, uint64_t *host_per_start, uint64_t *host_total);
+/* The same count (l=2, the default rank-sorted enumeration) ENQUEUED only: no read-back, no host synchronisation; the
+ * total stays in device memory.  For a step of a multi-GPU build (main.cpp:87-96 across devices) whose outputs were
+ * sized by an earlier pass: count_enqueue -> gnnpe_count_total_device (the word a collective sends) ->
+ * gnnpe_fill_paths_capped_device, with nothing on the host between the launches.  gnnpe_count_total fetches the
+ * number whenever the host wants it (synchronises); every entry point that needs it on the host does so itself. */
+int gnnpe_count_paths_enqueue(gnnpe_ctx *ctx, uint32_t l);
+int gnnpe_count_total(gnnpe_ctx *ctx, uint64_t *host_total);
+/* Copies the last count's total (one uint64) to caller-owned device memory on the context's stream. */
+int gnnpe_count_total_device(gnnpe_ctx *ctx, void *dev_u64);
 
 /* ---- R2 + R5: emit paths and their embeddings (gen_pde, custom.h:546-572) ----------------------- */
 /* Emits the slab-local paths [begin, end) in the reference's order (start vertices in processing
@@ -175,6 +184,10 @@ int gnnpe_fill_paths(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, uint32_t *hos
                      double *host_pde_label);
 int gnnpe_fill_paths_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *dev_vids, void *dev_pde,
                             void *dev_pde_label);
+/* Emits rows [0, min(total, cap_rows)) into buffers of cap_rows rows without the host knowing the total (after
+ * gnnpe_count_paths_enqueue): the kernel clips against the per-start output ranges, so nothing is written beyond
+ * cap_rows.  ids and pde only (either may be NULL). */
+int gnnpe_fill_paths_capped_device(gnnpe_ctx *ctx, uint64_t cap_rows, void *dev_vids, void *dev_pde);
 
 /* Order-sensitive 64-bit checksum of n_rows emitted rows (n_rows x L uint32 on the device) whose first
  * row has global path id first_id; checksums of consecutive chunks ADD (mod 2^64).  For outputs too large

@@ -98,6 +98,19 @@ class FakeEngine:
         self._paths = paths[(r >= self.slab[0]) & (r < self.slab[1])]
         return len(self._paths)
 
+    # enqueue-only count + capped fill (the real engine keeps the total on the device between the two)
+    def count_paths_enqueue(self, l=2):
+        self._total = self.count_paths(l)
+
+    def count_total_device(self, dev_u64):
+        dev_u64[0] = self._total
+
+    def count_total(self):
+        return self._total
+
+    def fill_paths_capped_device(self, cap, out_ids, out_pde):
+        self.fill_paths_device(0, min(cap, len(self._paths)), out_ids, out_pde, None)
+
     def fill_paths_device(self, b, e, out_ids, out_pde, out_pdl):
         p = self._paths[b:e]
         if out_ids is not None:

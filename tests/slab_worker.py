@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--ranges", default=None, help="world 1: JSON list of [begin, end) global id ranges to checksum")
     ap.add_argument("--weights", type=str, default="1,0,0", help="w_paths,w_owned,w_held of dist.plan_slabs")
     ap.add_argument("--threads", type=int, default=0, help="run this many ranks as threads of one process on device 0")
+    ap.add_argument("--force-rccl", type=int, default=0,
+                    help="world 1 only: a 1-rank process group over RCCL (backend nccl) and the N > 1 step -- halo plan, "
+                         "all-to-all-v, vde all-gather, totals all-gather, enqueue-only count + capped fill")
     ap.add_argument("--oracle", type=int, default=0,
                     help="l=2: compare every emitted id and double with the oracle's all-core pass (needs ~15 GB of host memory per 2e8 paths)")
     args = ap.parse_args()
@@ -127,8 +130,10 @@ def main():
     if same:
         local_rank = 0
     backend = "none"
-    if world > 1:
+    grouped = world > 1 or args.force_rccl
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = "gloo" if same else "nccl"
         torch.cuda.set_device(local_rank)
         if same:
@@ -136,7 +141,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     run_rank(args, g, rank, world, local_rank, backend, None)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -154,7 +159,8 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
     eng = binding.Engine(local_rank, stream=stream.cuda_stream)
     owned_entries = len(g["nbrs"])
     cap = len(g["nbrs"]) * (2 if args.l == 3 else 1)
-    if world == 1:
+    forced = bool(getattr(args, "force_rccl", 0)) and world == 1
+    if world == 1 and not forced:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     else:
         rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
@@ -164,8 +170,32 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(args.labels, e))
     sb = SlabBuild(eng, n, e, bounds, rank, world, dev, nbr_capacity=cap, owned_entries=owned_entries, l=args.l,
-                   comm=comm)
+                   comm=comm, force_collectives=forced)
     total, base = sb.step()
+    if forced:
+        # RCCL must really have carried the exchange: the vde table came back through the all-gather, the totals through
+        # theirs; then the step again with nothing read back before the fill (enqueue-only count, capped fill)
+        assert dist.get_backend() == "nccl" and sb.dist_on
+        cap_rows = int(total) + 5
+        ids2 = torch.zeros((cap_rows, L), dtype=torch.int32, device=dev)
+        pde2 = torch.full((cap_rows, L * e), -1.0, dtype=torch.float64, device=dev)
+        sb.step_enqueue(ids2, pde2, cap_rows)
+        assert sb.count_end() == base and sb.local_total == total and sb.global_total == total
+        ids1 = torch.empty((max(total, 1), L), dtype=torch.int32, device=dev)
+        pde1 = torch.empty((max(total, 1), L * e), dtype=torch.float64, device=dev)
+        eng.fill_paths_device(0, total, ids1, pde1, None)
+        torch.cuda.synchronize()
+        assert torch.equal(ids1[:total], ids2[:total]) and torch.equal(pde1[:total], pde2[:total])
+        assert bool((ids2[total:] == 0).all()) and bool((pde2[total:] == -1.0).all())  # nothing beyond the total
+        # a capacity below the total clips on the device
+        small = max(int(total) // 3, 1)
+        ids3 = torch.zeros((small + 7, L), dtype=torch.int32, device=dev)
+        eng.count_paths_enqueue(args.l)
+        eng.fill_paths_capped_device(small, ids3, None)
+        torch.cuda.synchronize()
+        assert torch.equal(ids3[:small], ids1[:small]) and bool((ids3[small:] == 0).all())
+        assert eng.count_total() == total
+        del ids1, ids2, ids3, pde1, pde2
     res = dict(rank=rank, world=world, backend=backend, total=int(total), base=int(base), global_total=int(sb.global_total),
                slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats), owned_entries=int(owned_entries))
 

@@ -37,7 +37,7 @@ def _query_plan(g):
                 degrees=deg[pick].astype(np.uint32), pde=vde[pick].reshape(12, 6))
 
 
-def _worker(rank, world, port, out_dir, bounds, l=2):
+def _worker(rank, world, port, out_dir, bounds, l=2, force=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from fake_engine import FakeEngine
@@ -51,14 +51,21 @@ def _worker(rank, world, port, out_dir, bounds, l=2):
     eng = FakeEngine(Oracle(), g["n"], g["labels"], rows, roff, rnbr, sn, 2)
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     sb = SlabBuild(eng, g["n"], 2, bounds, rank, world, torch.device("cpu"), nbr_capacity=2 * g["m"],
-                   owned_entries=int(roff[-1]), l=l)
+                   owned_entries=int(roff[-1]), l=l, force_collectives=force)
+    assert sb.dist_on
     L = l + 1
     res = []
     for rep in range(2):  # the step is repeatable
         total, base = sb.step()
         ids = torch.zeros((max(total, 1), L), dtype=torch.int32)
         pde = torch.zeros((max(total, 1), 2 * L), dtype=torch.float64)
-        total2, base2 = sb.step(ids, pde)
+        if rep == 1 and l == 2:
+            # the step with no host round trip before the fill: outputs sized by the earlier pass, totals collected after
+            sb.step_enqueue(ids, pde, ids.shape[0])
+            base2 = sb.count_end()
+            total2 = sb.local_total
+        else:
+            total2, base2 = sb.step(ids, pde)
         assert (total2, base2) == (total, base)
         res.append(dict(total=total, base=base, global_total=sb.global_total, ids=ids[:total].numpy(),
                         pde=pde[:total].numpy(), stats=dict(sb.stats)))
@@ -102,6 +109,22 @@ def test_slab_build_equals_single_rank(oracle, tmp_path, world, kind):
     assert sum(len(w) for w in want) > 0
     if kind == "planned":  # partitioning must actually move rows between ranks
         assert all(res[r][0]["stats"]["halo_rows"] > 0 for r in range(world))
+
+
+def test_one_rank_group_runs_the_collective_step(oracle, tmp_path):
+    """world_size 1 with force_collectives: the N > 1 step (halo plan, all-to-all-v, vde all-gather, totals all-gather)
+    over a 1-rank group -- what the single-GPU box runs over RCCL (tests/test_gpu_rccl.py), here over gloo."""
+    g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    bounds = np.array([0, g["n"]], np.uint32)
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), bounds, 2, True), nprocs=1, join=True)
+    ref_ids = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    x, nx, vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)
+    res = pickle.load(open(tmp_path / "r0.pkl", "rb"))
+    for rep in res:
+        assert rep["base"] == 0 and rep["total"] == rep["global_total"] == len(ref_ids)
+        assert np.array_equal(rep["ids"].astype(np.uint32), ref_ids)
+        assert np.array_equal(rep["pde"], vde[ref_ids].reshape(len(ref_ids), 6))
 
 
 def test_slab_build_l3_needs_the_second_hop(oracle, tmp_path):
