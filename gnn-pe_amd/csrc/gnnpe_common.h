@@ -111,6 +111,7 @@ struct gnnpe_ctx {
     uint64_t count_gen = 0, px_gen = 0;
     bool px_valid = false;  // R6 scratch + the assembled index.dat image
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
+    uint32_t halo_min_rank = 0;  // largest min_rank a halo row was truncated with (gnnpe_rows_append); 0 = none
 
     // ---- order (R1) ----
     bool have_order = false;

@@ -251,6 +251,7 @@ static int alloc_vertex_arrays(gnnpe_ctx *c, uint32_t n)
 
 static void invalidate_derived(gnnpe_ctx *c)
 {
+    c->halo_min_rank = 0;  // called by the loaders only: a freshly loaded graph has no halo rows
     c->have_vde = false;
     c->have_deg_all = false;
     c->have_pge = false;
@@ -450,6 +451,11 @@ int gnnpe_set_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end)
 {
     GNNPE_REQUIRE(c && c->have_graph, GNNPE_ERR_ARG, "gnnpe_set_slab: load the graph first");
     GNNPE_REQUIRE(begin <= end && end <= c->n, GNNPE_ERR_ARG, "slab [%u,%u) outside [0,%u]", begin, end, c->n);
+    // halo rows installed with min_rank (gnnpe_rows_append) hold only their entries ranked >= min_rank: a slab that starts
+    // earlier would count paths over incomplete rows
+    GNNPE_REQUIRE(begin >= c->halo_min_rank || begin == end, GNNPE_ERR_ARG,
+                  "slab [%u,%u) starts before rank %u, below which the halo rows on this device were truncated "
+                  "(gnnpe_rows_drop_halo and fetch them again)", begin, end, c->halo_min_rank);
     c->slab_begin = begin;
     c->slab_end = end;
     c->slab_set = true;
@@ -1209,6 +1215,7 @@ int gnnpe_rows_drop_halo(gnnpe_ctx *c)
     GNNPE_HIP_TRY(hipGetLastError());
     c->nbr_used = c->nbr_owned;
     c->n_held = c->n_rows;
+    c->halo_min_rank = 0;
     c->nbr_vde_valid = false;
     c->counted = false;
     return finish_rows(c, 0, nullptr);  // the hub list covers the held rows
@@ -1278,7 +1285,7 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
     if (min_rank > 0 && n_nbrs) {
         // drop the entries ranked before the slab: they can never close a path of this rank
         hipLaunchKernelGGL(k_rows_kept_counts, dim3(grid_for(n_rows * 16)), dim3(kBlock), 0, c->stream, n_rows, src_off,
-                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), min_rank, kept);
+                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), c->n, min_rank, kept);
         if ((rc = scan_u32_to_u64(c, kept, dst_off, n_rows + 1))) return rc;
         if ((rc = read_back_u64(c, dst_off + n_rows, 8, &n_keep))) return rc;
         roff = dst_off;
@@ -1288,7 +1295,7 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
                   (unsigned long long)c->nbr_used, (unsigned long long)n_keep, (unsigned long long)c->nbr_cap);
     if (roff == dst_off)
         hipLaunchKernelGGL(k_rows_compact, dim3(grid_for(n_rows * 64)), dim3(kBlock), 0, c->stream, n_rows, src_off,
-                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), min_rank, dst_off,
+                           (const uint32_t *)dev_nbrs, c->rank.as<uint32_t>(), c->n, min_rank, dst_off,
                            c->nbrs.as<uint32_t>() + c->nbr_used);
     else if (n_nbrs)
         GNNPE_HIP_TRY(hipMemcpyAsync(c->nbrs.as<uint32_t>() + c->nbr_used, dev_nbrs, n_nbrs * 4, hipMemcpyDeviceToDevice,
@@ -1300,6 +1307,7 @@ int gnnpe_rows_append(gnnpe_ctx *c, uint64_t n_rows, const void *dev_ids, const 
                        c->adj_deg.as<uint32_t>(), c->present.as<uint8_t>());
     GNNPE_HIP_TRY(hipGetLastError());
     const uint32_t first_new = c->n_held;
+    c->halo_min_rank = std::max(c->halo_min_rank, min_rank);  // these rows lack their entries ranked below min_rank
     c->nbr_used += n_keep;
     c->n_held += (uint32_t)n_rows;
     c->nbr_vde_valid = false;

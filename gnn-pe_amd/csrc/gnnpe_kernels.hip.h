@@ -442,8 +442,9 @@ __global__ void k_rows_pack(uint64_t n_req, const uint32_t *__restrict__ ids, co
 // Truncated halo rows (multi-GPU): a rank whose slab starts at processing position min_rank never emits a path through
 // a neighbour ranked before it (kept iff rank[c] > rank[s] >= min_rank), so the entries with rank < min_rank of a halo
 // row are dropped when the row is installed.  kept[k] = entries of packed row k that stay; 16 lanes per row.
+// (an id >= n is KEPT, never used as an index: the row validation that follows the install rejects it by name)
 __global__ void k_rows_kept_counts(uint64_t n_rows, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src,
-                                   const uint32_t *__restrict__ rank, uint32_t min_rank, uint32_t *__restrict__ kept)
+                                   const uint32_t *__restrict__ rank, uint32_t n, uint32_t min_rank, uint32_t *__restrict__ kept)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
@@ -453,7 +454,10 @@ __global__ void k_rows_kept_counts(uint64_t n_rows, const uint64_t *__restrict__
         uint32_t cnt = 0;
         if (g < n_rows) {
             const uint64_t a = src_off[g], b = src_off[g + 1];
-            for (uint64_t q = a + sub; q < b; q += 16) cnt += rank[src[q]] >= min_rank ? 1u : 0u;
+            for (uint64_t q = a + sub; q < b; q += 16) {
+                const uint32_t u = src[q];
+                cnt += (u >= n || rank[u] >= min_rank) ? 1u : 0u;
+            }
         }
         cnt += __shfl_xor(cnt, 8);
         cnt += __shfl_xor(cnt, 4);
@@ -466,8 +470,8 @@ __global__ void k_rows_kept_counts(uint64_t n_rows, const uint64_t *__restrict__
 
 // copy the kept entries of packed row k, in order, to dst[dst_off[k] ...): one wave per row
 __global__ void k_rows_compact(uint64_t n_rows, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src,
-                               const uint32_t *__restrict__ rank, uint32_t min_rank, const uint64_t *__restrict__ dst_off,
-                               uint32_t *__restrict__ dst)
+                               const uint32_t *__restrict__ rank, uint32_t n, uint32_t min_rank,
+                               const uint64_t *__restrict__ dst_off, uint32_t *__restrict__ dst)
 {
     const unsigned lane = lane_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -482,7 +486,7 @@ __global__ void k_rows_compact(uint64_t n_rows, const uint64_t *__restrict__ src
             bool keep = false;
             if (q < b) {
                 u = src[q];
-                keep = rank[u] >= min_rank;
+                keep = u >= n || rank[u] >= min_rank;
             }
             const uint64_t mask = __ballot(keep);
             if (keep) dst[o + __popcll(mask & lt)] = u;

@@ -211,7 +211,10 @@ static int load_path_rows(const char *paths_bin, const char *vde_bin, uint32_t n
     memcpy(&version, map + 8, 4);
     memcpy(&L, map + 12, 4);
     memcpy(&P_file, map + 16, 8);
-    if (version != 1 || L < 1 || L > 16 || (uint64_t)st.st_size != 24 + P_file * L * 4) {
+    // bound the count by the file size BEFORE multiplying: a crafted P_file (2^62, L = 4) would wrap the product back to
+    // the 24 header bytes, pass the check and size the buffers below from the wrapped value
+    const uint64_t body = (uint64_t)st.st_size - 24;
+    if (version != 1 || L < 1 || L > 16 || P_file > body / (4ull * L) || P_file * L * 4 != body) {
         munmap(map, (size_t)st.st_size);
         gnnpe::set_error("%s: bad header (version %u, L %u, %llu paths, %lld bytes)", paths_bin, version, L,
                          (unsigned long long)P_file, (long long)st.st_size);
@@ -226,6 +229,11 @@ static int load_path_rows(const char *paths_bin, const char *vde_bin, uint32_t n
         }
     const uint32_t *src = reinterpret_cast<const uint32_t *>(map + 24);
     const size_t D = (size_t)L * e;
+    if (e < 1 || e > 4096 || P > (SIZE_MAX / 16 - 1) / D) {  // (P * D + 1) * 8 must not wrap either
+        munmap(map, (size_t)st.st_size);
+        gnnpe::set_error("%s: %llu paths x %zu doubles do not fit the address space", paths_bin, (unsigned long long)P, D);
+        return GNNPE_ERR_ARG;
+    }
     uint32_t *o_v = (uint32_t *)malloc((P * L + 1) * 4), *o_l = (uint32_t *)malloc((P * L + 1) * 4), *o_d = (uint32_t *)malloc((P * L + 1) * 4);
     double *o_p = (double *)malloc((P * D + 1) * 8), *o_x = (double *)malloc((P * D + 1) * 8);
     if (!o_v || !o_l || !o_d || !o_p || !o_x) {
@@ -377,8 +385,10 @@ int gnnpe_host_load_aux_index(const char *path, uint32_t *n_nodes, uint32_t *L_o
     const bool hdr_ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "GNNPEAUX", 8) == 0 && fread(h, 4, 4, f) == 4 &&
                         fread(&N, 8, 1, f) == 1 && fstat(fileno(f), &st) == 0;
     const uint64_t L = h[1], D = h[2];
-    if (!hdr_ok || h[0] != 1 || L < 1 || L > 16 || D < 1 || D > 512 || N > 0x7FFFFFFFull ||
-        (uint64_t)st.st_size != 32 + N * (8 + 4 * L + 16 * D)) {
+    // N <= 2^31, L <= 16, D <= 512 keep N * (8 + 4L + 16D) far below 2^64; the count is still bounded by the file first
+    const uint64_t node_bytes = 8 + 4 * L + 16 * D;
+    if (!hdr_ok || h[0] != 1 || L < 1 || L > 16 || D < 1 || D > 512 || N > 0x7FFFFFFFull || st.st_size < 32 ||
+        N > ((uint64_t)st.st_size - 32) / node_bytes || (uint64_t)st.st_size != 32 + N * node_bytes) {
         fclose(f);
         gnnpe::set_error("%s: not an aux_index.bin (version %u, L %u, D %u, %llu nodes)", path, h[0], h[1], h[2], (unsigned long long)N);
         return GNNPE_ERR_ARG;

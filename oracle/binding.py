@@ -93,6 +93,8 @@ class Oracle:
         L.orc_offline_parallel.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint32, C.c_int, _f64p, _u64p,
                                            _u32p, _f64p, C.c_uint64]
         L.orc_max_threads.restype = C.c_int
+        L.orc_count_p4.restype = C.c_int
+        L.orc_count_p4.argtypes = [C.c_uint32, _u32p, _u32p, _u64p, _u64p]
         L.orc_filter_candidates.argtypes = [C.c_uint64, C.c_uint32, _u32p, C.c_uint32, _u32p, _u32p, _f64p, C.c_uint32,
                                             C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_double, _u32p]
         self.L = L
@@ -116,6 +118,15 @@ class Oracle:
         return bitmap_to_sets(bm, n)
 
     # all-core CPU port of the device-resident pass (bench.py's second CPU baseline)
+    def count_p4(self, offs, nbrs):
+        """(triangles, number of 4-vertex simple paths) in closed form -- the independent count for l = 3."""
+        offs = np.ascontiguousarray(offs, np.uint32)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        t, p4 = C.c_uint64(), C.c_uint64()
+        if self.L.orc_count_p4(len(offs) - 1, _p(offs, _u32p), _p(nbrs, _u32p), C.byref(t), C.byref(p4)) != 0:
+            raise MemoryError("orc_count_p4")
+        return int(t.value), int(p4.value)
+
     def max_threads(self):
         return int(self.L.orc_max_threads())
 

@@ -702,6 +702,75 @@ uint64_t orc_offline_parallel(uint32_t n, const uint32_t *offsets, const uint32_
     return P;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Independent count for l = 3 (BASELINE config 5; SURVEY D4: the reference's rule custom.h:66-92 with the DFS depth
+ * fixed -- 4-vertex simple paths s-b-c-d, each kept once, from the end whose rank is lower).  No enumeration: the
+ * number of 4-vertex simple paths of a simple graph is
+ *        P4 = sum over edges {u,v} of (deg u - 1)(deg v - 1)  -  3 T,        T = number of triangles
+ * (walks s-b-c-d with s != c and d != b over the middle edge {b,c}, minus those with s == d, which close a triangle:
+ * every triangle is subtracted once per edge).  Triangles by the forward algorithm: every edge oriented from the
+ * lower (degree, id) end to the higher, a triangle is found once at its lowest vertex by intersecting two forward
+ * lists (OpenMP over vertices).  Pinned on the small l = 3 graphs against the fixed-depth DFS (tests/test_oracle_golden.py).
+ * Rows must be ascending (graph.cpp:231-233).
+ * ------------------------------------------------------------------------------------------ */
+int orc_count_p4(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, uint64_t *triangles_out, uint64_t *p4_out)
+{
+    const uint64_t m2 = offsets[n];
+    uint64_t *foff = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    uint32_t *fwd = (uint32_t *)malloc((m2 / 2 + 1) * sizeof(uint32_t));
+    if (!foff || !fwd) {
+        free(foff);
+        free(fwd);
+        return -1;
+    }
+#define ORC_DEG(v) (offsets[(v) + 1] - offsets[(v)])
+#define ORC_BEFORE(a, b) (ORC_DEG(a) < ORC_DEG(b) || (ORC_DEG(a) == ORC_DEG(b) && (a) < (b)))
+    foff[0] = 0;
+    for (uint32_t v = 0; v < n; v++) {
+        uint64_t c = 0;
+        for (uint32_t q = offsets[v]; q < offsets[v + 1]; q++) c += ORC_BEFORE(v, neighbors[q]) ? 1u : 0u;
+        foff[v + 1] = foff[v] + c;
+    }
+    uint64_t tri = 0, edge_term = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : edge_term)
+    for (uint32_t v = 0; v < n; v++) {
+        uint64_t o = foff[v];
+        for (uint32_t q = offsets[v]; q < offsets[v + 1]; q++) {
+            const uint32_t u = neighbors[q];
+            if (ORC_BEFORE(v, u)) {
+                fwd[o++] = u;
+                edge_term += (uint64_t)(ORC_DEG(v) - 1) * (uint64_t)(ORC_DEG(u) - 1);
+            }
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : tri)
+    for (uint32_t v = 0; v < n; v++) {
+        for (uint64_t i = foff[v]; i < foff[v + 1]; i++) {
+            const uint32_t u = fwd[i];
+            uint64_t a = foff[v], ae = foff[v + 1], b = foff[u], be = foff[u + 1];
+            while (a < ae && b < be) {  /* both lists ascend by id (subsequences of ascending rows) */
+                const uint32_t x = fwd[a], y = fwd[b];
+                if (x == y) {
+                    tri++;
+                    a++;
+                    b++;
+                } else if (x < y) {
+                    a++;
+                } else {
+                    b++;
+                }
+            }
+        }
+    }
+#undef ORC_DEG
+#undef ORC_BEFORE
+    free(foff);
+    free(fwd);
+    if (triangles_out) *triangles_out = tri;
+    if (p4_out) *p4_out = edge_term - 3 * tri;
+    return 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -65,6 +65,8 @@ uint64_t orc_offline_parallel(uint32_t n, const uint32_t *offsets, const uint32_
                               const uint32_t *labels, const uint32_t *sorted_nodes, uint32_t e, int threads,
                               double *vde, uint64_t *start_off, uint32_t *ids, double *pde, uint64_t capacity);
 int orc_max_threads(void);
+/* closed-form count of 4-vertex simple paths (l = 3 rule, each path once): sum_E (du-1)(dv-1) - 3 T */
+int orc_count_p4(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, uint64_t *triangles_out, uint64_t *p4_out);
 
 /* ---- R3: label feature (custom.h:492-511), libstdc++ mt19937 + generate_canonical ------- */
 void orc_gen_vde_x(uint32_t label, uint32_t e, double *x_out);

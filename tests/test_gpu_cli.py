@@ -286,3 +286,30 @@ def test_l3_files_match_the_oracle_writers(tmp_path, oracle, gpus):
         oracle.write_partition_paths(exp, want, mem, pid)
         got = os.path.join(d, "gnn-pe", "partitions", f"partition-{pid}", "partition_paths.txt")
         assert open(got, "rb").read() == open(exp, "rb").read()
+
+
+@pytest.mark.parametrize("p,method", [(2, "lp"), (5, "lp"), (3, "bfs")])
+def test_prep_partition_through_engine_and_reference_online(tmp_path, p, method):
+    """SURVEY 8(f)2 end to end (replaces GNN-PE/gnnpe.py:60-76): our prep step partitions Test/data_graph.graph and
+    writes membership.txt + the partition directories, `gnnpe_main -m offline --index` builds all_paths.txt, the
+    partitions' path lists and their index.dat, and the UNTOUCHED reference `main -m online` answers from them.  The
+    answer count does not depend on the partition: 45426 for any p and any partitioner."""
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    import sys
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    query = os.path.join(GOLDEN, "test_graph", "query_graph.graph")
+    tmp = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "gnn-pe_amd", "prep.py"), "-f", tmp + "/", "-d", graph, "-p", str(p),
+                        "--method", method], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    part = np.array([int(l.split()[1]) for l in open(os.path.join(tmp, "gnn-pe", "membership.txt"))])
+    assert len(part) == 3112 and set(part.tolist()) == set(range(p))  # a real partition: every part is used
+    r = subprocess.run([CLI, "-f", tmp + "/", "-d", graph, "-m", "offline", "-p", str(p), "--index"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))["p1"]
+    assert _md5(os.path.join(tmp, "gnn-pe", "all_paths.txt")) == gold["all_paths_md5"]  # all_paths.txt ignores the partition
+    for i in range(p):
+        assert os.path.getsize(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) >= 8192
+    out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q", query, "-m", "online", "-p", str(p)], text=True)
+    assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426

@@ -49,6 +49,7 @@ def test_small_graphs_l3_match_the_fixed_depth_dfs(binding, oracle, ci):
     total, per_start = eng.count_paths(3, per_start=True)
     want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)  # the reference's dfs with the depth fixed
     assert total == len(want)
+    assert total == oracle.count_p4(g["offsets"], g["nbrs"])[1]  # and the closed form that checks config 5 at full size
     assert np.array_equal(per_start, oracle.count_per_start(g["offsets"], g["nbrs"], sn, 4))
     ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
     assert ids.shape == (total, 4) and np.array_equal(ids, want)

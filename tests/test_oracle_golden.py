@@ -149,6 +149,36 @@ def test_edge_cases(oracle):
     assert len(a) > 0 and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["gnm", "dense", "powerlaw", "triangle", "star"])
+def test_p4_closed_form_equals_the_fixed_depth_dfs(oracle, kind):
+    """The independent count used for config 5 at full size (tests/test_gpu_slabs_full.py): number of 4-vertex simple
+    paths = sum_E (du - 1)(dv - 1) - 3 T, against the oracle's restatement of the reference DFS (custom.h:66-92) with the
+    depth fixed to 4 vertices -- hash-set form and closed form -- on graphs small enough to enumerate."""
+    from gnnpe_amd import synth
+    if kind == "gnm":
+        g = synth.gnm_graph(600, 3000, n_labels=7, seed=31)
+    elif kind == "dense":  # many triangles
+        g = synth.gnm_graph(60, 900, n_labels=3, seed=2)
+    elif kind == "powerlaw":
+        g = synth.powerlaw_graph(3000, 20000, exponent=2.1, max_degree=200, seed=5)
+    elif kind == "triangle":
+        g = dict(n=3, offsets=np.array([0, 2, 4, 6], np.uint32), nbrs=np.array([1, 2, 0, 2, 0, 1], np.uint32))
+    else:  # a star has no 4-vertex path at all
+        g = dict(n=6, offsets=np.array([0, 5, 6, 7, 8, 9, 10], np.uint32), nbrs=np.array([1, 2, 3, 4, 5, 0, 0, 0, 0, 0], np.uint32))
+    sn = synth.degree_order(g["offsets"])
+    tri, p4 = oracle.count_p4(g["offsets"], g["nbrs"])
+    assert p4 == len(oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4))
+    if kind in ("dense", "triangle", "star"):
+        assert p4 == len(oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4))
+    # triangles against a dense count
+    n = g["n"]
+    A = np.zeros((n, n))
+    A[np.repeat(np.arange(n), np.diff(g["offsets"].astype(np.int64))), g["nbrs"]] = 1.0
+    assert tri == int(round(np.trace(A @ A @ A) / 6.0))
+    if kind == "triangle":
+        assert (tri, p4) == (1, 0)
+
+
 def test_all_core_port_equals_the_sequential_restatement(oracle):
     """bench.py's all-core CPU baseline (closed form, OpenMP) must produce exactly what the sequential oracle does."""
     from gnnpe_amd import synth

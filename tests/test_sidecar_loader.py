@@ -56,6 +56,13 @@ def test_loader_matches_the_reference_gen_pde(tmp_path):
         binding.host_load_path_sidecar(pb, vb, v["label"], v["degree"])
     with pytest.raises(binding.GnnpeError, match="cannot open"):
         binding.host_load_path_sidecar(str(tmp_path / "missing.bin"), vb, v["label"], v["degree"])
+    # a header whose count wraps the size check (2^62 paths x 4 vertices x 4 bytes = 0 mod 2^64 on a 24-byte file) must be
+    # rejected, not used to size the buffers
+    crafted = str(tmp_path / "crafted.bin")
+    with open(crafted, "wb") as f:
+        f.write(b"GNNPEPTH" + struct.pack("<IIQ", 1, 4, 1 << 62))
+    with pytest.raises(binding.GnnpeError, match="bad header"):
+        binding.host_load_path_sidecar(crafted, vb, v["label"], v["degree"])
 
 
 @pytest.mark.gpu
