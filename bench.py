@@ -240,8 +240,9 @@ def main():
     ap.add_argument("--no-index", action="store_true", help="skip the index-build, online-filter and end-to-end legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
-    ap.add_argument("--placements", type=int, default=5,
-                    help="candidate allocations of the output buffers; the one the emit kernel writes fastest is kept (1 = take what comes)")
+    ap.add_argument("--placements", type=int, default=8,
+                    help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
+                         "writes fastest is kept, the others freed); 1 = take what comes")
     ap.add_argument("--equal-paths", action="store_true",
                     help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
     args = ap.parse_args()
@@ -322,51 +323,51 @@ def main():
     # first pass sizes the outputs (and every internal buffer); not timed
     total, base = sb.step()
 
-    # Where the 12 GB of output land matters on this hardware: a fresh 9.6 GB allocation streams at either ~5.0 or
-    # ~5.7 TB/s (scripts/bw_regions.hip: per-allocation write bandwidth, no pattern between processes), and the emit
-    # kernel follows (3.4 vs 4.0 ms into the same records, scripts/fill_alloc_probe*.py).  A deployment allocates its
-    # output pool once, so the bench does what it would do: five candidate allocations, one untimed fill into each,
-    # the fastest kept, the others freed.  (A plain streaming write as the probe was tried: it does not predict the
-    # emit kernel's time well enough.)  All candidate times are reported; nothing in the timed region changes.
-    def alloc_outputs():
-        ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
-        pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
-        return ids, pde
-
-    cands, cand_ms = [], []
-    for _ in range(max(1, args.placements)):
-        ids_c, pde_c = alloc_outputs()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        eng.fill_paths_device(0, total, ids_c, pde_c, None)
-        ev1.record()
-        torch.cuda.synchronize()
-        cands.append((ids_c, pde_c))
-        cand_ms.append(ev0.elapsed_time(ev1))
-    pick = int(np.argmin(cand_ms))
-    out_ids, out_pde = cands[pick]
-    del cands, ids_c, pde_c
-    torch.cuda.empty_cache()
+    # Where the 12 GB of output land matters on this hardware (a buffer streams at ~5.0 or ~6.3 TB/s for
+    # its whole life, not predictable from its address), so the PRODUCT draws: the library's output pool
+    # (gnnpe_output_pool_create, also used by gnnpe_main and offline.py) allocates `--placements` candidates, times the emit
+    # kernel into each, keeps the fastest and frees the rest.  Every candidate's time is reported, and a plain
+    # take-what-comes allocation is timed beside the pool below (roofline.plain_allocation).
+    D_out = 0 if args.ids_only else e * L
+    pool = binding.OutputPool(eng, max(total, 1), L, D_out, candidates=max(1, args.placements))
+    pool_rep = pool.report()
+    out_ids, out_pde = pool.ids, (pool.pde if D_out else None)
+    cap_rows = pool.rows_cap
+    ids_view = pool.ids_tensor(device)
 
     fill_ms = []
+    enqueue_only = args.fill_variant == 4 and e in (1, 2, 3, 4, 8)
 
-    def one_step(timed):
-        ev0 = torch.cuda.Event(enable_timing=True)  # created before the count: nothing but the launch after its read-back
+    def one_step(timed, ids=None, pde=None, keep=None):
+        """vde [+ all-gather] -> count -> fill, ENQUEUED: no read-back between the launches (the count leaves its total on the
+        device, the fill clips against the buffers' capacity); N > 1 collects the ranks' totals after the fill is queued."""
+        ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        if world > 1:
-            sb.exchange_vde()
-            t = sb.count_begin()  # the all-gather of the ranks' totals runs beside the fill; collected below
+        o_ids, o_pde = (out_ids, out_pde) if ids is None else (ids, pde)
+        if not enqueue_only:  # the generic pair-wave kernel (A/B baseline, widths without a specialised kernel): count with read-back
+            if world > 1:
+                sb.exchange_vde()
+                t = sb.count_begin()
+            else:
+                eng.vde(want=False)
+                t = sb._count_single()
+            ev0.record()
+            eng.fill_paths_device(0, t, o_ids, o_pde, None)
+            ev1.record()
         else:
-            eng.vde(want=False)
-            t = sb._count_single()
-        ev0.record()
-        eng.fill_paths_device(0, t, out_ids, out_pde, None)
-        ev1.record()
+            if world > 1:
+                sb.exchange_vde()
+                sb.count_enqueue()  # count + async all-gather of the totals, straight from the engine's device word
+            else:
+                eng.vde(want=False)
+                eng.count_paths_enqueue(2)
+            ev0.record()
+            eng.fill_paths_capped_device(cap_rows, o_ids, o_pde)
+            ev1.record()
         if world > 1:
             sb.count_end()
         if timed:
-            fill_ms.append((ev0, ev1))
-        return t
+            (fill_ms if keep is None else keep).append((ev0, ev1))
 
     def barrier():
         if world > 1:
@@ -378,9 +379,32 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = one_step(True)
+        one_step(True)
     barrier()
     dt = time.perf_counter() - t0
+    if world == 1:
+        assert (eng.count_total() if enqueue_only else sb.local_total) == total, "the timed steps counted a different number of paths than the sizing pass"
+        sb.local_total = sb.global_total = total
+        sb.base = 0
+    else:
+        assert sb.local_total == total
+
+    # the same steps into ONE plain allocation that takes what comes (what a caller without the pool gets)
+    plain = None
+    if world == 1 and args.placements > 1:
+        p_ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
+        p_pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
+        p_ev = []
+        one_step(False, p_ids, p_pde)
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            one_step(True, p_ids, p_pde, p_ev)
+        barrier()
+        plain = dict(ms_per_step=(time.perf_counter() - tp) * 1e3 / max(3, args.steps // 2),
+                     fill_ms=float(np.mean([a.elapsed_time(b) for a, b in p_ev])))
+        del p_ids, p_pde
+        torch.cuda.empty_cache()
 
     # one more step, untimed, with a device sync after every phase: where the step time goes (reported, not `value`)
     def phase(fn):
@@ -397,13 +421,14 @@ def main():
         _, per_step["vde_ms"] = phase(lambda: eng.vde(want=False))
         t_, per_step["count_ms"] = phase(sb._count_single)
     _, per_step["fill_ms"] = phase(lambda: eng.fill_paths_device(0, t_, out_ids, out_pde, None))
+    per_step["note"] = "one untimed step with a device synchronisation after every phase; the timed steps run without any"
 
     # sanity of what was just timed (outside the timed region): global path count = sum C(deg, 2) and the
     # middle-vertex checksum sum_paths(b) = sum_v v * C(deg v, 2), both closed forms of the input graph
     deg64 = np.diff(g["offsets"].astype(np.int64))
     want_paths = int((deg64 * (deg64 - 1) // 2).sum())
     want_mid = int((np.arange(args.n, dtype=np.int64) * (deg64 * (deg64 - 1) // 2)).sum())
-    chk = torch.stack([out_ids[:total, 1].to(torch.int64).sum(), torch.tensor(total, device=device)]).to(torch.int64)
+    chk = torch.stack([ids_view[:total, 1].to(torch.int64).sum(), torch.tensor(total, device=device)]).to(torch.int64)
     if world > 1:
         chk_h = chk.cpu() if staged else chk
         dist.all_reduce(chk_h, op=dist.ReduceOp.SUM)
@@ -434,13 +459,24 @@ def main():
             traffic_note = (f"GB per launch from {os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command): "
                             f"written {d['write_bytes'] / 1e9:.2f} + read {d['read_bytes'] / 1e9:.2f} (128-byte fabric requests)")
     kname = {1: "k_fill_edge_wave", 4: "k_fill_ranked"}[args.fill_variant]
+    peak_bytes = total * bpp / 1e9  # GB per launch
+    cms = sorted(pool_rep["candidates_ms"])
+    med_ms = float(np.median(cms)) if len(cms) > 1 else None
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_note=traffic_note, bytes_per_path=bpp,
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r02_pmc_fill.json), not this run",
+                    traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms,
-                    output_placement=dict(candidates_fill_ms=[round(x, 3) for x in cand_ms], kept=pick,
-                                          note="one untimed fill into each candidate output allocation, fastest kept; HBM allocations on "
-                                               "this box stream at ~5.0 or ~5.7 TB/s depending on where they land (scripts/bw_regions.hip) "
-                                               "and the emit kernel follows (3.4 vs 4.0 ms); the engine's own buffers take what comes"),
+                    output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],
+                                     probe=pool_rep["probe"],
+                                     frac_median_candidate=(peak_bytes / (med_ms / 1e3) / HBM_PEAK_GBS) if med_ms else None,
+                                     frac_best_candidate=(peak_bytes / (cms[0] / 1e3) / HBM_PEAK_GBS) if med_ms else None,
+                                     note="gnnpe_output_pool_create (product API, also behind gnnpe_main and offline.py): independent candidate "
+                                          "allocations, the emit kernel timed into each, the fastest kept and the others freed; `frac` is the kept "
+                                          "buffer timed live over the steps, frac_median_candidate what the median draw would give"),
+                    plain_allocation=None if plain is None else dict(
+                        launch_ms=plain["fill_ms"], frac=peak_bytes / (plain["fill_ms"] / 1e3) / HBM_PEAK_GBS, ms_per_step=plain["ms_per_step"],
+                        value=global_total / (plain["ms_per_step"] / 1e3),
+                        note="the same steps into one torch.empty allocation that takes what comes (`--placements 1` for a whole run like this)"),
                     step_frac=(global_total * bpp / (ms_per_step / 1e3) / 1e9) / (HBM_PEAK_GBS * world),
                     step_frac_note="the same algorithmic bytes over the whole step (vde + count + scan + fill), per GPU")
 
@@ -517,8 +553,9 @@ def main():
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
     if legs and e == 2:
         out["online_filter"] = online_filter_leg(eng, g, args.seed)
+    del ids_view
+    pool.close()
     eng.close()
-    del out_ids, out_pde
     torch.cuda.empty_cache()
     g2 = None
     if legs and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):

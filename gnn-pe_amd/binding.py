@@ -60,6 +60,10 @@ SIGNATURES = {
     "gnnpe_count_paths": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
     "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
     "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    "gnnpe_output_pool_create": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "gnnpe_output_pool_acquire": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _u64p]),
+    "gnnpe_output_pool_report": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float), _u32p, _u32p, C.POINTER(C.c_int)]),
+    "gnnpe_output_pool_destroy": (None, [_vp]),
     "gnnpe_count_paths_enqueue": (C.c_int, [_vp, C.c_uint32]),
     "gnnpe_count_total": (C.c_int, [_vp, _u64p]),
     "gnnpe_count_total_device": (C.c_int, [_vp, _vp]),
@@ -296,6 +300,60 @@ def host_read_membership(path, n, p):
     if rc:
         raise GnnpeError(lib.gnnpe_last_error().decode())
     return sn, mem
+
+
+class _DevArray:
+    """A typed view of raw device memory for torch (`torch.as_tensor(view, device=...)` shares it, no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(int(x) for x in shape), typestr=typestr, data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+class OutputPool:
+    """gnnpe_output_pool_*: the emit kernel's output buffers (ids: rows_cap x L uint32, pde: rows_cap x D doubles): the
+    fastest of `candidates` independent allocations, each timed with the emit kernel (or, without a count on the engine,
+    a streaming write); the others are freed before the constructor returns.  `ids` / `pde` are raw device pointers (ints); ids_tensor() / pde_tensor() are torch
+    views of the same memory.  Create it AFTER eng.count_paths() so that the probe is the emit kernel itself."""
+
+    def __init__(self, eng, rows_cap, L, D, candidates=8):
+        self.eng, self.lib = eng, eng.lib
+        self.rows_cap, self.L, self.D = int(max(rows_cap, 1)), int(L), int(D)
+        h = C.c_void_p()
+        eng._ck(self.lib.gnnpe_output_pool_create(eng.ctx, self.rows_cap, self.L, self.D, int(candidates), C.byref(h)))
+        self.h = h
+        self._refresh()
+
+    def _refresh(self):
+        a, b, cap = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.eng._ck(self.lib.gnnpe_output_pool_acquire(self.h, C.byref(a), C.byref(b), C.byref(cap)))
+        self.ids, self.pde = int(a.value or 0), int(b.value or 0)
+
+    def report(self):
+        ms = (C.c_float * 64)()
+        n, kept, kern = C.c_uint32(), C.c_uint32(), C.c_int()
+        self.eng._ck(self.lib.gnnpe_output_pool_report(self.h, 64, ms, C.byref(n), C.byref(kept), C.byref(kern)))
+        return dict(candidates_ms=[round(float(ms[i]), 4) for i in range(n.value)], kept=int(kept.value),
+                    probe="emit kernel" if kern.value else "streaming write")
+
+    def ids_tensor(self, device):
+        import torch
+        return torch.as_tensor(_DevArray(self.ids, (self.rows_cap, self.L), "<i4"), device=device)
+
+    def pde_tensor(self, device):
+        import torch
+        return torch.as_tensor(_DevArray(self.pde, (self.rows_cap, self.D), "<f8"), device=device) if self.D else None
+
+    def close(self):
+        if self.h:
+            self.lib.gnnpe_output_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:

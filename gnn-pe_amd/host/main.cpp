@@ -394,7 +394,11 @@ int main(int argc, char **argv)
         const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(o.chunk_paths, devs[d].total));
         void *d_ids = nullptr, *d_part = nullptr, *d_sel = nullptr, *d_text = nullptr;
         const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
-        check(gnnpe_dev_alloc(ctx, chunk * L * 4, &d_ids), "alloc ids");
+        // the emitted rows live in the library's output pool: the fastest of a few candidate allocations (timed with the
+        // emit kernel itself when one chunk holds every path, with a streaming write otherwise)
+        gnnpe_pool *pool = nullptr;
+        check(gnnpe_output_pool_create(ctx, chunk, L, 0, 4, &pool), "output pool");
+        check(gnnpe_output_pool_acquire(pool, &d_ids, nullptr, nullptr), "output pool");
         check(gnnpe_dev_alloc(ctx, chunk * 4, &d_part), "alloc part");
         check(gnnpe_dev_alloc(ctx, chunk * 8, &d_sel), "alloc sel");
         check(gnnpe_dev_alloc(ctx, text_cap, &d_text), "alloc text");
@@ -427,7 +431,7 @@ int main(int argc, char **argv)
                 part_files[pid]->submit(pbuf, pb);
             }
         }
-        gnnpe_dev_free(ctx, d_ids);
+        gnnpe_output_pool_destroy(pool);
         gnnpe_dev_free(ctx, d_part);
         gnnpe_dev_free(ctx, d_sel);
         gnnpe_dev_free(ctx, d_text);

@@ -552,7 +552,17 @@ void rank_main(int r, Shared &S)
     // ---- sizing pass: bytes of this rank's rows of all_paths.txt (emit ids, count digits; nothing is rendered) ----
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(o.chunk_paths, 4ull << 20), std::max<uint64_t>(total, 1)));
     const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
-    DevMem d_ids(ctx, chunk * L * 4), d_part(ctx, chunk * 4), d_sel(ctx, chunk * 8), d_text(ctx, text_cap);
+    DevMem d_part(ctx, chunk * 4), d_sel(ctx, chunk * 8), d_text(ctx, text_cap);
+    struct PoolIds {  // the emitted rows: the library's output pool (fastest of a few candidate allocations)
+        gnnpe_pool *pool = nullptr;
+        void *p = nullptr;
+        PoolIds(gnnpe_ctx *c, uint64_t rows, uint32_t L_)
+        {
+            check(gnnpe_output_pool_create(c, rows, L_, 0, 4, &pool), "output pool");
+            check(gnnpe_output_pool_acquire(pool, &p, nullptr, nullptr), "output pool");
+        }
+        ~PoolIds() { gnnpe_output_pool_destroy(pool); }
+    } d_ids(ctx, chunk, L);
     uint64_t my_all_bytes = 0;
     for (uint64_t b = 0; b < total; b += chunk) {
         const uint64_t en = std::min(total, b + chunk);

@@ -189,6 +189,24 @@ int gnnpe_fill_paths_device(gnnpe_ctx *ctx, uint64_t begin, uint64_t end, void *
  * cap_rows.  ids and pde only (either may be NULL). */
 int gnnpe_fill_paths_capped_device(gnnpe_ctx *ctx, uint64_t cap_rows, void *dev_vids, void *dev_pde);
 
+/* ---- output pool: where the emitted rows live on the device -------------------------------------------------------
+ * The reference keeps `all_paths` / `pde` in host vectors (main.cpp:87-96, custom.h:546-572); here they are device
+ * buffers, and on MI355X the rate a kernel streams into a multi-GiB buffer differs by up to 25 % between allocations
+ * (stable for the life of a buffer, not predictable from its address: scripts/vmm_probe*.hip).
+ * A pool draws `candidates` independent allocations for rows_cap rows (ids: rows_cap x L uint32; pde: rows_cap x D
+ * doubles, D = 0 for none), times the consumer in each -- the emit kernel itself when the context holds an l = L-1
+ * count of at most rows_cap paths (call gnnpe_count_paths first), a streaming write otherwise -- keeps the fastest and
+ * frees the others before it returns (transient memory: candidates x the output size, bounded by the free memory).
+ * candidates = 1 takes what comes, unprobed.  The buffers stay valid until gnnpe_output_pool_destroy. */
+typedef struct gnnpe_pool gnnpe_pool;
+int gnnpe_output_pool_create(gnnpe_ctx *ctx, uint64_t rows_cap, uint32_t L, uint32_t D, uint32_t candidates, gnnpe_pool **pool);
+int gnnpe_output_pool_acquire(gnnpe_pool *pool, void **dev_ids, void **dev_pde, uint64_t *rows_cap);
+/* probe_ms[0 .. min(cap, candidates drawn)) = time of the probe in every candidate, *kept = the one in use,
+ * *probed_with_emit_kernel = 1 if the probe was the emit kernel (0: streaming write, or a single unprobed candidate). */
+int gnnpe_output_pool_report(gnnpe_pool *pool, uint32_t cap, float *probe_ms, uint32_t *n_candidates, uint32_t *kept,
+                             int *probed_with_emit_kernel);
+void gnnpe_output_pool_destroy(gnnpe_pool *pool);
+
 /* Order-sensitive 64-bit checksum of n_rows emitted rows (n_rows x L uint32 on the device) whose first
  * row has global path id first_id; checksums of consecutive chunks ADD (mod 2^64).  For outputs too large
  * to keep (config 5: count + checksum only) and for comparing rank counts. */
