@@ -421,7 +421,6 @@ def main():
         _, per_step["vde_ms"] = phase(lambda: eng.vde(want=False))
         t_, per_step["count_ms"] = phase(sb._count_single)
     _, per_step["fill_ms"] = phase(lambda: eng.fill_paths_device(0, t_, out_ids, out_pde, None))
-    per_step["note"] = "one untimed step with a device synchronisation after every phase; the timed steps run without any"
 
     # sanity of what was just timed (outside the timed region): global path count = sum C(deg, 2) and the
     # middle-vertex checksum sum_paths(b) = sum_v v * C(deg v, 2), both closed forms of the input graph
@@ -492,7 +491,8 @@ def main():
                phases_ms=dict(one_time={k: round(v, 3) for k, v in one_time.items()},
                               per_step={k: round(v, 3) for k, v in per_step.items()},
                               note="one_time = distributing / loading the graph structure (rows, reverse positions, halo rows); "
-                                   "per_step = what `value` times"))
+                                   "per_step = what `value` times, here from one untimed step with a device synchronisation after every "
+                                   "phase (the timed steps run without any)"))
     if world > 1:
         out["halo"] = dict(sb.stats, owned_entries=owned_entries, slab=[int(bounds[rank]), int(bounds[rank + 1])],
                            local_paths=int(total), note="rank 0's share; halo rows are truncated to the slab's rank range")

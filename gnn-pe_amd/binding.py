@@ -60,6 +60,8 @@ SIGNATURES = {
     "gnnpe_count_paths": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
     "gnnpe_fill_paths": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u32p, _f64p, _f64p]),
     "gnnpe_fill_paths_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp]),
+    "gnnpe_build_index_partition_aux_device": (C.c_int, [_vp, C.c_uint32, C.POINTER(_vp), _u64p, C.POINTER(C.c_int32), C.POINTER(_vp),
+                                                         C.POINTER(_vp), C.POINTER(_vp), _u32p]),
     "gnnpe_output_pool_create": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "gnnpe_output_pool_acquire": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _u64p]),
     "gnnpe_output_pool_report": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_float), _u32p, _u32p, C.POINTER(C.c_int)]),
@@ -322,6 +324,7 @@ class OutputPool:
         h = C.c_void_p()
         eng._ck(self.lib.gnnpe_output_pool_create(eng.ctx, self.rows_cap, self.L, self.D, int(candidates), C.byref(h)))
         self.h = h
+        eng._pools.append(self)
         self._refresh()
 
     def _refresh(self):
@@ -345,9 +348,12 @@ class OutputPool:
         return torch.as_tensor(_DevArray(self.pde, (self.rows_cap, self.D), "<f8"), device=device) if self.D else None
 
     def close(self):
-        if self.h:
+        """Frees the pool's memory.  A pool never outlives its engine: Engine.close() closes its pools first."""
+        if self.h and self.eng.ctx:
             self.lib.gnnpe_output_pool_destroy(self.h)
-            self.h = None
+            if self in self.eng._pools:
+                self.eng._pools.remove(self)
+        self.h = None
 
     def __del__(self):
         try:
@@ -368,12 +374,15 @@ class Engine:
         self.e = 0
         self.slab = (0, 0)
         self.total = None
+        self._pools = []
         self.stream_handle = None  # None = the context's own stream
         if stream is not None:
             self.set_stream(stream)
 
     def close(self):
         if self.ctx:
+            for p in list(getattr(self, "_pools", [])):
+                p.close()
             self.lib.gnnpe_destroy(self.ctx)
             self.ctx = None
 
@@ -613,6 +622,25 @@ class Engine:
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         aux = None if aux_paths is None else (C.c_char_p * len(aux_paths))(*[p.encode() for p in aux_paths])
         self._ck(self.lib.gnnpe_build_index_files(self.ctx, len(paths), arr, aux))
+
+    def build_index_partition_aux_device(self, pid, fetch=False):
+        """index.dat image of partition pid AND its auxiliary index in one build (leaf rows by the leaf kernel).  Returns
+        (image ptr, nbytes, hdr, key ptr, degrees ptr, label_mbr ptr, n_nodes); fetch=True returns host arrays instead of the
+        three pointers."""
+        img, nb = _vp(), C.c_uint64()
+        hdr = (C.c_int32 * 8)()
+        k, d, m = _vp(), _vp(), _vp()
+        N = C.c_uint32()
+        self._ck(self.lib.gnnpe_build_index_partition_aux_device(self.ctx, int(pid), C.byref(img), C.byref(nb), hdr, C.byref(k),
+                                                                 C.byref(d), C.byref(m), C.byref(N)))
+        if not fetch:
+            return img.value, nb.value, list(hdr), k.value, d.value, m.value, N.value
+        L, D, n = self.l + 1, (self.l + 1) * self.e, N.value
+        key, deg, mbr = np.zeros(n), np.zeros((n, L), np.uint32), np.zeros((n, 2 * D))
+        for host, dev in ((key, k), (deg, d), (mbr, m)):
+            if host.nbytes:
+                self._ck(self.lib.gnnpe_copy_to_host(self.ctx, host.ctypes.data_as(_vp), dev, host.nbytes))
+        return img.value, nb.value, list(hdr), key, deg, mbr, n
 
     def aux_index_device_ptrs(self, dev_image, nbytes, cnt, L, dev_tuples):
         """The same pass, results left on the device: (key ptr, degrees ptr, label_mbr ptr, n_nodes, D) -- context-owned

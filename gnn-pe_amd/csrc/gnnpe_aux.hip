@@ -13,6 +13,7 @@
 // insert loop wrote alike -- which is how the tests pin it: the same file through the compiled reference and through
 // this pass must give the same arrays, bit for bit.
 #include "gnnpe_common.h"
+#include "gnnpe_dpp.hip.h"
 
 #include <algorithm>
 #include <cstring>
@@ -33,51 +34,6 @@ __device__ __forceinline__ double ld_f64(const char *p)
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-// Wave-wide reductions on the VALU's data-parallel primitives (DPP: quad permutes, row mirrors, row broadcasts -- gfx9
-// family), result broadcast from lane 63.  The first version used __shfl_xor butterflies = ds_bpermute through the LDS
-// crossbar: 162 of them per leaf (27 dwords x 6 steps) made the LDS pipe of every CU the pass's bottleneck.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
-{
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-#define GNNPE_DPP_REDUCE(T, DPP, OP)                                            \
-    v = OP(v, DPP<0xB1, 0xF>(v));   /* quad_perm [1,0,3,2] */                   \
-    v = OP(v, DPP<0x4E, 0xF>(v));   /* quad_perm [2,3,0,1] */                   \
-    v = OP(v, DPP<0x141, 0xF>(v));  /* row_half_mirror */                       \
-    v = OP(v, DPP<0x140, 0xF>(v));  /* row_mirror: every row of 16 is reduced */ \
-    v = OP(v, DPP<0x142, 0xA>(v));  /* row_bcast15 into rows 1 and 3 */         \
-    v = OP(v, DPP<0x143, 0xC>(v));  /* row_bcast31 into rows 2 and 3: lane 63 holds the wave's result */
-__device__ __forceinline__ double lane63(double v)
-{
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-__device__ __forceinline__ double dpp_min_f64(double v)  // result in lane 63
-{
-    GNNPE_DPP_REDUCE(double, dpp_f64, fmin)
-    return v;
-}
-__device__ __forceinline__ double dpp_max_f64(double v)
-{
-    GNNPE_DPP_REDUCE(double, dpp_f64, fmax)
-    return v;
-}
-__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v)
-{
-    GNNPE_DPP_REDUCE(uint32_t, dpp_u32, max)
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64(v)); }
-__device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }
-
 // err[0] = first problem seen (0 none, 1 leaf son outside the partition's paths, 2 child block id outside the file,
 // 3 vertex id outside the graph, 4 entry count beyond the block), err[1] = the block it was seen in
 __device__ __forceinline__ void aux_fail(uint32_t *err, uint32_t code, uint32_t blk)
@@ -287,6 +243,52 @@ __global__ __launch_bounds__(256) void k_aux_leaves(const char *__restrict__ ima
     }
 }
 
+__global__ void k_aux_iota(uint32_t n, uint32_t first, uint32_t *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = first + (uint32_t)i;
+}
+
+int ensure_vertex_words(gnnpe_ctx *c)
+{
+    GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
+                  "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
+    int rc;
+    if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8))) return rc;
+    const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
+    if (c->n)
+        hipLaunchKernelGGL(k_aux_pack_vertex, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, deg, c->labels.as<uint32_t>(),
+                           c->aux_vdl.as<uint64_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    return GNNPE_OK;
+}
+
+// The levels above the leaves, bottom-up, for an image whose leaf rows of c->aux_deg / c->aux_mbr are already filled (the
+// pair-major leaf kernel of gnnpe_index.hip computes them while it assembles the leaves) and whose c->aux_key is cleared.
+// Bulk-loaded images keep the leaves in node blocks [0, n_leaves) and the inner nodes behind them.
+int aux_upper_levels(gnnpe_ctx *c, const char *image, uint32_t n_nodes, uint32_t n_leaves, uint32_t D, uint32_t L, int root_level)
+{
+    if (root_level < 1 || n_nodes <= n_leaves) return GNNPE_OK;
+    int rc;
+    if ((rc = c->aux_upper.reserve(((size_t)n_nodes + 1) * 4))) return rc;
+    uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2411 of the context's small buffer: error code, block, list length
+    uint32_t *d_nup = d_err + 2;
+    const uint32_t n_up = n_nodes - n_leaves;
+    GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 8, c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(d_nup, &n_up, 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_aux_iota, dim3(grid_for(n_up)), dim3(kBlock), 0, c->stream, n_up, n_leaves, c->aux_upper.as<uint32_t>());
+    for (int level = 1; level <= root_level; level++)
+        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)n_up * 64)), dim3(kBlock), 0, c->stream, image, n_nodes, level, D, L, c->e,
+                           (uint64_t)0, (const uint32_t *)nullptr, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
+                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
+                           c->aux_upper.as<uint32_t>(), d_nup);
+    GNNPE_HIP_TRY(hipGetLastError());
+    uint32_t err[2] = {0, 0};
+    GNNPE_HIP_TRY(hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // (also: n_up was read from this frame)
+    GNNPE_REQUIRE(err[0] == 0, GNNPE_ERR_ARG, "index image, node block %u: inconsistent inner node (code %u)", err[1], err[0]);
+    return GNNPE_OK;
+}
+
 }  // namespace gnnpe
 
 using namespace gnnpe;
@@ -330,6 +332,7 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     GNNPE_REQUIRE(root_level >= 0 && root_level < 32, GNNPE_ERR_ARG, "index image: root level %d", (int)root_level);
 
     int rc;
+    c->img_aux_valid = false;  // the arrays are about to hold this image's index
     if ((rc = c->aux_key.reserve(((size_t)N + 1) * 8)) || (rc = c->aux_deg.reserve(((size_t)N * L + 1) * 4)) ||
         (rc = c->aux_mbr.reserve(((size_t)N * 2 * D + 1) * 8)))
         return rc;
@@ -340,11 +343,7 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     uint32_t *d_nup = d_err + 2;
     GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 12, c->stream));
     if ((rc = c->aux_upper.reserve(((size_t)N + 1) * 4))) return rc;
-    const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
-    if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8))) return rc;
-    if (c->n)
-        hipLaunchKernelGGL(k_aux_pack_vertex, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, deg, c->labels.as<uint32_t>(),
-                           c->aux_vdl.as<uint64_t>());
+    if ((rc = ensure_vertex_words(c))) return rc;
     // the leaf level -- almost all of the nodes -- through the specialised kernel where there is one (D >= 4: one entry per lane)
     int first_generic = 0;
 #define GNNPE_AUXL(LL, EE)                                                                                               \

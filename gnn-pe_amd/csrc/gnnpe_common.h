@@ -17,6 +17,10 @@ struct gnnpe_ctx;
 namespace gnnpe {
 
 void set_error(const char *fmt, ...);
+// gnnpe_aux.hip: {degree, label} word of every vertex (c->aux_vdl); the levels above the leaves of an image's auxiliary
+// index, given the leaf rows of c->aux_deg / c->aux_mbr (nodes [0, n_leaves) are the leaves, the rest inner nodes)
+int ensure_vertex_words(gnnpe_ctx *c);
+int aux_upper_levels(gnnpe_ctx *c, const char *image, uint32_t n_nodes, uint32_t n_leaves, uint32_t D, uint32_t L, int root_level);
 int resolve_total(gnnpe_ctx *c);  // gnnpe_engine.hip: fetch the count's total if the last count was enqueue-only
 
 #define GNNPE_HIP_TRY(expr)                                                                       \
@@ -83,8 +87,14 @@ inline int grid_for(uint64_t items, int per_block = kBlock)
 
 }  // namespace gnnpe
 
+struct gnnpe_pool;
+namespace gnnpe {
+void pool_free(gnnpe_pool *p);  // gnnpe_pool.hip: releases a pool's memory (the context is still alive)
+}
+
 struct gnnpe_ctx {
     int device = 0;
+    std::vector<gnnpe_pool *> pools;  // output pools created on this context and not yet destroyed: freed with it
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
 
@@ -110,6 +120,14 @@ struct gnnpe_ctx {
     std::vector<uint64_t> px_bounds, px_points;  // first sorted pair / first point of every partition (p + 1 entries)
     uint64_t count_gen = 0, px_gen = 0;
     bool px_valid = false;  // R6 scratch + the assembled index.dat image
+    gnnpe::DevBuf px_raux;  // {degree, label} strips beside the row blocks (k_px_raux), valid for one count like the pair order
+    bool px_raux_valid = false;
+    // the pair-major leaf kernel stores used prefixes only: which buffer's block tails are known to be zero, and from which byte
+    const void *img_scrub_ptr = nullptr;
+    size_t img_scrub_bytes = 0;
+    uint32_t img_scrub_from = 0;
+    bool img_aux_valid = false;  // c->aux_key / aux_deg / aux_mbr hold the auxiliary index of the image in index_image
+    uint32_t img_aux_nodes = 0;
     uint32_t n_held = 0;  // rows with adjacency on this device (owned, then appended halo rows)
     uint32_t halo_min_rank = 0;  // largest min_rank a halo row was truncated with (gnnpe_rows_append); 0 = none
 

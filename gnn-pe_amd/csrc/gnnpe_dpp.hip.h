@@ -1,0 +1,56 @@
+// gnnpe_dpp.hip.h -- wave-wide reductions on the VALU's data-parallel primitives (DPP), shared by the auxiliary-index pass
+// (gnnpe_aux.hip) and the index leaf kernel (gnnpe_index.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gnnpe {
+
+// Wave-wide reductions on the VALU's data-parallel primitives (DPP: quad permutes, row mirrors, row broadcasts -- gfx9
+// family), result broadcast from lane 63.  The first version used __shfl_xor butterflies = ds_bpermute through the LDS
+// crossbar: 162 of them per leaf (27 dwords x 6 steps) made the LDS pipe of every CU the pass's bottleneck.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+#define GNNPE_DPP_REDUCE(T, DPP, OP)                                            \
+    v = OP(v, DPP<0xB1, 0xF>(v));   /* quad_perm [1,0,3,2] */                   \
+    v = OP(v, DPP<0x4E, 0xF>(v));   /* quad_perm [2,3,0,1] */                   \
+    v = OP(v, DPP<0x141, 0xF>(v));  /* row_half_mirror */                       \
+    v = OP(v, DPP<0x140, 0xF>(v));  /* row_mirror: every row of 16 is reduced */ \
+    v = OP(v, DPP<0x142, 0xA>(v));  /* row_bcast15 into rows 1 and 3 */         \
+    v = OP(v, DPP<0x143, 0xC>(v));  /* row_bcast31 into rows 2 and 3: lane 63 holds the wave's result */
+__device__ __forceinline__ double lane63(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double dpp_min_f64(double v)  // result in lane 63
+{
+    GNNPE_DPP_REDUCE(double, dpp_f64, fmin)
+    return v;
+}
+__device__ __forceinline__ double dpp_max_f64(double v)
+{
+    GNNPE_DPP_REDUCE(double, dpp_f64, fmax)
+    return v;
+}
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v)
+{
+    GNNPE_DPP_REDUCE(uint32_t, dpp_u32, max)
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64(v)); }
+__device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }
+
+}  // namespace gnnpe

@@ -146,6 +146,8 @@ void gnnpe_destroy(gnnpe_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (gnnpe_pool *p : c->pools) pool_free(p);  // output pools the caller did not destroy
+    c->pools.clear();
     // every DevBuf member releases itself in ~gnnpe_ctx
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gnnpe_common.h"
+#include "gnnpe_dpp.hip.h"
 #include "gnnpe_records.h"
 
 namespace gnnpe {
@@ -420,10 +421,23 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
 // Which leaves a query opens: labels of s and b exact, their embeddings in one quantisation cell, c free --
 // scripts/index_key_study.py counts 55 leaves per query against 34 for the per-path label-major key and 10 087 in
 // path order (64 labels), at the same number of level-1 nodes.
-struct __attribute__((aligned(16))) PairX {
-    uint32_t s, b, block, cnt;
-    uint64_t G, son0;  // son0: index inside the partition of the pair's first path (the pair's paths follow in id order)
+// E doubles of vde[s] ride in the record: the leaf kernel then fetches nothing per pair but the record itself and b's row
+// block (round 2 gathered vde[s] from the table: 4-5 random 128-byte line fills per leaf for 16 useful bytes each).
+// ds / ls: degree and label of s, for the leaf's auxiliary index (custom.h:276-311); b's and c's come from raux (below).
+template <int E> struct __attribute__((aligned(16))) PairXE {
+    uint32_t block, cnt;  // row block of b (kRowAlign units); paths of the unit (| kUnitHub)
+    uint64_t G, son0;     // son0: index inside the partition of the unit's first path (hub unit: first row entry << 32)
+    uint32_t ds, ls;
+    double vs[E];
 };
+
+// leaf fill: entries per node.  The reference's node capacity is (4096 - 5) / (16 D + 4) (rtnode.cpp:27-28) and its own
+// insert path splits a node that reaches capacity - 1 (rtnode.cpp:528), so capacity - 1 is the fullest node it ever
+// holds itself; round 2 filled to capacity - 2.
+__host__ __device__ constexpr uint32_t index_fanout(uint32_t D)
+{
+    return (kBlockLen - 5) / (16 * D + 4) - 1 < 64 ? (kBlockLen - 5) / (16 * D + 4) - 1 : 64;
+}
 
 // partition-local first path index of every start vertex: starts sorted by partition, then an exclusive scan
 __global__ void k_px_start_parts(uint32_t len, const StartRec *__restrict__ srec, uint32_t *__restrict__ part, uint32_t *__restrict__ idx)
@@ -457,7 +471,7 @@ __global__ void k_px_pbase(uint32_t len, const uint32_t *__restrict__ sorted_par
 
 // Sorted items are UNITS: a pair whose middle row has at most 64 entries is one unit (its records are addressed through
 // G), a hub pair is cut into units of 64 consecutive entries of the id-ordered hub row, each with the 64-bit mask of the
-// entries ranked after s (the r-th path of the unit is the r-th set bit).  PairX.cnt bit 31 marks a hub unit, whose
+// entries ranked after s (the r-th path of the unit is the r-th set bit).  PairXE.cnt bit 31 marks a hub unit, whose
 // first record index rides in the high half of son0.
 constexpr uint32_t kUnitHub = 0x80000000u;
 
@@ -492,11 +506,12 @@ __device__ __forceinline__ uint64_t px_key(uint64_t part, uint64_t ks, uint64_t 
 }
 
 // one record + one sort key per ordinary pair, at the pair's unit slot; 16 lanes per start vertex
-template <typename KeyT>
+template <int E, typename KeyT>
 __global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
                            const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
-                           const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst, uint32_t e, uint32_t lb,
-                           uint32_t sbits, uint32_t zbits, PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+                           const double *__restrict__ vde, const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst,
+                           uint32_t lb, uint32_t sbits, uint32_t zbits, PairXE<E> *__restrict__ px, KeyT *__restrict__ keys,
+                           uint32_t *__restrict__ vals)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
@@ -504,16 +519,27 @@ __global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__res
     for (; g < len; g += ng) {
         const StartRec sr = srec[g];
         const uint64_t ks = vkey[sr.s];
+        double vs[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) vs[k] = vde[(uint64_t)sr.s * E + k];
         for (uint32_t k = sub; k < sr.ds; k += 16) {
             const uint32_t q = sr.e0 + k;
             const RankedPair pr = pairs[q];
             if (pr.cnt & kHubFlag) continue;  // k_px_hub_units
             const uint64_t at = ufirst ? ufirst[q] : (uint64_t)q;
             const uint32_t b = nbrs[sr.a_s + k];
-            PairX x = {sr.s, b, pr.block, pr.cnt, pr.G, pbase[g] + (eoff[q] - sr.base)};
+            PairXE<E> x;
+            x.block = pr.block;
+            x.cnt = pr.cnt;
+            x.G = pr.G;
+            x.son0 = pbase[g] + (eoff[q] - sr.base);
+            x.ds = sr.ds;
+            x.ls = (uint32_t)(ks >> 32);
+#pragma unroll
+            for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vs[k2];
             px[at] = x;
             // pairs without paths sort behind every partition (partition field = n_parts)
-            keys[at] = (KeyT)px_key(pr.cnt ? sr.part : n_parts, ks, vkey[b], e, lb, sbits, zbits);
+            keys[at] = (KeyT)px_key(pr.cnt ? sr.part : n_parts, ks, vkey[b], E, lb, sbits, zbits);
             vals[at] = (uint32_t)at;
         }
     }
@@ -525,10 +551,10 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
                                                       const uint2 *__restrict__ hub_list, const StartRec *__restrict__ srec,
                                                       const RankedPair *__restrict__ pairs, const uint64_t *__restrict__ eoff,
                                                       const uint32_t *__restrict__ nbrs, const char *__restrict__ recs,
-                                                      const uint64_t *__restrict__ vkey, const uint64_t *__restrict__ pbase,
-                                                      const uint64_t *__restrict__ ufirst, uint32_t lb, uint32_t sbits,
-                                                      uint32_t zbits, PairX *__restrict__ px, KeyT *__restrict__ keys,
-                                                      uint32_t *__restrict__ vals)
+                                                      const uint64_t *__restrict__ vkey, const double *__restrict__ vde,
+                                                      const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst,
+                                                      uint32_t lb, uint32_t sbits, uint32_t zbits, PairXE<E> *__restrict__ px,
+                                                      KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const unsigned lane = threadIdx.x & 63u;
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -539,8 +565,9 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
         const RankedPair pr = pairs[q];
         const uint32_t d = (uint32_t)pr.G, thr = slab_begin + g, b = nbrs[sr.a_s + (q - sr.e0)];
         const RecWide<E> *row = reinterpret_cast<const RecWide<E> *>(recs + (uint64_t)pr.block * kRowAlign + 8 * E);
-        const uint64_t key_ok = px_key(sr.part, vkey[sr.s], vkey[b], E, lb, sbits, zbits);
-        const uint64_t key_no = px_key(n_parts, vkey[sr.s], vkey[b], E, lb, sbits, zbits);
+        const uint64_t ks = vkey[sr.s];
+        const uint64_t key_ok = px_key(sr.part, ks, vkey[b], E, lb, sbits, zbits);
+        const uint64_t key_no = px_key(n_parts, ks, vkey[b], E, lb, sbits, zbits);
         uint64_t son = pbase[g] + (eoff[q] - sr.base);
         const uint64_t at0 = ufirst[q];
         for (uint32_t u = 0; u * 64u < d; u++) {
@@ -549,7 +576,15 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
             const uint64_t mask = __ballot(keep);
             const uint32_t cnt = (uint32_t)__popcll(mask);
             if (lane == 0) {
-                PairX x = {sr.s, b, pr.block, cnt | kUnitHub, mask, son | ((uint64_t)(u * 64u) << 32)};
+                PairXE<E> x;
+                x.block = pr.block;
+                x.cnt = cnt | kUnitHub;
+                x.G = mask;
+                x.son0 = son | ((uint64_t)(u * 64u) << 32);
+                x.ds = sr.ds;
+                x.ls = (uint32_t)(ks >> 32);
+#pragma unroll
+                for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vde[(uint64_t)sr.s * E + k2];
                 px[at0 + u] = x;
                 keys[at0 + u] = (KeyT)(cnt ? key_ok : key_no);
                 vals[at0 + u] = (uint32_t)(at0 + u);
@@ -558,12 +593,13 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
         }
     }
 }
-__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairX *__restrict__ px, PairX *__restrict__ out)
+template <int E>
+__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairXE<E> *__restrict__ px, PairXE<E> *__restrict__ out)
 {
     for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < ne; k += (uint64_t)gridDim.x * blockDim.x) out[k] = px[order[k]];
 }
-struct CntOfPairX {
-    __host__ __device__ uint64_t operator()(const PairX &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
+template <int E> struct CntOfPairX {
+    __host__ __device__ uint64_t operator()(const PairXE<E> &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
 };
 struct U32ToU64 {
     __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
@@ -597,39 +633,88 @@ __global__ void k_px_leaf_first(uint64_t n_leaves, uint32_t F, uint64_t r0, uint
     }
 }
 
-// One wave per leaf.  The leaf's points are 38 consecutive points of the sorted pairs: lane t first holds sorted pair
-// first[j] + t (its record and its first point), then entry t: pair by binary search in the wave's strip, record r of the
-// pair's row block, vde[s] from the table (one row per pair, shared by its lanes), vde[b] from the block header.
-// Window assembly, node MBR and the shifted 16-byte stores are those of k_pack_leaves_paths.
+// {degree, label} words beside the row blocks, for the leaves' auxiliary index: word 0 of a block's strip = the row's
+// vertex b, word 1 + r = the vertex of the block's record r.  The strip of the block at unit `blk` starts at word
+// blk * kRauxPerUnit; a block of d records spans at least (8E + 12 d) / 128 units, so 16 words per unit always hold its
+// 1 + d words.  One wave per held row, once per count (the record order is the count's): 2m gathers from an n x 8 byte table.
+constexpr uint32_t kRauxPerUnit = kRowAlign / 8;
 template <int E, bool PACKED>
-__global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint32_t F, uint64_t r0,
-                                                                        uint64_t r1, const uint64_t *__restrict__ pref,
+__global__ __launch_bounds__(256) void k_px_raux(uint32_t n_held, const uint32_t *__restrict__ held,
+                                                 const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rblock,
+                                                 const char *__restrict__ recs, const uint64_t *__restrict__ vdl,
+                                                 uint64_t *__restrict__ raux)
+{
+    typedef typename RecOf<E, PACKED>::type Rec;
+    const unsigned lane = threadIdx.x & 63u;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w < n_held; w += nw) {
+        const uint32_t b = held ? held[w] : (uint32_t)w;
+        const uint32_t d = adj_deg[b];
+        if (d == 0) continue;
+        const uint32_t blk = rblock[b];
+        const char *base = recs + (uint64_t)blk * kRowAlign + 8 * E;
+        uint64_t *out = raux + (uint64_t)blk * kRauxPerUnit;
+        if (lane == 0) out[0] = vdl[b];
+        for (uint32_t r = lane; r < d; r += 64) {
+            uint32_t id;
+            if (d > kHubDegree) {
+                id = reinterpret_cast<const RecWide<E> *>(base)[r].id;
+            } else if constexpr (PACKED) {
+                id = reinterpret_cast<const Rec *>(base)[r].idp & ((1u << kPackedIdBits) - 1u);
+            } else {
+                id = reinterpret_cast<const Rec *>(base)[r].id;
+            }
+            out[1 + r] = vdl[id];
+        }
+    }
+}
+
+// zero the bytes [from, 4096) of every block of the image: the leaf kernel below stores only a leaf's used prefix
+__global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint32_t from)
+{
+    const uint32_t per = (kBlockLen - from) / 16;  // 16-byte pieces per block
+    const uint64_t tot = n_blocks * per;
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<uint4 *>(image + (i / per) * (uint64_t)kBlockLen + from + (i % per) * 16) = z;
+}
+
+// One wave per leaf.  The leaf's points are F consecutive points of the sorted pairs: lane t first holds sorted pair
+// first[j] + t (its record and its first point) IN REGISTERS -- the entry lanes fetch their pair's fields from that lane
+// through the crossbar (ds_bpermute), so the wave's LDS is the leaf window alone and eight waves per SIMD still fit at
+// F = 39 -- then entry t: pair by binary search over the pairs' first entries, record r of the pair's row block, vde[s]
+// from the pair record, vde[b] from the block header.
+// Auxiliary index of the leaf (Partition::build_auxiliary_index, custom.h:276-311), when `adeg` is given: the entry's
+// three vertices' {degree, label} come from the pair record (s) and from the raux strip beside b's row block (b, c),
+// the label features from the label table, the L + 2D reductions run side by side on DPP -- what round 2 computed in a
+// second pass that re-read the whole image and gathered every path's tuple (7.6 ms at config 3).
+// Stores: a leaf's used prefix only (kStoreU4 16-byte pieces); the image's tails are zeroed once per buffer (k_scrub_tails).
+template <int E, bool PACKED>
+__global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint64_t r0, uint64_t r1,
+                                                                        const uint64_t *__restrict__ pref,
                                                                         const uint32_t *__restrict__ first,
-                                                                        const PairX *__restrict__ px, const char *__restrict__ recs,
-                                                                        const double *__restrict__ vde, char *__restrict__ image,
-                                                                        double *__restrict__ node_mbr)
+                                                                        const PairXE<E> *__restrict__ px, const char *__restrict__ recs,
+                                                                        const uint64_t *__restrict__ raux,
+                                                                        const double *__restrict__ xtab, char *__restrict__ image,
+                                                                        double *__restrict__ node_mbr, uint32_t *__restrict__ adeg,
+                                                                        double *__restrict__ ambr)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int D = 3 * E;
     constexpr int kEnt = 4 * D + 1;
-    // LDS per wave decides the waves per SIMD here (24 VGPRs): the window holds the header and the entries only (the
-    // block's zero tail is produced by the stores), the strip one pair per possible entry plus the one that continues
-    // into the next leaf.  E = 2: 4.9 KB per wave = 8 waves per SIMD (6 with a full 4 KiB window and 64-pair strips:
-    // 7.1 -> 6.x ms, scripts/index_ab.py).
-    constexpr int kCap = (kBlockLen - 5) / (16 * D + 4) - 2 < 64 ? (kBlockLen - 5) / (16 * D + 4) - 2 : 64;  // = F (build_image)
-    constexpr int kWin = (2 + kCap * kEnt + 4 + 3) / 4 * 4;  // dwords, a multiple of 4; the last 4 feed the shifted reads
-    constexpr int kStrip = kCap + 1 < 64 ? (kCap + 1 + 7) / 8 * 8 : 64;
+    constexpr int F = (int)index_fanout(D);
+    constexpr int kWin = (2 + F * kEnt + 4 + 3) / 4 * 4;  // dwords, a multiple of 4; the last 4 feed the shifted reads
+    constexpr int kStrip = F + 1 < 64 ? (F + 1 + 7) / 8 * 8 : 64;
+    constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;  // 16-byte pieces of a full leaf's used prefix
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
-    __shared__ uint32_t s_s[kLeafWaves][kStrip], s_blk[kLeafWaves][kStrip], s_first[kLeafWaves][kStrip];
-    __shared__ uint64_t s_G[kLeafWaves][kStrip], s_son[kLeafWaves][kStrip];
     __shared__ uint8_t s_pp[kLeafWaves][kStrip];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t *w = s_win[wv];
     const uint64_t pbase = pref[r0];
     // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
-    // sorted pairs, and the block scheduler balances the tail.  Same-process A/B at config 3 (scripts/index_ab.py):
-    // 2048 resident-sized blocks walking strided leaves with the next leaf's strip prefetched 8.34 ms, 24576 blocks 7.42,
-    // one leaf per wave 7.11.
+    // sorted pairs, and the block scheduler balances the tail (round 2, scripts/index_ab.py: 2048 resident-sized blocks
+    // walking strided leaves 8.34 ms, 24576 blocks 7.42, one leaf per wave 7.11).
     const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
     if (j < n_leaves) {
         const uint64_t g0 = j * F;
@@ -638,24 +723,25 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         const uint64_t f_end = j + 1 < n_leaves ? (uint64_t)first[j + 1] : r1;
         const uint64_t kk = (uint64_t)first[j] + lane;
         uint64_t rel_cur = ~0ull;
-        PairX x_cur;
-        x_cur.s = x_cur.b = x_cur.block = x_cur.cnt = 0;
+        PairXE<E> x_cur;
+        x_cur.block = x_cur.cnt = x_cur.ds = x_cur.ls = 0;
         x_cur.G = x_cur.son0 = 0;
+#pragma unroll
+        for (int k = 0; k < E; k++) x_cur.vs[k] = 0.0;
         if (kk < r1 && kk <= f_end) {
             rel_cur = pref[kk] - pbase;
             x_cur = px[kk];
         }
-        // the wave's strip of pairs
+        // this lane's pair as the entry lanes will ask for it
         uint32_t pp = 0xFFu;
+        uint32_t p_first = 0;
+        uint64_t p_son = 0;
         if (rel_cur < g0 + ne && lane < kStrip) {
             pp = (uint32_t)(rel_cur >= g0 ? rel_cur - g0 : 0u);  // first entry of the pair inside this leaf
-            s_s[wv][lane] = x_cur.s;
-            s_blk[wv][lane] = x_cur.block;
-            s_G[wv][lane] = x_cur.G;
             // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
-            s_first[wv][lane] = (x_cur.cnt & kUnitHub) ? ((uint32_t)(x_cur.son0 >> 32) | kUnitHub) : 0u;
+            p_first = (x_cur.cnt & kUnitHub) ? ((uint32_t)(x_cur.son0 >> 32) | kUnitHub) : 0u;
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
-            s_son[wv][lane] = ((x_cur.son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
+            p_son = ((x_cur.son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
         }
         if (lane < kStrip) s_pp[wv][lane] = (uint8_t)pp;
         if (lane == 0) {
@@ -666,22 +752,45 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((uint32_t)lane < ne) {
-            uint32_t a = 0, bnd = kStrip;  // largest a with s_pp[a] <= lane (unused slots hold 0xFF)
+        const bool act = (uint32_t)lane < ne;
+        uint32_t a = 0;  // largest a with s_pp[a] <= lane (unused slots hold 0xFF)
+        if (act) {
+            uint32_t bnd = kStrip;
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const uint32_t mid = (a + bnd) >> 1;
                 if ((uint32_t)s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
             }
-            const uint64_t sw = s_son[wv][a];
-            const uint32_t r = (uint32_t)lane - s_pp[wv][a] + (uint32_t)(sw & 0xFFu);  // point inside the unit
-            const char *const blk = recs + (uint64_t)s_blk[wv][a] * kRowAlign;
-            const uint32_t fh = s_first[wv][a];
+        }
+        // the pair's fields from lane a (wave-wide shuffles: every lane takes part, idle lanes read lane 0)
+        const uint32_t e_pp = (uint32_t)__shfl((int)pp, (int)a);
+        const uint32_t e_blk = (uint32_t)__shfl((int)x_cur.block, (int)a);
+        const uint32_t fh = (uint32_t)__shfl((int)p_first, (int)a);
+        const uint64_t e_G = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x_cur.G >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)x_cur.G, (int)a);
+        const uint64_t sw = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(p_son >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)p_son, (int)a);
+        double vs[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) vs[k] = __shfl(x_cur.vs[k], (int)a);
+        uint32_t e_ds = 0, e_ls = 0;
+        if (adeg) {
+            e_ds = (uint32_t)__shfl((int)x_cur.ds, (int)a);
+            e_ls = (uint32_t)__shfl((int)x_cur.ls, (int)a);
+        }
+        uint32_t dg[3] = {0u, 0u, 0u};
+        double llo[D], lhi[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            llo[k] = __builtin_huge_val();
+            lhi[k] = -__builtin_huge_val();
+        }
+        if (act) {
+            const uint32_t r = (uint32_t)lane - e_pp + (uint32_t)(sw & 0xFFu);  // point inside the unit
+            const char *const blk = recs + (uint64_t)e_blk * kRowAlign;
             double vc[E];
-            uint32_t son;
+            uint32_t son, rec_at;
             if (fh & kUnitHub) {
                 // hub unit: the r-th entry ranked after s = the r-th set bit of the mask; paths follow in id order
-                uint64_t m = s_G[wv][a];
+                uint64_t m = e_G;
                 uint32_t rr = r, pos = 0;
 #pragma unroll
                 for (int sh = 32; sh > 0; sh >>= 1) {
@@ -692,13 +801,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                         pos += sh;
                     }
                 }
-                const RecWide<E> rec = reinterpret_cast<const RecWide<E> *>(blk + 8 * E)[(fh & ~kUnitHub) + pos];
+                rec_at = (fh & ~kUnitHub) + pos;
+                const RecWide<E> rec = reinterpret_cast<const RecWide<E> *>(blk + 8 * E)[rec_at];
 #pragma unroll
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
                 son = (uint32_t)(sw >> 8) + r;
             } else {
-                // read once by this leaf: non-temporal (same-process A/B at config 3, scripts/index_ab.py: 6.80 -> 6.63 ms per
-                // further partition; the sorted pair rows, shared with the neighbouring leaves, must stay cached: 6.98)
+                // read once by this leaf: non-temporal (round 2 A/B: 6.80 -> 6.63 ms per further partition)
                 Rec rec;
                 {
                     const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E) + (uint64_t)r * (sizeof(Rec) / 4);
@@ -711,9 +820,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
 #pragma unroll
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
-                son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(s_G[wv][a] & ((1ull << ip) - 1ull)));
+                son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(e_G & ((1ull << ip) - 1ull)));
+                rec_at = r;
             }
-            const double *vs = vde + (uint64_t)s_s[wv][a] * E;
             const double *vb = reinterpret_cast<const double *>(blk);
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
@@ -727,12 +836,40 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 ent[4 * k + 3] = y;
             }
             ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
+            if (adeg) {
+                const uint64_t *strip = raux + (uint64_t)e_blk * kRauxPerUnit;
+                const uint64_t wb = strip[0], wc = strip[1 + rec_at];
+                dg[0] = e_ds;
+                dg[1] = (uint32_t)wb;
+                dg[2] = (uint32_t)wc;
+                const uint32_t lab[3] = {e_ls, (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
+#pragma unroll
+                for (int k = 0; k < D; k++) llo[k] = lhi[k] = xtab[(uint64_t)lab[k / E] * E + k % E];  // pde_label (custom.h:561-567)
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (adeg) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 3; q++) dg[q] = dpp_max_u32(dg[q]);
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                llo[k] = dpp_min_f64(llo[k]);
+                lhi[k] = dpp_max_f64(lhi[k]);
+            }
+            if (lane == 63) {  // the reductions end in the last lane
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    ambr[(j * D + k) * 2] = llo[k];
+                    ambr[(j * D + k) * 2 + 1] = lhi[k];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) adeg[j * 3 + q] = dg[q];
+            }
+        }
         // node MBR for the parent level: kMbrParts lanes per dimension, each scanning every kMbrParts-th assembled entry,
-        // then a butterfly over the dimension's lanes (one lane per dimension walking all 38 entries was 0.6 of the
+        // then a butterfly over the dimension's lanes (one lane per dimension walking all entries was 0.6 of the
         // kernel's time)
         constexpr int kMbrParts = D * 16 <= 64 ? 16 : D * 8 <= 64 ? 8 : D * 4 <= 64 ? 4 : 2;
         static_assert(D * kMbrParts <= 64, "embedding width too large for the leaf kernel's MBR lanes");
@@ -757,21 +894,23 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         }
         uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
 #pragma unroll
-        for (int rr = 0; rr < kBlockLen / 16 / 64; rr++) {
+        for (int rr = 0; rr < (kStoreU4 + 63) / 64; rr++) {
             const int c = lane + 64 * rr;
-            uint4 o = {0u, 0u, 0u, 0u};  // beyond the window: the block's zero tail
-            if (4 * c + 4 < kWin) {
-                const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
-                const uint32_t nx = w[4 * c + 4];
-                o.x = (lo4.x >> 24) | (lo4.y << 8);
-                o.y = (lo4.y >> 24) | (lo4.z << 8);
-                o.z = (lo4.z >> 24) | (lo4.w << 8);
-                o.w = (lo4.w >> 24) | (nx << 8);
+            if (c < kStoreU4) {
+                uint4 o = {0u, 0u, 0u, 0u};  // beyond the window: zeros
+                if (4 * c + 4 < kWin) {
+                    const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
+                    const uint32_t nx = w[4 * c + 4];
+                    o.x = (lo4.x >> 24) | (lo4.y << 8);
+                    o.y = (lo4.y >> 24) | (lo4.z << 8);
+                    o.z = (lo4.z >> 24) | (lo4.w << 8);
+                    o.w = (lo4.w >> 24) | (nx << 8);
+                }
+                __builtin_nontemporal_store(o.x, &dst[c].x);
+                __builtin_nontemporal_store(o.y, &dst[c].y);
+                __builtin_nontemporal_store(o.z, &dst[c].z);
+                __builtin_nontemporal_store(o.w, &dst[c].w);
             }
-            __builtin_nontemporal_store(o.x, &dst[c].x);
-            __builtin_nontemporal_store(o.y, &dst[c].y);
-            __builtin_nontemporal_store(o.z, &dst[c].z);
-            __builtin_nontemporal_store(o.w, &dst[c].w);
         }
     }
 }
@@ -910,6 +1049,8 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     c->img_valid = false;  // the image buffer is about to hold something else
     if ((rc = c->index_image.reserve(image_bytes))) return rc;
     char *image = c->index_image.as<char>();
+    c->img_scrub_ptr = nullptr;  // this builder fills whole blocks: the pair-major build scrubs the tails again before its next use
+    c->img_aux_valid = false;
     GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
 
     int32_t hdr[8] = {kBlockLen, (int32_t)n_nodes, (int32_t)D, (int32_t)cnt, (int32_t)level_n[0],
@@ -1279,14 +1420,16 @@ static uint32_t bits_for(uint64_t max_value)
     return b;
 }
 
+}  // extern "C" (templates need C++ linkage)
+
 // once per count: units (pairs; hub pairs cut into 64-entry units) sorted by [partition | label(s) | label(b) | z(s, b)],
 // their records in that order, the prefix of their path counts and every partition's range
-static int ensure_pair_order(gnnpe_ctx *c)
+template <int E> static int build_pair_order(gnnpe_ctx *c)
 {
-    if (c->px_valid && c->px_gen == c->count_gen) return GNNPE_OK;
+    typedef PairXE<E> PX;
     int rc;
     if ((rc = ensure_vkey(c))) return rc;
-    const uint32_t len = c->slab_end - c->slab_begin, e = c->e, D = 3 * e, p = c->p;
+    const uint32_t len = c->slab_end - c->slab_begin, D = 3 * E, p = c->p;
     const uint64_t ne = c->n_edges;
     const StartRec *srec = c->srec.as<StartRec>();
     const RankedPair *pairs = c->rpairs.as<RankedPair>();
@@ -1329,8 +1472,8 @@ static int ensure_pair_order(gnnpe_ctx *c)
     const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
                  o_pos = o_cnt + ((size_t)len + 2) * 8, o_keys = o_pos + ((size_t)len + 2) * 8, o_vals = o_keys + (nu + 1) * 16,
                  o_bnd = o_vals + (nu + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
-    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((nu + 1) * sizeof(PairX))) ||
-        (rc = c->px_sorted.reserve((nu + 1) * sizeof(PairX))) || (rc = c->px_pref.reserve((nu + 2) * 8)) ||
+    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((nu + 1) * sizeof(PX))) ||
+        (rc = c->px_sorted.reserve((nu + 1) * sizeof(PX))) || (rc = c->px_pref.reserve((nu + 2) * 8)) ||
         (rc = c->px_pbase.reserve(((size_t)len + 1) * 8)))
         return rc;
     char *tmp = c->px_tmp.as<char>();
@@ -1357,32 +1500,23 @@ static int ensure_pair_order(gnnpe_ctx *c)
         hipLaunchKernelGGL(k_px_pbase, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, part_out, idx_out, pos, c->px_pbase.as<uint64_t>());
     }
     // 2. unit records + keys, sorted, permuted, scanned
-    const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * D, sbits = c->vkey_zb ? (c->vkey_zb - 1) * D + e : 0;
+    const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * D, sbits = c->vkey_zb ? (c->vkey_zb - 1) * D + E : 0;
     const uint32_t shift = 2 * lb + zbits, kbits = bits_for(p) + shift;
     GNNPE_REQUIRE(kbits <= 64, GNNPE_ERR_UNSUPPORTED, "pair key needs %u bits", kbits);
-    PairX *px = c->px_recs.as<PairX>(), *pxs = c->px_sorted.as<PairX>();
-    GNNPE_HIP_TRY(hipMemsetAsync(pxs + nu, 0, sizeof(PairX), c->stream));  // sentinel of the scan
-#define GNNPE_PX_HUB(KT, EE)                                                                                            \
-    hipLaunchKernelGGL((k_px_hub_units<EE, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,             \
-                       (uint32_t)n_hub_pairs, p, c->slab_begin, c->px_hubs.as<uint2>(), srec, pairs, c->eoff.as<uint64_t>(), \
-                       c->nbrs.as<uint32_t>(), c->rrecs.as<char>(), c->vkey.as<uint64_t>(), c->px_pbase.as<uint64_t>(), ufirst, \
-                       lb, sbits, zbits, px, k_in, v_in)
+    PX *px = c->px_recs.as<PX>(), *pxs = c->px_sorted.as<PX>();
+    GNNPE_HIP_TRY(hipMemsetAsync(pxs + nu, 0, sizeof(PX), c->stream));  // sentinel of the scan
 #define GNNPE_PX_SORT(KT)                                                                                               \
     do {                                                                                                                \
         KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                        \
         if (len)                                                                                                        \
-            hipLaunchKernelGGL((k_px_pairs<KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
-                               pairs, c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(),           \
-                               c->px_pbase.as<uint64_t>(), ufirst, e, lb, sbits, zbits, px, k_in, v_in);                \
-        if (n_hub_pairs) {                                                                                              \
-            switch (e) {                                                                                                \
-            case 1: GNNPE_PX_HUB(KT, 1); break;                                                                         \
-            case 2: GNNPE_PX_HUB(KT, 2); break;                                                                         \
-            case 3: GNNPE_PX_HUB(KT, 3); break;                                                                         \
-            case 4: GNNPE_PX_HUB(KT, 4); break;                                                                         \
-            default: GNNPE_PX_HUB(KT, 8); break;                                                                        \
-            }                                                                                                           \
-        }                                                                                                               \
+            hipLaunchKernelGGL((k_px_pairs<E, KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
+                               pairs, c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(), c->vde.as<double>(), \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
+        if (n_hub_pairs)                                                                                                \
+            hipLaunchKernelGGL((k_px_hub_units<E, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,     \
+                               (uint32_t)n_hub_pairs, p, c->slab_begin, c->px_hubs.as<uint2>(), srec, pairs, c->eoff.as<uint64_t>(), \
+                               c->nbrs.as<uint32_t>(), c->rrecs.as<char>(), c->vkey.as<uint64_t>(), c->vde.as<double>(),  \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
         tb = 0;                                                                                                         \
         GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
         if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                   \
@@ -1392,19 +1526,35 @@ static int ensure_pair_order(gnnpe_ctx *c)
     } while (0)
     if (nu) {
         if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
-        hipLaunchKernelGGL(k_px_permute, dim3(grid_for(nu)), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
+        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu)), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
     } else {
         GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
     }
 #undef GNNPE_PX_SORT
-#undef GNNPE_PX_HUB
     {
-        hipcub::TransformInputIterator<uint64_t, CntOfPairX, const PairX *> it(pxs, CntOfPairX());
+        hipcub::TransformInputIterator<uint64_t, CntOfPairX<E>, const PX *> it(pxs, CntOfPairX<E>());
         tb = 0;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;
         tb = c->cub_tmp.bytes;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
+    }
+    // 2b. the {degree, label} strips beside the row blocks (the leaves' auxiliary index reads them): record order = this count's
+    c->px_raux_valid = false;
+    if (c->rows_identity || c->have_deg_all) {
+        if ((rc = ensure_vertex_words(c))) return rc;
+        if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kRowAlign))) return rc;
+        const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+        if (c->n_held) {
+            if (c->n <= (1u << kPackedIdBits))
+                hipLaunchKernelGGL((k_px_raux<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                                   c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+            else
+                hipLaunchKernelGGL((k_px_raux<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                                   c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+        }
+        c->px_raux_valid = true;
     }
     GNNPE_HIP_TRY(hipGetLastError());
     // 3. partition ranges and their first points, to the host
@@ -1420,19 +1570,37 @@ static int ensure_pair_order(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+extern "C" {
+
+static int ensure_pair_order(gnnpe_ctx *c)
+{
+    if (c->px_valid && c->px_gen == c->count_gen) return GNNPE_OK;
+    switch (c->e) {
+    case 1: return build_pair_order<1>(c);
+    case 2: return build_pair_order<2>(c);
+    case 3: return build_pair_order<3>(c);
+    case 4: return build_pair_order<4>(c);
+    default: return build_pair_order<8>(c);
+    }
+}
+
+// with_aux: also the leaves' auxiliary arrays (c->aux_deg / c->aux_mbr rows of the leaf nodes) and, through
+// gnnpe::aux_upper_levels, the upper levels and the keys -- the whole Partition::build_auxiliary_index of this image
+static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8], bool with_aux = false)
 {
     int rc;
     if ((rc = ensure_pair_order(c))) return rc;
     const uint64_t r0 = c->px_bounds[pid], r1 = c->px_bounds[pid + 1], cnt = c->px_points[pid + 1] - c->px_points[pid];
     GNNPE_REQUIRE(cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu entries exceeds the format's int32 counts", (unsigned long long)cnt);
     const uint32_t e = c->e, D = 3 * e;
-    const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);
-    const uint32_t F = std::min(cap - 2, 64u);
+    const uint32_t F = index_fanout(D);
+    c->img_aux_valid = false;
     if (cnt == 0) {  // the reference's empty tree
         LeafSrc S = {nullptr, c->vde.as<double>(), nullptr, 3, e, D};
         return build_image(c, 0, S, dev_image, nbytes, hdr_out);
     }
+    GNNPE_REQUIRE(!with_aux || c->px_raux_valid, GNNPE_ERR_UNSUPPORTED,
+                  "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
     std::vector<uint64_t> level_n;
     const uint64_t n_nodes = plan_levels(cnt, F, level_n);
     GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
@@ -1443,20 +1611,41 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
         (rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8)))
         return rc;
     char *image = c->index_image.as<char>();
+    // the leaf kernel stores a leaf's used prefix only: the tails of the buffer's blocks are zeroed once per buffer (and again
+    // after a builder that fills blocks further, see mark_image_tails_dirty)
+    const uint32_t tail_from = (5 + F * (16 * D + 4) + 15) / 16 * 16;
+    if (c->img_scrub_ptr != image || c->img_scrub_bytes != c->index_image.bytes || c->img_scrub_from != tail_from) {
+        if (tail_from < (uint32_t)kBlockLen)
+            hipLaunchKernelGGL(k_scrub_tails, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, image, (uint64_t)(c->index_image.bytes / kBlockLen),
+                               tail_from);
+        c->img_scrub_ptr = image;
+        c->img_scrub_bytes = c->index_image.bytes;
+        c->img_scrub_from = tail_from;
+    }
     double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
     GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
     int32_t hdr[8] = {kBlockLen, (int32_t)n_nodes, (int32_t)D, (int32_t)cnt, (int32_t)level_n[0], (int32_t)(n_nodes - level_n[0]), 0,
                       (int32_t)(n_nodes - 1)};
     const uint64_t nl = level_n[0];
+    uint32_t *adeg = nullptr;
+    double *ambr = nullptr;
+    if (with_aux) {
+        if ((rc = c->aux_key.reserve((n_nodes + 1) * 8)) || (rc = c->aux_deg.reserve((n_nodes * 3 + 1) * 4)) ||
+            (rc = c->aux_mbr.reserve((n_nodes * 2 * D + 1) * 8)))
+            return rc;
+        GNNPE_HIP_TRY(hipMemsetAsync(c->aux_key.p, 0, n_nodes * 8, c->stream));  // the root keeps 0 (custom.h:159)
+        adeg = c->aux_deg.as<uint32_t>();
+        ambr = c->aux_mbr.as<double>();
+    }
     hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(nl)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
                        c->px_first.as<uint32_t>());
     const bool packed = c->n <= (1u << kPackedIdBits);
     GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
     const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
 #define GNNPE_PXL(EE, PK)                                                                                               \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, F, r0, r1,    \
-                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairX>(), c->rrecs.as<char>(), \
-                       c->vde.as<double>(), image, mbr_a)
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, r0, r1,       \
+                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
+                       c->px_raux.as<uint64_t>(), c->xtab.as<double>(), image, mbr_a, adeg, ambr)
 #define GNNPE_PXE(EE)                                          \
     do {                                                       \
         if (packed) GNNPE_PXL(EE, true); else GNNPE_PXL(EE, false); \
@@ -1473,6 +1662,11 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     GNNPE_HIP_TRY(hipGetLastError());
     if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
     if ((rc = write_header(c, image, hdr))) return rc;
+    if (with_aux) {
+        if ((rc = aux_upper_levels(c, image, (uint32_t)n_nodes, (uint32_t)nl, D, 3, (int)level_n.size() - 1))) return rc;
+        c->img_aux_valid = true;
+        c->img_aux_nodes = (uint32_t)n_nodes;
+    }
     *dev_image = image;
     *nbytes = image_bytes;
     if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
@@ -1532,7 +1726,9 @@ static int collect_partition_tuples(gnnpe_ctx *c, uint32_t pid, DevBuf &mine, ui
     return rc;
 }
 
-int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+static bool fused_aux_ok(const gnnpe_ctx *c) { return pair_major_ok(c) && (c->rows_identity || c->have_deg_all); }
+
+static int build_partition(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8], bool with_aux)
 {
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
     GNNPE_REQUIRE(c->counted && c->have_vde && c->have_order, GNNPE_ERR_ARG,
@@ -1542,8 +1738,9 @@ int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_im
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc;
     c->img_valid = false;
+    c->img_aux_valid = false;
     if (pair_major_ok(c)) {
-        rc = build_partition_image(c, pid, dev_image, nbytes, hdr_out);
+        rc = build_partition_image(c, pid, dev_image, nbytes, hdr_out, with_aux && fused_aux_ok(c));
     } else {
         // l = 3 or the generic enumeration: the partition's tuples, then the tuple-array build
         DevBuf mine;
@@ -1559,6 +1756,40 @@ int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_im
         c->img_bytes = *nbytes;
     }
     return rc;
+}
+
+int gnnpe_build_index_partition_device(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+{
+    return build_partition(c, pid, dev_image, nbytes, hdr_out, false);
+}
+
+// the partition's tuples -> the generic pass of gnnpe_aux.hip (images the leaf kernel did not annotate: l = 3, slab-only
+// contexts without the degree table, foreign trees)
+static int aux_generic(gnnpe_ctx *c, uint32_t pid, const void *image, uint64_t nbytes, uint32_t *N, uint32_t *D)
+{
+    int rc;
+    DevBuf mine;
+    uint64_t cnt = 0;
+    if ((rc = collect_partition_tuples(c, pid, mine, &cnt))) return rc;
+    void *d_key = nullptr, *d_deg = nullptr, *d_mbr = nullptr;
+    rc = gnnpe_aux_index_device(c, image, nbytes, cnt, c->l + 1, mine.p, &d_key, &d_deg, &d_mbr, N, D);
+    (void)hipStreamSynchronize(c->stream);  // `mine` is released on return
+    return rc;
+}
+
+int gnnpe_build_index_partition_aux_device(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8],
+                                           void **dev_key, void **dev_degrees, void **dev_label_mbr, uint32_t *n_nodes)
+{
+    GNNPE_REQUIRE(dev_key && dev_degrees && dev_label_mbr && n_nodes, GNNPE_ERR_ARG, "null argument");
+    int rc = build_partition(c, pid, dev_image, nbytes, hdr_out, true);
+    if (rc) return rc;
+    uint32_t N = c->img_aux_nodes, D = 0;
+    if (!c->img_aux_valid && (rc = aux_generic(c, pid, *dev_image, *nbytes, &N, &D))) return rc;
+    *dev_key = c->aux_key.p;
+    *dev_degrees = c->aux_deg.p;
+    *dev_label_mbr = c->aux_mbr.p;
+    *n_nodes = N;
+    return GNNPE_OK;
 }
 
 int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
@@ -1578,13 +1809,11 @@ int gnnpe_build_index(gnnpe_ctx *c, uint32_t pid, const char *path)
 static int aux_to_file(gnnpe_ctx *c, uint32_t pid, const void *image, uint64_t nbytes, const char *path)
 {
     int rc;
-    DevBuf mine;
-    uint64_t cnt = 0;
-    if ((rc = collect_partition_tuples(c, pid, mine, &cnt))) return rc;
-    void *d_key = nullptr, *d_deg = nullptr, *d_mbr = nullptr;
-    uint32_t N = 0, D = 0;
     const uint32_t L = c->l + 1;
-    if ((rc = gnnpe_aux_index_device(c, image, nbytes, cnt, L, mine.p, &d_key, &d_deg, &d_mbr, &N, &D))) return rc;
+    uint32_t N = c->img_aux_nodes, D = L * c->e;
+    // the arrays of the image in index_image when the leaf kernel annotated it, the generic pass otherwise
+    if (!(c->img_aux_valid && image == c->index_image.p) && (rc = aux_generic(c, pid, image, nbytes, &N, &D))) return rc;
+    const void *d_key = c->aux_key.p, *d_deg = c->aux_deg.p, *d_mbr = c->aux_mbr.p;
     std::vector<char> host((size_t)N * (8 + 4 * (size_t)L + 16 * (size_t)D));
     char *hk = host.data(), *hd = hk + (size_t)N * 8, *hm = hd + (size_t)N * L * 4;
     GNNPE_HIP_TRY(hipMemcpyAsync(hk, d_key, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1614,8 +1843,13 @@ int gnnpe_build_index_files(gnnpe_ctx *c, uint32_t n_parts, const char *const *p
         GNNPE_REQUIRE(paths[pid] && (!aux_paths || aux_paths[pid]), GNNPE_ERR_ARG, "null path for partition %u", pid);
     int rc = GNNPE_OK;
     if (n_parts == 1) {
-        if ((rc = gnnpe_build_index(c, 0, paths[0]))) return rc;
-        return aux_paths ? gnnpe_build_aux_index(c, 0, aux_paths[0]) : GNNPE_OK;
+        void *image = nullptr;
+        uint64_t nbytes = 0;
+        if ((rc = build_partition(c, 0, &image, &nbytes, nullptr, aux_paths != nullptr))) return rc;
+        if (aux_paths && (rc = aux_to_file(c, 0, image, nbytes, aux_paths[0]))) return rc;
+        rc = write_device_image(c, (const char *)image, nbytes, paths[0]);
+        (void)hipStreamSynchronize(c->stream);
+        return rc;
     }
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     // The images are built first (milliseconds each) and kept, then their files are written side by side (one writer per
@@ -1658,7 +1892,7 @@ int gnnpe_build_index_files(gnnpe_ctx *c, uint32_t n_parts, const char *const *p
     for (uint32_t pid = 0; pid < n_parts && !rc; pid++) {
         void *image = nullptr;
         uint64_t nbytes = 0;
-        if ((rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr))) break;
+        if ((rc = build_partition(c, pid, &image, &nbytes, nullptr, aux_paths != nullptr))) break;
         if (aux_paths && (rc = aux_to_file(c, pid, image, nbytes, aux_paths[pid]))) break;
         if (!room_for(nbytes) && !wave.empty()) {  // this wave is full: write it out, then look again
             if ((rc = flush())) break;
@@ -1696,9 +1930,10 @@ int gnnpe_build_aux_index(gnnpe_ctx *c, uint32_t pid, const char *path)
     int rc;
     void *image = c->index_image.p;
     uint64_t nbytes = c->img_bytes;
-    if (!(c->img_valid && c->img_pid == pid && c->img_gen == c->count_gen) &&
-        (rc = gnnpe_build_index_partition_device(c, pid, &image, &nbytes, nullptr)))
-        return rc;
+    // (an image built without its auxiliary arrays is built again with them where the leaf kernel can supply them: cheaper
+    // than the generic pass over the finished image)
+    const bool have = c->img_valid && c->img_pid == pid && c->img_gen == c->count_gen;
+    if ((!have || (!c->img_aux_valid && fused_aux_ok(c))) && (rc = build_partition(c, pid, &image, &nbytes, nullptr, true))) return rc;
     return aux_to_file(c, pid, image, nbytes, path);
 }
 

@@ -21,6 +21,7 @@
 #include "gnnpe_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -44,6 +45,13 @@ __global__ void k_pool_stream(f4 *__restrict__ dst, uint64_t n)
         __builtin_nontemporal_store(v, &dst[i]);
 }
 
+void pool_free(gnnpe_pool *p)
+{
+    if (!p) return;
+    if (p->base) (void)hipFree(p->base);
+    delete p;
+}
+
 }  // namespace gnnpe
 
 using namespace gnnpe;
@@ -61,25 +69,27 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     // [ pde rows | id rows ], each on a 2 MiB boundary
     const uint64_t pde_bytes = (rows_cap * D * 8 + MiB2 - 1) / MiB2 * MiB2, ids_bytes = (rows_cap * L * 4 + MiB2 - 1) / MiB2 * MiB2;
     const uint64_t bytes = pde_bytes + ids_bytes;
-    // every candidate is alive until the choice is made: as many as fit beside a quarter of the free memory
-    size_t free_b = 0, tot_b = 0;
-    GNNPE_HIP_TRY(hipMemGetInfo(&free_b, &tot_b));
-    const uint64_t fit = (uint64_t)free_b / 4 * 3 / bytes;
-    GNNPE_REQUIRE(fit >= 1, GNNPE_ERR_HIP, "gnnpe_output_pool_create: %llu bytes of output do not fit the %llu free bytes of the device",
-                  (unsigned long long)bytes, (unsigned long long)free_b);
-    const uint32_t K = (uint32_t)std::min<uint64_t>(candidates, fit);
+    // below half a GiB a buffer's class is not measurable (the probe would be launch latency): take what comes.
+    // (GNNPE_POOL_MIN_PROBE_BYTES: testing aid, lowers that bound so that small test graphs exercise the draw)
+    uint64_t min_probe = 512ull << 20;
+    if (const char *ev = getenv("GNNPE_POOL_MIN_PROBE_BYTES")) min_probe = strtoull(ev, nullptr, 10);
+    uint32_t K = 1;
+    if (candidates > 1 && bytes >= min_probe) {
+        // every candidate is alive until the choice is made: as many as fit beside a quarter of the free memory
+        size_t free_b = 0, tot_b = 0;
+        GNNPE_HIP_TRY(hipMemGetInfo(&free_b, &tot_b));
+        const uint64_t fit = (uint64_t)free_b / 4 * 3 / bytes;
+        K = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(candidates, fit));
+    }
 
     // the probe: the emit kernel into the candidate when the context holds an l = L-1 count that fits, a streaming write otherwise
     int rc = resolve_total(c);
     const bool with_kernel = rc == GNNPE_OK && c->counted && c->l + 1 == L && c->counted_variant == 4 && c->total_paths > 0 &&
                              c->total_paths <= rows_cap && (D == 0 || (c->have_vde && D == L * c->e));
     const bool debug = getenv("GNNPE_POOL_DEBUG") != nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (K > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) {
-        set_error("gnnpe_output_pool_create: hipEventCreate failed");
-        if (e0) (void)hipEventDestroy(e0);
-        return GNNPE_ERR_HIP;
-    }
+    // timed on the host around stream synchronisations: the probes are milliseconds long, the launch latency inside the
+    // bracket is microseconds and the same for every candidate
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<char *> cand;
     std::vector<float> ms_of;
     rc = GNNPE_OK;
@@ -99,26 +109,22 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
         if (K > 1) {
             best = 1e30f;
             for (int rep = 0; rep < 3 && rc == GNNPE_OK; rep++) {  // first pass touches the pages (untimed), then best of two
-                (void)hipEventRecord(e0, c->stream);
+                const auto t0 = std::chrono::steady_clock::now();
                 if (with_kernel)
                     rc = gnnpe_fill_paths_device(c, 0, c->total_paths, at + pde_bytes, D ? at : nullptr, nullptr);
                 else
                     hipLaunchKernelGGL(k_pool_stream, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, (f4 *)at, bytes / 16);
-                (void)hipEventRecord(e1, c->stream);
-                if (rc == GNNPE_OK && hipEventSynchronize(e1) != hipSuccess) {
+                if (rc == GNNPE_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
                     set_error("gnnpe_output_pool_create: probe launch failed: %s", hipGetErrorString(hipGetLastError()));
                     rc = GNNPE_ERR_HIP;
                 }
-                float ms = 0.f;
-                if (rc == GNNPE_OK) (void)hipEventElapsedTime(&ms, e0, e1);
+                const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 if (rep > 0) best = std::min(best, ms);
             }
         }
         ms_of.push_back(best);
         if (debug) fprintf(stderr, "[pool] candidate %u at %p: %.3f ms (%s)\n", k, (void *)at, best, with_kernel ? "emit kernel" : "stream");
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     (void)hipStreamSynchronize(c->stream);
     int kept = 0;
     for (size_t k = 1; k < ms_of.size(); k++)
@@ -138,6 +144,7 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     p->probe_ms = ms_of;
     p->kept = kept;
     p->probed_with_kernel = with_kernel && K > 1;
+    c->pools.push_back(p);
     *out = p;
     return GNNPE_OK;
 }
@@ -165,12 +172,12 @@ int gnnpe_output_pool_report(gnnpe_pool *p, uint32_t cap, float *probe_ms, uint3
 void gnnpe_output_pool_destroy(gnnpe_pool *p)
 {
     if (!p) return;
-    if (p->ctx) {
-        (void)hipSetDevice(p->ctx->device);
-        (void)hipStreamSynchronize(p->ctx->stream);
-    }
-    if (p->base) (void)hipFree(p->base);
-    delete p;
+    // (a pool must not outlive its context: gnnpe_destroy frees the pools still registered with it)
+    gnnpe_ctx *c = p->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->pools.erase(std::remove(c->pools.begin(), c->pools.end(), p), c->pools.end());
+    pool_free(p);
 }
 
 }  // extern "C"

@@ -451,6 +451,11 @@ void rank_main(int r, Shared &S)
 
     gnnpe_ctx *ctx = gnnpe_create(o.same_device ? 0 : r);
     if (!ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
+    // declared first, destroyed last: every device buffer and the output pool below free themselves through the context
+    struct CtxGuard {
+        gnnpe_ctx *c;
+        ~CtxGuard() { gnnpe_destroy(c); }
+    } ctx_guard{ctx};
     tp.init_rank(r);
 
     // ---- this rank's rows only ----
@@ -680,7 +685,6 @@ void rank_main(int r, Shared &S)
     S.t_emit[r] = secs(t2, t3);
     S.t_index[r] = secs(t3, t4);
     tp.finish_rank(r);
-    gnnpe_destroy(ctx);
 }
 
 void rank_entry(int r, Shared &S)

@@ -246,6 +246,12 @@ int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const voi
  * gnnpe_build_index_device.  Same file format, same
  * consumer constraints; the image stays valid until the next index call on the context. */
 int gnnpe_build_index_partition_device(gnnpe_ctx *ctx, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8]);
+/* The same image together with the tree's auxiliary index (Partition::build_auxiliary_index, custom.h:268-364: per node
+ * block key, degrees[L], label_mbr[2D]; layout as gnnpe_aux_index_device).  For the pair-major build (l = 2, whole graph
+ * or gnnpe_set_degrees) the leaf kernel computes the leaves' rows while it assembles them and only the few upper levels
+ * are a separate pass; otherwise the generic pass over the finished image runs.  Arrays are context-owned. */
+int gnnpe_build_index_partition_aux_device(gnnpe_ctx *ctx, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8],
+                                           void **dev_key, void **dev_degrees, void **dev_label_mbr, uint32_t *n_nodes);
 /* Whole job for partition `pid` of the context's slab: build (gnnpe_build_index_partition_device), write `path`
  * (<f>gnn-pe/partitions/partition-<pid>/index.dat).  The reference online run then skips its insert
  * loop (custom.h:222-235 only tests that the file exists). */

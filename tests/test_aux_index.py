@@ -256,3 +256,44 @@ def test_aux_index_of_a_large_partition_by_properties(oracle):
         assert np.array_equal(got["degrees"][b], deg[h_ids[son]].max(axis=0))
         assert np.array_equal(got["label_mbr"][b, 0::2], pl[son].min(axis=0)) and np.array_equal(got["label_mbr"][b, 1::2], pl[son].max(axis=0))
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1)])
+def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, kind, e, p):
+    """gnnpe_build_index_partition_aux_device: the auxiliary index the pair-major LEAF KERNEL computes while it assembles
+    the leaves (+ the upper levels) must equal, bit for bit, the generic pass over the finished image with the partition's
+    tuples (gnnpe_aux_index_device) -- which the tests above pin to the reference's constructor.  Hub rows (power-law, Test/),
+    several partitions, every specialised embedding width."""
+    import torch
+    if kind == "gnm":
+        g = synth.gnm_graph(6000, 48000, n_labels=11, seed=5)
+    elif kind == "powerlaw":
+        g = synth.powerlaw_graph(8000, 40000, exponent=2.1, max_degree=300, n_labels=9, seed=6)
+    else:
+        g = dict(n=test_graph["meta"]["n"], offsets=test_graph["offsets"], nbrs=test_graph["nbrs"], labels=test_graph["labels"])
+    sn = synth.degree_order(g["offsets"])
+    mem = (np.arange(g["n"]) % p).astype(np.uint32)
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1, e))
+    eng.vde(want=False)
+    total = eng.count_paths(2)
+    dev = torch.device("cuda:0")
+    ids = torch.empty((max(total, 1), 3), dtype=torch.int32, device=dev)
+    eng.fill_paths_device(0, total, ids, None, None)
+    part = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    eng.path_partitions_device(0, total, part)
+    for pid in range(p):
+        img_ptr, nbytes, hdr, key, deg, mbr, N = eng.build_index_partition_aux_device(pid, fetch=True)
+        mine = ids[:total][part[:total] == pid].contiguous()
+        assert hdr[3] == len(mine) and N == hdr[1]
+        # consumer constraints of the image itself (leaves now hold up to capacity - 1 entries)
+        info = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert info["num_data"] == len(mine) and np.array_equal(np.sort(info["leaf_son"]), np.arange(len(mine)))
+        want = eng.aux_index_device(img_ptr, nbytes, len(mine), 3, mine)
+        assert np.array_equal(key.view(np.uint64), want["key"].view(np.uint64)), (pid, "key")
+        assert np.array_equal(deg, want["degrees"]), (pid, "degrees")
+        assert np.array_equal(mbr.view(np.uint64), want["label_mbr"].view(np.uint64)), (pid, "label_mbr")
+    eng.close()

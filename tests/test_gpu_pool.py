@@ -17,7 +17,8 @@ def binding():
 
 
 @pytest.mark.parametrize("candidates,with_count", [(1, True), (5, True), (3, False)])
-def test_pool_rows_equal_plain_rows(binding, oracle, candidates, with_count):
+def test_pool_rows_equal_plain_rows(binding, oracle, candidates, with_count, monkeypatch):
+    monkeypatch.setenv("GNNPE_POOL_MIN_PROBE_BYTES", "0")  # the draw is for multi-GiB outputs; let a small graph exercise it
     g = synth.gnm_graph(20000, 160000, n_labels=16, seed=3)
     sn = synth.degree_order(g["offsets"])
     eng = binding.Engine(0)
@@ -52,6 +53,14 @@ def test_pool_rows_equal_plain_rows(binding, oracle, candidates, with_count):
         assert eng.count_total() == total
         assert np.array_equal(pool.pde_tensor(dev)[:total].cpu().numpy(), vde[want].reshape(total, 6))
         assert np.array_equal(ids[:total].cpu().numpy().view(np.uint32), want) and bool((ids[total:] == 0).all())
+    pool.close()
+    eng.close()
+
+
+def test_small_outputs_are_not_probed(binding):
+    eng = binding.Engine(0)
+    pool = binding.OutputPool(eng, 1000, 3, 6, candidates=5)
+    assert len(pool.report()["candidates_ms"]) == 1 and pool.ids and pool.pde
     pool.close()
     eng.close()
 
