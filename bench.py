@@ -191,6 +191,59 @@ def device_pass(torch, stream, local_rank, g, sn, labels, e, steps):
                 value=total / (ms / 1e3), unit="paths/s", fill_ms=fms, fill_frac=total * bpp / (fms / 1e3) / 1e9 / HBM_PEAK_GBS)
 
 
+def config5_leg(torch, stream, local_rank, labels, seed):
+    """BASELINE config 5 on ONE GPU (the 8-GPU split of it is in tests/test_gpu_slabs_full.py): power-law 4M / 64M, l = 3
+    (4-vertex paths: the reference's rule with the depth fixed, SURVEY D4 -- parity unpinned, the count is checked in the
+    tests against the closed form sum_E (du-1)(dv-1) - 3T), e = 8.  The 2.4e13 paths fit nowhere, so the leg times the count
+    (vde + per-row rank sort + k_deep3_count + scans) and the emit kernel k_deep3 on sampled ranges of 2^24 paths."""
+    L, e = 4, 8
+    t0 = time.perf_counter()
+    g = synth.powerlaw_graph(4_000_000, 64_000_000, exponent=2.1, max_degree=3000, n_labels=labels, seed=seed)
+    sn = synth.degree_order(g["offsets"])
+    t_gen = time.perf_counter() - t0
+    dev = torch.device("cuda", local_rank)
+    eng = binding.Engine(local_rank, stream=stream.cuda_stream)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(labels, e))
+    eng.vde(want=False)
+    total = eng.count_paths(3)  # sizes every internal buffer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.vde(want=False)
+    total2 = eng.count_paths(3)
+    torch.cuda.synchronize()
+    t_count = time.perf_counter() - t0
+    assert total2 == total
+    chunk = 1 << 24
+    ids = torch.empty((chunk, L), dtype=torch.int32, device=dev)
+    pde = torch.empty((chunk, L * e), dtype=torch.float64, device=dev)
+    bpp = bytes_per_path(L, e)
+    samples = []
+    for frac_at in (0.0, 0.37, 0.81):
+        b = min(int(total * frac_at), total - chunk) if total > chunk else 0
+        c = min(chunk, total - b)
+        ms = []
+        for _ in range(3):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            eng.fill_paths_device(b, b + c, ids, pde, None)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms.append(ev0.elapsed_time(ev1))
+        m = min(ms[1:])
+        samples.append(dict(first_path=b, paths=c, emit_ms=m, frac=c * bpp / (m / 1e3) / 1e9 / HBM_PEAK_GBS))
+    eng.close()
+    del ids, pde
+    torch.cuda.empty_cache()
+    deg = np.diff(g["offsets"].astype(np.int64))
+    return dict(workload=f"config 5: power-law n=4000000 m=64000000 (max degree {int(deg.max())}), l=3, e=8, one GPU", paths=total,
+                vde_count_s=t_count, count_paths_per_s=total / t_count, kernel="k_deep3", bytes_per_path=bpp, emit_samples=samples,
+                emit_frac=float(np.mean([x["frac"] for x in samples])), host_graph_generation_s=t_gen,
+                parity="unpinned: the reference cannot run l=3 (SURVEY D4); the count equals the closed form sum_E (du-1)(dv-1) - 3T "
+                       "computed by the oracle at full size (tests/test_gpu_slabs_full.py::test_config5_4m_64m_powerlaw_l3_e8)")
+
+
 def e2e_leg(g, sn, p, index, label):
     """Wall-clock of `gnnpe_main -m offline` on text inputs (load + emit + render + file writes [+ index.dat])."""
     free = shutil.disk_usage(tempfile.gettempdir()).free
@@ -239,6 +292,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index", action="store_true", help="skip the index-build, online-filter and end-to-end legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (power-law 4M/64M, l=3, e=8: about a minute of host graph generation)")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
     ap.add_argument("--placements", type=int, default=8,
                     help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
@@ -525,10 +579,21 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             ib_tuple.append(ev0.elapsed_time(ev1))
-        # the tree's auxiliary index (custom.h:268-364; the reference rebuilds it at every online start): device pass only
+        # image AND the tree's auxiliary index (custom.h:268-364; the reference rebuilds it at every online start) in one
+        # build: the leaf kernel computes the leaves' rows while it assembles them, the upper levels are a short pass
+        fused_ms = []
+        for _ in range(3):
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            eng.build_index_partition_aux_device(0)  # pair order cached by the calls above: compare with next_partition_ms
+            ev1.record()
+            torch.cuda.synchronize()
+            fused_ms.append(ev0.elapsed_time(ev1))
+        # the generic pass over a finished image (what a foreign tree or an l = 3 image goes through), for comparison
         aux_ms = []
         img, nbytes, hdr = eng.build_index_partition_device(0)
-        for _ in range(3):
+        for _ in range(2):
             ev0 = torch.cuda.Event(enable_timing=True)
             ev1 = torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -537,9 +602,13 @@ def main():
             torch.cuda.synchronize()
             aux_ms.append(ev0.elapsed_time(ev1))
         out["index_build"] = dict(wallclock_ms=min(ib[1:]), points=total, file_bytes=nbytes, node_blocks=hdr[1], leaves=hdr[4],
-                                  aux_index_ms=min(aux_ms),
-                                  aux_index_note="Partition::build_auxiliary_index (custom.h:268-364) over the finished image: one "
-                                                 "bottom-up pass per tree level on the device; not part of wallclock_ms",
+                                  image_and_aux_index_ms=min(ib_cached) and min(fused_ms),
+                                  aux_index_added_ms=min(fused_ms) - min(ib_cached),
+                                  aux_index_note="Partition::build_auxiliary_index (custom.h:268-364): image_and_aux_index_ms builds the image "
+                                                 "WITH the auxiliary index (leaf rows by the leaf kernel, upper levels by a short pass) from the "
+                                                 "cached pair order -- compare next_partition_ms, the same build without it; "
+                                                 "generic_aux_pass_ms is the stand-alone pass over a finished image (foreign trees, l = 3)",
+                                  generic_aux_pass_ms=min(aux_ms),
                                   where="device image of index.dat (partition 0 of p = 1), pair-major build from the enumeration "
                                         "state: pair sort + leaves + upper levels; the files on disk are timed under e2e",
                                   next_partition_ms=min(ib_cached),
@@ -561,6 +630,8 @@ def main():
     if legs and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
         g2 = synth.gnm_graph(100_000, 1_000_000, n_labels=args.labels, seed=args.seed)
         out["config2"] = device_pass(torch, stream, local_rank, g2, synth.degree_order(g2["offsets"]), args.labels, e, args.steps)
+    if legs and not args.no_config5 and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
+        out["config5"] = config5_leg(torch, stream, local_rank, args.labels, args.seed)
     if rank == 0:
         # (b) files on disk + end-to-end wall-clock of the drop-in CLI
         if legs and not args.no_e2e and not args.powerlaw and os.path.exists(CLI):

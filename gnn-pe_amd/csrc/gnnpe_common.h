@@ -88,8 +88,11 @@ inline int grid_for(uint64_t items, int per_block = kBlock)
 }  // namespace gnnpe
 
 struct gnnpe_pool;
+struct gnnpe_ctx;
 namespace gnnpe {
 void pool_free(gnnpe_pool *p);  // gnnpe_pool.hip: releases a pool's memory (the context is still alive)
+// gnnpe_pool.hip: the fastest of `candidates` allocations of `bytes` under a streaming write
+int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void **out);
 }
 
 struct gnnpe_ctx {
@@ -143,6 +146,10 @@ struct gnnpe_ctx {
     bool have_table = false, have_vde = false;
     bool labels_checked = false;  // every label indexes the table (checked once per label / table upload)
     gnnpe::DevBuf xtab, x, nx, vde, nbr_vde;
+    // the label table by rank: xrank[label * e + k] = position of xtab[label][k] among the labels' values of dimension k
+    // (equal values share a rank), xsorted[k * n_labels + r] = the value at rank r.  Min / max of label features over a set
+    // of paths become min / max of 16-bit ranks (the index leaf kernel reduces them packed, two per dword)
+    gnnpe::DevBuf xrank, xsorted;
     bool nbr_vde_valid = false;
 
     // ---- enumeration state (R2) ----

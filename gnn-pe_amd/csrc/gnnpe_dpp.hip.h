@@ -49,6 +49,23 @@ __device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v)
     GNNPE_DPP_REDUCE(uint32_t, dpp_u32, max)
     return v;
 }
+// two 16-bit lanes per dword (v_pk_max_u16): the index leaf kernel's label ranks
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const u16x2 z = __builtin_elementwise_max(x, y);
+    uint32_t r;
+    __builtin_memcpy(&r, &z, 4);
+    return r;
+}
+__device__ __forceinline__ uint32_t dpp_max_pk_u16(uint32_t v)
+{
+    GNNPE_DPP_REDUCE(uint32_t, dpp_u32, pk_max_u16)
+    return v;
+}
 __device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64(v)); }
 __device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }

@@ -474,6 +474,24 @@ int gnnpe_set_label_table(gnnpe_ctx *c, uint32_t n_labels, uint32_t e, const dou
     int rc;
     if ((rc = c->xtab.reserve((size_t)n_labels * e * 8))) return rc;
     GNNPE_HIP_TRY(hipMemcpyAsync(c->xtab.p, x_table, (size_t)n_labels * e * 8, hipMemcpyHostToDevice, c->stream));
+    // rank form of the table (see gnnpe_common.h): per dimension the distinct values in ascending order
+    std::vector<uint16_t> xr;
+    std::vector<double> xs((size_t)n_labels * e, 0.0);
+    if (n_labels <= 65536) {
+        xr.assign((size_t)n_labels * e, 0);
+        std::vector<double> col(n_labels);
+        for (uint32_t k = 0; k < e; k++) {
+            for (uint32_t l = 0; l < n_labels; l++) col[l] = x_table[(size_t)l * e + k];
+            std::sort(col.begin(), col.end());
+            const size_t nd = std::unique(col.begin(), col.end()) - col.begin();
+            for (size_t r = 0; r < nd; r++) xs[(size_t)k * n_labels + r] = col[r];
+            for (uint32_t l = 0; l < n_labels; l++)
+                xr[(size_t)l * e + k] = (uint16_t)(std::lower_bound(col.begin(), col.begin() + nd, x_table[(size_t)l * e + k]) - col.begin());
+        }
+        if ((rc = c->xrank.reserve(xr.size() * 2 + 16)) || (rc = c->xsorted.reserve(xs.size() * 8 + 16))) return rc;
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->xrank.p, xr.data(), xr.size() * 2, hipMemcpyHostToDevice, c->stream));
+        GNNPE_HIP_TRY(hipMemcpyAsync(c->xsorted.p, xs.data(), xs.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_labels = n_labels;
     c->e = e;

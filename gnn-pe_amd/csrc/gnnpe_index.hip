@@ -696,7 +696,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                                                                         const uint32_t *__restrict__ first,
                                                                         const PairXE<E> *__restrict__ px, const char *__restrict__ recs,
                                                                         const uint64_t *__restrict__ raux,
-                                                                        const double *__restrict__ xtab, char *__restrict__ image,
+                                                                        const uint16_t *__restrict__ xrank,
+                                                                        const double *__restrict__ xsorted, uint32_t n_labels,
+                                                                        uint32_t xrank_lds, char *__restrict__ image,
                                                                         double *__restrict__ node_mbr, uint32_t *__restrict__ adeg,
                                                                         double *__restrict__ ambr)
 {
@@ -709,7 +711,15 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;  // 16-byte pieces of a full leaf's used prefix
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
     __shared__ uint8_t s_pp[kLeafWaves][kStrip];
+    // the label table by rank (gen_vde_x rows, custom.h:492-511; gnnpe_common.h: xrank / xsorted) for the leaves' label MBR:
+    // the 16-bit ranks in LDS when the table is small (xrank_lds entries; 64 labels x e = 2: 256 bytes), global otherwise
+    extern __shared__ uint16_t s_xrank[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (adeg && xrank_lds) {
+        for (uint32_t i = threadIdx.x; i < xrank_lds; i += 64 * kLeafWaves) s_xrank[i] = xrank[i];
+        __syncthreads();
+    }
+    const uint16_t *const xr = (adeg && xrank_lds) ? s_xrank : xrank;
     uint32_t *w = s_win[wv];
     const uint64_t pbase = pref[r0];
     // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
@@ -776,13 +786,14 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             e_ds = (uint32_t)__shfl((int)x_cur.ds, (int)a);
             e_ls = (uint32_t)__shfl((int)x_cur.ls, (int)a);
         }
+        // per entry: degrees of its three vertices, and per dimension the rank of its label feature twice -- as it is (the
+        // wave's max gives the MBR's upper bound) and complemented (max of the complement = the lower bound); idle lanes
+        // hold zeros, the identity of max
+        constexpr int kRk = (2 * D + 1) / 2;  // dwords of packed 16-bit ranks
         uint32_t dg[3] = {0u, 0u, 0u};
-        double llo[D], lhi[D];
+        uint32_t rk[kRk];
 #pragma unroll
-        for (int k = 0; k < D; k++) {
-            llo[k] = __builtin_huge_val();
-            lhi[k] = -__builtin_huge_val();
-        }
+        for (int k = 0; k < kRk; k++) rk[k] = 0u;
         if (act) {
             const uint32_t r = (uint32_t)lane - e_pp + (uint32_t)(sw & 0xFFu);  // point inside the unit
             const char *const blk = recs + (uint64_t)e_blk * kRowAlign;
@@ -843,8 +854,16 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 dg[1] = (uint32_t)wb;
                 dg[2] = (uint32_t)wc;
                 const uint32_t lab[3] = {e_ls, (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
+                uint16_t h[2 * D + 1];
+                h[2 * D] = 0;
 #pragma unroll
-                for (int k = 0; k < D; k++) llo[k] = lhi[k] = xtab[(uint64_t)lab[k / E] * E + k % E];  // pde_label (custom.h:561-567)
+                for (int k = 0; k < D; k++) {  // pde_label (custom.h:561-567), by rank
+                    const uint16_t r16 = xr[(uint64_t)lab[k / E] * E + k % E];
+                    h[2 * k] = r16;
+                    h[2 * k + 1] = (uint16_t)~r16;
+                }
+#pragma unroll
+                for (int k = 0; k < kRk; k++) rk[k] = (uint32_t)h[2 * k] | ((uint32_t)h[2 * k + 1] << 16);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -854,15 +873,14 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
             for (int q = 0; q < 3; q++) dg[q] = dpp_max_u32(dg[q]);
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-                llo[k] = dpp_min_f64(llo[k]);
-                lhi[k] = dpp_max_f64(lhi[k]);
-            }
-            if (lane == 63) {  // the reductions end in the last lane
+            for (int k = 0; k < kRk; k++) rk[k] = dpp_max_pk_u16(rk[k]);
+            if (lane == 63) {  // the reductions end in the last lane: ranks back to the table's doubles
 #pragma unroll
                 for (int k = 0; k < D; k++) {
-                    ambr[(j * D + k) * 2] = llo[k];
-                    ambr[(j * D + k) * 2 + 1] = lhi[k];
+                    const uint32_t word = rk[k];  // dword k holds {rank max, complemented rank max} of dimension k
+                    const uint32_t hi_r = word & 0xFFFFu, lo_r = (~(word >> 16)) & 0xFFFFu;
+                    ambr[(j * D + k) * 2] = xsorted[(uint64_t)(k % E) * n_labels + lo_r];
+                    ambr[(j * D + k) * 2 + 1] = xsorted[(uint64_t)(k % E) * n_labels + hi_r];
                 }
 #pragma unroll
                 for (int q = 0; q < 3; q++) adeg[j * 3 + q] = dg[q];
@@ -1406,6 +1424,26 @@ int gnnpe_build_box_index_device(gnnpe_ctx *c, uint64_t cnt, uint32_t dim, const
 // ---- pair-major build, host side -----------------------------------------------------------------------------------
 static bool fast_dim(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
+// The image buffer (grow-only).  The leaf kernel is 80 % stores into it, and the rate a buffer takes them at is a property of
+// the allocation, so a long-lived context may place it by a draw: GNNPE_IMAGE_CANDIDATES=k allocates k
+// candidates, streams into each and keeps the fastest (measured at config 3: candidates at 4.69 / 3.79 / 3.83 ms per 24 GB,
+// leaf kernel 5.9 -> 5.1 ms).  Off by default: three 24 GB allocations cost 1.2 s, more than a one-shot build ever gets back.
+static int reserve_image(gnnpe_ctx *c, uint64_t need)
+{
+    if (need <= c->index_image.bytes) return GNNPE_OK;
+    uint32_t cands = 1;
+    if (const char *ev = getenv("GNNPE_IMAGE_CANDIDATES")) cands = (uint32_t)std::max(1, atoi(ev));
+    if (need < (1ull << 30) || cands < 2) return c->index_image.reserve(need);
+    c->index_image.release();
+    const uint64_t want = need + need / 8 + 256;
+    void *q = nullptr;
+    int rc = draw_device_buffer(c, want, cands, &q);
+    if (rc) return rc;
+    c->index_image.p = q;
+    c->index_image.bytes = want;
+    return GNNPE_OK;
+}
+
 // the enumeration state this build reads: ranked records of an l = 2 count carrying the current vde table
 static bool pair_major_ok(const gnnpe_ctx *c)
 {
@@ -1607,7 +1645,7 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
     uint64_t max_level = 0;
     for (uint64_t v : level_n) max_level = std::max(max_level, v);
-    if ((rc = c->index_image.reserve(image_bytes)) || (rc = c->px_first.reserve((level_n[0] + 1) * 4)) ||
+    if ((rc = reserve_image(c, image_bytes)) || (rc = c->px_first.reserve((level_n[0] + 1) * 4)) ||
         (rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8)))
         return rc;
     char *image = c->index_image.as<char>();
@@ -1642,10 +1680,13 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     const bool packed = c->n <= (1u << kPackedIdBits);
     GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
     const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
+    // the label ranks ride in LDS when they fit beside the windows without costing a wave of occupancy (<= 4 KB)
+    const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 2048) ? c->n_labels * e : 0u;
 #define GNNPE_PXL(EE, PK)                                                                                               \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, r0, r1,       \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 2, c->stream, cnt, nl, r0, r1, \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
-                       c->px_raux.as<uint64_t>(), c->xtab.as<double>(), image, mbr_a, adeg, ambr)
+                       c->px_raux.as<uint64_t>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds, image, \
+                       mbr_a, adeg, ambr)
 #define GNNPE_PXE(EE)                                          \
     do {                                                       \
         if (packed) GNNPE_PXL(EE, true); else GNNPE_PXL(EE, false); \
@@ -1726,7 +1767,10 @@ static int collect_partition_tuples(gnnpe_ctx *c, uint32_t pid, DevBuf &mine, ui
     return rc;
 }
 
-static bool fused_aux_ok(const gnnpe_ctx *c) { return pair_major_ok(c) && (c->rows_identity || c->have_deg_all); }
+static bool fused_aux_ok(const gnnpe_ctx *c)
+{
+    return pair_major_ok(c) && (c->rows_identity || c->have_deg_all) && c->n_labels <= 65536;  // 16-bit label ranks
+}
 
 static int build_partition(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8], bool with_aux)
 {

@@ -45,6 +45,52 @@ __global__ void k_pool_stream(f4 *__restrict__ dst, uint64_t n)
         __builtin_nontemporal_store(v, &dst[i]);
 }
 
+// The same draw for a library-owned buffer (the index image, 22 GB at config 3, written once front to back by the leaf
+// kernel): `candidates` allocations alive at once, a streaming write timed into each, the fastest kept.  *out = nullptr
+// and an error code when not even one allocation fits.
+int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void **out)
+{
+    *out = nullptr;
+    size_t free_b = 0, tot_b = 0;
+    GNNPE_HIP_TRY(hipMemGetInfo(&free_b, &tot_b));
+    const uint32_t K = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(candidates, (uint64_t)free_b / 4 * 3 / std::max<uint64_t>(bytes, 1)));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<void *> cand;
+    std::vector<float> ms_of;
+    for (uint32_t k = 0; k < K; k++) {
+        void *q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        cand.push_back(q);
+        float best = 0.f;
+        if (K > 1) {
+            best = 1e30f;
+            for (int rep = 0; rep < 3; rep++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                hipLaunchKernelGGL(k_pool_stream, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, (f4 *)q, bytes / 16);
+                if (hipStreamSynchronize(c->stream) != hipSuccess) break;
+                const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (rep > 0) best = std::min(best, ms);
+            }
+        }
+        ms_of.push_back(best);
+        if (getenv("GNNPE_POOL_DEBUG")) fprintf(stderr, "[draw] %llu bytes, candidate %u at %p: %.3f ms\n", (unsigned long long)bytes, k, q, best);
+    }
+    if (cand.empty()) {
+        set_error("hipMalloc(%llu) failed", (unsigned long long)bytes);
+        return GNNPE_ERR_HIP;
+    }
+    size_t kept = 0;
+    for (size_t k = 1; k < cand.size(); k++)
+        if (ms_of[k] < ms_of[kept]) kept = k;
+    for (size_t k = 0; k < cand.size(); k++)
+        if (k != kept) (void)hipFree(cand[k]);
+    *out = cand[kept];
+    return GNNPE_OK;
+}
+
 void pool_free(gnnpe_pool *p)
 {
     if (!p) return;
