@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
             reinterpret_cast<Rec *>(base + 8 * E)[cnt] = rec;
             if (rp != kNoEdge && po != kNoEdge) {  // (u, b) is a pair of this slab: u starts here and its row is held
                 RankedPair pr = {blk, cnt, G};
+                // the one random store per adjacency entry.  Round-3 knock-outs at config 3 (count phase, same process: 1.07 ms):
+                // without this store 0.74; stored at the entry's own, coalesced position instead 0.80; 8 bytes instead of 16
+                // 1.07; a 32-byte slot written in two halves 1.19 -- it is the REQUEST that costs, and moving it to the reading
+                // side (the emit kernel gathering from b-major pairs) costs the dominant kernel more than it saves here
                 pairs[po + rp] = pr;
             }
         }
