@@ -109,7 +109,7 @@ SIGNATURES = {
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
 }
 
-ABI_VERSION = 2  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
+ABI_VERSION = 3  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
 _lib = None
 
 

@@ -1047,7 +1047,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
         const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
 #define GNNPE_L(EE)                                                                                                \
-    hipLaunchKernelGGL((k_deep3<EE>), dim3(grid_for((u_hi - u_lo) * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,   \
+    hipLaunchKernelGGL((k_deep3<EE>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(u_hi - u_lo, 1u << 20))),      \
+                       dim3(64 * kDeepWaves), 0, c->stream, P,   \
                        c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
         if (fast_e(e)) {
             GNNPE_BY_E(e, GNNPE_L)

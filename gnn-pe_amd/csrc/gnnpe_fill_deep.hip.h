@@ -123,6 +123,16 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3_count(FillParams P, c
 }
 
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
+//
+// One WORKGROUP (kDeepWaves waves) per unit since round 3; round 1 gave a unit to one wave.  On a power-law graph a unit
+// behind a hub middle vertex holds 64 third vertices of degree up to thousands -- 10^5 candidates, 80 MB of output -- and
+// a sampled range of config 5 (2^24 paths) is covered by a few hundred such units: a few hundred waves on a chip that
+// holds eight thousand, the longest of them running for milliseconds (bench.py config5 leg, round 3: 0.06-0.10 of the HBM
+// spec).  The flattened candidate space of the unit is now cut into kDeepWaves equal pieces at CANDIDATE granularity (a
+// single hub third vertex is split too).  Output slots need the kept rows before a piece, so the waves walk their
+// pieces twice: pass A reads the candidates' ranks only and counts (4 bytes per candidate against ~140 written per
+// candidate in pass B), an LDS prefix over the waves gives every piece its first slot, pass B emits.  A piece whose slots
+// lie outside the requested range [P.begin, P.end) skips pass B.
 template <int E>
 __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint32_t *__restrict__ upair,
                                                            const uint64_t *__restrict__ ufirst,
@@ -130,125 +140,146 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
 {
     __shared__ uint32_t s_off[kDeepWaves][65], s_st[kDeepWaves][64], s_c[kDeepWaves][64];
     __shared__ uint32_t s_kc[kDeepWaves][64], s_kd[kDeepWaves][64], s_kp[kDeepWaves][64];  // kept rows of one step
+    __shared__ uint32_t s_piece[kDeepWaves];  // kept rows of every wave's piece (pass A)
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
     uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
-    uint64_t u = u_begin + ((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6);
-    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
-    for (; u < u_end; u += nw) {
+    for (uint64_t u = u_begin + blockIdx.x; u < u_end; u += gridDim.x) {  // block-uniform: every wave takes part in the barriers
         const uint64_t base = uoff[u], nxt = uoff[u + 1];
         if (nxt == base || base >= P.end || nxt <= P.begin) continue;
         const uint32_t w = upair[u];
         const uint32_t i = P.erow[w], b = P.pnbr[w];
         const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
         const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
+        const uint32_t k0 = (uint32_t)(u - ufirst[w]) * 64u;  // this unit's 64 third vertices
+        // one lane per third vertex c (every wave builds its own copy of the unit's segment table: no barrier needed for it)
+        const uint32_t k = k0 + lane;
+        uint32_t c = 0, cd = 0, cst = 0;
+        if (k < bd) {
+            c = P.nbrs[bst + k];
+            if (c != s) {  // (a missing 2-hop row was reported by the count pass)
+                cd = P.adj_deg[c];
+                cst = P.adj_start[c];
+            }
+        }
+        uint32_t incl = cd;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += t;
+        }
+        off[lane] = incl - cd;
+        rst[lane] = cst;
+        rc[lane] = c;
+        const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (lane == 0) off[64] = n_cand;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // this wave's piece of the flattened candidates: whole steps of 64, the pieces as equal as that allows
+        const uint32_t n_steps = (n_cand + 63u) / 64u;
+        const uint32_t q_lo = min(n_cand, (n_steps * wv / kDeepWaves) * 64u), q_hi = min(n_cand, (n_steps * (wv + 1) / kDeepWaves) * 64u);
+        auto locate = [&](uint32_t q, uint32_t &seg, uint32_t &pos) {
+            uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (off[lo + step] <= q) lo += step;
+            seg = lo;
+            pos = rst[lo] + (q - off[lo]);
+        };
+        // pass A: kept rows of the piece (ranks only)
+        uint32_t mine = 0;
+        for (uint32_t q0 = q_lo; q0 < q_hi; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            bool keep = false;
+            if (q < q_hi) {
+                uint32_t seg, pos;
+                locate(q, seg, pos);
+                keep = P.nbr_rank[pos] > thr && P.nbrs[pos] != b;
+            }
+            mine += (uint32_t)__popcll(__ballot(keep));
+        }
+        if (lane == 0) s_piece[wv] = mine;
+        __syncthreads();
         uint64_t running = 0;
-        {
-            const uint32_t k0 = (uint32_t)(u - ufirst[w]) * 64u;  // this unit's 64 third vertices
-            // one lane per third vertex c
-            const uint32_t k = k0 + lane;
-            uint32_t c = 0, cd = 0, cst = 0;
-            if (k < bd) {
-                c = P.nbrs[bst + k];
-                if (c != s) {  // (a missing 2-hop row was reported by the count pass)
-                    cd = P.adj_deg[c];
-                    cst = P.adj_start[c];
-                }
+        for (unsigned v = 0; v < wv; v++) running += s_piece[v];
+        __syncthreads();  // s_piece is rewritten by the next unit
+        const uint64_t piece0 = base + running;
+        if (mine == 0 || piece0 >= P.end || piece0 + mine <= P.begin) continue;  // (after both barriers: block-uniform control flow above)
+        running = 0;
+        // pass B: flattened candidates of the piece, 64 per step
+        for (uint32_t q0 = q_lo; q0 < q_hi; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool act = q < q_hi;
+            uint32_t lo = 0, pos = 0;
+            if (act) locate(q, lo, pos);
+            uint32_t d = 0, rd = 0;
+            if (act) {
+                d = P.nbrs[pos];
+                rd = P.nbr_rank[pos];
             }
-            uint32_t incl = cd;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o, 64);
-                if ((int)lane >= o) incl += t;
-            }
-            off[lane] = incl - cd;
-            rst[lane] = cst;
-            rc[lane] = c;
-            const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (lane == 0) off[64] = n_cand;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // flattened candidates, 64 per step
-            for (uint32_t q0 = 0; q0 < n_cand; q0 += 64) {
-                const uint32_t q = q0 + lane;
-                const bool act = q < n_cand;
-                uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
-#pragma unroll
-                for (int step = 32; step > 0; step >>= 1)
-                    if (off[lo + step] <= q) lo += step;
-                const uint32_t pos = rst[lo] + (q - off[lo]);
-                uint32_t d = 0, rd = 0;
-                if (act) {
-                    d = P.nbrs[pos];
-                    rd = P.nbr_rank[pos];
-                }
-                const bool keep = act && rd > thr && d != b;
-                const uint64_t mask = __ballot(keep);
-                {
-                    // rows of this step occupy slots [slot0, slot0 + cnt): compact (c, d, entry) into LDS, then the
-                    // wave writes the rows as one contiguous region, consecutive lanes on consecutive elements
-                    const uint32_t cnt = (uint32_t)__popcll(mask);
-                    const uint64_t slot0 = base + running;
-                    if (cnt && slot0 < P.end && slot0 + cnt > P.begin) {
-                        if (keep) {
-                            const uint32_t r = (uint32_t)__popcll(mask & lt);
-                            kc[r] = rc[lo];
-                            kd[r] = d;
-                            kp[r] = pos;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const uint32_t r_lo = slot0 < P.begin ? (uint32_t)(P.begin - slot0) : 0u;
-                        const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
-                        const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
-                        const uint32_t rows = r_hi - r_lo;
-                        if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
-                            const uint32_t r = r_lo + lane;
-                            uint32_t *dst = P.out_ids + (o0 + lane) * 4;
-                            __builtin_nontemporal_store(s, dst);
-                            __builtin_nontemporal_store(b, dst + 1);
-                            __builtin_nontemporal_store(kc[r], dst + 2);
-                            __builtin_nontemporal_store(kd[r], dst + 3);
-                        }
-                        if (P.out_pde) {
-                            auto elem = [&](uint32_t t) -> double {
-                                const uint32_t r = r_lo + t / D, k = t % D, which = k / e, comp = k % e;
-                                return which == 0   ? P.vde[(uint64_t)s * e + comp]
-                                       : which == 1 ? P.vde[(uint64_t)b * e + comp]
-                                       : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
-                                                    : P.nbr_vde[(uint64_t)kp[r] * e + comp];
-                            };
-                            // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
-                            typedef double dbl2 __attribute__((ext_vector_type(2)));
-                            dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
-                            for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
-                                dbl2 v;
-                                v.x = elem(2 * t2);
-                                v.y = elem(2 * t2 + 1);
-                                __builtin_nontemporal_store(v, dst + t2);
-                            }
-                        }
-                        if (P.out_pdl)
-                            for (uint32_t t = lane; t < rows * D; t += 64) {
-                                const uint32_t r = r_lo + t / D, k = t % D, which = k / e, comp = k % e;
-                                const uint32_t v = which == 0 ? s : which == 1 ? b : which == 2 ? kc[r] : kd[r];
-                                P.out_pdl[o0 * D + t] = P.x[(uint64_t)v * e + comp];
-                            }
-                        if (P.out_part && lane < rows) P.out_part[o0 + lane] = P.member[s];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool keep = act && rd > thr && d != b;
+            const uint64_t mask = __ballot(keep);
+            {
+                // rows of this step occupy slots [slot0, slot0 + cnt): compact (c, d, entry) into LDS, then the
+                // wave writes the rows as one contiguous region, consecutive lanes on consecutive elements
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                const uint64_t slot0 = piece0 + running;
+                if (cnt && slot0 < P.end && slot0 + cnt > P.begin) {
+                    if (keep) {
+                        const uint32_t r = (uint32_t)__popcll(mask & lt);
+                        kc[r] = rc[lo];
+                        kd[r] = d;
+                        kp[r] = pos;
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t r_lo = slot0 < P.begin ? (uint32_t)(P.begin - slot0) : 0u;
+                    const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
+                    const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
+                    const uint32_t rows = r_hi - r_lo;
+                    if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
+                        const uint32_t r = r_lo + lane;
+                        uint32_t *dst = P.out_ids + (o0 + lane) * 4;
+                        __builtin_nontemporal_store(s, dst);
+                        __builtin_nontemporal_store(b, dst + 1);
+                        __builtin_nontemporal_store(kc[r], dst + 2);
+                        __builtin_nontemporal_store(kd[r], dst + 3);
+                    }
+                    if (P.out_pde) {
+                        auto elem = [&](uint32_t t) -> double {
+                            const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
+                            return which == 0   ? P.vde[(uint64_t)s * e + comp]
+                                   : which == 1 ? P.vde[(uint64_t)b * e + comp]
+                                   : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
+                                                : P.nbr_vde[(uint64_t)kp[r] * e + comp];
+                        };
+                        // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
+                        typedef double dbl2 __attribute__((ext_vector_type(2)));
+                        dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
+                        for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
+                            dbl2 v;
+                            v.x = elem(2 * t2);
+                            v.y = elem(2 * t2 + 1);
+                            __builtin_nontemporal_store(v, dst + t2);
+                        }
+                    }
+                    if (P.out_pdl)
+                        for (uint32_t t = lane; t < rows * D; t += 64) {
+                            const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
+                            const uint32_t v = which == 0 ? s : which == 1 ? b : which == 2 ? kc[r] : kd[r];
+                            P.out_pdl[o0 * D + t] = P.x[(uint64_t)v * e + comp];
+                        }
+                    if (P.out_part && lane < rows) P.out_part[o0 + lane] = P.member[s];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                running += __popcll(mask);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            running += __popcll(mask);
         }
     }
 }

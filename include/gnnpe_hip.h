@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNPE_ABI_VERSION 2
+#define GNNPE_ABI_VERSION 3
 
 #define GNNPE_OK 0
 #define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
