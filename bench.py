@@ -43,7 +43,7 @@ from gnnpe_amd import binding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_fill.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_fill.json")
 
 
 def bytes_per_path(L, e):
@@ -501,7 +501,7 @@ def main():
     fill_avg_ms = float(np.mean([a.elapsed_time(b) for a, b in fill_ms])) if fill_ms else float("nan")
     bpp = (4 * L + 16) if args.ids_only else bytes_per_path(L, e)
     achieved = total * bpp / (fill_avg_ms / 1e3) / 1e9
-    # HBM traffic of the fill launch from this round's PMC passes (profiles/, same command and config): WRITE_SIZE +
+    # HBM traffic of the fill launch from the committed PMC passes (profiles/, same command and config): WRITE_SIZE +
     # the fabric read requests by size (TCC_EA0_RDREQ_{32,64,128}B); counters cannot be collected inside this run
     traffic, traffic_note = None, None
     if (os.path.exists(PMC_FILE) and world == 1 and args.fill_variant == 4 and not args.ids_only and not args.powerlaw
@@ -516,7 +516,7 @@ def main():
     cms = sorted(pool_rep["candidates_ms"])
     med_ms = float(np.median(cms)) if len(cms) > 1 else None
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r02_pmc_fill.json), not this run",
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r03_pmc_fill.json: separate --pmc passes of this command), not this run",
                     traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms,
                     output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],

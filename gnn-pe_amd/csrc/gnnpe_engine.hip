@@ -1046,15 +1046,21 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, d_range, 16, hipMemcpyDeviceToHost, c->stream));
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
         const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
-#define GNNPE_L(EE)                                                                                                \
-    hipLaunchKernelGGL((k_deep3<EE>), dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(u_hi - u_lo, 1u << 20))),      \
-                       dim3(64 * kDeepWaves), 0, c->stream, P,   \
-                       c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
+        // waves per unit: 16 on graphs with hub rows (a unit behind a hub holds 10^5 candidates), 4 otherwise
+        const unsigned n_blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(u_hi - u_lo, 1u << 20));
+#define GNNPE_LW(EE, WW)                                                                                           \
+    hipLaunchKernelGGL((k_deep3<EE, WW>), dim3(n_blocks), dim3(64 * WW), 0, c->stream, P, c->upair.as<uint32_t>(),   \
+                       c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
+#define GNNPE_L(EE)                                     \
+    do {                                                \
+        if (c->n_hub) GNNPE_LW(EE, 16); else GNNPE_LW(EE, 4); \
+    } while (0)
         if (fast_e(e)) {
             GNNPE_BY_E(e, GNNPE_L)
         } else {
             GNNPE_L(0);
         }
+#undef GNNPE_LW
 #undef GNNPE_L
     } else if (var == kVarRanked) {
         // a resident grid: every wave walks its share of the start vertices (w, w + waves, ...): the waves in flight

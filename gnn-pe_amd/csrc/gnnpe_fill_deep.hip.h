@@ -124,23 +124,24 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3_count(FillParams P, c
 
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
 //
-// One WORKGROUP (kDeepWaves waves) per unit since round 3; round 1 gave a unit to one wave.  On a power-law graph a unit
+// One WORKGROUP (WAVES waves) per unit since round 3; round 1 gave a unit to one wave.  On a power-law graph a unit
 // behind a hub middle vertex holds 64 third vertices of degree up to thousands -- 10^5 candidates, 80 MB of output -- and
 // a sampled range of config 5 (2^24 paths) is covered by a few hundred such units: a few hundred waves on a chip that
 // holds eight thousand, the longest of them running for milliseconds (bench.py config5 leg, round 3: 0.06-0.10 of the HBM
-// spec).  The flattened candidate space of the unit is now cut into kDeepWaves equal pieces at CANDIDATE granularity (a
+// spec).  The flattened candidate space of the unit is now cut into WAVES equal pieces at CANDIDATE granularity (a
 // single hub third vertex is split too).  Output slots need the kept rows before a piece, so the waves walk their
+// (WAVES = 4 where no row is longer than 64 entries -- units of a few hundred candidates -- and 16 on graphs with hub rows.)
 // pieces twice: pass A reads the candidates' ranks only and counts (4 bytes per candidate against ~140 written per
 // candidate in pass B), an LDS prefix over the waves gives every piece its first slot, pass B emits.  A piece whose slots
 // lie outside the requested range [P.begin, P.end) skips pass B.
-template <int E>
-__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const uint32_t *__restrict__ upair,
+template <int E, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32_t *__restrict__ upair,
                                                            const uint64_t *__restrict__ ufirst,
                                                            const uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end)
 {
-    __shared__ uint32_t s_off[kDeepWaves][65], s_st[kDeepWaves][64], s_c[kDeepWaves][64];
-    __shared__ uint32_t s_kc[kDeepWaves][64], s_kd[kDeepWaves][64], s_kp[kDeepWaves][64];  // kept rows of one step
-    __shared__ uint32_t s_piece[kDeepWaves];  // kept rows of every wave's piece (pass A)
+    __shared__ uint32_t s_off[WAVES][65], s_st[WAVES][64], s_c[WAVES][64];
+    __shared__ uint32_t s_kc[WAVES][64], s_kd[WAVES][64], s_kp[WAVES][64];  // kept rows of one step
+    __shared__ uint32_t s_piece[WAVES];  // kept rows of every wave's piece (pass A)
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_deep3(FillParams P, const u
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // this wave's piece of the flattened candidates: whole steps of 64, the pieces as equal as that allows
         const uint32_t n_steps = (n_cand + 63u) / 64u;
-        const uint32_t q_lo = min(n_cand, (n_steps * wv / kDeepWaves) * 64u), q_hi = min(n_cand, (n_steps * (wv + 1) / kDeepWaves) * 64u);
+        const uint32_t q_lo = min(n_cand, (n_steps * wv / WAVES) * 64u), q_hi = min(n_cand, (n_steps * (wv + 1) / WAVES) * 64u);
         auto locate = [&](uint32_t q, uint32_t &seg, uint32_t &pos) {
             uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
 #pragma unroll
