@@ -164,6 +164,7 @@ struct gnnpe_ctx {
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
+    gnnpe::DevBuf rank_arg, rb_cnt, rb_first;  // ... the entry each sorted rank came from; row-batches (64 third vertices) per row
     gnnpe::DevBuf ufirst, upair, uoff;  // l=3 work units: first unit of a pair, pair of a unit, output slot of a unit
     uint64_t n_units = 0;
     gnnpe::DevBuf deg_all;          // online filter on a slab: degree of EVERY vertex (gnnpe_set_degrees)

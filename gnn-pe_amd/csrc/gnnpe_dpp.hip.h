@@ -66,6 +66,23 @@ __device__ __forceinline__ uint32_t dpp_max_pk_u16(uint32_t v)
     GNNPE_DPP_REDUCE(uint32_t, dpp_u32, pk_max_u16)
     return v;
 }
+// wave sum (result in lane 63): the masked row-broadcast steps must contribute the identity to the rows they skip, so the
+// "old" operand of the DPP move is 0 here (the min / max reductions above pass the value itself, their identity)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_u32_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v)
+{
+    v += dpp_u32_zero<0xB1, 0xF>(v);
+    v += dpp_u32_zero<0x4E, 0xF>(v);
+    v += dpp_u32_zero<0x141, 0xF>(v);
+    v += dpp_u32_zero<0x140, 0xF>(v);
+    v += dpp_u32_zero<0x142, 0xA>(v);
+    v += dpp_u32_zero<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_add_u32(v), 63); }
 __device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64(v)); }
 __device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }

@@ -873,25 +873,34 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
             if ((rc = c->upair.reserve((nu + 1) * 4)) || (rc = c->uoff.reserve((nu + 2) * 8))) return rc;
             hipLaunchKernelGGL(k_deep_unit_pairs, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne, ufirst,
                                c->upair.as<uint32_t>());
-            // every row's neighbour ranks in ascending order: the count is then one binary search per (s, b, c)
-            if ((rc = c->rank_sorted.reserve((c->nbr_used + 1) * 4)) || (rc = c->adj_end.reserve(((size_t)c->n + 1) * 4))) return rc;
+            // every row's neighbour ranks in ascending order, with the entry each came from: the count is then one forward merge
+            // per (row, third vertex) over all the row's slab neighbours (k_deep3_count_rows)
+            if ((rc = c->rank_sorted.reserve((c->nbr_used + 1) * 4)) || (rc = c->adj_end.reserve(((size_t)c->n + 1) * 4)) ||
+                (rc = c->rank_arg.reserve((c->nbr_used + 1) * 4)) || (rc = c->scratch.reserve((c->nbr_used + 1) * 4)) ||
+                (rc = c->rb_first.reserve(((size_t)c->n + 2) * 4)) || (rc = c->rb_cnt.reserve(((size_t)c->n + 2) * 4)))
+                return rc;
+            GNNPE_HIP_TRY(hipMemsetAsync(c->uoff.p, 0, (nu + 1) * 8, c->stream));
             if (c->nbr_used) {
                 hipLaunchKernelGGL(k_row_ends, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->adj_start.as<uint32_t>(),
                                    c->adj_deg.as<uint32_t>(), c->adj_end.as<uint32_t>());
+                hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(c->nbr_used)), dim3(kBlock), 0, c->stream, c->nbr_used, c->scratch.as<uint32_t>());
                 size_t ts = 0;
-                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
-                    nullptr, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n,
-                    c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
+                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(
+                    nullptr, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), c->scratch.as<uint32_t>(), c->rank_arg.as<uint32_t>(),
+                    (int)c->nbr_used, (int)c->n, c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
                 if ((rc = c->cub_tmp.reserve(ts))) return rc;
                 ts = c->cub_tmp.bytes;
-                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(
-                    c->cub_tmp.p, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), (int)c->nbr_used, (int)c->n,
-                    c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
+                GNNPE_HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortPairs(
+                    c->cub_tmp.p, ts, c->nbr_rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), c->scratch.as<uint32_t>(), c->rank_arg.as<uint32_t>(),
+                    (int)c->nbr_used, (int)c->n, c->adj_start.as<uint32_t>(), c->adj_end.as<uint32_t>(), 0, 32, c->stream));
             }
-            hipLaunchKernelGGL(k_deep3_count, dim3(grid_for(nu * 64 + 1)), dim3(64 * kDeepWaves), 0, c->stream, P,
+            hipLaunchKernelGGL(k_deep_row_batches, dim3(grid_for((uint64_t)c->n + 1)), dim3(kBlock), 0, c->stream, c->n, c->adj_deg.as<uint32_t>(),
+                               c->rb_cnt.as<uint32_t>());
+            if ((rc = scan_u32(c, c->rb_cnt.as<uint32_t>(), c->rb_first.as<uint32_t>(), (uint64_t)c->n + 1))) return rc;
+            hipLaunchKernelGGL(k_deep3_count_rows, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
                                c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
-                               c->rank_sorted.as<uint32_t>(), c->upair.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), nu,
-                               d_missing);
+                               c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->rb_first.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), nu, d_missing);
             uint64_t miss = 0;
             if ((rc = read_back_u64(c, d_missing, 4, &miss))) return rc;
             GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,

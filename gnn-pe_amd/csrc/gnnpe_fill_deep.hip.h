@@ -23,6 +23,7 @@
 // candidates at all; its per-unit totals are 64-bit (hub pairs of a power-law graph pass 2^32).
 #pragma once
 
+#include "gnnpe_dpp.hip.h"
 #include "gnnpe_kernels.hip.h"
 
 namespace gnnpe {
@@ -78,46 +79,118 @@ __global__ void k_row_ends(uint32_t n, const uint32_t *__restrict__ adj_start, c
         adj_end[v] = adj_start[v] + adj_deg[v];
 }
 
-// Count pass without walking candidates: with every row's neighbour RANKS sorted (one segmented sort per order), the
-// kept fourth vertices of (s, b, c) number |{d in N(c): rank d > rank s}| - [rank b > rank s] -- one binary search in
-// row c.  One wave per unit, one lane per third vertex.
-__global__ __launch_bounds__(64 * kDeepWaves) void k_deep3_count(FillParams P, const uint8_t *__restrict__ present,
-                                                                 const uint32_t *__restrict__ rank,
-                                                                 const uint32_t *__restrict__ sorted_ranks,
-                                                                 const uint32_t *__restrict__ upair,
-                                                                 const uint64_t *__restrict__ ufirst,
-                                                                 uint64_t *__restrict__ uoff, uint64_t n_units,
-                                                                 uint32_t *__restrict__ missing_row)
+// ---- the count, row-major (round 3) -----------------------------------------------------------------------------------
+// With every row's neighbour RANKS sorted (one segmented sort per order), the kept fourth vertices of (s, b, c) number
+// |{d in N(c): rank d > rank s}| - [rank b > rank s].  Rounds 1-2 answered every (s, b, c) with its own binary search in row
+// c (one wave per unit, one lane per third vertex): 1.4e11 searches of ~12 dependent loads at config 5 -- 11.7 s, all of
+// the count (profiles/r03_deep_kernel_stats.csv, k_deep3_count).  For a fixed (b, c) the answer is monotone in
+// rank[s], and the start vertices that have b as a neighbour are N(b) itself: so one wave takes a ROW-BATCH (b, 64 third
+// vertices c = one lane each) and answers ALL of b's slab neighbours s in ascending rank order with one merge per lane --
+// a pointer into row c's sorted ranks that only moves forward (after one binary search for the first threshold).  Per
+// threshold: the lanes advance, subtract, a DPP wave sum, and the unit (s, b, batch) gets its count.  Thresholds are taken
+// 64 at a time (their rank, start vertex and unit slot loaded by the lanes, broadcast by readlane), so the loop body has no
+// dependent global load but the pointer advance, which walks consecutive words of a line.
+// rb_first[v] = first row-batch of row v (prefix of ceil(deg / 64) over the rows); rb_first[n] = their number.
+__global__ void k_deep_row_batches(uint32_t n, const uint32_t *__restrict__ adj_deg, uint32_t *__restrict__ out)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v <= n; v += (uint64_t)gridDim.x * blockDim.x)
+        out[v] = v < n ? (adj_deg[v] + 63u) / 64u : 0u;
+}
+__global__ void k_iota_u32(uint64_t n, uint32_t *__restrict__ out)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void k_deep3_count_rows(FillParams P, uint32_t n, uint32_t slab_len, const uint8_t *__restrict__ present,
+                                                          const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sorted_ranks,
+                                                          const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos,
+                                                          const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ rb_first,
+                                                          const uint64_t *__restrict__ ufirst, uint64_t *__restrict__ uoff,
+                                                          uint64_t n_units, uint32_t *__restrict__ missing_row)
 {
     const unsigned lane = lane_id();
-    uint64_t u = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_rb = rb_first[n];
+    uint64_t rb = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (; u < n_units; u += nw) {
-        const uint32_t w = upair[u];
-        const uint32_t i = P.erow[w], b = P.pnbr[w];
-        const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+    const uint32_t sb = P.slab_begin, se = P.slab_begin + slab_len;
+    for (; rb < n_rb; rb += nw) {
+        uint32_t lo = 0, hi = n;  // the row of this batch: largest b with rb_first[b] <= rb (rows without entries share a value)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rb_first[mid] <= rb) lo = mid; else hi = mid;
+        }
+        const uint32_t b = lo, j = (uint32_t)rb - rb_first[b];
         const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
-        const uint32_t b_kept = rank[b] > thr ? 1u : 0u;  // b itself is a neighbour of every c and must not close the path
-        const uint32_t k = (uint32_t)(u - ufirst[w]) * 64u + lane;
-        uint32_t cnt = 0;
+        const uint32_t *sr_b = sorted_ranks + bst;
+        // b's neighbours that start paths here = its sorted ranks inside [sb, se)
+        uint32_t t_lo = 0, t_hi = bd;
+        {
+            uint32_t a = 0, z = bd;
+            while (a < z) {
+                const uint32_t mid = (a + z) >> 1;
+                if (sr_b[mid] < sb) a = mid + 1; else z = mid;
+            }
+            t_lo = a;
+            z = bd;
+            while (a < z) {
+                const uint32_t mid = (a + z) >> 1;
+                if (sr_b[mid] < se) a = mid + 1; else z = mid;
+            }
+            t_hi = a;
+        }
+        if (t_lo == t_hi) continue;  // (a row two hops out: a third vertex only)
+        const uint32_t rank_b = rank[b];
+        const uint32_t k = j * 64u + lane;
+        uint32_t c = 0xFFFFFFFFu, cd = 0, cst = 0;
         if (k < bd) {
-            const uint32_t c = P.nbrs[bst + k];
-            if (c != s) {
-                if (present && !present[c]) atomicMin(missing_row, c);  // 2-hop row not on this device
-                else {
-                    const uint32_t st = P.adj_start[c], d = P.adj_deg[c];
-                    uint32_t lo = 0, hi = d;  // first position with rank > thr
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (sorted_ranks[st + mid] <= thr) lo = mid + 1; else hi = mid;
-                    }
-                    cnt = d - lo - b_kept;
-                }
+            c = P.nbrs[bst + k];
+            if (present && !present[c]) {
+                atomicMin(missing_row, c);  // 2-hop row not on this device
+            } else {
+                cd = P.adj_deg[c];
+                cst = P.adj_start[c];
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        if (lane == 0) uoff[u] = cnt;  // counts; scanned in place by the caller
+        const uint32_t *sr_c = sorted_ranks + cst;
+        // first position of row c ranked after the first threshold: one binary search per (b, c); from there on the pointer
+        // only moves forward.  nxt = the rank under the pointer (all ones past the row's end: no rank reaches it)
+        uint32_t ptr = 0;
+        {
+            const uint32_t r0 = sr_b[t_lo];
+            uint32_t a = 0, z = cd;
+            while (a < z) {
+                const uint32_t mid = (a + z) >> 1;
+                if (sr_c[mid] <= r0) a = mid + 1; else z = mid;
+            }
+            ptr = a;
+        }
+        uint32_t nxt = ptr < cd ? sr_c[ptr] : 0xFFFFFFFFu;
+        for (uint32_t t0 = t_lo; t0 < t_hi; t0 += 64) {
+            const uint32_t tt = t0 + lane;
+            uint32_t r_l = 0, s_l = 0xFFFFFFFFu;
+            uint64_t u_l = 0;
+            if (tt < t_hi) {
+                r_l = sr_b[tt];
+                const uint32_t q = rank_arg[bst + tt];  // entry of row b that holds this neighbour
+                s_l = P.nbrs[q];
+                const uint32_t rp = revpos[q];  // position of b inside N(s): s starts paths here, so its row is an owned one
+                u_l = rp != 0xFFFFFFFFu ? ufirst[poffs[r_l - sb] + rp] + j : ~0ull;  // the pair (s, b), this batch
+            }
+            const uint32_t nt = min(64u, t_hi - t0);
+            uint32_t my_sum = 0;
+            for (uint32_t i = 0; i < nt; i++) {
+                const uint32_t r_t = rl32(r_l, (int)i), s = rl32(s_l, (int)i);
+                while (__any(nxt <= r_t))
+                    if (nxt <= r_t) {
+                        ptr++;
+                        nxt = ptr < cd ? sr_c[ptr] : 0xFFFFFFFFu;
+                    }
+                const uint32_t b_kept = rank_b > r_t ? 1u : 0u;  // b is a neighbour of every c and must not close the path
+                const uint32_t cnt = (cd && c != s) ? cd - ptr - b_kept : 0u;
+                const uint32_t sum = wave_sum_u32(cnt);
+                if (lane == i) my_sum = sum;
+            }
+            if (tt < t_hi && u_l < n_units) uoff[u_l] = my_sum;  // counts; scanned in place by the caller
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) uoff[n_units] = 0;
 }

@@ -313,3 +313,27 @@ def test_prep_partition_through_engine_and_reference_online(tmp_path, p, method)
         assert os.path.getsize(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) >= 8192
     out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q", query, "-m", "online", "-p", str(p)], text=True)
     assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
+
+
+def test_rank_thread_error_is_a_clean_exit(tmp_path):
+    """an error inside one rank thread of `--gpus N` (here: rank 0 cannot create all_paths.txt because the
+    dataset's gnn-pe directory is read-only) must end the process with exit code 1 and the rank's message -- the other
+    ranks are released from their barrier and joined -- not with exit() under running siblings (SIGABRT)."""
+    g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
+    sn = synth.degree_order(g["offsets"])
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "ro")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 2)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, synth.block_membership(3000, 2))
+    os.chmod(os.path.join(d, "gnn-pe"), 0o555)
+    try:
+        if os.access(os.path.join(d, "gnn-pe"), os.W_OK):
+            pytest.skip("running as a user who can write into a read-only directory")
+        r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "2", "--gpus", "3", "--same-device"], capture_output=True, text=True, timeout=300)
+    finally:
+        os.chmod(os.path.join(d, "gnn-pe"), 0o755)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1000:])
+    assert "rank 0" in r.stderr and "all_paths.txt" in r.stderr
+    assert "terminate called" not in r.stderr

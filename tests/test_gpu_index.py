@@ -278,3 +278,40 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
         seen += len(mine)
     assert seen == total
     eng.close()
+
+
+def test_index_files_in_memory_budgeted_waves(tmp_path, monkeypatch):
+    """gnnpe_build_index_files keeps device copies of the images only as far as memory allows: with the kept
+    bytes capped (GNNPE_INDEX_KEEP_BYTES, testing aid) the partitions go out in several waves, or one by one straight from
+    the build buffer, and every file -- index.dat AND aux_index.bin -- equals the unconstrained run's.  Files appear under
+    their names only when complete (no .tmp left behind)."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(20000, 160000, n_labels=9, seed=8)
+    sn = synth.degree_order(g["offsets"])
+    p = 5
+    mem = (np.arange(g["n"]) % p).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, 2)
+    eng.vde(want=False)
+    eng.count_paths(2)
+    outs = {}
+    for name, cap in (("all", None), ("two", str(2 * 28 << 20)), ("none", "1")):
+        d = tmp_path / name
+        d.mkdir()
+        if cap is None:
+            monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("GNNPE_INDEX_KEEP_BYTES", cap)
+        paths = [str(d / f"index{i}.dat") for i in range(p)]
+        aux = [str(d / f"aux{i}.bin") for i in range(p)]
+        eng.build_index_files(paths, aux)
+        assert sorted(os.listdir(d)) == sorted([f"index{i}.dat" for i in range(p)] + [f"aux{i}.bin" for i in range(p)])
+        outs[name] = [open(x, "rb").read() for x in paths + aux]
+        assert all(len(b) >= 8192 for b in outs[name][:p])
+    assert outs["two"] == outs["all"] and outs["none"] == outs["all"]
+    # a path that cannot be written leaves nothing behind, not a truncated file
+    monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+    bad = [str(tmp_path / "missing_dir" / f"index{i}.dat") for i in range(p)]
+    with pytest.raises(binding.GnnpeError):
+        eng.build_index_files(bad)
+    assert not (tmp_path / "missing_dir").exists()
+    eng.close()
