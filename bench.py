@@ -294,7 +294,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (power-law 4M/64M, l=3, e=8: about a minute of host graph generation)")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
-    ap.add_argument("--placements", type=int, default=8,
+    ap.add_argument("--placements", type=int, default=12,
                     help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
                          "writes fastest is kept, the others freed); 1 = take what comes")
     ap.add_argument("--equal-paths", action="store_true",

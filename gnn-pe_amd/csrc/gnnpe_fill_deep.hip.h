@@ -179,11 +179,23 @@ __global__ __launch_bounds__(256) void k_deep3_count_rows(FillParams P, uint32_t
             uint32_t my_sum = 0;
             for (uint32_t i = 0; i < nt; i++) {
                 const uint32_t r_t = rl32(r_l, (int)i), s = rl32(s_l, (int)i);
-                while (__any(nxt <= r_t))
-                    if (nxt <= r_t) {
-                        ptr++;
-                        nxt = ptr < cd ? sr_c[ptr] : 0xFFFFFFFFu;
+                if (nxt <= r_t) {
+                    // advance to the first entry ranked after r_t: gallop (1, 2, 4, ... entries), then bisect the last stride --
+                    // a hub third vertex behind a low-degree middle vertex jumps hundreds of entries per threshold (stepping
+                    // one entry at a time: count phase 1.08 s at config 5; galloping: 0.66 s)
+                    uint32_t lo_p = ptr + 1, step = 1;  // every entry before lo_p is ranked <= r_t
+                    while (lo_p + step <= cd && sr_c[lo_p + step - 1] <= r_t) {
+                        lo_p += step;
+                        step <<= 1;
                     }
+                    uint32_t hi_p = min(cd, lo_p + step - 1);
+                    while (lo_p < hi_p) {
+                        const uint32_t mid = (lo_p + hi_p) >> 1;
+                        if (sr_c[mid] <= r_t) lo_p = mid + 1; else hi_p = mid;
+                    }
+                    ptr = lo_p;
+                    nxt = ptr < cd ? sr_c[ptr] : 0xFFFFFFFFu;
+                }
                 const uint32_t b_kept = rank_b > r_t ? 1u : 0u;  // b is a neighbour of every c and must not close the path
                 const uint32_t cnt = (cd && c != s) ? cd - ptr - b_kept : 0u;
                 const uint32_t sum = wave_sum_u32(cnt);

@@ -97,6 +97,12 @@ def test_random_case_matches_the_oracle(oracle, seed):
                 key, adeg, ambr = oracle.aux_index(raw, L, deg[mine].reshape(len(mine), L), ox[mine].reshape(len(mine), L * e))
                 assert np.array_equal(aux["key"].view(np.uint64), key.view(np.uint64)), (l, pid)
                 assert np.array_equal(aux["degrees"], adeg) and np.array_equal(aux["label_mbr"].view(np.uint64), ambr.view(np.uint64))
+                # the same arrays from the one-pass build (leaf rows by the pair-major leaf kernel where it applies, the
+                # generic pass otherwise), on an image that must be the same bytes
+                img2, nbytes2, hdr2, fkey, fdeg, fmbr, fn = eng.build_index_partition_aux_device(pid, fetch=True)
+                assert nbytes2 == nbytes and eng.copy_to_host(img2, nbytes2).tobytes() == raw, (l, pid)
+                assert fn == len(key) and np.array_equal(fkey.view(np.uint64), key.view(np.uint64)), (l, pid)
+                assert np.array_equal(fdeg, adeg) and np.array_equal(fmbr.view(np.uint64), ambr.view(np.uint64)), (l, pid)
                 if len(mine) == 0:  # the reference's own empty tree: one empty leaf that is the root (rtree.cpp:11-32)
                     assert nbytes == 2 * 4096 and hdr == [4096, 1, L * e, 0, 1, 0, 1, 0]
                     continue
