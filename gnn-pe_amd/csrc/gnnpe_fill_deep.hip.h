@@ -224,46 +224,48 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
                                                            const uint64_t *__restrict__ ufirst,
                                                            const uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end)
 {
-    __shared__ uint32_t s_off[WAVES][65], s_st[WAVES][64], s_c[WAVES][64];
+    // the unit's segment table (first candidate, row start and id of each of its 64 third vertices): built by wave 0, read by
+    // every wave; two copies, used alternately, so that wave 0 may build the next unit's table while the others still emit
+    __shared__ uint32_t s_off[2][65], s_st[2][64], s_c[2][64];
     __shared__ uint32_t s_kc[WAVES][64], s_kd[WAVES][64], s_kp[WAVES][64];  // kept rows of one step
     __shared__ uint32_t s_piece[WAVES];  // kept rows of every wave's piece (pass A)
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
     uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
+    unsigned flip = 0;
     for (uint64_t u = u_begin + blockIdx.x; u < u_end; u += gridDim.x) {  // block-uniform: every wave takes part in the barriers
         const uint64_t base = uoff[u], nxt = uoff[u + 1];
         if (nxt == base || base >= P.end || nxt <= P.begin) continue;
         const uint32_t w = upair[u];
         const uint32_t i = P.erow[w], b = P.pnbr[w];
         const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
-        const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
-        const uint32_t k0 = (uint32_t)(u - ufirst[w]) * 64u;  // this unit's 64 third vertices
-        // one lane per third vertex c (every wave builds its own copy of the unit's segment table: no barrier needed for it)
-        const uint32_t k = k0 + lane;
-        uint32_t c = 0, cd = 0, cst = 0;
-        if (k < bd) {
-            c = P.nbrs[bst + k];
-            if (c != s) {  // (a missing 2-hop row was reported by the count pass)
-                cd = P.adj_deg[c];
-                cst = P.adj_start[c];
+        flip ^= 1u;
+        uint32_t *off = s_off[flip], *rst = s_st[flip], *rc = s_c[flip];
+        if (wv == 0) {
+            const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
+            const uint32_t k = (uint32_t)(u - ufirst[w]) * 64u + lane;  // this unit's 64 third vertices, one lane each
+            uint32_t c = 0, cd = 0, cst = 0;
+            if (k < bd) {
+                c = P.nbrs[bst + k];
+                if (c != s) {  // (a missing 2-hop row was reported by the count pass)
+                    cd = P.adj_deg[c];
+                    cst = P.adj_start[c];
+                }
             }
-        }
-        uint32_t incl = cd;
+            uint32_t incl = cd;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += t;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, 64);
+                if ((int)lane >= o) incl += t;
+            }
+            off[lane] = incl - cd;
+            rst[lane] = cst;
+            rc[lane] = c;
+            if (lane == 63) off[64] = incl;
         }
-        off[lane] = incl - cd;
-        rst[lane] = cst;
-        rc[lane] = c;
-        const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (lane == 0) off[64] = n_cand;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __syncthreads();
+        const uint32_t n_cand = off[64];
         // this wave's piece of the flattened candidates: whole steps of 64, the pieces as equal as that allows
         const uint32_t n_steps = (n_cand + 63u) / 64u;
         const uint32_t q_lo = min(n_cand, (n_steps * wv / WAVES) * 64u), q_hi = min(n_cand, (n_steps * (wv + 1) / WAVES) * 64u);
