@@ -433,7 +433,7 @@ struct Shared {
     std::vector<uint64_t> part_total;
     // reporting
     std::vector<uint64_t> held_entries, owned_entries, halo_rows;
-    std::vector<double> t_halo, t_count, t_emit, t_index;
+    std::vector<double> t_halo, t_count, t_emit, t_index, t_sizing, t_init;
     uint64_t bytes_all = 0, bytes_part = 0;
 };
 
@@ -457,6 +457,7 @@ void rank_main(int r, Shared &S)
         ~CtxGuard() { gnnpe_destroy(c); }
     } ctx_guard{ctx};
     tp.init_rank(r);
+    S.t_init[r] = secs(t0, Clock::now());  // context + communicator (librccl start-up when the transport is rccl)
 
     // ---- this rank's rows only ----
     std::vector<uint32_t> rows(sn.begin() + lo, sn.begin() + hi);
@@ -576,6 +577,7 @@ void rank_main(int r, Shared &S)
         check(gnnpe_text_paths(ctx, en - b, L, d_ids.p, nullptr, 0, &nb), "text size");
         my_all_bytes += nb;
     }
+    S.t_sizing[r] = secs(t2, Clock::now());  // what the second enumeration costs: reported, see DESIGN section 4
     // offsets of my bytes inside every file
     const std::vector<uint64_t> all_sizes = tp.gather_word(r, my_all_bytes);
     const std::string hdr_all = std::to_string(P) + "\n";
@@ -705,7 +707,9 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
     const int R = o.gpus;
     const bool use_rccl = !o.same_device && o.transport != "copy";
     try {
-    Transport tp(R, use_rccl);
+    const auto t_tp = Clock::now();
+    Transport tp(R, use_rccl);  // loads librccl when the transport is rccl: seconds (its code objects), once per process
+    const double rccl_load_s = secs(t_tp, Clock::now());
     Shared S;
     S.o = &o;
     S.g = &g;
@@ -722,6 +726,8 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
     S.t_count.assign(R, 0);
     S.t_emit.assign(R, 0);
     S.t_index.assign(R, 0);
+    S.t_sizing.assign(R, 0);
+    S.t_init.assign(R, 0);
     std::vector<std::thread> th;
     for (int r = 0; r < R; r++) th.emplace_back(rank_entry, r, std::ref(S));
     for (auto &t : th) t.join();
@@ -739,11 +745,11 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
             per += std::string(r ? ", " : "") + "{\"owned_entries\": " + std::to_string(S.owned_entries[r]) + ", \"held_entries\": " +
                    std::to_string(S.held_entries[r]) + ", \"halo_rows\": " + std::to_string(S.halo_rows[r]) + "}";
         fprintf(stderr,
-                "{\"paths\": %llu, \"gpus\": %d, \"transport\": \"%s\", \"load_s\": %.3f, \"setup_halo_s\": %.3f, \"vde_count_s\": %.3f, "
-                "\"emit_render_write_s\": %.3f, \"index_build_s\": %.3f, \"end_to_end_s\": %.3f, \"all_paths_bytes\": %llu, "
+                "{\"paths\": %llu, \"gpus\": %d, \"transport\": \"%s\", \"load_s\": %.3f, \"librccl_load_s\": %.3f, \"context_comm_init_s\": %.3f, \"setup_halo_s\": %.3f, \"vde_count_s\": %.3f, "
+                "\"emit_render_write_s\": %.3f, \"sizing_pass_s\": %.3f, \"index_build_s\": %.3f, \"end_to_end_s\": %.3f, \"all_paths_bytes\": %llu, "
                 "\"partition_bytes\": %llu, \"csr_entries\": %llu, \"ranks\": [%s]}\n",
-                (unsigned long long)S.P, R, use_rccl ? "rccl" : "copy", secs(t_start, t_loaded), mx(S.t_halo), mx(S.t_count), mx(S.t_emit),
-                mx(S.t_index), secs(t_start, Clock::now()), (unsigned long long)S.bytes_all, (unsigned long long)S.bytes_part,
+                (unsigned long long)S.P, R, use_rccl ? "rccl" : "copy", secs(t_start, t_loaded), rccl_load_s, mx(S.t_init), mx(S.t_halo), mx(S.t_count), mx(S.t_emit),
+                mx(S.t_sizing), mx(S.t_index), secs(t_start, Clock::now()), (unsigned long long)S.bytes_all, (unsigned long long)S.bytes_part,
                 (unsigned long long)g.offsets[g.n], per.c_str());
     }
     } catch (const std::exception &ex) {

@@ -206,7 +206,8 @@ def test_cli_aux_index_on_the_test_graph_with_a_hub_row(oracle, test_graph, tmp_
 
 
 @pytest.mark.gpu
-def test_aux_index_of_a_large_partition_by_properties(oracle):
+@pytest.mark.parametrize("source", ["generic pass", "leaf kernel"])
+def test_aux_index_of_a_large_partition_by_properties(oracle, source):
     """config 2 size (100K/1M, 2.0e7 paths, ~5.4e5 nodes): too large for the host walk in a test, so the arrays are
     checked through what must hold for any tree: the root's label MBR / degrees are the extremes over all paths, every
     node's arrays are dominated by its parent's (checked from the image's entries), keys are the negated upper-bound
@@ -219,8 +220,12 @@ def test_aux_index_of_a_large_partition_by_properties(oracle):
     dev = torch.device("cuda:0")
     ids = torch.empty((total, 3), dtype=torch.int32, device=dev)
     eng.fill_paths_device(0, total, ids, None, None)
-    img_ptr, nbytes, hdr = eng.build_index_partition_device(0)
-    got = eng.aux_index_device(img_ptr, nbytes, total, 3, ids)
+    if source == "generic pass":
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(0)
+        got = eng.aux_index_device(img_ptr, nbytes, total, 3, ids)
+    else:  # the one-pass build: leaf rows by the pair-major leaf kernel, upper levels by k_aux_level
+        img_ptr, nbytes, hdr, key, deg_, mbr, n_nodes = eng.build_index_partition_aux_device(0, fetch=True)
+        got = dict(key=key, degrees=deg_, label_mbr=mbr)
     img = eng.copy_to_host(img_ptr, nbytes)
     N, root, D, esz = hdr[1], hdr[7], 6, 100
     assert len(got["key"]) == N
