@@ -619,7 +619,9 @@ def main():
                                   tuple_array_build_ms=min(ib_tuple),
                                   first_call_ms=ib[0],
                                   first_call_note="the first call allocates the grow-only buffers (the 22 GB image, pair records) and loads "
-                                                  "the kernels; later calls only enqueue kernels",
+                                                  "the kernels; later calls only enqueue kernels.  It follows the output pool's draw in this "
+                                                  "process: hipMalloc of 24 GB right after 130 GB of candidates were freed waits for the driver "
+                                                  "to reclaim them (38 ms when the pool drew 8, seconds after 12)",
                                   reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
     # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
