@@ -324,8 +324,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     staged = same_device  # collectives over gloo with host staging instead of RCCL: explicit, for every rank alike
-    if world > 1:
+    # GNNPE_BENCH_FORCE_RCCL=1 (validation aid for single-GPU boxes): a 1-rank process group over RCCL and the N > 1 code of
+    # this file -- slab rows, halo plan, vde all-gather, totals all-gather -- so that the multi-GPU path of the bench itself
+    # has run before the first N > 1 launch (tests/test_gpu_rccl.py)
+    force_rccl = os.environ.get("GNNPE_BENCH_FORCE_RCCL") == "1" and world == 1 and not same_device
+    multi = world > 1 or force_rccl
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")  # (torch.distributed.run sets its own)
         if staged:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -358,7 +364,7 @@ def main():
     owned_entries = len(g["nbrs"])
     one_time = {}
     t_load = time.perf_counter()
-    if world == 1:
+    if not multi:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     else:
         rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
@@ -370,8 +376,9 @@ def main():
     eng.set_fill_variant(args.fill_variant)
     torch.cuda.synchronize()
     one_time["load_rows_revpos_ms"] = (time.perf_counter() - t_load) * 1e3
-    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=len(g["nbrs"]), owned_entries=owned_entries)
-    if world > 1:  # distribute the graph: the halo rows arrive once and stay (like the CSR of a single-GPU run)
+    sb = SlabBuild(eng, args.n, e, bounds, rank, world, device, nbr_capacity=len(g["nbrs"]), owned_entries=owned_entries,
+                   force_collectives=force_rccl)
+    if multi:  # distribute the graph: the halo rows arrive once and stay (like the CSR of a single-GPU run)
         t_h = time.perf_counter()
         sb.install_halo()
         torch.cuda.synchronize()
@@ -402,7 +409,7 @@ def main():
         ev1 = torch.cuda.Event(enable_timing=True)
         o_ids, o_pde = (out_ids, out_pde) if ids is None else (ids, pde)
         if not enqueue_only:  # the generic pair-wave kernel (A/B baseline, widths without a specialised kernel): count with read-back
-            if world > 1:
+            if multi:
                 sb.exchange_vde()
                 t = sb.count_begin()
             else:
@@ -412,7 +419,7 @@ def main():
             eng.fill_paths_device(0, t, o_ids, o_pde, None)
             ev1.record()
         else:
-            if world > 1:
+            if multi:
                 sb.exchange_vde()
                 sb.count_enqueue()  # count + async all-gather of the totals, straight from the engine's device word
             else:
@@ -421,13 +428,13 @@ def main():
             ev0.record()
             eng.fill_paths_capped_device(cap_rows, o_ids, o_pde)
             ev1.record()
-        if world > 1:
+        if multi:
             sb.count_end()
         if timed:
             (fill_ms if keep is None else keep).append((ev0, ev1))
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -439,7 +446,7 @@ def main():
         one_step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world == 1:
+    if not multi:
         assert (eng.count_total() if enqueue_only else sb.local_total) == total, "the timed steps counted a different number of paths than the sizing pass"
         sb.local_total = sb.global_total = total
         sb.base = 0
@@ -448,7 +455,7 @@ def main():
 
     # the same steps into ONE plain allocation that takes what comes (what a caller without the pool gets)
     plain = None
-    if world == 1 and args.placements > 1:
+    if not multi and args.placements > 1:
         p_ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
         p_pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
         p_ev = []
@@ -471,7 +478,7 @@ def main():
         torch.cuda.synchronize()
         return r, (time.perf_counter() - t) * 1e3
     per_step = {}
-    if world > 1:
+    if multi:
         _, per_step["vde_and_allgather_ms"] = phase(sb.exchange_vde)
         t_, per_step["count_ms"] = phase(sb.count)
     else:
@@ -485,7 +492,7 @@ def main():
     want_paths = int((deg64 * (deg64 - 1) // 2).sum())
     want_mid = int((np.arange(args.n, dtype=np.int64) * (deg64 * (deg64 - 1) // 2)).sum())
     chk = torch.stack([ids_view[:total, 1].to(torch.int64).sum(), torch.tensor(total, device=device)]).to(torch.int64)
-    if world > 1:
+    if multi:
         chk_h = chk.cpu() if staged else chk
         dist.all_reduce(chk_h, op=dist.ReduceOp.SUM)
         chk = chk_h
@@ -493,7 +500,7 @@ def main():
     if (got_paths, got_mid) != (want_paths, want_mid) or sb.global_total != want_paths:
         raise SystemExit(f"bench sanity check failed: paths {got_paths} (want {want_paths}), middle checksum {got_mid} "
                          f"(want {want_mid})")
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -550,12 +557,12 @@ def main():
                               note="one_time = distributing / loading the graph structure (rows, reverse positions, halo rows); "
                                    "per_step = what `value` times, here from one untimed step with a device synchronisation after every "
                                    "phase (the timed steps run without any)"))
-    if world > 1:
+    if multi:
         out["halo"] = dict(sb.stats, owned_entries=owned_entries, slab=[int(bounds[rank]), int(bounds[rank + 1])],
                            local_paths=int(total), note="rank 0's share; halo rows are truncated to the slab's rank range")
         out["config"]["collectives"] = "gloo, staged through host memory (GNNPE_BENCH_SAME_DEVICE=1)" if staged else "rccl"
 
-    legs = world == 1 and not args.no_index and not args.ids_only
+    legs = not multi and not args.no_index and not args.ids_only
     # index-build wallclock (second half of BASELINE.json's metric), measured outside the timed steps.
     # (a) device image: R*-tree file image of every path (p = 1), bulk-loaded on the device
     if legs:
@@ -661,7 +668,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

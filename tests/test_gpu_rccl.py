@@ -86,3 +86,20 @@ def test_slabbuild_one_rank_process_group_over_rccl(tmp_path):
     assert a["total"] == b["total"] == b["global_total"] == synth.expected_paths_l2(g["offsets"])
     assert a["checksum"] == b["checksum"] and a["middle_sum"] == b["middle_sum"]
     assert all(b["props"].values()), b["props"]
+
+
+def test_bench_multi_gpu_path_over_a_one_rank_rccl_group(tmp_path):
+    """bench.py's OWN N > 1 code (slab rows, halo plan, vde all-gather, enqueue-only count with the asynchronous all-gather of
+    the totals, capped fill, RCCL all-reduce of the sanity numbers) over a 1-rank process group: GNNPE_BENCH_FORCE_RCCL=1.
+    What the driver launches on 2/4/8 GPUs has then run end to end on this box, at a smaller graph."""
+    env = dict(os.environ, GNNPE_BENCH_FORCE_RCCL="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--vertices", "200000", "--edges", "2000000", "--steps", "3",
+                        "--warmup", "1", "--placements", "3", "--no-cpu-baseline", "--no-index"], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    g = synth.gnm_graph(200_000, 2_000_000)
+    assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["config"]["paths"] == synth.expected_paths_l2(g["offsets"])
+    assert d["value"] > 1e9 and d["halo"]["owned_entries"] == 2 * g["m"] and d["halo"]["halo_rows"] == 0
+    assert "vde_and_allgather_ms" in d["phases_ms"]["per_step"]
