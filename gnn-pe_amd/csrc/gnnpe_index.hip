@@ -1577,23 +1577,7 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
         tb = c->cub_tmp.bytes;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
     }
-    // 2b. the {degree, label} strips beside the row blocks (the leaves' auxiliary index reads them): record order = this count's
-    c->px_raux_valid = false;
-    if (c->rows_identity || c->have_deg_all) {
-        if ((rc = ensure_vertex_words(c))) return rc;
-        if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kRowAlign))) return rc;
-        const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
-        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
-        if (c->n_held) {
-            if (c->n <= (1u << kPackedIdBits))
-                hipLaunchKernelGGL((k_px_raux<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                                   c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
-            else
-                hipLaunchKernelGGL((k_px_raux<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                                   c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
-        }
-        c->px_raux_valid = true;
-    }
+    c->px_raux_valid = false;  // the {degree, label} strips are built by the first build that asks for the auxiliary index
     GNNPE_HIP_TRY(hipGetLastError());
     // 3. partition ranges and their first points, to the host
     c->px_bounds.assign((size_t)p + 1, 0);
@@ -1608,7 +1592,43 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+// The {degree, label} strips beside the row blocks (the leaves' auxiliary index reads them): record order = this count's, so
+// they are valid for one count like the pair order, and built by the first build of that count that wants the auxiliary index
+template <int E> static int build_raux(gnnpe_ctx *c)
+{
+    int rc;
+    GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
+                  "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
+    if ((rc = ensure_vertex_words(c))) return rc;
+    if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kRowAlign))) return rc;
+    const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
+    const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+    if (c->n_held) {
+        if (c->n <= (1u << kPackedIdBits))
+            hipLaunchKernelGGL((k_px_raux<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+        else
+            hipLaunchKernelGGL((k_px_raux<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->px_raux_valid = true;
+    return GNNPE_OK;
+}
+
 extern "C" {
+
+static int ensure_raux(gnnpe_ctx *c)
+{
+    if (c->px_raux_valid) return GNNPE_OK;
+    switch (c->e) {
+    case 1: return build_raux<1>(c);
+    case 2: return build_raux<2>(c);
+    case 3: return build_raux<3>(c);
+    case 4: return build_raux<4>(c);
+    default: return build_raux<8>(c);
+    }
+}
 
 static int ensure_pair_order(gnnpe_ctx *c)
 {
@@ -1637,8 +1657,7 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
         LeafSrc S = {nullptr, c->vde.as<double>(), nullptr, 3, e, D};
         return build_image(c, 0, S, dev_image, nbytes, hdr_out);
     }
-    GNNPE_REQUIRE(!with_aux || c->px_raux_valid, GNNPE_ERR_UNSUPPORTED,
-                  "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
+    if (with_aux && (rc = ensure_raux(c))) return rc;
     std::vector<uint64_t> level_n;
     const uint64_t n_nodes = plan_levels(cnt, F, level_n);
     GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
