@@ -148,8 +148,13 @@ public:
     }
     void finish_rank(int r)
     {
-        if (rccl_on_ && comms_[r]) rccl_.CommDestroy(comms_[r]);
-        comms_[r] = nullptr;
+        ncclComm_t mine = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(fail_mu_);  // fail() on another thread may be aborting the communicators
+            mine = comms_[r];
+            comms_[r] = nullptr;
+        }
+        if (rccl_on_ && mine) rccl_.CommDestroy(mine);
     }
     // a rank failed: keep the first message, let the peers out of their barriers and out of RCCL
     void fail(int r, const std::string &msg)
@@ -160,9 +165,16 @@ public:
             failed_ = true;
         }
         bar_.abort();
+        std::vector<ncclComm_t> live;
+        {
+            std::lock_guard<std::mutex> lk(fail_mu_);  // every communicator is aborted or destroyed exactly once
+            for (auto &cm : comms_) {
+                if (cm) live.push_back(cm);
+                cm = nullptr;
+            }
+        }
         if (rccl_on_)
-            for (auto &cm : comms_)
-                if (cm) rccl_.CommAbort(cm);
+            for (ncclComm_t cm : live) rccl_.CommAbort(cm);
     }
     bool failed() const { return failed_; }
     const std::string &first_error() const { return first_error_; }
