@@ -1055,6 +1055,51 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, d_range, 16, hipMemcpyDeviceToHost, c->stream));
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
         const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
+        // slices where hub rows put 10^5 candidates behind one unit; one workgroup per unit (a single kernel) where every
+        // unit is a few hundred candidates.  GNNPE_DEEP_EMIT=slices|units overrides (tests run both on the same graphs).
+        const char *mode = getenv("GNNPE_DEEP_EMIT");
+        const bool slices = mode && !strcmp(mode, "slices") ? true : mode && !strcmp(mode, "units") ? false : c->n_hub != 0;
+        if (slices && u_hi > u_lo) {
+            // slices (gnnpe_fill_deep.hip.h): units -> slices per unit -> kept rows per slice -> emit, one wave per slice
+            GNNPE_REQUIRE(u_hi - u_lo < (1ull << 31), GNNPE_ERR_ARG, "l=3 range covers %llu units; emit in smaller chunks",
+                          (unsigned long long)(u_hi - u_lo));
+            const uint32_t n_u = (uint32_t)(u_hi - u_lo);
+            if ((rc = c->dsl_first.reserve(((size_t)n_u + 2) * 4))) return rc;
+            uint32_t *sfirst = c->dsl_first.as<uint32_t>();
+            hipLaunchKernelGGL(k_deep_slice_counts, dim3(grid_for(((uint64_t)n_u + 1) * 64)), dim3(kBlock), 0, c->stream, P,
+                               c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, n_u, sfirst);
+            size_t tb = 0;
+            GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sfirst, sfirst, (int64_t)n_u + 1, c->stream));
+            if ((rc = c->cub_tmp.reserve(tb))) return rc;
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, sfirst, sfirst, (int64_t)n_u + 1, c->stream));
+            GNNPE_HIP_TRY(hipMemcpyAsync(c->h_pinned, sfirst + n_u, 4, hipMemcpyDeviceToHost, c->stream));
+            GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+            const uint32_t n_sl = *reinterpret_cast<const uint32_t *>(c->h_pinned);
+            if (n_sl == 0) return GNNPE_OK;
+            if ((rc = c->dsl_kept.reserve(((size_t)n_sl + 1) * 16))) return rc;
+            uint64_t *skept = c->dsl_kept.as<uint64_t>(), *sscan = skept + n_sl + 1;
+            const dim3 sgrid(grid_for((uint64_t)n_sl * 64)), sblock(256);
+#define GNNPE_L(EE)                                                                                                      \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL((k_deep3_slices<EE, false>), sgrid, sblock, 0, c->stream, P, c->upair.as<uint32_t>(),         \
+                           c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, n_u, sfirst, n_sl, skept, sscan);     \
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, skept, sscan, (int64_t)n_sl, c->stream));            \
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                    \
+        tb = c->cub_tmp.bytes;                                                                                           \
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, skept, sscan, (int64_t)n_sl, c->stream));       \
+        hipLaunchKernelGGL((k_deep3_slices<EE, true>), sgrid, sblock, 0, c->stream, P, c->upair.as<uint32_t>(),          \
+                           c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, n_u, sfirst, n_sl, skept, sscan);     \
+    } while (0)
+            if (fast_e(e)) {
+                GNNPE_BY_E(e, GNNPE_L)
+            } else {
+                GNNPE_L(0);
+            }
+#undef GNNPE_L
+            GNNPE_HIP_TRY(hipGetLastError());
+            return GNNPE_OK;
+        }
         // waves per unit: 16 on graphs with hub rows (a unit behind a hub holds 10^5 candidates), 4 otherwise
         const unsigned n_blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(u_hi - u_lo, 1u << 20));
 #define GNNPE_LW(EE, WW)                                                                                           \

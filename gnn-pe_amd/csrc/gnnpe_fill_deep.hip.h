@@ -207,6 +207,113 @@ __global__ __launch_bounds__(256) void k_deep3_count_rows(FillParams P, uint32_t
     if (blockIdx.x == 0 && threadIdx.x == 0) uoff[n_units] = 0;
 }
 
+// The kept rows of one 64-candidate step -- (c, d, entry) compacted in LDS by the caller -- written as one contiguous piece of
+// every output: rows [r_lo, r_lo + rows) of the step to output rows o0 ....  pde: a row is 4e doubles = 2e pieces of 16 bytes.
+// For e = 2, 4, 8 the pieces of a row (or of half a row) divide the wave, so a lane keeps ONE column for the whole step: the
+// columns of s and b hold the same 16 bytes in every row (loaded once per unit: `fixed`), the columns of c and d take one
+// 16-byte load per row (vde[c], nbr_vde[entry]), and all loads of a step are issued before its first store.  (Rounds 1-2
+// computed (row, column) per element with two 8-byte loads each, s and b included, a pass of the wave at a time: a load ->
+// store -> next load chain per KB written, each link waiting for the stores before it.)  Other widths keep that form.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+template <int E>
+__device__ __forceinline__ dbl2 deep_fixed_piece(const FillParams &P, uint32_t s, uint32_t b, unsigned lane)
+{
+    dbl2 v = {0.0, 0.0};
+    if constexpr (E == 4 || E == 8) {  // lane -> one of the 2H pieces of the row's first half (s | b)
+        constexpr uint32_t H = E / 2;
+        const uint32_t piece = lane % (2 * H);
+        if (P.out_pde) v = reinterpret_cast<const dbl2 *>(P.vde)[(uint64_t)(piece / H ? b : s) * H + piece % H];
+    } else if constexpr (E == 2) {  // lane -> one of the row's four pieces (s, b, c, d)
+        const uint32_t col = lane % 4;
+        if (P.out_pde && col < 2) v = reinterpret_cast<const dbl2 *>(P.vde)[col ? b : s];
+    }
+    return v;
+}
+
+template <int E>
+__device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, uint32_t b, dbl2 fixed, const uint32_t *kc,
+                                               const uint32_t *kd, const uint32_t *kp, uint32_t r_lo, uint32_t rows, uint64_t o0,
+                                               unsigned lane)
+{
+    const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
+    if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
+        const uint32_t r = r_lo + lane;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+        v.x = s;
+        v.y = b;
+        v.z = kc[r];
+        v.w = kd[r];
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(P.out_ids) + (o0 + lane));
+    }
+    if (P.out_pde) {
+        // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
+        dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
+        if constexpr (E == 4 || E == 8) {
+            // half a row (s | b, then c | d) is 2H pieces: the wave takes 64 / 2H rows per pass, every lane one piece of the
+            // c | d half -- ALL of the step's loads first (2H per lane), then the stores: the lane's fixed piece into the
+            // first half of its rows, the loaded pieces into the second (e = 8: 128-byte halves, whole lines per store)
+            constexpr uint32_t H = E / 2, HP = 2 * H, RP = 64 / HP;
+            const uint32_t piece = lane % HP, rsub = lane / HP, cp = piece % H;
+            const bool is_d = piece >= H;
+            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(P.nbr_vde);
+            dbl2 v[HP];
+#pragma unroll
+            for (uint32_t j = 0; j < HP; j++) {
+                const uint32_t r = j * RP + rsub;
+                v[j] = fixed;
+                if (r < rows) v[j] = is_d ? nv2[(uint64_t)kp[r_lo + r] * H + cp] : vde2[(uint64_t)kc[r_lo + r] * H + cp];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < HP; j++) {
+                const uint32_t r = j * RP + rsub;
+                if (r < rows) {
+                    __builtin_nontemporal_store(fixed, dst + (uint64_t)r * (2 * HP) + piece);
+                    __builtin_nontemporal_store(v[j], dst + (uint64_t)r * (2 * HP) + HP + piece);
+                }
+            }
+        } else if constexpr (E == 2) {
+            // a row is four pieces (s, b, c, d): a lane keeps one column, sixteen rows per pass
+            const uint32_t col = lane % 4, rsub = lane / 4;
+            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(P.nbr_vde);
+            dbl2 v[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t r = j * 16 + rsub;
+                v[j] = fixed;
+                if (col >= 2 && r < rows) v[j] = col == 2 ? vde2[kc[r_lo + r]] : nv2[kp[r_lo + r]];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t r = j * 16 + rsub;
+                if (r < rows) __builtin_nontemporal_store(v[j], dst + (uint64_t)j * 64 + lane);
+            }
+        } else {
+            auto elem = [&](uint32_t t) -> double {
+                const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
+                return which == 0   ? P.vde[(uint64_t)s * e + comp]
+                       : which == 1 ? P.vde[(uint64_t)b * e + comp]
+                       : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
+                                    : P.nbr_vde[(uint64_t)kp[r] * e + comp];
+            };
+            for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
+                dbl2 v;
+                v.x = elem(2 * t2);
+                v.y = elem(2 * t2 + 1);
+                __builtin_nontemporal_store(v, dst + t2);
+            }
+        }
+    }
+    if (P.out_pdl)
+        for (uint32_t t = lane; t < rows * D; t += 64) {
+            const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
+            const uint32_t v = which == 0 ? s : which == 1 ? b : which == 2 ? kc[r] : kd[r];
+            P.out_pdl[o0 * D + t] = P.x[(uint64_t)v * e + comp];
+        }
+    if (P.out_part && lane < rows) P.out_part[o0 + lane] = P.member[s];
+}
+
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
 //
 // One WORKGROUP (WAVES waves) per unit since round 3; round 1 gave a unit to one wave.  On a power-law graph a unit
@@ -232,7 +339,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
-    const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
     unsigned flip = 0;
     for (uint64_t u = u_begin + blockIdx.x; u < u_end; u += gridDim.x) {  // block-uniform: every wave takes part in the barriers
         const uint64_t base = uoff[u], nxt = uoff[u + 1];
@@ -240,6 +346,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
         const uint32_t w = upair[u];
         const uint32_t i = P.erow[w], b = P.pnbr[w];
         const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+        const dbl2 fixed = deep_fixed_piece<E>(P, s, b, lane);
         flip ^= 1u;
         uint32_t *off = s_off[flip], *rst = s_st[flip], *rc = s_c[flip];
         if (wv == 0) {
@@ -329,45 +436,195 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
                     const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
                     const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
                     const uint32_t rows = r_hi - r_lo;
-                    if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
-                        const uint32_t r = r_lo + lane;
-                        uint32_t *dst = P.out_ids + (o0 + lane) * 4;
-                        __builtin_nontemporal_store(s, dst);
-                        __builtin_nontemporal_store(b, dst + 1);
-                        __builtin_nontemporal_store(kc[r], dst + 2);
-                        __builtin_nontemporal_store(kd[r], dst + 3);
-                    }
-                    if (P.out_pde) {
-                        auto elem = [&](uint32_t t) -> double {
-                            const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
-                            return which == 0   ? P.vde[(uint64_t)s * e + comp]
-                                   : which == 1 ? P.vde[(uint64_t)b * e + comp]
-                                   : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
-                                                : P.nbr_vde[(uint64_t)kp[r] * e + comp];
-                        };
-                        // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
-                        typedef double dbl2 __attribute__((ext_vector_type(2)));
-                        dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
-                        for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
-                            dbl2 v;
-                            v.x = elem(2 * t2);
-                            v.y = elem(2 * t2 + 1);
-                            __builtin_nontemporal_store(v, dst + t2);
-                        }
-                    }
-                    if (P.out_pdl)
-                        for (uint32_t t = lane; t < rows * D; t += 64) {
-                            const uint32_t r = r_lo + t / D, k2 = t % D, which = k2 / e, comp = k2 % e;
-                            const uint32_t v = which == 0 ? s : which == 1 ? b : which == 2 ? kc[r] : kd[r];
-                            P.out_pdl[o0 * D + t] = P.x[(uint64_t)v * e + comp];
-                        }
-                    if (P.out_part && lane < rows) P.out_part[o0 + lane] = P.member[s];
+                    deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, rows, o0, lane);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
             running += __popcll(mask);
+        }
+    }
+}
+
+// ---- emission by slices (round 3) ---------------------------------------------------------------------------------------
+// k_deep3 above gives a unit to one workgroup.  Counters of a 2^26-path range of config 5 under it (profiles/
+// r03_deep_pmc.txt): 1 376 units, 22 016 waves over the kernel's life on a chip that holds 8 192 at once, the waves waiting
+// 87 % of their cycles.  Behind a hub the unit of WORK is therefore a SLICE: kSliceSteps x 64 consecutive candidates of a
+// unit's flattened candidate space, one wave each, however many a unit needs:
+//   k_deep_slice_counts       one wave per unit of the requested range: its candidates -> its number of slices   (+ scan)
+//   k_deep3_slices<E, false>  one wave per slice: the kept rows among its candidates (ranks only)                 (+ scan)
+//   k_deep3_slices<E, true>   one wave per slice: first slot = the unit's + the kept rows of its earlier slices; emit
+// Every wave rebuilds its unit's segment table (64 lanes x three loads, served by the L2 for the slices of one unit) in its
+// own corner of the LDS: no workgroup barrier anywhere; the candidates of the next step are fetched before the rows of this
+// one are written.  Same process, same output buffers (scripts/deep_ab.py, e = 8, fraction of the 8 TB/s spec at 352
+// algorithmic bytes per path): config-5 graph, ranges of 2^24 paths -- units 0.47-0.49, slices 0.50-0.58; ranges of 2^26 --
+// 0.53-0.61 both ways; G(100K, 1M), every unit a few hundred candidates -- units 0.72, slices 0.58-0.60 (three kernels and
+// three table builds per unit).  The library takes slices on graphs with hub rows, units elsewhere (fill_device).
+constexpr uint32_t kSliceSteps = 16;  // 8 ... 32 time alike on the config-5 graph; 2 and 4 lose to the table rebuilds
+
+// segment table of unit u for one wave: first candidate, row start and id of each of its 64 third vertices; returns the
+// unit's candidates
+__device__ __forceinline__ uint32_t deep_unit_table(const FillParams &P, uint32_t w, uint32_t part, uint32_t s, uint32_t b,
+                                                    unsigned lane, uint32_t *off, uint32_t *rst, uint32_t *rc)
+{
+    const uint32_t bst = P.adj_start[b], bd = P.adj_deg[b];
+    const uint32_t k = part * 64u + lane;  // this unit's 64 third vertices, one lane each
+    uint32_t c = 0, cd = 0, cst = 0;
+    if (k < bd) {
+        c = P.nbrs[bst + k];
+        if (c != s) {  // (a missing 2-hop row was reported by the count pass)
+            cd = P.adj_deg[c];
+            cst = P.adj_start[c];
+        }
+    }
+    uint32_t incl = cd;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
+    }
+    if (off) {
+        off[lane] = incl - cd;
+        rst[lane] = cst;
+        rc[lane] = c;
+        if (lane == 63) off[64] = incl;
+    }
+    return rl32(incl, 63);
+}
+
+__global__ __launch_bounds__(256) void k_deep_slice_counts(FillParams P, const uint32_t *__restrict__ upair,
+                                                           const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
+                                                           uint64_t u_lo, uint32_t n_u, uint32_t *__restrict__ nsl)
+{
+    const unsigned lane = lane_id();
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t ui = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6; ui <= n_u; ui += nw) {
+        uint32_t out = 0;
+        if (ui < n_u) {
+            const uint64_t u = u_lo + ui, base = uoff[u], nxt = uoff[u + 1];
+            if (nxt != base && base < P.end && nxt > P.begin) {
+                const uint32_t w = upair[u];
+                const uint32_t i = P.erow[w], b = P.pnbr[w];
+                const uint32_t n_cand = deep_unit_table(P, w, (uint32_t)(u - ufirst[w]), P.sorted[P.slab_begin + i], b, lane,
+                                                        nullptr, nullptr, nullptr);
+                out = ((n_cand + 63u) / 64u + kSliceSteps - 1u) / kSliceSteps;
+            }
+        }
+        if (lane == 0) nsl[ui] = out;
+    }
+}
+
+template <int E, bool EMIT>
+__global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32_t *__restrict__ upair,
+                                                      const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
+                                                      uint64_t u_lo, uint32_t n_u, const uint32_t *__restrict__ sfirst,
+                                                      uint32_t n_slices, uint64_t *__restrict__ skept,
+                                                      const uint64_t *__restrict__ sscan)
+{
+    __shared__ uint32_t s_off[4][65], s_st[4][64], s_c[4][64];
+    __shared__ uint32_t s_kc[4][64], s_kd[4][64], s_kp[4][64];  // kept rows of one step
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
+    uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t sl = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6; sl < n_slices; sl += nw) {
+        uint32_t lo_u = 0, hi_u = n_u;  // the slice's unit: the last one whose first slice is <= sl (units without slices share a value)
+        while (hi_u - lo_u > 1) {
+            const uint32_t mid = (lo_u + hi_u) >> 1;
+            if (sfirst[mid] <= sl) lo_u = mid; else hi_u = mid;
+        }
+        const uint32_t first_sl = sfirst[lo_u], part = (uint32_t)sl - first_sl;
+        const uint64_t u = u_lo + lo_u;
+        uint64_t piece0 = 0;
+        if (EMIT) {
+            const uint64_t mine = skept[sl];
+            piece0 = uoff[u] + (sscan[sl] - sscan[first_sl]);
+            if (mine == 0 || piece0 >= P.end || piece0 + mine <= P.begin) continue;
+        }
+        const uint32_t w = upair[u];
+        const uint32_t i = P.erow[w], b = P.pnbr[w];
+        const uint32_t s = P.sorted[P.slab_begin + i], thr = P.slab_begin + i;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous slice's table reads are done
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_cand = deep_unit_table(P, w, (uint32_t)(u - ufirst[w]), s, b, lane, off, rst, rc);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t q_lo = part * (kSliceSteps * 64u), q_hi = min(n_cand, q_lo + kSliceSteps * 64u);
+        auto locate = [&](uint32_t q, uint32_t &seg, uint32_t &pos) {
+            uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (off[lo + step] <= q) lo += step;
+            seg = lo;
+            pos = rst[lo] + (q - off[lo]);
+        };
+        if (!EMIT) {  // kept rows of the slice (ranks only)
+            uint32_t mine = 0;
+            for (uint32_t q0 = q_lo; q0 < q_hi; q0 += 64) {
+                const uint32_t q = q0 + lane;
+                bool keep = false;
+                if (q < q_hi) {
+                    uint32_t seg, pos;
+                    locate(q, seg, pos);
+                    keep = P.nbr_rank[pos] > thr && P.nbrs[pos] != b;
+                }
+                mine += (uint32_t)__popcll(__ballot(keep));
+            }
+            if (lane == 0) skept[sl] = mine;
+            continue;
+        }
+        const dbl2 fixed = deep_fixed_piece<E>(P, s, b, lane);
+        uint64_t running = 0;
+        // the candidates of a step: segment, entry, fourth vertex and its rank -- fetched one step ahead of the rows being written
+        auto fetch = [&](uint32_t q0, uint32_t &seg, uint32_t &pos, uint32_t &d, uint32_t &rd) {
+            const uint32_t q = q0 + lane;
+            seg = pos = d = rd = 0;
+            if (q < q_hi) {
+                locate(q, seg, pos);
+                d = P.nbrs[pos];
+                rd = P.nbr_rank[pos];
+            }
+            return q < q_hi;
+        };
+        uint32_t lo, pos, d, rd;
+        bool act = fetch(q_lo, lo, pos, d, rd);
+        for (uint32_t q0 = q_lo; q0 < q_hi; q0 += 64) {
+            uint32_t n_lo = 0, n_pos = 0, n_d = 0, n_rd = 0;
+            bool n_act = false;
+            if (q0 + 64 < q_hi) n_act = fetch(q0 + 64, n_lo, n_pos, n_d, n_rd);
+            const bool keep = act && rd > thr && d != b;
+            const uint64_t mask = __ballot(keep);
+            // rows of this step occupy slots [slot0, slot0 + cnt): compact (c, d, entry) into LDS, then the wave writes the
+            // rows as one contiguous region, consecutive lanes on consecutive elements
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            const uint64_t slot0 = piece0 + running;
+            running += cnt;
+            if (cnt && slot0 < P.end && slot0 + cnt > P.begin) {
+                if (keep) {
+                    const uint32_t r = (uint32_t)__popcll(mask & lt);
+                    kc[r] = rc[lo];
+                    kd[r] = d;
+                    kp[r] = pos;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t r_lo = slot0 < P.begin ? (uint32_t)(P.begin - slot0) : 0u;
+                const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
+                const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
+                deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, r_hi - r_lo, o0, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            act = n_act;
+            lo = n_lo;
+            pos = n_pos;
+            d = n_d;
+            rd = n_rd;
         }
     }
 }

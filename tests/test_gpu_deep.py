@@ -112,6 +112,33 @@ def test_l3_hub_rows_beyond_one_wave(binding, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["slices", "units"])
+@pytest.mark.parametrize("e", [2, 3, 4, 8])
+def test_l3_both_emit_paths_agree_with_the_checker(binding, oracle, monkeypatch, mode, e):
+    """The library picks slices (one wave per 2048 candidates) on graphs with hub rows and one workgroup per unit elsewhere;
+    both are forced here on a hub graph and on a flat one, every embedding-width specialisation of the row writer, whole
+    and in ragged chunks that cut units and slices."""
+    monkeypatch.setenv("GNNPE_DEEP_EMIT", mode)
+    for g in (synth.powerlaw_graph(1200, 7000, exponent=2.0, max_degree=300, n_labels=6, seed=9),
+              synth.gnm_graph(500, 2500, n_labels=6, seed=4)):
+        sn = synth.degree_order(g["offsets"])
+        eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, e)
+        x, nx, vde = eng.vde()
+        total = eng.count_paths(3)
+        want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+        assert total == len(want)
+        ids, pde, pdl = eng.fill_paths(pde=True, pde_label=True)
+        assert np.array_equal(ids, want)
+        assert np.array_equal(pde, vde[want].reshape(total, 4 * e))
+        assert np.array_equal(pdl, x[want].reshape(total, 4 * e))
+        cuts = [0, 1, 63, 64, 4097, total // 3, total // 2 + 7, total - 1, total]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            i2, p2, _ = eng.fill_paths(a, b, pde=True)
+            assert np.array_equal(i2, want[a:b]), (a, b)
+            assert np.array_equal(p2, vde[want[a:b]].reshape(b - a, 4 * e)), (a, b)
+        eng.close()
+
+
 def test_l3_properties_at_scale(binding):
     """size-independent properties on a graph the CPU checker would take minutes for: simple paths, real edges,
     rank[last] > rank[first], lexicographic order inside a start, counts consistent with the l=2 run"""
