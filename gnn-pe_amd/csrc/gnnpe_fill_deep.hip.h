@@ -461,6 +461,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
 // algorithmic bytes per path): config-5 graph, ranges of 2^24 paths -- units 0.47-0.49, slices 0.50-0.58; ranges of 2^26 --
 // 0.53-0.61 both ways; G(100K, 1M), every unit a few hundred candidates -- units 0.72, slices 0.58-0.60 (three kernels and
 // three table builds per unit).  The library takes slices on graphs with hub rows, units elsewhere (fill_device).
+// (Tried and dropped: collecting kept rows across steps in an LDS ring and writing them 64 at a time -- within 1 % on every
+// range, the sparse ones behind high-ranked starts included: the steps' round trips are not what the slices wait for.)
 constexpr uint32_t kSliceSteps = 16;  // 8 ... 32 time alike on the config-5 graph; 2 and 4 lose to the table rebuilds
 
 // segment table of unit u for one wave: first candidate, row start and id of each of its 64 third vertices; returns the
