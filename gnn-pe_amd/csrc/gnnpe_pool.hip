@@ -110,6 +110,7 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     GNNPE_REQUIRE(candidates >= 1 && candidates <= 64, GNNPE_ERR_ARG, "gnnpe_output_pool_create: 1..64 candidate allocations");
     *out = nullptr;
     GNNPE_HIP_TRY(hipSetDevice(c->device));
+    GNNPE_REQUIRE(rows_cap <= (1ull << 40), GNNPE_ERR_ARG, "gnnpe_output_pool_create: %llu rows", (unsigned long long)rows_cap);
     const uint64_t MiB2 = 2ull << 20;
     rows_cap = std::max<uint64_t>(rows_cap, 1);
     // [ pde rows | id rows ], each on a 2 MiB boundary
@@ -130,7 +131,7 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
 
     // the probe: the emit kernel into the candidate when the context holds an l = L-1 count that fits, a streaming write otherwise
     int rc = resolve_total(c);
-    const bool with_kernel = rc == GNNPE_OK && c->counted && c->l + 1 == L && c->counted_variant == 4 && c->total_paths > 0 &&
+    const bool with_kernel = rc == GNNPE_OK && c->counted && c->l + 1 == L && c->total_paths > 0 &&
                              c->total_paths <= rows_cap && (D == 0 || (c->have_vde && D == L * c->e));
     const bool debug = getenv("GNNPE_POOL_DEBUG") != nullptr;
     // timed on the host around stream synchronisations: the probes are milliseconds long, the launch latency inside the

@@ -72,3 +72,28 @@ def test_pool_rejects_bad_arguments(binding):
     with pytest.raises(binding.GnnpeError):
         binding.OutputPool(eng, 1000, 0, 6, candidates=2)
     eng.close()
+
+
+def test_pool_probes_with_the_l3_emission_too(binding, oracle, monkeypatch):
+    """4-vertex paths: the pool's probe is whichever emit path the context's count selects (here the l = 3 one)"""
+    monkeypatch.setenv("GNNPE_POOL_MIN_PROBE_BYTES", "0")
+    g = synth.gnm_graph(600, 3000, n_labels=5, seed=8)
+    sn = synth.degree_order(g["offsets"])
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, np.zeros(g["n"], np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(5, 2))
+    x, nx, vde = eng.vde()
+    want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert eng.count_paths(3) == len(want)
+    pool = binding.OutputPool(eng, len(want), 4, 8, candidates=3)
+    assert pool.report()["probe"] == "emit kernel"
+    eng.fill_paths_device(0, len(want), pool.ids, pool.pde, None)
+    eng.sync()
+    dev = torch.device("cuda", 0)
+    assert np.array_equal(pool.ids_tensor(dev).cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(pool.pde_tensor(dev).cpu().numpy(), vde[want].reshape(len(want), 8))
+    with pytest.raises(binding.GnnpeError):
+        binding.OutputPool(eng, 1 << 41, 4, 8, candidates=1)
+    pool.close()
+    eng.close()
