@@ -157,6 +157,97 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
     }
 }
 
+// The upper levels again (level >= 1, walking the list the leaf-level launch left): k_aux_level reduces one value at a time
+// -- load the child's degree or bound, reduce, store, next -- and a node cost a resident wave ~25 us, every load waiting
+// for the reduction before it (0.40 ms for the 131 K level-1 nodes of config 3).  Here a lane fetches eight of its child's
+// values before the first reduction (all L degrees, then the bounds four dimensions at a time as 16-byte pairs, then the
+// entry's own upper bounds for the child's key), so a node is three round trips instead of L + 2D + D.
+__global__ __launch_bounds__(256) void k_aux_upper(const char *__restrict__ image, uint32_t n_nodes, int level, uint32_t D,
+                                                   uint32_t L, double *__restrict__ key, uint32_t *__restrict__ adeg,
+                                                   double *__restrict__ ambr, uint32_t *__restrict__ err,
+                                                   const uint32_t *__restrict__ upper, const uint32_t *__restrict__ n_upper)
+{
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const unsigned lane = threadIdx.x & 63u;
+    const uint64_t w0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
+    const uint64_t n_visit = (uint64_t)*n_upper;
+    for (uint64_t it = w0; it < n_visit; it += nw) {
+        const uint64_t b = (uint64_t)upper[it];
+        const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;
+        if ((int)blk[0] != level) continue;
+        const int32_t ne_raw = ld_i32(blk + 1);
+        if (ne_raw < 0 || (uint32_t)ne_raw > cap) {
+            if (lane == 0) aux_fail(err, 4u, (uint32_t)b);
+            continue;
+        }
+        const uint32_t ne = (uint32_t)ne_raw;
+        for (uint32_t t0 = 0; t0 < ne; t0 += 64) {  // more than 64 entries only when D <= 3: chunks combine through lane 0's stores
+            const uint32_t t = t0 + lane;
+            bool ok = t < ne;
+            const char *ent = blk + 5 + (uint64_t)(ok ? t : 0) * esz;
+            uint32_t son = 0;
+            if (ok) {
+                son = (uint32_t)ld_i32(ent + 16 * D);
+                if (son >= n_nodes) {
+                    aux_fail(err, 2u, (uint32_t)b);
+                    ok = false;
+                    son = 0;
+                }
+            }
+            for (uint32_t j0 = 0; j0 < L; j0 += 8) {
+                uint32_t dv[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) dv[i] = (ok && j0 + i < L) ? adeg[(uint64_t)son * L + j0 + i] : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if (j0 + i >= L) break;
+                    uint32_t dmax = wave_max_u32(dv[i]);
+                    if (lane == 0) {
+                        if (t0) dmax = max(dmax, adeg[b * L + j0 + i]);
+                        adeg[b * L + j0 + i] = dmax;
+                    }
+                }
+            }
+            const dbl2 *cm = reinterpret_cast<const dbl2 *>(ambr) + (uint64_t)son * D;
+            for (uint32_t k0 = 0; k0 < D; k0 += 8) {
+                dbl2 mv[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    mv[i].x = __builtin_huge_val();
+                    mv[i].y = -__builtin_huge_val();
+                    if (ok && k0 + i < D) mv[i] = cm[k0 + i];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if (k0 + i >= D) break;
+                    double lo = wave_min(mv[i].x), hi = wave_max(mv[i].y);
+                    if (lane == 0) {
+                        const uint64_t at = (b * D + k0 + i) * 2;
+                        if (t0) {
+                            lo = fmin(lo, ambr[at]);
+                            hi = fmax(hi, ambr[at + 1]);
+                        }
+                        ambr[at] = lo;
+                        ambr[at + 1] = hi;
+                    }
+                }
+            }
+            double kv = 0.0;
+            for (uint32_t k0 = 0; k0 < D; k0 += 8) {
+                double h[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) h[i] = k0 + i < D ? ld_f64(ent + (2 * (k0 + i) + 1) * 8) : 0.0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++)
+                    if (k0 + i < D) kv -= h[i];  // custom.h:324-328, same order
+            }
+            if (ok) key[son] = kv;
+        }
+    }
+}
+
 // The leaf level again, for compile-time path length and embedding width (what gnnpe_count_paths produces: L = 3 or 4,
 // e with a specialised emit kernel).  The generic kernel above walks a leaf as twelve dependent steps -- header, entry
 // count, son, then per path position vertex -> degree / label -> feature row -> a wave-wide reduction -- and a leaf cost a
@@ -243,11 +334,6 @@ __global__ __launch_bounds__(256) void k_aux_leaves(const char *__restrict__ ima
     }
 }
 
-__global__ void k_aux_iota(uint32_t n, uint32_t first, uint32_t *__restrict__ out)
-{
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = first + (uint32_t)i;
-}
-
 int ensure_vertex_words(gnnpe_ctx *c)
 {
     GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
@@ -259,33 +345,6 @@ int ensure_vertex_words(gnnpe_ctx *c)
         hipLaunchKernelGGL(k_aux_pack_vertex, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, deg, c->labels.as<uint32_t>(),
                            c->aux_vdl.as<uint64_t>());
     GNNPE_HIP_TRY(hipGetLastError());
-    return GNNPE_OK;
-}
-
-// The levels above the leaves, bottom-up, for an image whose leaf rows of c->aux_deg / c->aux_mbr are already filled (the
-// pair-major leaf kernel of gnnpe_index.hip computes them while it assembles the leaves) and whose c->aux_key is cleared.
-// Bulk-loaded images keep the leaves in node blocks [0, n_leaves) and the inner nodes behind them.
-int aux_upper_levels(gnnpe_ctx *c, const char *image, uint32_t n_nodes, uint32_t n_leaves, uint32_t D, uint32_t L, int root_level)
-{
-    if (root_level < 1 || n_nodes <= n_leaves) return GNNPE_OK;
-    int rc;
-    if ((rc = c->aux_upper.reserve(((size_t)n_nodes + 1) * 4))) return rc;
-    uint32_t *d_err = c->small.as<uint32_t>() + 600;  // bytes 2400..2411 of the context's small buffer: error code, block, list length
-    uint32_t *d_nup = d_err + 2;
-    const uint32_t n_up = n_nodes - n_leaves;
-    GNNPE_HIP_TRY(hipMemsetAsync(d_err, 0, 8, c->stream));
-    GNNPE_HIP_TRY(hipMemcpyAsync(d_nup, &n_up, 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_aux_iota, dim3(grid_for(n_up)), dim3(kBlock), 0, c->stream, n_up, n_leaves, c->aux_upper.as<uint32_t>());
-    for (int level = 1; level <= root_level; level++)
-        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)n_up * 64)), dim3(kBlock), 0, c->stream, image, n_nodes, level, D, L, c->e,
-                           (uint64_t)0, (const uint32_t *)nullptr, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
-                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
-                           c->aux_upper.as<uint32_t>(), d_nup);
-    GNNPE_HIP_TRY(hipGetLastError());
-    uint32_t err[2] = {0, 0};
-    GNNPE_HIP_TRY(hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));  // (also: n_up was read from this frame)
-    GNNPE_REQUIRE(err[0] == 0, GNNPE_ERR_ARG, "index image, node block %u: inconsistent inner node (code %u)", err[1], err[0]);
     return GNNPE_OK;
 }
 
@@ -356,10 +415,14 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     }
     GNNPE_AUXL(3, 2) GNNPE_AUXL(3, 3) GNNPE_AUXL(3, 4) GNNPE_AUXL(3, 8) GNNPE_AUXL(4, 1) GNNPE_AUXL(4, 2) GNNPE_AUXL(4, 3) GNNPE_AUXL(4, 4) GNNPE_AUXL(4, 8)
 #undef GNNPE_AUXL
-    for (int level = first_generic; level <= (int)root_level; level++)
-        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, level, D,
+    if (first_generic == 0)  // the leaf level of any other (L, e), one value at a time; it lists the inner nodes as well
+        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, 0, D,
                            L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
                            c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
+                           c->aux_upper.as<uint32_t>(), d_nup);
+    for (int level = 1; level <= (int)root_level; level++)
+        hipLaunchKernelGGL(k_aux_upper, dim3(grid_for((uint64_t)N * 64 / 32 + 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N,
+                           level, D, L, c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
                            c->aux_upper.as<uint32_t>(), d_nup);
     GNNPE_HIP_TRY(hipGetLastError());
     uint32_t err[2] = {0, 0};

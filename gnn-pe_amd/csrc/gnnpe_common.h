@@ -17,10 +17,8 @@ struct gnnpe_ctx;
 namespace gnnpe {
 
 void set_error(const char *fmt, ...);
-// gnnpe_aux.hip: {degree, label} word of every vertex (c->aux_vdl); the levels above the leaves of an image's auxiliary
-// index, given the leaf rows of c->aux_deg / c->aux_mbr (nodes [0, n_leaves) are the leaves, the rest inner nodes)
+// gnnpe_aux.hip: {degree, label} word of every vertex (c->aux_vdl)
 int ensure_vertex_words(gnnpe_ctx *c);
-int aux_upper_levels(gnnpe_ctx *c, const char *image, uint32_t n_nodes, uint32_t n_leaves, uint32_t D, uint32_t L, int root_level);
 int resolve_total(gnnpe_ctx *c);  // gnnpe_engine.hip: fetch the count's total if the last count was enqueue-only
 
 #define GNNPE_HIP_TRY(expr)                                                                       \

@@ -176,50 +176,127 @@ __global__ __launch_bounds__(64) void k_pack_leaves(uint64_t cnt, uint32_t F, Le
 }
 
 // internal node j of a level: children = nodes [child0 + j*F, child0 + min((j+1)*F, n_child)) of the
-// level below; block id = node0 + j.
-__global__ __launch_bounds__(64) void k_pack_inner(uint64_t n_child, uint64_t child0, uint64_t node0, uint32_t F,
-                                                   uint32_t D, int level, const double *__restrict__ child_mbr,
-                                                   char *__restrict__ image, double *__restrict__ node_mbr)
+// level below; block id = node0 + j.  One wave per node (a resident grid of four-wave workgroups), one lane per child entry.  An entry (16D bytes of bounces + the
+// son's block id) starts at byte 5 + t * (16D + 4) of the block: always one byte past a dword boundary, so the lane shifts
+// its dwords by three bytes on the way into the LDS image (a byte and a half-word in front, whole dwords, a byte behind;
+// round 2 moved every entry a byte at a time: 0.42-0.54 ms for the 131 K level-1 nodes of config 3); the node's own
+// bounding box is a DPP min / max over the lanes.
+// With `adeg` (the pair-major build with the auxiliary index): also the node's rows of Partition::build_auxiliary_index
+// (custom.h:268-364) from its children's -- max degree per path position, label-feature box, and every child's key = minus the
+// sum of its entry's upper bounds, dimensions in ascending order (custom.h:324-328) -- so that no pass reads the image back.
+__global__ __launch_bounds__(256) void k_pack_inner(uint64_t n_nodes, uint64_t n_child, uint64_t child0, uint64_t node0, uint32_t F,
+                                                    uint32_t D, int level, const double *__restrict__ child_mbr,
+                                                    char *__restrict__ image, double *__restrict__ node_mbr, uint32_t L,
+                                                    double *__restrict__ key, uint32_t *__restrict__ adeg, double *__restrict__ ambr)
 {
-    __shared__ __attribute__((aligned(16))) char s_blk[kBlockLen];
-    __shared__ double s_lo[64], s_hi[64];
-    const uint32_t esz = 16 * D + 4;
-    const uint64_t j = blockIdx.x;
-    const uint64_t c0 = j * F;
-    const uint32_t ne = (uint32_t)min((uint64_t)F, n_child - c0);
-    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_blk)[i] = 0u;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s_blk[0] = (char)level;
-        const int32_t n32 = (int32_t)ne;
-        lds_put(s_blk + 1, &n32, 4);
-    }
-    if (threadIdx.x < ne) {
-        char *ent = s_blk + 5 + threadIdx.x * esz;
-        const double *m = child_mbr + (c0 + threadIdx.x) * 2 * D;
-        lds_put(ent, m, 16 * D);  // (lo, hi) pairs already interleaved
-        const int32_t s32 = (int32_t)(child0 + c0 + threadIdx.x);  // son = child's block id
-        lds_put(ent + 16 * D, &s32, 4);
-    }
-    for (uint32_t k = 0; k < D; k++) {
-        s_lo[threadIdx.x] = threadIdx.x < ne ? child_mbr[((c0 + threadIdx.x) * D + k) * 2] : 1e300;
-        s_hi[threadIdx.x] = threadIdx.x < ne ? child_mbr[((c0 + threadIdx.x) * D + k) * 2 + 1] : -1e300;
-        __syncthreads();
-        for (int s = 32; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) {
-                s_lo[threadIdx.x] = fmin(s_lo[threadIdx.x], s_lo[threadIdx.x + s]);
-                s_hi[threadIdx.x] = fmax(s_hi[threadIdx.x], s_hi[threadIdx.x + s]);
+    __shared__ __attribute__((aligned(16))) char s_all[4][kBlockLen];
+    char *s_blk = s_all[threadIdx.x >> 6];
+    const uint32_t esz = 16 * D + 4, t = threadIdx.x & 63u;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t j = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6; j < n_nodes; j += nw) {  // a wave per node
+        const uint64_t c0 = j * F;
+        const uint32_t ne = (uint32_t)min((uint64_t)F, n_child - c0);
+        for (uint32_t i = t; i < kBlockLen / 16; i += 64) reinterpret_cast<uint4 *>(s_blk)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (t == 0) {
+            s_blk[0] = (char)level;
+            const int32_t n32 = (int32_t)ne;
+            lds_put(s_blk + 1, &n32, 4);
+        }
+        // the entry's (lo, hi) pairs, eight dimensions' loads in flight at a time; every dword but the first goes out joined to
+        // the top byte of the one before it; the node's own box is reduced from the same registers
+        const bool live = t < ne;
+        const uint4 *src = reinterpret_cast<const uint4 *>(child_mbr + (c0 + (live ? t : 0)) * 2 * D);
+        const uint32_t son = (uint32_t)(child0 + c0 + t);  // the child's block id
+        char *ent = s_blk + 5 + t * esz;
+        uint32_t *out = reinterpret_cast<uint32_t *>(ent + 3);  // dword-aligned
+        uint32_t prev = 0, m = 0;
+        double kv = 0.0;
+        auto join = [&](uint32_t w) {
+            if (live) out[m] = (prev >> 24) | (w << 8);
+            m++;
+            prev = w;
+        };
+        for (uint32_t q0 = 0; q0 < D; q0 += 8) {
+            uint4 buf[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++)
+                if (q0 + i < D) buf[i] = src[q0 + i];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                if (q0 + i >= D) break;
+                const uint4 v = buf[i];
+                if (q0 + i == 0) {
+                    if (live) {
+                        ent[0] = (char)(v.x & 0xFFu);
+                        *reinterpret_cast<uint16_t *>(ent + 1) = (uint16_t)(v.x >> 8);
+                    }
+                    prev = v.x;
+                } else {
+                    join(v.x);
+                }
+                join(v.y);
+                join(v.z);
+                join(v.w);
+                const double my_hi = __longlong_as_double((long long)(((uint64_t)v.w << 32) | v.z));
+                kv -= my_hi;
+                const double lo = wave_min(live ? __longlong_as_double((long long)(((uint64_t)v.y << 32) | v.x)) : 1e300);
+                const double hi = wave_max(live ? my_hi : -1e300);
+                if (t == 0) {
+                    node_mbr[(j * D + q0 + i) * 2] = lo;
+                    node_mbr[(j * D + q0 + i) * 2 + 1] = hi;
+                }
             }
-            __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            node_mbr[(j * D + k) * 2] = s_lo[0];
-            node_mbr[(j * D + k) * 2 + 1] = s_hi[0];
+        join(son);
+        if (live) ent[esz - 1] = (char)(son >> 24);
+        if (adeg) {
+            typedef double dbl2 __attribute__((ext_vector_type(2)));
+            const uint64_t b = node0 + j, sn = live ? son : 0u;
+            if (live) key[son] = kv;
+            for (uint32_t j0 = 0; j0 < L; j0 += 8) {
+                uint32_t dv[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) dv[i] = (live && j0 + i < L) ? adeg[sn * L + j0 + i] : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if (j0 + i >= L) break;
+                    const uint32_t dmax = wave_max_u32(dv[i]);
+                    if (t == 0) adeg[b * L + j0 + i] = dmax;
+                }
+            }
+            const dbl2 *cm = reinterpret_cast<const dbl2 *>(ambr) + sn * D;
+            for (uint32_t k0 = 0; k0 < D; k0 += 8) {
+                dbl2 mv[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    mv[i].x = __builtin_huge_val();
+                    mv[i].y = -__builtin_huge_val();
+                    if (live && k0 + i < D) mv[i] = cm[k0 + i];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if (k0 + i >= D) break;
+                    const double lo = wave_min(mv[i].x), hi = wave_max(mv[i].y);
+                    if (t == 0) {
+                        ambr[(b * D + k0 + i) * 2] = lo;
+                        ambr[(b * D + k0 + i) * 2 + 1] = hi;
+                    }
+                }
+            }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *dst = reinterpret_cast<u32x4 *>(image + (node0 + j + 1) * (uint64_t)kBlockLen);
+        for (uint32_t i = t; i < kBlockLen / 16; i += 64) __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(s_blk)[i], dst + i);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    uint32_t *dst = reinterpret_cast<uint32_t *>(image + (node0 + j + 1) * (uint64_t)kBlockLen);
-    for (uint32_t i = threadIdx.x; i < kBlockLen / 4; i += blockDim.x) dst[i] = reinterpret_cast<uint32_t *>(s_blk)[i];
 }
 
 // ---- fast path: 3-vertex paths with a compile-time embedding width (D = 3E) -------------------------
@@ -998,12 +1075,12 @@ static int ensure_vkey(gnnpe_ctx *c)
 
 // one launch per upper level: parents packed from consecutive children
 static int pack_upper_levels(gnnpe_ctx *c, const std::vector<uint64_t> &level_n, uint32_t F, uint32_t D, char *image, double *mbr_a,
-                             double *mbr_b)
+                             double *mbr_b, uint32_t L = 0, double *key = nullptr, uint32_t *adeg = nullptr, double *ambr = nullptr)
 {
     uint64_t child0 = 0, node0 = level_n[0];
     for (size_t lv = 1; lv < level_n.size(); lv++) {
-        hipLaunchKernelGGL(k_pack_inner, dim3((uint32_t)level_n[lv]), dim3(64), 0, c->stream, level_n[lv - 1], child0,
-                           node0, F, D, (int)lv, mbr_a, image, mbr_b);
+        hipLaunchKernelGGL(k_pack_inner, dim3(grid_for(level_n[lv] * 64)), dim3(kBlock), 0, c->stream, level_n[lv], level_n[lv - 1],
+                           child0, node0, F, D, (int)lv, mbr_a, image, mbr_b, L, key, adeg, ambr);
         std::swap(mbr_a, mbr_b);
         child0 = node0;
         node0 += level_n[lv];
@@ -1642,8 +1719,8 @@ static int ensure_pair_order(gnnpe_ctx *c)
     }
 }
 
-// with_aux: also the leaves' auxiliary arrays (c->aux_deg / c->aux_mbr rows of the leaf nodes) and, through
-// gnnpe::aux_upper_levels, the upper levels and the keys -- the whole Partition::build_auxiliary_index of this image
+// with_aux: also the auxiliary arrays (c->aux_deg / c->aux_mbr rows of the leaves from the leaf kernel, of the inner nodes
+// and every node's key from k_pack_inner) -- the whole Partition::build_auxiliary_index of this image
 static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8], bool with_aux = false)
 {
     int rc;
@@ -1720,10 +1797,10 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
 #undef GNNPE_PXE
 #undef GNNPE_PXL
     GNNPE_HIP_TRY(hipGetLastError());
-    if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
+    // (with_aux: the upper levels' auxiliary rows and all keys come out of the same launches, bottom-up)
+    if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b, 3, with_aux ? c->aux_key.as<double>() : nullptr, adeg, ambr))) return rc;
     if ((rc = write_header(c, image, hdr))) return rc;
     if (with_aux) {
-        if ((rc = aux_upper_levels(c, image, (uint32_t)n_nodes, (uint32_t)nl, D, 3, (int)level_n.size() - 1))) return rc;
         c->img_aux_valid = true;
         c->img_aux_nodes = (uint32_t)n_nodes;
     }
