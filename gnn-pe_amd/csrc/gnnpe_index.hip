@@ -694,19 +694,16 @@ __global__ void k_px_bounds(uint64_t ne, uint32_t n_parts, const KeyT *__restric
     }
     bounds[pt] = lo;
 }
-// first[j] = sorted pair that holds the first point of leaf j (the largest k with pref[k] <= point index)
+// first[j] = sorted pair that holds the first point of leaf j (the largest k with pref[k] <= point index).  Pair-driven: a
+// pair with points [a, z) of the partition names the leaves whose first point j * F falls inside -- none or one for most
+// pairs -- so the pass streams the prefix once (round 2 searched it once per leaf: 24 dependent loads each, 0.15 ms).
 __global__ void k_px_leaf_first(uint64_t n_leaves, uint32_t F, uint64_t r0, uint64_t r1, const uint64_t *__restrict__ pref,
                                 uint32_t *__restrict__ first)
 {
     const uint64_t base = pref[r0];
-    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n_leaves; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t g = base + j * F;
-        uint64_t lo = r0, hi = r1;
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (pref[mid] <= g) lo = mid; else hi = mid;
-        }
-        first[j] = (uint32_t)lo;
+    for (uint64_t q = r0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < r1; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t a = pref[q] - base, z = pref[q + 1] - base;
+        for (uint64_t j = (a + F - 1) / F; j * F < z && j < n_leaves; j++) first[j] = (uint32_t)q;
     }
 }
 
@@ -1771,7 +1768,7 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
         adeg = c->aux_deg.as<uint32_t>();
         ambr = c->aux_mbr.as<double>();
     }
-    hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(nl)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
+    hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(r1 - r0)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
                        c->px_first.as<uint32_t>());
     const bool packed = c->n <= (1u << kPackedIdBits);
     GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
