@@ -799,6 +799,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
     // sorted pairs, and the block scheduler balances the tail (round 2, scripts/index_ab.py: 2048 resident-sized blocks
     // walking strided leaves 8.34 ms, 24576 blocks 7.42, one leaf per wave 7.11).
+    // Round 3 tried the resident grid again WITH the next leaf's pairs and the bounds of the one after it fetched ahead (two of
+    // a leaf's three dependent round trips hidden): 64 VGPRs with 7 spilled at 8 waves per SIMD, 6.2 ms against 5.1 -- in a loop
+    // the next leaf's loads queue behind this leaf's stores, which a wave that simply ends never waits for.
     const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
     if (j < n_leaves) {
         const uint64_t g0 = j * F;
