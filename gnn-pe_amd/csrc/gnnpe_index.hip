@@ -802,6 +802,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // Round 3 tried the resident grid again WITH the next leaf's pairs and the bounds of the one after it fetched ahead (two of
     // a leaf's three dependent round trips hidden): 64 VGPRs with 7 spilled at 8 waves per SIMD, 6.2 ms against 5.1 -- in a loop
     // the next leaf's loads queue behind this leaf's stores, which a wave that simply ends never waits for.
+    // (Held to 4 waves per SIMD the one-leaf-per-wave kernel takes 7.1 ms against 5.1 at 8: T = B + L / occupancy puts the
+    // line-traffic floor B near 3.1 ms and the dependent round trips at 2.0 ms of today's time.)
     const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
     if (j < n_leaves) {
         const uint64_t g0 = j * F;
