@@ -804,6 +804,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // the next leaf's loads queue behind this leaf's stores, which a wave that simply ends never waits for.
     // (Held to 4 waves per SIMD the one-leaf-per-wave kernel takes 7.1 ms against 5.1 at 8: T = B + L / occupancy puts the
     // line-traffic floor B near 3.1 ms and the dependent round trips at 2.0 ms of today's time.)
+    // Touching ahead -- every wave also loading a word of the pairs and of the row blocks' first lines of the leaf 2 048 ...
+    // 16 384 leaves on, to leave them in the L2 -- cost 0.5 ms at every distance (scripts/index_ab.py: 5.95 -> 6.43-6.53 ms per
+    // further partition): the kernel is short of request slots, not of patience.
     const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
     if (j < n_leaves) {
         const uint64_t g0 = j * F;
