@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                     const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E) + (uint64_t)r * (sizeof(Rec) / 4);
                     uint32_t wq[sizeof(Rec) / 4];
 #pragma unroll
-                    for (int z = 0; z < (int)(sizeof(Rec) / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);
+                    for (int z = 0; z < (int)(sizeof(Rec) / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);  // (dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower, 5.43 -> 5.69 ms)
                     __builtin_memcpy(&rec, wq, sizeof(Rec));
                 }
                 uint32_t ip;
@@ -992,12 +992,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 node_mbr[(j * D + k) * 2 + 1] = hi;
             }
         }
-        uint4 *dst = reinterpret_cast<uint4 *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *dst = reinterpret_cast<u32x4 *>(image + (j + 1) * (uint64_t)kBlockLen);  // node j -> file block j+1
 #pragma unroll
         for (int rr = 0; rr < (kStoreU4 + 63) / 64; rr++) {
             const int c = lane + 64 * rr;
             if (c < kStoreU4) {
-                uint4 o = {0u, 0u, 0u, 0u};  // beyond the window: zeros
+                u32x4 o = {0u, 0u, 0u, 0u};  // beyond the window: zeros
                 if (4 * c + 4 < kWin) {
                     const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * c);
                     const uint32_t nx = w[4 * c + 4];
@@ -1006,10 +1007,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                     o.z = (lo4.z >> 24) | (lo4.w << 8);
                     o.w = (lo4.w >> 24) | (nx << 8);
                 }
-                __builtin_nontemporal_store(o.x, &dst[c].x);
-                __builtin_nontemporal_store(o.y, &dst[c].y);
-                __builtin_nontemporal_store(o.z, &dst[c].z);
-                __builtin_nontemporal_store(o.w, &dst[c].w);
+                __builtin_nontemporal_store(o, dst + c);  // (one 16-byte store or four dword stores: the same time)
             }
         }
     }
