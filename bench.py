@@ -42,6 +42,7 @@ import gnnpe_amd  # noqa: E402,F401
 from gnnpe_amd import binding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LEAF_TRAFFIC_BYTES = 29.6e9  # index leaf kernel at config 3, per launch: profiles/r03_leaf_mem_pmc.txt
 CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_fill.json")
 
@@ -615,13 +616,21 @@ def main():
                                   image_and_aux_index_ms=min(ib_cached) and min(fused_ms),
                                   aux_index_added_ms=min(fused_ms) - min(ib_cached),
                                   aux_index_note="Partition::build_auxiliary_index (custom.h:268-364): image_and_aux_index_ms builds the image "
-                                                 "WITH the auxiliary index (leaf rows by the leaf kernel, upper levels by a short pass) from the "
-                                                 "cached pair order -- compare next_partition_ms, the same build without it; "
+                                                 "WITH the auxiliary index (leaf rows by the leaf kernel, inner nodes' rows and all keys by the "
+                                                 "inner-node kernel) from the cached pair order -- compare next_partition_ms, the same build without it; "
                                                  "generic_aux_pass_ms is the stand-alone pass over a finished image (foreign trees, l = 3)",
                                   generic_aux_pass_ms=min(aux_ms),
                                   where="device image of index.dat (partition 0 of p = 1), pair-major build from the enumeration "
                                         "state: pair sort + leaves + upper levels; the files on disk are timed under e2e",
                                   next_partition_ms=min(ib_cached),
+                                  hbm=dict(file_bytes_frac=nbytes / (min(ib[1:]) / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                           leaf_pass_traffic_bytes=LEAF_TRAFFIC_BYTES if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
+                                           leaf_pass_traffic_frac=(LEAF_TRAFFIC_BYTES / (min(ib_cached) / 1e3) / 1e9 / HBM_PEAK_GBS)
+                                           if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
+                                           note="file_bytes_frac = the image's bytes over wallclock_ms (pair sort included); "
+                                                "leaf_pass_traffic_* = what the leaf kernel moves per launch at config 3 by the counters of the "
+                                                "committed profile (profiles/r03_leaf_mem_pmc.txt: 8.6 GB of 128-byte fabric reads + 21.0 GB of "
+                                                "64-byte writes), over next_partition_ms (leaf kernel + first-pair pass + inner nodes)"),
                                   next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
                                   tuple_array_build_ms=min(ib_tuple),
                                   first_call_ms=ib[0],
