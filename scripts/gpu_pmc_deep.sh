@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counters of k_deep3 (l = 3 emit) on the config-5 graph, one 2^26-path range: two rocprofv3 --pmc passes over bench_deep.py
+# Counters of the l = 3 emission (k_deep3_slices) and count on the config-5 graph, one 2^26-path range: two rocprofv3 --pmc passes over bench_deep.py
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -15,12 +15,12 @@ i = sys.argv[1]
 for f in glob.glob(f"gpurun_out/deep_pmc_{i}/*/*_counter_collection.csv"):
     per = {}
     for r in csv.DictReader(open(f)):
-        for kn in ("k_deep3<", "k_deep3_count_rows"):
+        for kn in ("k_deep3_slices<8, true", "k_deep3_slices<8, false", "k_deep3_count_rows"):
             if kn in r["Kernel_Name"]:
                 per.setdefault((kn, r["Counter_Name"]), {}).setdefault(int(r["Dispatch_Id"]), 0.0)
                 per[(kn, r["Counter_Name"])][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for (kn, c), v in sorted(per.items()):
         vals = list(v.values())
-        print(f"{kn:22s} {c:36s} mean {sum(vals)/len(vals):.5g} over {len(vals)} launches")
+        print(f"{kn:26s} {c:36s} mean {sum(vals)/len(vals):.5g} over {len(vals)} launches")
 PY
 done
