@@ -50,31 +50,25 @@ __global__ void k_aux_pack_vertex(uint32_t n, const uint32_t *__restrict__ degre
         vdl[v] = (uint64_t)degree[v] | ((uint64_t)labels[v] << 32);
 }
 
-// One wave per node block; blocks of another level return after reading their first bytes.
-//   level 0: entry -> son = index of a path of the partition -> its vertices -> their degrees and label features
-//   level k: entry -> son = child block (already done: the launches go bottom-up) -> the child's arrays; the entry's
-//            upper bounds give the child's key
-__global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ image, uint32_t n_nodes, int level, uint32_t D,
-                                                   uint32_t L, uint32_t e, uint64_t cnt, const uint32_t *__restrict__ tuples,
-                                                   uint32_t n, const uint64_t *__restrict__ vdl,
-                                                   const double *__restrict__ xtab, double *__restrict__ key,
-                                                   uint32_t *__restrict__ adeg, double *__restrict__ ambr,
-                                                   uint32_t *__restrict__ err, uint32_t *__restrict__ upper,
-                                                   uint32_t *__restrict__ n_upper)
+// The leaf level for any path length and embedding width, one wave per node block: entry -> son = index of a path of the
+// partition -> its vertices -> their degrees and label features.  It visits every block and lists the inner nodes it passes
+// (a few per thousand blocks) for the upper levels' launches (k_aux_upper), which then walk that list instead of the whole
+// image (five launches over 5.4 M block headers were 2.5 ms of the pass at config 3).
+__global__ __launch_bounds__(256) void k_aux_leaves_any(const char *__restrict__ image, uint32_t n_nodes, uint32_t D, uint32_t L,
+                                                        uint32_t e, uint64_t cnt, const uint32_t *__restrict__ tuples, uint32_t n,
+                                                        const uint64_t *__restrict__ vdl, const double *__restrict__ xtab,
+                                                        uint32_t *__restrict__ adeg, double *__restrict__ ambr,
+                                                        uint32_t *__restrict__ err, uint32_t *__restrict__ upper,
+                                                        uint32_t *__restrict__ n_upper)
 {
-    // level 0 visits every block and lists the inner nodes it passes (a few per thousand blocks); the launches of the
-    // upper levels walk that list instead of the whole image (five launches over 5.4 M block headers were 2.5 ms of the
-    // pass at config 3)
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t w0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t esz = 16 * D + 4, cap = (kAuxBlockLen - 5) / esz;
-    const uint64_t n_visit = level == 0 ? (uint64_t)n_nodes : (uint64_t)*n_upper;
-    for (uint64_t it = w0; it < n_visit; it += nw) {
-        const uint64_t b = level == 0 ? it : (uint64_t)upper[it];
+    for (uint64_t b = w0; b < n_nodes; b += nw) {
         const char *blk = image + (b + 1) * (uint64_t)kAuxBlockLen;  // block 0 of the file is the header (blk_file.cpp:110)
-        if ((int)blk[0] != level) {
-            if (level == 0 && lane == 0) upper[atomicAdd(n_upper, 1u)] = (uint32_t)b;
+        if (blk[0] != 0) {
+            if (lane == 0) upper[atomicAdd(n_upper, 1u)] = (uint32_t)b;
             continue;
         }
         const int32_t ne_raw = ld_i32(blk + 1);
@@ -91,12 +85,11 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
         for (uint32_t t0 = 0; t0 < ne; t0 += 64) {
             const uint32_t t = t0 + lane;
             bool ok = t < ne;
-            const char *ent = blk + 5 + (uint64_t)t * esz;
             uint32_t son = 0;
             if (ok) {
-                son = (uint32_t)ld_i32(ent + 16 * D);
-                if (level == 0 ? son >= cnt : son >= n_nodes) {
-                    aux_fail(err, level == 0 ? 1u : 2u, (uint32_t)b);
+                son = (uint32_t)ld_i32(blk + 5 + (uint64_t)t * esz + 16 * D);
+                if (son >= cnt) {
+                    aux_fail(err, 1u, (uint32_t)b);
                     ok = false;
                 }
             }
@@ -104,18 +97,14 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                 uint32_t d = 0, lab = 0;
                 bool okv = ok;
                 if (ok) {
-                    if (level == 0) {
-                        const uint32_t v = tuples[(uint64_t)son * L + j];
-                        if (v >= n) {
-                            aux_fail(err, 3u, (uint32_t)b);
-                            okv = false;
-                        } else {
-                            const uint64_t w = vdl[v];  // {degree, label}: an 8 MB table, unlike the n x e table of x rows
-                            d = (uint32_t)w;
-                            lab = (uint32_t)(w >> 32);
-                        }
+                    const uint32_t v = tuples[(uint64_t)son * L + j];
+                    if (v >= n) {
+                        aux_fail(err, 3u, (uint32_t)b);
+                        okv = false;
                     } else {
-                        d = adeg[(uint64_t)son * L + j];
+                        const uint64_t w = vdl[v];  // {degree, label}: an 8 MB table, unlike the n x e table of x rows
+                        d = (uint32_t)w;
+                        lab = (uint32_t)(w >> 32);
                     }
                 }
                 uint32_t dmax = wave_max_u32(d);
@@ -125,17 +114,10 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                 }
                 for (uint32_t kk = 0; kk < e; kk++) {
                     const uint32_t k = j * e + kk;
+                    // pde_label (custom.h:561-567) = x of the path's vertices = the label's row of the table
+                    // (gen_vde_x, custom.h:492-511): a 1 KB table instead of a random 8-byte gather per dimension
                     double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
-                    if (okv) {
-                        if (level == 0) {
-                            // pde_label (custom.h:561-567) = x of the path's vertices = the label's row of the table
-                            // (gen_vde_x, custom.h:492-511): a 1 KB table instead of a random 8-byte gather per dimension
-                            lo = hi = xtab[(uint64_t)lab * e + kk];
-                        } else {
-                            lo = ambr[((uint64_t)son * D + k) * 2];
-                            hi = ambr[((uint64_t)son * D + k) * 2 + 1];
-                        }
-                    }
+                    if (okv) lo = hi = xtab[(uint64_t)lab * e + kk];
                     lo = wave_min(lo);
                     hi = wave_max(hi);
                     if (lane == 0) {
@@ -148,18 +130,14 @@ __global__ __launch_bounds__(256) void k_aux_level(const char *__restrict__ imag
                     }
                 }
             }
-            if (level > 0 && ok) {
-                double kv = 0.0;
-                for (uint32_t k = 0; k < D; k++) kv -= ld_f64(ent + (2 * k + 1) * 8);  // custom.h:324-328, same order
-                key[son] = kv;
-            }
         }
     }
 }
 
-// The upper levels again (level >= 1, walking the list the leaf-level launch left): k_aux_level reduces one value at a time
-// -- load the child's degree or bound, reduce, store, next -- and a node cost a resident wave ~25 us, every load waiting
-// for the reduction before it (0.40 ms for the 131 K level-1 nodes of config 3).  Here a lane fetches eight of its child's
+// The upper levels (level >= 1, walking the list the leaf-level launch left), bottom-up, one launch per level: entry -> son =
+// child block (already done) -> the child's arrays; the entry's upper bounds give the child's key.  Round 2 reduced one value
+// at a time -- load the child's degree or bound, reduce, store, next -- and a node cost a resident wave ~25 us, every load
+// waiting for the reduction before it (0.40 ms for the 131 K level-1 nodes of config 3).  Here a lane fetches eight of its child's
 // values before the first reduction (all L degrees, then the bounds four dimensions at a time as 16-byte pairs, then the
 // entry's own upper bounds for the child's key), so a node is three round trips instead of L + 2D + D.
 __global__ __launch_bounds__(256) void k_aux_upper(const char *__restrict__ image, uint32_t n_nodes, int level, uint32_t D,
@@ -416,10 +394,9 @@ int gnnpe_aux_index_device(gnnpe_ctx *c, const void *dev_image, uint64_t nbytes,
     GNNPE_AUXL(3, 2) GNNPE_AUXL(3, 3) GNNPE_AUXL(3, 4) GNNPE_AUXL(3, 8) GNNPE_AUXL(4, 1) GNNPE_AUXL(4, 2) GNNPE_AUXL(4, 3) GNNPE_AUXL(4, 4) GNNPE_AUXL(4, 8)
 #undef GNNPE_AUXL
     if (first_generic == 0)  // the leaf level of any other (L, e), one value at a time; it lists the inner nodes as well
-        hipLaunchKernelGGL(k_aux_level, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, 0, D,
+        hipLaunchKernelGGL(k_aux_leaves_any, dim3(grid_for((uint64_t)N * 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N, D,
                            L, c->e, cnt, (const uint32_t *)dev_tuples, c->n, c->aux_vdl.as<uint64_t>(), c->xtab.as<double>(),
-                           c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
-                           c->aux_upper.as<uint32_t>(), d_nup);
+                           c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err, c->aux_upper.as<uint32_t>(), d_nup);
     for (int level = 1; level <= (int)root_level; level++)
         hipLaunchKernelGGL(k_aux_upper, dim3(grid_for((uint64_t)N * 64 / 32 + 64)), dim3(kBlock), 0, c->stream, (const char *)dev_image, N,
                            level, D, L, c->aux_key.as<double>(), c->aux_deg.as<uint32_t>(), c->aux_mbr.as<double>(), d_err,
