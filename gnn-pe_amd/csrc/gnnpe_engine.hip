@@ -733,7 +733,9 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
     if (c->n_held) {
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
-        const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+        // one row per wave, workgroups in launch order (the kernel's loop is then a single pass): the blocks are written as one
+        // dense front; against the resident grid 1.063 -> 1.050 ms for the count phase at config 3 (scripts/count_ab.py)
+        const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 3) / 4, 1u << 30)), block(kBlock);
 #define GNNPE_RRK(EE, PK)                                                                                           \
     hipLaunchKernelGGL((k_rows_rank<EE, PK>), grid, block, 0, c->stream, c->n_held, held, c->adj_start.as<uint32_t>(), \
                        c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->vinfo.as<double>(),                     \
