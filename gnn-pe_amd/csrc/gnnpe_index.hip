@@ -673,7 +673,14 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
 template <int E>
 __global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairXE<E> *__restrict__ px, PairXE<E> *__restrict__ out)
 {
-    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < ne; k += (uint64_t)gridDim.x * blockDim.x) out[k] = px[order[k]];
+    // one 16-byte piece per thread: consecutive lanes store consecutive pieces (a record per thread stored its three pieces
+    // 48 bytes apart: 0.70 ms for 2.0e7 records at config 3)
+    constexpr uint64_t PC = sizeof(PairXE<E>) / 16;
+    static_assert(sizeof(PairXE<E>) % 16 == 0, "pair records are whole 16-byte pieces");
+    const uint4 *src = reinterpret_cast<const uint4 *>(px);
+    uint4 *dst = reinterpret_cast<uint4 *>(out);
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < ne * PC; t += (uint64_t)gridDim.x * blockDim.x)
+        dst[t] = src[(uint64_t)order[t / PC] * PC + t % PC];
 }
 template <int E> struct CntOfPairX {
     __host__ __device__ uint64_t operator()(const PairXE<E> &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
@@ -1644,7 +1651,7 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
     } while (0)
     if (nu) {
         if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
-        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu)), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
+        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu * (sizeof(PairXE<E>) / 16))), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
     } else {
         GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
     }
