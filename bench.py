@@ -44,7 +44,7 @@ from gnnpe_amd import binding, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LEAF_TRAFFIC_BYTES = 29.6e9  # index leaf kernel at config 3, per launch: profiles/r03_leaf_mem_pmc.txt
 CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_fill.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_fill.json")
 
 
 def bytes_per_path(L, e):
@@ -298,9 +298,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (power-law 4M/64M, l=3, e=8: about a minute of host graph generation)")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
-    ap.add_argument("--placements", type=int, default=12,
+    ap.add_argument("--placements", type=int, default=1,
                     help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
-                         "writes fastest is kept, the others freed); 1 = take what comes")
+                         "writes fastest is kept, the others freed); 1 (default) = one allocation that takes what comes -- the "
+                         "pool then only measures which of the two emit shapes is faster into it")
     ap.add_argument("--equal-paths", action="store_true",
                     help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
     args = ap.parse_args()
@@ -388,17 +389,20 @@ def main():
     # first pass sizes the outputs (and every internal buffer); not timed
     total, base = sb.step()
 
-    # Where the 12 GB of output land matters on this hardware (a buffer streams at ~5.0 or ~6.3 TB/s for
-    # its whole life, not predictable from its address), so the PRODUCT draws: the library's output pool
-    # (gnnpe_output_pool_create, also used by gnnpe_main and offline.py) allocates `--placements` candidates, times the emit
-    # kernel into each, keeps the fastest and frees the rest.  Every candidate's time is reported, and a plain
-    # take-what-comes allocation is timed beside the pool below (roofline.plain_allocation).
+    # Where the 12 GB of output land matters on this hardware (a resident store loop streams into a buffer at
+    # ~5.0 or ~6.3 TB/s for the buffer's whole life, not predictable from its address).  Since round 4 the headline run takes
+    # ONE allocation as it comes (`--placements 1`) and the library measures which EMIT SHAPE is faster into it
+    # (gnnpe_emit_calibrate_device, run by gnnpe_output_pool_create on the buffer it keeps: start-vertex waves win in the fast
+    # allocations, output tiles in the slow ones).  `--placements N` still draws N candidate allocations (kept for comparison;
+    # the run then also times a plain allocation beside the kept one, roofline.plain_allocation).
     D_out = 0 if args.ids_only else e * L
     pool = binding.OutputPool(eng, max(total, 1), L, D_out, candidates=max(1, args.placements))
     pool_rep = pool.report()
     out_ids, out_pde = pool.ids, (pool.pde if D_out else None)
     cap_rows = pool.rows_cap
     ids_view = pool.ids_tensor(device)
+    # both emit shapes timed into the kept buffer (the pool has done this already; again here for the numbers)
+    shapes = eng.emit_calibrate_device(out_ids, out_pde) if (args.fill_variant == 4 and total > 0) else None
 
     fill_ms = []
     enqueue_only = args.fill_variant == 4 and e in (1, 2, 3, 4, 8)
@@ -460,6 +464,7 @@ def main():
         p_ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
         p_pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
         p_ev = []
+        eng.emit_calibrate_device(p_ids, p_pde)
         one_step(False, p_ids, p_pde)
         barrier()
         tp = time.perf_counter()
@@ -517,26 +522,32 @@ def main():
     traffic, traffic_note = None, None
     if (os.path.exists(PMC_FILE) and world == 1 and args.fill_variant == 4 and not args.ids_only and not args.powerlaw
             and (args.n, args.m, e) == (1_000_000, 10_000_000, 2)):
-        d = json.load(open(PMC_FILE)).get("derived", {})
+        d = json.load(open(PMC_FILE)).get(kname, {}).get("derived", {})
         if "traffic_bytes" in d:
             traffic = d["traffic_bytes"] / 1e9
             traffic_note = (f"GB per launch from {os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command): "
                             f"written {d['write_bytes'] / 1e9:.2f} + read {d['read_bytes'] / 1e9:.2f} (128-byte fabric requests)")
-    kname = {1: "k_fill_edge_wave", 4: "k_fill_ranked"}[args.fill_variant]
+    kname = eng.emit_kernel_name() if args.fill_variant == 4 else "k_fill_edge_wave"
     peak_bytes = total * bpp / 1e9  # GB per launch
     cms = sorted(pool_rep["candidates_ms"])
     med_ms = float(np.median(cms)) if len(cms) > 1 else None
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r03_pmc_fill.json: separate --pmc passes of this command), not this run",
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r04_pmc_fill.json: separate --pmc passes over the same kernel, graph and buffers' size), not this run",
                     traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms,
+                    emit_shapes=None if shapes is None else dict(
+                        starts_ms=round(shapes["starts_ms"], 3), tiles_ms=round(shapes["tiles_ms"], 3), kept=shapes["kept"],
+                        note="gnnpe_emit_calibrate_device: both emit kernels timed into the output buffer (host clock around stream "
+                             "synchronisations, best of two after a first touch), the faster kept for it: k_fill_ranked = one wave per "
+                             "start vertex, resident grid; k_fill_tiles = one wave per 128-row output tile, launch order"),
                     output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],
                                      probe=pool_rep["probe"],
                                      frac_median_candidate=(peak_bytes / (med_ms / 1e3) / HBM_PEAK_GBS) if med_ms else None,
                                      frac_best_candidate=(peak_bytes / (cms[0] / 1e3) / HBM_PEAK_GBS) if med_ms else None,
-                                     note="gnnpe_output_pool_create (product API, also behind gnnpe_main and offline.py): independent candidate "
-                                          "allocations, the emit kernel timed into each, the fastest kept and the others freed; `frac` is the kept "
-                                          "buffer timed live over the steps, frac_median_candidate what the median draw would give"),
+                                     placements=args.placements,
+                                     note="gnnpe_output_pool_create (product API, also behind gnnpe_main and offline.py); with --placements 1 (default "
+                                          "since round 4) ONE allocation that takes what comes; with N > 1 independent candidate allocations, the emit "
+                                          "kernel timed into each, the fastest kept and the others freed. `frac` is the kept buffer timed live over the steps"),
                     plain_allocation=None if plain is None else dict(
                         launch_ms=plain["fill_ms"], frac=peak_bytes / (plain["fill_ms"] / 1e3) / HBM_PEAK_GBS, ms_per_step=plain["ms_per_step"],
                         value=global_total / (plain["ms_per_step"] / 1e3),

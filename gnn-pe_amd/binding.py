@@ -107,9 +107,12 @@ SIGNATURES = {
     "gnnpe_pge_build_index": (C.c_int, [_vp, C.c_uint64, _u32p, C.c_char_p]),
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
+    "gnnpe_set_emit_shape": (C.c_int, [_vp, C.c_int]),
+    "gnnpe_emit_kernel_name": (C.c_char_p, [_vp]),
+    "gnnpe_emit_calibrate_device": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
-ABI_VERSION = 3  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
+ABI_VERSION = 4  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
 _lib = None
 
 
@@ -307,23 +310,28 @@ def host_read_membership(path, n, p):
 class _DevArray:
     """A typed view of raw device memory for torch (`torch.as_tensor(view, device=...)` shares it, no copy)."""
 
-    def __init__(self, ptr, shape, typestr):
+    def __init__(self, ptr, shape, typestr, owner=None):
+        self.owner = owner  # keeps the pool (and through it the engine) alive for as long as a tensor shares the memory
         self.__cuda_array_interface__ = dict(shape=tuple(int(x) for x in shape), typestr=typestr, data=(int(ptr), False),
                                              version=2, strides=None)
 
 
 class OutputPool:
-    """gnnpe_output_pool_*: the emit kernel's output buffers (ids: rows_cap x L uint32, pde: rows_cap x D doubles): the
-    fastest of `candidates` independent allocations, each timed with the emit kernel (or, without a count on the engine,
-    a streaming write); the others are freed before the constructor returns.  `ids` / `pde` are raw device pointers (ints); ids_tensor() / pde_tensor() are torch
-    views of the same memory.  Create it AFTER eng.count_paths() so that the probe is the emit kernel itself."""
+    """gnnpe_output_pool_*: the emit kernel's output buffers (ids: rows_cap x L uint32, pde: rows_cap x D doubles).  One
+    allocation by default; with `candidates` > 1 the fastest of that many independent allocations, each timed with the emit
+    kernel (or, without a count on the engine, a streaming write), the others freed before the constructor returns.  With an
+    l = 2 count on the engine the pool also times both emit shapes into the buffer it keeps (gnnpe_emit_calibrate_device).
+    `ids` / `pde` are raw device pointers (ints); ids_tensor() / pde_tensor() are torch views of the same memory: close() refuses
+    while one of them is alive (Engine.close() does not ask -- drop the views before closing the engine).  Create the pool
+    AFTER eng.count_paths() so that the probe is the emit kernel itself."""
 
-    def __init__(self, eng, rows_cap, L, D, candidates=8):
+    def __init__(self, eng, rows_cap, L, D, candidates=1):
         self.eng, self.lib = eng, eng.lib
         self.rows_cap, self.L, self.D = int(max(rows_cap, 1)), int(L), int(D)
         h = C.c_void_p()
         eng._ck(self.lib.gnnpe_output_pool_create(eng.ctx, self.rows_cap, self.L, self.D, int(candidates), C.byref(h)))
         self.h = h
+        self._views = []  # weak references to the arrays handed to torch
         eng._pools.append(self)
         self._refresh()
 
@@ -341,14 +349,22 @@ class OutputPool:
 
     def ids_tensor(self, device):
         import torch
-        return torch.as_tensor(_DevArray(self.ids, (self.rows_cap, self.L), "<i4"), device=device)
+        return torch.as_tensor(self._view(self.ids, (self.rows_cap, self.L), "<i4"), device=device)
 
     def pde_tensor(self, device):
         import torch
-        return torch.as_tensor(_DevArray(self.pde, (self.rows_cap, self.D), "<f8"), device=device) if self.D else None
+        return torch.as_tensor(self._view(self.pde, (self.rows_cap, self.D), "<f8"), device=device) if self.D else None
 
-    def close(self):
-        """Frees the pool's memory.  A pool never outlives its engine: Engine.close() closes its pools first."""
+    def _view(self, ptr, shape, typestr):
+        import weakref
+        a = _DevArray(ptr, shape, typestr, owner=self)
+        self._views.append(weakref.ref(a))
+        return a
+
+    def close(self, force=False):
+        """Frees the pool's memory.  A pool never outlives its engine: Engine.close() closes its pools first (force)."""
+        if not force and any(r() is not None for r in self._views):
+            raise GnnpeError("OutputPool.close(): a tensor from ids_tensor() / pde_tensor() still shares the pool's memory; drop it first")
         if self.h and self.eng.ctx:
             self.lib.gnnpe_output_pool_destroy(self.h)
             if self in self.eng._pools:
@@ -357,7 +373,7 @@ class OutputPool:
 
     def __del__(self):
         try:
-            self.close()
+            self.close(force=True)
         except Exception:
             pass
 
@@ -382,7 +398,7 @@ class Engine:
     def close(self):
         if self.ctx:
             for p in list(getattr(self, "_pools", [])):
-                p.close()
+                p.close(force=True)
             self.lib.gnnpe_destroy(self.ctx)
             self.ctx = None
 
@@ -477,8 +493,19 @@ class Engine:
         """The count enqueued only (no read-back); count_total() fetches the number, count_total_device() copies it
         to a device word a collective can send."""
         self._ck(self.lib.gnnpe_count_paths_enqueue(self.ctx, l))
-        self.total = None
+        self._total = None  # resolved by the first reader of .total (one read-back)
         self.l = l
+
+    @property
+    def total(self):
+        """Paths of the last count; after an enqueue-only count the first read fetches it (count_total)."""
+        if getattr(self, "_total", None) is None and getattr(self, "l", None) is not None:
+            self.count_total()
+        return getattr(self, "_total", None)
+
+    @total.setter
+    def total(self, value):
+        self._total = value
 
     def count_total(self):
         tot = C.c_uint64()
@@ -544,6 +571,19 @@ class Engine:
 
     def set_fill_variant(self, v):
         self._ck(self.lib.gnnpe_set_fill_variant(self.ctx, int(v)))
+
+    def set_emit_shape(self, shape):
+        """0 = by graph, 1 = one wave per start vertex (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles)."""
+        self._ck(self.lib.gnnpe_set_emit_shape(self.ctx, int(shape)))
+
+    def emit_kernel_name(self):
+        return self.lib.gnnpe_emit_kernel_name(self.ctx).decode()
+
+    def emit_calibrate_device(self, dev_vids=None, dev_pde=None):
+        """Times both emit shapes into these buffers and keeps the faster for them: dict(starts_ms, tiles_ms, kept)."""
+        a, b, k = C.c_float(), C.c_float(), C.c_int()
+        self._ck(self.lib.gnnpe_emit_calibrate_device(self.ctx, _dev(dev_vids), _dev(dev_pde), C.byref(a), C.byref(b), C.byref(k)))
+        return dict(starts_ms=a.value, tiles_ms=b.value, kept={1: "starts", 2: "tiles"}[k.value])
 
     # halo exchange helpers (SURVEY 8(e))
     def halo_need(self, slab_bounds, dev_ids, cap):

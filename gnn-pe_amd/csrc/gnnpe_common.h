@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gnnpe_hip.h"
@@ -159,6 +160,16 @@ struct gnnpe_ctx {
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
     int fill_variant = 4, counted_variant = 4;  // 4 = rank-sorted neighbour records (default), 1 = generic pair-wave
     bool slab_struct_valid = false;  // poffs / n_edges match the current graph, order and slab
+    // output-tile-driven emit (gnnpe_fill_tiles.hip.h): {start, middle} of every pair (structure, valid with poffs) and the
+    // tile table of one count (first pair of every 64-row output tile), built by the first fill that wants it
+    gnnpe::DevBuf pst, tfirst;
+    bool pst_valid = false;
+    uint32_t tile_rows = 0;  // rows per tile the table was built for
+    uint64_t tile_gen = 0, tile_cap = 0;  // count the table belongs to; tiles it covers (+ 1 sentinel entry)
+    // emit shape measured per output buffer (gnnpe_emit_calibrate_device): {buffer, faster shape}; consulted when emit_shape is 0
+    std::vector<std::pair<const void *, int>> emit_prefs;
+    const char *last_emit_kernel = "";
+    int emit_shape = 0;  // 0 = by graph (tiles unless the graph has hub rows), 1 = start-vertex waves, 2 = output tiles
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order

@@ -9,10 +9,13 @@
 #include <random>
 #include <vector>
 
+#include <chrono>
+
 #include "gnnpe_common.h"
 #include "gnnpe_kernels.hip.h"
 #include "gnnpe_fill_pairwave.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
+#include "gnnpe_fill_tiles.hip.h"
 #include "gnnpe_fill_deep.hip.h"
 
 namespace gnnpe {
@@ -802,6 +805,36 @@ static int ensure_slab_struct(gnnpe_ctx *c)
     if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
     c->n_edges = (uint32_t)w;
     c->slab_struct_valid = true;
+    c->pst_valid = false;
+    return GNNPE_OK;
+}
+
+// what the output-tile-driven emit needs beside the count: the pairs' end points (once per graph / order / slab) and the
+// tile table of this count for the tiles of rows [0, rows_hi)
+static int ensure_tile_table(gnnpe_ctx *c, uint64_t rows_hi, uint32_t ts)
+{
+    const uint32_t len = c->slab_end - c->slab_begin;
+    const uint64_t ne = c->n_edges;
+    int rc;
+    if (!c->pst_valid) {
+        if ((rc = c->pst.reserve((ne + 1) * sizeof(uint2)))) return rc;
+        if (len)
+            hipLaunchKernelGGL(k_pair_ends, dim3(grid_for((uint64_t)len * 64)), dim3(kBlock), 0, c->stream, len, c->slab_begin,
+                               c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->nbrs.as<uint32_t>(), c->pst.as<uint2>());
+        GNNPE_HIP_TRY(hipGetLastError());
+        c->pst_valid = true;
+    }
+    const uint64_t need = (rows_hi + ts - 1) / ts + 1;  // tiles + the sentinel entry
+    if (c->tile_gen == c->count_gen && c->tile_cap >= need && c->tile_rows == ts) return GNNPE_OK;
+    if ((rc = c->tfirst.reserve((need + 1) * 8))) return rc;
+    if (ne)
+        hipLaunchKernelGGL(k_tile_first, dim3(grid_for(ne)), dim3(kBlock), 0, c->stream, ne, c->eoff.as<uint64_t>(), ts, need,
+                           c->tfirst.as<uint64_t>());
+    GNNPE_HIP_TRY(hipGetLastError());
+    c->tile_gen = c->count_gen;
+    c->tile_cap = need;
+    c->tile_rows = ts;
     return GNNPE_OK;
 }
 
@@ -1140,8 +1173,70 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             if ((rc = c->scratch.reserve((end - begin) * 12 + 16))) return rc;
             P.out_ids = c->scratch.as<uint32_t>();
         }
-        if (P.out_ids || d_pde) {
+        // which shape emits: one wave per start vertex (default: it is the faster one, profiles/r04_emit_ab.txt), or one
+        // wave per output tile when asked for (graphs without hub rows)
+        int shape = c->emit_shape;
+        if (shape == 0) {  // by what was measured into this buffer, if anything was
+            const void *key = d_pde ? d_pde : d_vids;
+            for (const auto &pr : c->emit_prefs)
+                if (pr.first == key) shape = pr.second;
+        }
+        if (const char *ev = getenv("GNNPE_EMIT")) shape = !strcmp(ev, "tiles") ? 2 : !strcmp(ev, "starts") ? 1 : shape;
+        const bool tiles = c->n_hub == 0 && shape == 2 && c->n_edges != 0;
+        if (tiles && (P.out_ids || d_pde)) {
+            // rows per tile in units of 64 (GNNPE_TILE_SHAPE=<units> for A/B runs)
+            int kt = 2;
+            if (const char *ev = getenv("GNNPE_TILE_SHAPE")) kt = atoi(ev) == 1 ? 1 : 2;
+            if (e > 2) kt = 1;
+            const uint32_t ts = 64u * (uint32_t)kt;
+            if ((rc = ensure_tile_table(c, end, ts))) return rc;
+            const uint64_t t_lo = begin / ts, t_hi = (end + ts - 1) / ts;
+            const uint64_t total_arg = c->total_known ? c->total_paths : ~0ull;
+            // GNNPE_TILE_EXP (diagnostic instantiation, e = 2 with packed ids only): bit 0 no stores, bit 1 no record loads,
+            // bit 4 in-kernel stamps (cycles per phase of one wave in 64, printed to stderr)
+            uint32_t xf = 0;
+            if (const char *ev = getenv("GNNPE_TILE_EXP")) xf = (uint32_t)atoi(ev);
+            if (!(e == 2 && packed)) xf = 0;
+            const dim3 grid((unsigned)((t_hi - t_lo + 3) / 4)), block(kBlock);
+            unsigned long long *d_stamps = nullptr;
+            if (xf & 16u) {
+                d_stamps = reinterpret_cast<unsigned long long *>(c->small.as<char>() + 2048);
+                GNNPE_HIP_TRY(hipMemsetAsync(d_stamps, 0, 64, c->stream));
+            }
+#define GNNPE_LTK(EE, PK, KT, SP, DG)                                                                                    \
+    hipLaunchKernelGGL((k_fill_tiles<EE, PK, KT, SP, 4, DG>), grid, block, 0, c->stream, P, c->tfirst.as<uint64_t>(),    \
+                       c->rpairs.as<RankedPair>(), c->pst.as<uint2>(), c->rrecs.as<char>(), t_lo, t_hi, total_arg, xf, d_stamps)
+#define GNNPE_LTS(EE, KT, SP)                                                         \
+    do {                                                                              \
+        if (packed) GNNPE_LTK(EE, true, KT, SP, false); else GNNPE_LTK(EE, false, KT, SP, false); \
+    } while (0)
+            if (xf) {
+                if (kt == 2) GNNPE_LTK(2, true, 2, 64, true); else GNNPE_LTK(2, true, 1, 64, true);
+            } else if (e == 1) {
+                if (kt == 2) GNNPE_LTS(1, 2, 64); else GNNPE_LTS(1, 1, 64);
+            } else if (e == 2) {
+                if (kt == 2) GNNPE_LTS(2, 2, 64); else GNNPE_LTS(2, 1, 64);
+            } else if (e == 3) {
+                GNNPE_LTS(3, 1, 32);
+            } else if (e == 4) {
+                GNNPE_LTS(4, 1, 32);
+            } else {
+                GNNPE_LTS(8, 1, 16);
+            }
+#undef GNNPE_LTS
+#undef GNNPE_LTK
+            if (d_stamps) {
+                unsigned long long h[8];
+                GNNPE_HIP_TRY(hipMemcpyAsync(h, d_stamps, 64, hipMemcpyDeviceToHost, c->stream));
+                GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+                const double nwv = (double)((t_hi - t_lo + 63) / 64);
+                fprintf(stderr, "[tile stamps] cycles per wave: table %.0f  pairs %.0f  records %.0f  park+issue %.0f  store drain %.0f\n",
+                        h[0] / nwv, h[1] / nwv, h[2] / nwv, h[3] / nwv, h[4] / nwv);
+            }
+            c->last_emit_kernel = "k_fill_tiles";
+        } else if (P.out_ids || d_pde) {
             GNNPE_BY_E(e, GNNPE_L)
+            c->last_emit_kernel = "k_fill_ranked";
         }
 #undef GNNPE_L
 #undef GNNPE_LK
@@ -1226,6 +1321,59 @@ int gnnpe_rows_checksum_device(gnnpe_ctx *c, uint64_t n_rows, uint32_t L, const 
                            (const uint32_t *)dev_ids, first_id, d_sum);
     GNNPE_HIP_TRY(hipGetLastError());
     return read_back_u64(c, d_sum, 8, host_sum);
+}
+
+int gnnpe_set_emit_shape(gnnpe_ctx *c, int shape)
+{
+    GNNPE_REQUIRE(c && shape >= 0 && shape <= 2, GNNPE_ERR_ARG, "emit shape must be 0 (by graph), 1 (start waves) or 2 (output tiles)");
+    c->emit_shape = shape;
+    return GNNPE_OK;
+}
+
+const char *gnnpe_emit_kernel_name(gnnpe_ctx *c) { return c ? c->last_emit_kernel : ""; }
+
+int gnnpe_emit_calibrate_device(gnnpe_ctx *c, void *dev_vids, void *dev_pde, float *ms_starts, float *ms_tiles, int *shape_kept)
+{
+    GNNPE_REQUIRE(c && (dev_vids || dev_pde), GNNPE_ERR_ARG, "gnnpe_emit_calibrate_device: no output buffer");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    int rc = resolve_total(c);
+    if (rc) return rc;
+    GNNPE_REQUIRE(c->counted && c->counted_variant == kVarRanked && c->l == 2, GNNPE_ERR_ARG,
+                  "gnnpe_emit_calibrate_device: needs an l=2 count of the rank-sorted enumeration on this context");
+    const void *key = dev_pde ? dev_pde : dev_vids;
+    for (size_t k = 0; k < c->emit_prefs.size(); k++)
+        if (c->emit_prefs[k].first == key) c->emit_prefs.erase(c->emit_prefs.begin() + (long)k--);
+    float ms[3] = {0.f, 0.f, 0.f};
+    int kept = 1;
+    // only one shape exists for graphs with hub rows or without paths; below 2^24 paths a launch is too short to tell
+    if (c->n_hub == 0 && c->total_paths >= (1ull << 24)) {
+        const int saved = c->emit_shape;
+        GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int shape = 1; shape <= 2 && rc == GNNPE_OK; shape++) {
+            c->emit_shape = shape;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3 && rc == GNNPE_OK; rep++) {  // the first launch touches the pages and builds the tile table
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = fill_device(c, 0, c->total_paths, dev_vids, dev_pde, nullptr, nullptr);
+                if (rc == GNNPE_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+                    set_error("gnnpe_emit_calibrate_device: launch failed: %s", hipGetErrorString(hipGetLastError()));
+                    rc = GNNPE_ERR_HIP;
+                }
+                const float t = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (rep > 0) best = std::min(best, t);
+            }
+            ms[shape] = best;
+        }
+        c->emit_shape = saved;
+        if (rc) return rc;
+        kept = ms[2] < ms[1] ? 2 : 1;
+    }
+    if (c->emit_prefs.size() >= 16) c->emit_prefs.erase(c->emit_prefs.begin());
+    c->emit_prefs.emplace_back(key, kept);
+    if (ms_starts) *ms_starts = ms[1];
+    if (ms_tiles) *ms_tiles = ms[2];
+    if (shape_kept) *shape_kept = kept;
+    return GNNPE_OK;
 }
 
 int gnnpe_set_fill_variant(gnnpe_ctx *c, int variant)

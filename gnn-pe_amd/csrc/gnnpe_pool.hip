@@ -193,6 +193,10 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     p->probed_with_kernel = with_kernel && K > 1;
     c->pools.push_back(p);
     *out = p;
+    // which emit shape is faster into the buffer that was kept (both are timed: six launches)
+    if (with_kernel && bytes >= min_probe && c->l == 2 &&
+        (rc = gnnpe_emit_calibrate_device(c, p->base + p->ids_off, D ? p->base + p->pde_off : nullptr, nullptr, nullptr, nullptr)) != GNNPE_OK)
+        (void)hipGetLastError();  // a failed calibration leaves the default shape; the pool is usable
     return GNNPE_OK;
 }
 

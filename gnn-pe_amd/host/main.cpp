@@ -394,10 +394,10 @@ int main(int argc, char **argv)
         const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(o.chunk_paths, devs[d].total));
         void *d_ids = nullptr, *d_part = nullptr, *d_sel = nullptr, *d_text = nullptr;
         const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
-        // the emitted rows live in the library's output pool: the fastest of a few candidate allocations (timed with the
-        // emit kernel itself when one chunk holds every path, with a streaming write otherwise)
+        // the emitted rows live in the library's output pool: one allocation (no candidate draw since round 4); when one
+        // chunk holds every path the pool times both emit shapes into it and later fills take the faster one
         gnnpe_pool *pool = nullptr;
-        check(gnnpe_output_pool_create(ctx, chunk, L, 0, 4, &pool), "output pool");
+        check(gnnpe_output_pool_create(ctx, chunk, L, 0, 1, &pool), "output pool");
         check(gnnpe_output_pool_acquire(pool, &d_ids, nullptr, nullptr), "output pool");
         check(gnnpe_dev_alloc(ctx, chunk * 4, &d_part), "alloc part");
         check(gnnpe_dev_alloc(ctx, chunk * 8, &d_sel), "alloc sel");

@@ -571,12 +571,12 @@ void rank_main(int r, Shared &S)
     const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(o.chunk_paths, 4ull << 20), std::max<uint64_t>(total, 1)));
     const uint64_t text_cap = chunk * (11ull * L + 1) + 64;
     DevMem d_part(ctx, chunk * 4), d_sel(ctx, chunk * 8), d_text(ctx, text_cap);
-    struct PoolIds {  // the emitted rows: the library's output pool (fastest of a few candidate allocations)
+    struct PoolIds {  // the emitted rows: the library's output pool (one allocation, no candidate draw)
         gnnpe_pool *pool = nullptr;
         void *p = nullptr;
         PoolIds(gnnpe_ctx *c, uint64_t rows, uint32_t L_)
         {
-            check(gnnpe_output_pool_create(c, rows, L_, 0, 4, &pool), "output pool");
+            check(gnnpe_output_pool_create(c, rows, L_, 0, 1, &pool), "output pool");
             check(gnnpe_output_pool_acquire(pool, &p, nullptr, nullptr), "output pool");
         }
         ~PoolIds() { gnnpe_output_pool_destroy(pool); }

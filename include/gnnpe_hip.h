@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNPE_ABI_VERSION 3
+#define GNNPE_ABI_VERSION 4
 
 #define GNNPE_OK 0
 #define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
@@ -366,6 +366,24 @@ const char *gnnpe_fill_kernel_name(void);
  *   1 one wave per (start, middle) pair, direct stores, run-time embedding width: the generic form used for widths
  *     without a specialised instantiation (e not in {1,2,3,4,8}); selectable as the A/B baseline */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
+/* Shape of the emit launch of variant 4 (the reference's dfs + gen_pde, custom.h:66-92, 546-572); outputs are identical:
+ *   0    whichever gnnpe_emit_calibrate_device measured faster into the fill's output buffer; shape 1 for a buffer nobody
+ *        calibrated (default)
+ *   1    one wave per start vertex, resident grid (k_fill_ranked): 3.1 / 3.6 ms at BASELINE config 3 into a fast / slow
+ *        allocation (profiles/r04_emit_ab.txt)
+ *   2    one wave per output tile of 128 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.25 /
+ *        3.4 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
+ * The environment variable GNNPE_EMIT=tiles|starts overrides the context's setting (same-process A/B runs). */
+int gnnpe_set_emit_shape(gnnpe_ctx *ctx, int shape);
+/* Times both emit shapes into the caller's output buffers (rows [0, total) of the context's current l=2 count, three launches
+ * each: the buffers are overwritten with the paths) and remembers the faster one FOR THESE BUFFERS: with emit shape 0
+ * later fills into them take it.  The rate a kernel reaches depends on the allocation it writes to and on its shape
+ * (DESIGN.md section 4): start-vertex waves are faster into some allocations, output tiles into others.  ms_starts /
+ * ms_tiles / shape_kept may be null; both times are 0 when only one shape applies (hub rows, fewer than 2^24 paths).
+ * gnnpe_output_pool_create calibrates the buffer it keeps. */
+int gnnpe_emit_calibrate_device(gnnpe_ctx *ctx, void *dev_vids, void *dev_pde, float *ms_starts, float *ms_tiles, int *shape_kept);
+/* Name of the emit kernel the context's last fill launched ("" before the first fill): the rocprofv3 row to match. */
+const char *gnnpe_emit_kernel_name(gnnpe_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,7 @@ def test_random_case_matches_the_oracle(oracle, seed):
     rng, g, sn, mem, p, e = _case(seed)
     n = g["n"]
     eng = binding.Engine(0)
+    eng.set_emit_shape(1 + seed % 2)  # odd seeds emit by output tiles (graphs without hub rows; the others fall back)
     eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
     eng.set_order(sn, mem, p)
     eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1 if n else 1, e))

@@ -345,6 +345,11 @@ def test_graph_beyond_2_26_vertices_takes_the_wide_records(oracle):
     assert np.array_equal(pdl.view(np.uint64), ox[want].reshape(len(want), 6).view(np.uint64))
     cuts = [0, 1, total // 3, total - 1, total]  # chunked emission
     assert np.array_equal(np.concatenate([eng.fill_paths(a_, b_, pde=False)[0] for a_, b_ in zip(cuts[:-1], cuts[1:])]), want)
+    eng.set_emit_shape(2)  # the wide-record instantiation of the output-tile kernel
+    ids2, pde2, _ = eng.fill_paths()
+    assert eng.emit_kernel_name() == "k_fill_tiles"
+    assert np.array_equal(ids2, want) and np.array_equal(pde2.view(np.uint64), pde.view(np.uint64))
+    eng.set_emit_shape(0)
     img, nbytes, hdr = eng.build_index_partition_device(0)  # pair-major build over the wide records
     d = oracle.index_validate(eng.copy_to_host(img, nbytes).tobytes())
     order = np.argsort(d["leaf_son"], kind="stable")

@@ -53,6 +53,9 @@ def test_pool_rows_equal_plain_rows(binding, oracle, candidates, with_count, mon
         assert eng.count_total() == total
         assert np.array_equal(pool.pde_tensor(dev)[:total].cpu().numpy(), vde[want].reshape(total, 6))
         assert np.array_equal(ids[:total].cpu().numpy().view(np.uint32), want) and bool((ids[total:] == 0).all())
+    with pytest.raises(binding.GnnpeError):  # a tensor still shares the pool's memory
+        pool.close()
+    del ids, pde
     pool.close()
     eng.close()
 
