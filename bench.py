@@ -520,6 +520,7 @@ def main():
     # HBM traffic of the fill launch from the committed PMC passes (profiles/, same command and config): WRITE_SIZE +
     # the fabric read requests by size (TCC_EA0_RDREQ_{32,64,128}B); counters cannot be collected inside this run
     traffic, traffic_note = None, None
+    kname = eng.emit_kernel_name() if args.fill_variant == 4 else "k_fill_edge_wave"
     if (os.path.exists(PMC_FILE) and world == 1 and args.fill_variant == 4 and not args.ids_only and not args.powerlaw
             and (args.n, args.m, e) == (1_000_000, 10_000_000, 2)):
         d = json.load(open(PMC_FILE)).get(kname, {}).get("derived", {})
@@ -527,7 +528,6 @@ def main():
             traffic = d["traffic_bytes"] / 1e9
             traffic_note = (f"GB per launch from {os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command): "
                             f"written {d['write_bytes'] / 1e9:.2f} + read {d['read_bytes'] / 1e9:.2f} (128-byte fabric requests)")
-    kname = eng.emit_kernel_name() if args.fill_variant == 4 else "k_fill_edge_wave"
     peak_bytes = total * bpp / 1e9  # GB per launch
     cms = sorted(pool_rep["candidates_ms"])
     med_ms = float(np.median(cms)) if len(cms) > 1 else None
