@@ -19,7 +19,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -55,6 +57,16 @@ struct RankError : std::runtime_error {
 void check(int rc, const char *what)
 {
     if (rc != 0) die(std::string(what) + ": " + gnnpe_last_error());
+}
+// Test hook (tests/test_gpu_cli.py): GNNPE_FAULT_RANK=<rank>:<stage> makes that rank fail at the named stage ("init" =
+// between the two barriers of the communicator set-up, "halo" = before the halo exchange, "emit" = before the emission),
+// so that the failure path of an N > 1 run -- the peers' release from barriers and RCCL, the exit code -- is exercised.
+void fault_point(int r, const char *stage)
+{
+    static const char *spec = getenv("GNNPE_FAULT_RANK");
+    if (!spec) return;
+    const char *colon = strchr(spec, ':');
+    if (colon && atoi(spec) == r && !strcmp(colon + 1, stage)) die(std::string("injected fault at stage ") + stage);
 }
 
 class Barrier {
@@ -142,9 +154,31 @@ public:
         if (!rccl_on_) return;
         if (r == 0 && rccl_.GetUniqueId(&uid_) != ncclSuccess) die("ncclGetUniqueId failed");
         barrier();
-        ncclResult_t rc = rccl_.CommInitRank(&comms_[r], n_, uid_, r);
+        fault_point(r, "init");
+        // ncclCommInitRank returns only when all n ranks have called it: a peer that died after the barrier above leaves
+        // this call blocked for good -- nothing on this thread can end it, the main thread's deadline does (run_offline_slabs)
+        ncclComm_t mine = nullptr;
+        ncclResult_t rc = rccl_.CommInitRank(&mine, n_, uid_, r);
         if (rc != ncclSuccess) die(std::string("ncclCommInitRank: ") + rccl_.GetErrorString(rc));
+        {
+            std::lock_guard<std::mutex> lk(fail_mu_);
+            if (!failed_) {
+                comms_[r] = mine;
+                mine = nullptr;
+            }
+        }
+        if (mine) {  // another rank failed meanwhile: fail() will not see this communicator
+            rccl_.CommAbort(mine);
+            die("stopped: another rank failed");
+        }
         barrier();
+    }
+    // a rank's communicator for a call; never a null handle into RCCL (fail() on another thread clears the entries)
+    ncclComm_t comm_of(int r)
+    {
+        std::lock_guard<std::mutex> lk(fail_mu_);
+        if (!comms_[r]) die("stopped: another rank failed");
+        return comms_[r];
     }
     void finish_rank(int r)
     {
@@ -176,7 +210,11 @@ public:
         if (rccl_on_)
             for (ncclComm_t cm : live) rccl_.CommAbort(cm);
     }
-    bool failed() const { return failed_; }
+    bool failed()
+    {
+        std::lock_guard<std::mutex> lk(fail_mu_);
+        return failed_;
+    }
     const std::string &first_error() const { return first_error_; }
 
     // every rank contributes one word per peer; returns what the peers addressed to me: out[p] = word rank p gave for r
@@ -205,10 +243,12 @@ public:
             void *stream = nullptr;
             check(gnnpe_get_stream(ctx, &stream), "get_stream");
             if (scount[r] != rcount[r]) die("all_to_all_v: a rank's piece for itself has two sizes");
+            // (ncclCommAbort from fail() on another thread may end the calls below with an error: that is its purpose)
+            const ncclComm_t comm = comm_of(r);
             nccl_ok(rccl_.GroupStart(), "ncclGroupStart");
             for (int p = 0; p < n_; p++) {  // p == r included: the self piece is an RCCL send/recv pair like the others
-                if (scount[p]) nccl_ok(rccl_.Send((const char *)send + soff[p] * esize, scount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
-                if (rcount[p]) nccl_ok(rccl_.Recv((char *)recv + roff[p] * esize, rcount[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
+                if (scount[p]) nccl_ok(rccl_.Send((const char *)send + soff[p] * esize, scount[p] * esize, ncclUint8, p, comm, (hipStream_t)stream), "ncclSend");
+                if (rcount[p]) nccl_ok(rccl_.Recv((char *)recv + roff[p] * esize, rcount[p] * esize, ncclUint8, p, comm, (hipStream_t)stream), "ncclRecv");
             }
             nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
             check(gnnpe_sync(ctx), "sync");
@@ -236,10 +276,11 @@ public:
         if (rccl_on_) {
             void *stream = nullptr;
             check(gnnpe_get_stream(ctx, &stream), "get_stream");
+            const ncclComm_t comm = comm_of(r);
             nccl_ok(rccl_.GroupStart(), "ncclGroupStart");
             for (int p = 0; p < n_; p++) {  // p == r included
-                if (counts[r]) nccl_ok(rccl_.Send(send, counts[r] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclSend");
-                if (counts[p]) nccl_ok(rccl_.Recv((char *)recv + off[p] * esize, counts[p] * esize, ncclUint8, p, comms_[r], (hipStream_t)stream), "ncclRecv");
+                if (counts[r]) nccl_ok(rccl_.Send(send, counts[r] * esize, ncclUint8, p, comm, (hipStream_t)stream), "ncclSend");
+                if (counts[p]) nccl_ok(rccl_.Recv((char *)recv + off[p] * esize, counts[p] * esize, ncclUint8, p, comm, (hipStream_t)stream), "ncclRecv");
             }
             nccl_ok(rccl_.GroupEnd(), "ncclGroupEnd");
             check(gnnpe_sync(ctx), "sync");
@@ -485,6 +526,7 @@ void rank_main(int r, Shared &S)
     check(gnnpe_set_slab(ctx, lo, hi), "set_slab");
     check(gnnpe_set_label_table(ctx, std::max<uint32_t>(g.labels_count, 1), e, S.table->data()), "set_label_table");
 
+    fault_point(r, "halo");
     // ---- halo: one all-to-all-v of adjacency lists per hop (graph structure: done once) ----
     {
         DevMem d_need(ctx, ((uint64_t)n + 1) * 4), d_degin(ctx, ((uint64_t)n + 1) * 4);
@@ -701,13 +743,23 @@ void rank_main(int r, Shared &S)
     tp.finish_rank(r);
 }
 
-void rank_entry(int r, Shared &S)
+// what the main thread waits on: the ranks that have returned, and whether one of them failed
+struct Done {
+    std::mutex mu;
+    std::condition_variable cv;
+    int returned = 0;
+};
+
+void rank_entry(int r, Shared &S, Done &done)
 {
     try {
         rank_main(r, S);
     } catch (const std::exception &ex) {
         S.tp->fail(r, ex.what());
     }
+    std::lock_guard<std::mutex> lk(done.mu);
+    done.returned++;
+    done.cv.notify_all();
 }
 
 }  // namespace
@@ -741,7 +793,32 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
     S.t_sizing.assign(R, 0);
     S.t_init.assign(R, 0);
     std::vector<std::thread> th;
-    for (int r = 0; r < R; r++) th.emplace_back(rank_entry, r, std::ref(S));
+    Done done;
+    for (int r = 0; r < R; r++) th.emplace_back(rank_entry, r, std::ref(S), std::ref(done));
+    {
+        // Once a rank has failed its peers get a deadline: a peer blocked inside RCCL where no abort reaches it (e.g.
+        // ncclCommInitRank waiting for the rank that died) would hold a join for ever.  The process then ends from HERE with
+        // the first error and exit code 1 -- a plain _exit, no re-exec, no destructors racing the stuck threads.
+        std::unique_lock<std::mutex> lk(done.mu);
+        bool deadline_set = false;
+        Clock::time_point deadline;
+        while (done.returned < R) {
+            if (!deadline_set && tp.failed()) {
+                deadline_set = true;
+                deadline = Clock::now() + std::chrono::seconds(20);
+            }
+            if (deadline_set) {
+                if (done.cv.wait_until(lk, deadline) == std::cv_status::timeout && done.returned < R) {
+                    fprintf(stderr, "%s: %s (%d of %d ranks did not return within 20 s of the failure: still inside a collective)\n", o.tool,
+                            tp.first_error().c_str(), R - done.returned, R);
+                    fflush(stderr);
+                    _exit(1);
+                }
+            } else {
+                done.cv.wait_for(lk, std::chrono::milliseconds(200));
+            }
+        }
+    }
     for (auto &t : th) t.join();
     if (tp.failed()) {  // every rank thread has returned: a clean non-zero exit from the main thread
         fprintf(stderr, "%s: %s\n", o.tool, tp.first_error().c_str());

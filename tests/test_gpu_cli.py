@@ -337,3 +337,29 @@ def test_rank_thread_error_is_a_clean_exit(tmp_path):
     assert r.returncode == 1, (r.returncode, r.stderr[-1000:])
     assert "rank 0" in r.stderr and "all_paths.txt" in r.stderr
     assert "terminate called" not in r.stderr
+
+
+@pytest.mark.parametrize("case", [("3", "--same-device", "1:halo"), ("3", "--same-device", "2:init"), ("1", "--transport=rccl", "0:init")])
+def test_injected_rank_fault_ends_every_rank(tmp_path, case):
+    """the failure path of `--gpus N` with a fault injected into ONE rank (GNNPE_FAULT_RANK=<rank>:<stage>) while its
+    peers sit in barriers / exchanges: the process ends with exit code 1 and that rank's message, well inside the join
+    deadline (a peer stuck in a collective for good is ended by the main thread after 20 s)."""
+    gpus, transport, fault = case
+    g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
+    sn = synth.degree_order(g["offsets"])
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "ds")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 2)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, synth.block_membership(3000, 2))
+    args = [CLI, "-f", d + "/", "-d", gp, "-p", "2", "--gpus", gpus] + (["--same-device"] if transport == "--same-device" else ["--transport", "rccl"])
+    import time
+    t0 = time.time()
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120, env=dict(os.environ, GNNPE_FAULT_RANK=fault))
+    assert r.returncode == 1, (r.returncode, r.stderr[-1000:])
+    assert f"rank {fault.split(':')[0]}: injected fault at stage {fault.split(':')[1]}" in r.stderr
+    assert "terminate called" not in r.stderr and time.time() - t0 < 60
+    # and without the fault the same command succeeds
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
