@@ -360,6 +360,11 @@ int main(int argc, char **argv)
     }
     std::vector<uint64_t> part_count(o.partition_num, 0);  // main.cpp:102: header of partition_paths.txt
     for (uint32_t i = 0; i < g.n; i++) part_count[membership[sorted_nodes[i]]] += per_start[i];
+    if (o.write_index) {  // before anything is written
+        const std::string big = index_size_problem(part_count, P, (o.path_length + 1) * o.vde_dim);
+        if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
+        if (!big.empty()) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
+    }
     for (int d = 0; d < o.gpus; d++) {
         if (o.gpus > 1) {
             check(gnnpe_set_slab(devs[d].ctx, devs[d].slab_begin, devs[d].slab_end), "set_slab");

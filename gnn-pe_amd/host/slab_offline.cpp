@@ -649,6 +649,11 @@ void rank_main(int r, Shared &S)
         part_off[pid] = part_hdr[pid].size();
         for (int q = 0; q < r; q++) part_off[pid] += by[q];
     }
+    if (o.write_index) {  // every rank sees the same totals: all of them stop here, before any file exists
+        const std::string big = index_size_problem(part_tot, P, L * e);
+        if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
+        if (!big.empty() && r == 0) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
+    }
     const std::string partitions_path = o.dataset_path + "gnn-pe/partitions/";
     if (r == 0) {  // create the files at their final size, headers first (main.cpp:102,113)
         auto create = [&](const std::string &path, const std::string &hdr, uint64_t body) {

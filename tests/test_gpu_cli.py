@@ -339,7 +339,7 @@ def test_rank_thread_error_is_a_clean_exit(tmp_path):
     assert "terminate called" not in r.stderr
 
 
-@pytest.mark.parametrize("case", [("3", "--same-device", "1:halo"), ("3", "--same-device", "2:init"), ("1", "--transport=rccl", "0:init")])
+@pytest.mark.parametrize("case", [("3", "--same-device", "1:halo"), ("3", "--same-device", "2:halo"), ("1", "--transport=rccl", "0:init")])
 def test_injected_rank_fault_ends_every_rank(tmp_path, case):
     """the failure path of `--gpus N` with a fault injected into ONE rank (GNNPE_FAULT_RANK=<rank>:<stage>) while its
     peers sit in barriers / exchanges: the process ends with exit code 1 and that rank's message, well inside the join

@@ -315,3 +315,42 @@ def test_index_files_in_memory_budgeted_waves(tmp_path, monkeypatch):
         eng.build_index_files(bad)
     assert not (tmp_path / "missing_dir").exists()
     eng.close()
+
+
+def test_index_size_guard_and_every_partition_through_the_reference(tmp_path):
+    """VERDICT r3 item 5.  (1) `gnnpe_main --index` refuses BEFORE writing anything when a partition's index.dat would reach
+    2 GiB -- the untouched consumer seeks with 32-bit arithmetic (include/blockfile/blk_file.h:32-33) -- and names the smallest
+    -p that fits (BASELINE config 2 with p = 1: 2.1 GB, the size at which the reference's own tree crashes its own reader,
+    tests/golden/large_index/reference_config2_p1_crash.json).  (2) At a p for which every file is consumable, ALL
+    partitions go through `ref_main -m online` and the answer equals the one the reference printed from the trees it
+    inserted itself (G(70K, 700K), p = 4: tests/golden/large_index/reference_p4.json, a 33-minute run of the reference)."""
+    g = synth.gnm_graph(100_000, 1_000_000)
+    gp = str(tmp_path / "c2.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "c2")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 1)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), np.zeros(g["n"], np.uint32))
+    r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-m", "offline", "-p", "1", "--index"], capture_output=True, text=True)
+    assert r.returncode == 1, r.stderr[-500:]
+    assert "2 GiB" in r.stderr and "blk_file.h:33" in r.stderr and "from -p 2" in r.stderr and "--allow-large" in r.stderr
+    assert not os.path.exists(os.path.join(d, "gnn-pe", "all_paths.txt"))
+    assert not os.path.exists(os.path.join(d, "gnn-pe", "partitions", "partition-0", "index.dat"))
+
+    ref = json.load(open(os.path.join(GOLDEN, "large_index", "reference_p4.json")))
+    query = os.path.join(GOLDEN, "large_index", "query.graph")
+    g = synth.gnm_graph(70_000, 700_000)
+    gp = str(tmp_path / "g70.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "g70")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 4)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), synth.block_membership(g["n"], 4))
+    subprocess.check_call([CLI, "-f", d + "/", "-d", gp, "-m", "offline", "-p", "4", "--index"], stdout=subprocess.DEVNULL)
+    assert int(open(os.path.join(d, "gnn-pe", "all_paths.txt")).readline()) == ref["paths"]
+    for i in range(4):
+        assert 8192 <= os.path.getsize(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) < (1 << 31)
+    out = subprocess.run([ref_main_path(), "-f", d + "/", "-d", gp, "-q", query, "-m", "online", "-p", "4"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-300:]
+    assert "This R-Tree contains" not in out.stdout  # it inserted nothing: every partition's tree came from our files
+    assert int(re.search(r"Answer Number: (\d+)", out.stdout).group(1)) == ref["answer_number"] == 2
