@@ -52,14 +52,16 @@ def bytes_per_path(L, e):
     return 4 * L + 8 * e * L + 16 + 8 * e
 
 
-def cpu_baseline(sample_n, sample_m, seed):
-    """Time the reference's own offline step on a bounded sample.  Only this leg (and tests /
-    smoke) may touch oracle/."""
+def cpu_baseline(sample_n, sample_m, seed, named=None):
+    """Time the reference's own offline step on a bounded sample (or on a whole BASELINE config: `named`).  Only this leg
+    (and tests / smoke) may touch oracle/."""
     from oracle import Oracle, ref_main_path
     g = synth.gnm_graph(sample_n, sample_m, seed=seed)
     sn = synth.degree_order(g["offsets"])
     P = synth.expected_paths_l2(g["offsets"])
     sample = f"G(n={sample_n}, m={sample_m}) same generator/seed family, l=2, p=1: {P} paths"
+    if named:
+        sample = f"{named} at FULL size: " + sample
     if os.path.exists(ref_main_path()):
         with tempfile.TemporaryDirectory() as wd:
             gp = os.path.join(wd, "g.graph")
@@ -84,8 +86,8 @@ def cpu_baseline(sample_n, sample_m, seed):
         kind = "port"
         sample += "; oracle hash-set DFS + text formatting"
     return dict(value=P / dt, unit="paths/s", cores=1, kind=kind, sample=sample, seconds=dt,
-                note="the small sample flatters the reference: its hash set still fits the caches here; at the headline size "
-                     "(1M/10M, 2.0e8 paths) the same binary measured 1.14e5 paths/s (1 749 s, 29.9 GB RSS; BASELINE.md section 2.1)")
+                note=("a BASELINE config timed on this box's host cores; " if named else "the small sample flatters the reference: its hash set still fits the caches here; ") +
+                     "at the headline size (1M/10M, 2.0e8 paths) the same binary measured 1.14e5 paths/s (1 749 s, 29.9 GB RSS; BASELINE.md section 2.1)")
 
 
 def cpu_baseline_all_cores(sample_n, sample_m, e, seed):
@@ -192,6 +194,46 @@ def device_pass(torch, stream, local_rank, g, sn, labels, e, steps):
                 value=total / (ms / 1e3), unit="paths/s", fill_ms=fms, fill_frac=total * bpp / (fms / 1e3) / 1e9 / HBM_PEAK_GBS)
 
 
+def pge_leg(torch, stream, local_rank, g, labels, e, steps):
+    """SURVEY 8(f)1, GNN-PGE offline (GNN-PGE/src/main.cpp:91-195): per-vertex path groups (segmented min / max over the
+    neighbours' embeddings and label features) and the R-tree over the vertices' boxes, on the headline graph."""
+    eng = binding.Engine(local_rank, stream=stream.cuda_stream)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(np.arange(g["n"], dtype=np.uint32), np.zeros(g["n"], np.uint32), 1)
+    eng.set_label_table(binding.host_label_table(labels, e))
+    eng.vde(want=False)
+    pg, _ = eng.pge_groups_device()
+    ev = []
+    for it in range(steps + 2):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.pge_groups_device()
+        b.record()
+        if it >= 2:
+            ev.append((a, b))
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    n, m2 = g["n"], len(g["nbrs"])
+    # algorithmic bytes: per vertex its row bounds (8) and the two output rows (2 x 4e doubles); per adjacency entry the
+    # neighbour id (4), its label (4) and its embedding (8e); the two memsets of the outputs are part of the call
+    bytes_alg = n * (8 + 2 * 32 * e) + m2 * (8 + 8 * e)
+    idx = []
+    for it in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img, nbytes, hdr = eng.build_box_index_device(n, 2 * e, pg)  # every vertex' box, one partition (p = 1)
+        torch.cuda.synchronize()
+        idx.append((time.perf_counter() - t0) * 1e3)
+    out = dict(workload=f"GNN-PGE offline on G(n={n}, m={m2 // 2}), e={e}: path_group + path_label_group of every vertex, R-tree over the {n} boxes",
+               kernel="k_pge_groups", groups_ms=ms, algorithmic_bytes=bytes_alg, groups_frac=bytes_alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+               vertices_per_s=n / (ms / 1e3), index_first_call_ms=idx[0], index_build_ms=min(idx[1:]), index_bytes=int(nbytes),
+               data_vertices_bin_bytes=4 + n * (12 + 8 + 8 * (3 * e + 8 * e)),
+               note="bound by the 2m random gathers of vde[u] (one per adjacency entry), not by bytes; the reference computes the same "
+                    "values with 2e gathers per entry on one thread (GNN-PGE/src/main.cpp:141-176)")
+    eng.close()
+    return out
+
+
 def config5_leg(torch, stream, local_rank, labels, seed):
     """BASELINE config 5 on ONE GPU (the 8-GPU split of it is in tests/test_gpu_slabs_full.py): power-law 4M / 64M, l = 3
     (4-vertex paths: the reference's rule with the depth fixed, SURVEY D4 -- parity unpinned, the count is checked in the
@@ -248,7 +290,7 @@ def config5_leg(torch, stream, local_rank, labels, seed):
                        "computed by the oracle at full size (tests/test_gpu_slabs_full.py::test_config5_4m_64m_powerlaw_l3_e8)")
 
 
-def e2e_leg(g, sn, p, index, label):
+def e2e_leg(g, sn, p, index, label, allow_large=False):
     """Wall-clock of `gnnpe_main -m offline` on text inputs (load + emit + render + file writes [+ index.dat])."""
     free = shutil.disk_usage(tempfile.gettempdir()).free
     P = synth.expected_paths_l2(g["offsets"])
@@ -260,7 +302,7 @@ def e2e_leg(g, sn, p, index, label):
         synth.write_graph_file(gp, g)
         synth.make_dataset_dir(wd, p)
         synth.write_membership(os.path.join(wd, "gnn-pe", "membership.txt"), sn, synth.block_membership(g["n"], p))
-        args = [CLI, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", str(p), "--timing"] + (["--index"] if index else [])
+        args = [CLI, "-f", wd + "/", "-d", gp, "-m", "offline", "-p", str(p), "--timing"] + (["--index"] if index else []) + (["--allow-large"] if allow_large else [])
         t0 = time.perf_counter()
         r = subprocess.run(args, capture_output=True, text=True)
         dt = time.perf_counter() - t0
@@ -280,6 +322,8 @@ def e2e_leg(g, sn, p, index, label):
 
 
 def main():
+    global T_START
+    T_START = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -298,6 +342,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (file-writing) legs only")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (power-law 4M/64M, l=3, e=8: about a minute of host graph generation)")
     ap.add_argument("--cpu-sample", type=str, default="30000,300000")
+    ap.add_argument("--cpu-config2", choices=("auto", "yes", "no"), default="auto",
+                    help="time the unmodified reference's `main -m offline` on BASELINE config 2 at full size (100K/1M, 2.0e7 paths: about "
+                         "160 s on one host core) as `cpu_baseline`; auto = when the run is younger than --cpu-config2-before seconds by then")
+    ap.add_argument("--cpu-config2-before", type=float, default=240.0)
     ap.add_argument("--placements", type=int, default=1,
                     help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
                          "writes fastest is kept, the others freed); 1 (default) = one allocation that takes what comes -- the "
@@ -662,6 +710,8 @@ def main():
     if legs and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
         g2 = synth.gnm_graph(100_000, 1_000_000, n_labels=args.labels, seed=args.seed)
         out["config2"] = device_pass(torch, stream, local_rank, g2, synth.degree_order(g2["offsets"]), args.labels, e, args.steps)
+    if legs and not args.powerlaw and e in (1, 2, 4, 8):
+        out["gnn_pge"] = pge_leg(torch, stream, local_rank, g, args.labels, e, args.steps)
     if legs and not args.no_config5 and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
         out["config5"] = config5_leg(torch, stream, local_rank, args.labels, args.seed)
     if rank == 0:
@@ -671,11 +721,16 @@ def main():
             name = "config 3: G(1M, 10M)" if big else f"G({args.n}, {args.m})"
             e2e = {}
             e2e["text_p1"] = e2e_leg(g, sn, 1, False, name + ", p=1, text files only")
-            e2e["text_index_p1"] = e2e_leg(g, sn, 1, True, name + ", p=1, text files + index.dat")
-            e2e["text_index_p8"] = e2e_leg(g, sn, 8, True, name + ", p=8, text files + 8 x index.dat")
+            # index files the UNTOUCHED reference online binary can read: every index.dat below 2 GiB (its block file seeks with
+            # 32-bit arithmetic, blk_file.h:32-33; gnnpe_main --index refuses larger ones unless --allow-large)
+            pc = 16 if big else max(1, int(np.ceil(synth.expected_paths_l2(g["offsets"]) * 108 / (1 << 31))))
+            e2e[f"text_index_p{pc}"] = e2e_leg(g, sn, pc, True, name + f", p={pc}, text files + {pc} x index.dat, every file < 2 GiB (consumable)")
+            if big:
+                e2e["text_index_p8_allow_large"] = e2e_leg(g, sn, 8, True, name + ", p=8, text files + 8 x index.dat of 2.7 GB (--allow-large: "
+                                                           "not readable by the reference's online binary; kept for comparison with round 3)", allow_large=True)
             if big and g2 is not None:
-                e2e["config2_text_index_p1"] = e2e_leg(g2, synth.degree_order(g2["offsets"]), 1, True,
-                                                       "config 2: G(100K, 1M), p=1, text files + index.dat")
+                e2e["config2_text_index_p2"] = e2e_leg(g2, synth.degree_order(g2["offsets"]), 2, True,
+                                                       "config 2: G(100K, 1M), p=2, text files + 2 x index.dat (p=1 would be 2.1 GB)")
             e2e["reference"] = "BASELINE.md: config 3 offline 1 749 s, config 2 offline 158.8 s (1 thread); its index build is ~96 us per insert"
             out["e2e"] = e2e
             if "index_build" in out:
@@ -683,8 +738,16 @@ def main():
                                                for k, v in e2e.items() if isinstance(v, dict) and "index_build_s" in v}
         if world == 1 and not args.no_cpu_baseline:
             sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))
-            out["cpu_baseline"] = cpu_baseline(sn_, sm_, args.seed)
+            small = cpu_baseline(sn_, sm_, args.seed)
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(300_000, 3_000_000, e, args.seed)
+            from oracle import ref_main_path
+            age = time.perf_counter() - T_START
+            if os.path.exists(ref_main_path()) and (args.cpu_config2 == "yes" or (args.cpu_config2 == "auto" and age < args.cpu_config2_before)):
+                out["cpu_baseline"] = cpu_baseline(100_000, 1_000_000, args.seed, named="BASELINE config 2")
+                out["cpu_baseline_small_sample"] = small
+            else:
+                out["cpu_baseline"] = small
+                out["cpu_baseline"]["config2_skipped"] = f"the run was {age:.0f} s old (limit {args.cpu_config2_before:.0f} s) or the reference binary is absent"
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

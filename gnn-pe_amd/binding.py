@@ -104,6 +104,7 @@ SIGNATURES = {
     "gnnpe_build_box_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
                                                C.POINTER(C.c_int32)]),
     "gnnpe_pge_groups": (C.c_int, [_vp, _f64p, _f64p]),
+    "gnnpe_pge_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     "gnnpe_pge_build_index": (C.c_int, [_vp, C.c_uint64, _u32p, C.c_char_p]),
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
@@ -717,6 +718,13 @@ class Engine:
         plg = np.zeros((self.n, 4 * self.e))
         self._ck(self.lib.gnnpe_pge_groups(self.ctx, _ptr(pg, _f64p), _ptr(plg, _f64p)))
         return pg, plg
+
+    def pge_groups_device(self):
+        """The same computation left on the device: (path_group, path_label_group) device addresses."""
+        self._ck(self.lib.gnnpe_pge_groups(self.ctx, None, None))
+        a, b = _vp(), _vp()
+        self._ck(self.lib.gnnpe_pge_device_ptr(self.ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def pge_build_index(self, vertices, path):
         v = _np(vertices, np.uint32)

@@ -560,9 +560,12 @@ static int run_vde(gnnpe_ctx *c)
         const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
         dim3 grid((nr + 255) / 256), block(256);
         const size_t tab_lds = (uint64_t)c->n_labels * e <= (uint64_t)kVdeTabMax ? (size_t)c->n_labels * e * 8 : 0;
+        // rows longer than 64 go to k_vde_hubs when the width has an instantiation (the hub list covers every held row;
+        // the kernel skips the ones this device does not own)
+        const bool hub_split = c->n_hub != 0 && (e == 1 || e == 2 || e == 4 || e == 8);
 #define GNNPE_VDE_ARGS                                                                                   \
     nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbr_label.as<uint32_t>(),      \
-        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>()
+        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>(), hub_split
         switch (e) {
         case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
         case 2: hipLaunchKernelGGL((k_vde<2>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
@@ -572,6 +575,22 @@ static int run_vde(gnnpe_ctx *c)
         default: hipLaunchKernelGGL((k_vde<0>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
         }
 #undef GNNPE_VDE_ARGS
+        if (hub_split) {
+            const uint8_t *owned = c->rows_identity ? nullptr : c->owned.as<uint8_t>();
+            const uint32_t rpw = 64 / e;
+            const dim3 hgrid(grid_for(((uint64_t)c->n_hub + rpw - 1) / rpw * 64));
+#define GNNPE_VH(EE)                                                                                                  \
+    hipLaunchKernelGGL((k_vde_hubs<EE>), hgrid, block, tab_lds, c->stream, c->n_hub, c->hub_rows.as<uint32_t>(), owned, \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbr_label.as<uint32_t>(),            \
+                       c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, c->nx.as<double>(), c->vde.as<double>())
+            switch (e) {
+            case 1: GNNPE_VH(1); break;
+            case 2: GNNPE_VH(2); break;
+            case 4: GNNPE_VH(4); break;
+            default: GNNPE_VH(8); break;
+            }
+#undef GNNPE_VH
+        }
     }
     GNNPE_HIP_TRY(hipGetLastError());
     c->have_vde = true;

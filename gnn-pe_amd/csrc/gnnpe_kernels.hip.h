@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
                                              const uint32_t *__restrict__ nbr_label,
                                              const uint32_t *__restrict__ labels,
                                              const double *__restrict__ xtab, uint32_t n_labels, uint32_t e_rt,
-                                             double *__restrict__ nx, double *__restrict__ vde)
+                                             double *__restrict__ nx, double *__restrict__ vde, bool hub_split)
 {
     const int e = E ? E : (int)e_rt;
     __shared__ uint32_t s_lab[kVdeStage];
@@ -105,10 +105,15 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
     const uint32_t q_end = adj_start[vl] + adj_deg[vl];
 
     uint32_t v = 0, my_b = 0, my_e = 0;
+    bool hub = false;
     if (r < n_rows) {
         v = rows ? rows[r] : r;
         my_b = adj_start[v];
         my_e = my_b + adj_deg[v];
+        // a row longer than kHubDegree is summed by k_vde_hubs (one lane per (row, dimension)): a single thread of this
+        // block walking 4 500 entries while the other 255 wait made k_vde<8> 12.5 ms at BASELINE config 5
+        hub = hub_split && adj_deg[v] > kHubDegree;
+        if (hub) my_e = my_b;
     }
     double acc[E ? E : 32];
 #pragma unroll
@@ -131,13 +136,58 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
         }
         __syncthreads();
     }
-    if (r < n_rows) {
+    if (r < n_rows && !hub) {
         const uint32_t lv = labels[v];
         for (int k = 0; k < e; k++) {
             const double xv = tab_in_lds ? s_tab[lv * e + k] : xtab[(uint64_t)lv * e + k];
             nx[(uint64_t)v * e + k] = acc[k];
             vde[(uint64_t)v * e + k] = xv + acc[k];
         }
+    }
+}
+
+// gen_vde for the rows longer than kHubDegree (custom.h:523-541).  The sum of a row is one fp64 chain in ascending
+// neighbour order (bit-exactness), so the parallelism is across rows and across the e dimensions: one LANE per (hub row,
+// dimension), 64 / E rows per wave; the lanes of a row read the same label (one address, broadcast), every lane looks its
+// own dimension up in the table and adds.  Four entries are fetched ahead of the chain's adds.
+template <int E>
+__global__ __launch_bounds__(256) void k_vde_hubs(uint32_t n_hub, const uint32_t *__restrict__ hub_rows,
+                                                  const uint8_t *__restrict__ owned, const uint32_t *__restrict__ adj_start,
+                                                  const uint32_t *__restrict__ adj_deg,
+                                                  const uint32_t *__restrict__ nbr_label,
+                                                  const uint32_t *__restrict__ labels, const double *__restrict__ xtab,
+                                                  uint32_t n_labels, double *__restrict__ nx, double *__restrict__ vde)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    const bool tab_in_lds = (uint64_t)n_labels * E <= (uint64_t)kVdeTabMax;
+    if (tab_in_lds)
+        for (uint32_t i = threadIdx.x; i < n_labels * E; i += blockDim.x) s_tab[i] = xtab[i];
+    __syncthreads();
+    constexpr uint32_t RPW = 64 / E;  // rows per wave
+    const unsigned lane = lane_id();
+    const uint32_t k = lane % E, rw = lane / E;
+    uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (; w * RPW < n_hub; w += nw) {
+        const uint64_t h = w * RPW + rw;
+        if (rw >= RPW || h >= n_hub) continue;
+        const uint32_t v = hub_rows[h];
+        if (owned && !owned[v]) continue;  // halo rows are summed by their owners (their labels are not held here)
+        const uint32_t st = adj_start[v], d = adj_deg[v];
+        const double *tab = tab_in_lds ? s_tab : xtab;
+        double acc = 0.0;
+        uint32_t j = 0;
+        for (; j + 4 <= d; j += 4) {
+            const uint32_t l0 = nbr_label[st + j], l1 = nbr_label[st + j + 1], l2 = nbr_label[st + j + 2], l3 = nbr_label[st + j + 3];
+            const double a0 = tab[(uint64_t)l0 * E + k], a1 = tab[(uint64_t)l1 * E + k], a2 = tab[(uint64_t)l2 * E + k], a3 = tab[(uint64_t)l3 * E + k];
+            acc += a0;
+            acc += a1;
+            acc += a2;
+            acc += a3;
+        }
+        for (; j < d; j++) acc += tab[(uint64_t)nbr_label[st + j] * E + k];
+        nx[(uint64_t)v * E + k] = acc;
+        vde[(uint64_t)v * E + k] = tab[(uint64_t)labels[v] * E + k] + acc;
     }
 }
 

@@ -14,17 +14,92 @@
 
 namespace gnnpe {
 
-// one thread per held row; min / max are order-independent, so the result is bit-identical to the
-// reference's sequential compare-and-replace loop (main.cpp:151-176)
+// Sixteen lanes per held row (a DPP row): lane t takes the row's entries t, t + 16, ... -- neighbour ids and their labels
+// arrive coalesced, vde[u] is ONE gather of e doubles per entry and x[u] comes from the label table (the reference reads
+// both per dimension: 2e gathers per entry) -- and keeps the running [min, max] of every dimension; four DPP steps inside
+// the row of sixteen leave the row's result in every lane.  min / max are order-independent, so the result is bit-identical
+// to the reference's sequential compare-and-replace loop (main.cpp:151-176).
+template <int CTRL> __device__ __forceinline__ double dpp16_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)b, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(b >> 32), (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+#define GNNPE_ROW16(OP, v)                                             \
+    v = OP(v, dpp16_f64<0xB1>(v));  /* quad_perm [1,0,3,2] */          \
+    v = OP(v, dpp16_f64<0x4E>(v));  /* quad_perm [2,3,0,1] */          \
+    v = OP(v, dpp16_f64<0x141>(v)); /* row_half_mirror */              \
+    v = OP(v, dpp16_f64<0x140>(v)); /* row_mirror: all sixteen lanes hold the row's result */
+
 template <int E>
 __global__ __launch_bounds__(256) void k_pge_groups(uint32_t n_rows, const uint32_t *__restrict__ rows,
                                                     const uint32_t *__restrict__ adj_start,
                                                     const uint32_t *__restrict__ adj_deg,
-                                                    const uint32_t *__restrict__ nbrs, const double *__restrict__ x,
-                                                    const double *__restrict__ vde, uint32_t e_rt,
-                                                    double *__restrict__ pg, double *__restrict__ plg)
+                                                    const uint32_t *__restrict__ nbrs, const uint32_t *__restrict__ nbr_label,
+                                                    const uint32_t *__restrict__ labels, const double *__restrict__ xtab,
+                                                    const double *__restrict__ vde, double *__restrict__ pg,
+                                                    double *__restrict__ plg)
 {
-    const uint32_t e = E ? E : e_rt, D = 2 * e;
+    constexpr int D = 2 * E;
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t r = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t nr16 = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    for (; r < n_rows; r += nr16) {  // (n_rows is rounded up by the launch so that whole waves iterate together)
+        const uint32_t v = rows ? rows[r] : (uint32_t)r;
+        const uint32_t st = adj_start[v], d = adj_deg[v];
+        double lo[E], hi[E], llo[E], lhi[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            lo[k] = llo[k] = inf;
+            hi[k] = lhi[k] = -inf;
+        }
+        for (uint32_t j = sub; j < d; j += 16) {
+            const uint32_t u = nbrs[st + j], lb = nbr_label[st + j];
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double a = vde[(uint64_t)u * E + k], b = xtab[(uint64_t)lb * E + k];
+                lo[k] = fmin(lo[k], a);
+                hi[k] = fmax(hi[k], a);
+                llo[k] = fmin(llo[k], b);
+                lhi[k] = fmax(lhi[k], b);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            GNNPE_ROW16(fmin, lo[k])
+            GNNPE_ROW16(fmax, hi[k])
+            GNNPE_ROW16(fmin, llo[k])
+            GNNPE_ROW16(fmax, lhi[k])
+        }
+        if (sub == 0) {
+            double *g = pg + (uint64_t)v * 2 * D, *lg = plg + (uint64_t)v * 2 * D;
+            const uint32_t lv = labels[v];
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                const double a = vde[(uint64_t)v * E + k], b = xtab[(uint64_t)lv * E + k];
+                g[2 * k] = g[2 * k + 1] = a;
+                lg[2 * k] = lg[2 * k + 1] = b;
+                // a vertex without neighbours keeps zeros in the second half (main.cpp:104-121)
+                g[2 * (E + k)] = d ? lo[k] : 0.0;
+                g[2 * (E + k) + 1] = d ? hi[k] : 0.0;
+                lg[2 * (E + k)] = d ? llo[k] : 0.0;
+                lg[2 * (E + k) + 1] = d ? lhi[k] : 0.0;
+            }
+        }
+    }
+}
+
+// any other embedding width: one thread per held row (round 1's form)
+__global__ __launch_bounds__(256) void k_pge_groups_any(uint32_t n_rows, const uint32_t *__restrict__ rows,
+                                                        const uint32_t *__restrict__ adj_start,
+                                                        const uint32_t *__restrict__ adj_deg,
+                                                        const uint32_t *__restrict__ nbrs, const double *__restrict__ x,
+                                                        const double *__restrict__ vde, uint32_t e,
+                                                        double *__restrict__ pg, double *__restrict__ plg)
+{
+    const uint32_t D = 2 * e;
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t v = rows ? rows[r] : (uint32_t)r;
         const uint32_t st = adj_start[v], d = adj_deg[v];
@@ -84,16 +159,22 @@ int gnnpe_pge_groups(gnnpe_ctx *c, double *host_path_group, double *host_path_la
     GNNPE_HIP_TRY(hipMemsetAsync(c->pge_plg.p, 0, bytes, c->stream));
     if (c->n_rows) {
         const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
-        const dim3 grid(grid_for(c->n_rows)), block(kBlock);
-#define GNNPE_PG(EE)                                                                                               \
-    hipLaunchKernelGGL((k_pge_groups<EE>), grid, block, 0, c->stream, c->n_rows, rows, c->adj_start.as<uint32_t>(), \
-                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->x.as<double>(), c->vde.as<double>(), e, \
+        const dim3 block(kBlock);
+#define GNNPE_PG(EE)                                                                                                     \
+    hipLaunchKernelGGL((k_pge_groups<EE>), dim3(grid_for((uint64_t)c->n_rows * 16)), block, 0, c->stream, c->n_rows, rows, \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),                    \
+                       c->nbr_label.as<uint32_t>(), c->labels.as<uint32_t>(), c->xtab.as<double>(), c->vde.as<double>(),  \
                        c->pge_pg.as<double>(), c->pge_plg.as<double>())
         switch (e) {
+        case 1: GNNPE_PG(1); break;
         case 2: GNNPE_PG(2); break;
         case 4: GNNPE_PG(4); break;
         case 8: GNNPE_PG(8); break;
-        default: GNNPE_PG(0); break;
+        default:
+            hipLaunchKernelGGL(k_pge_groups_any, dim3(grid_for(c->n_rows)), block, 0, c->stream, c->n_rows, rows,
+                               c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->x.as<double>(),
+                               c->vde.as<double>(), e, c->pge_pg.as<double>(), c->pge_plg.as<double>());
+            break;
         }
 #undef GNNPE_PG
         GNNPE_HIP_TRY(hipGetLastError());
@@ -103,6 +184,14 @@ int gnnpe_pge_groups(gnnpe_ctx *c, double *host_path_group, double *host_path_la
     if (host_path_label_group)
         GNNPE_HIP_TRY(hipMemcpyAsync(host_path_label_group, c->pge_plg.p, bytes, hipMemcpyDeviceToHost, c->stream));
     if (host_path_group || host_path_label_group) GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    return GNNPE_OK;
+}
+
+int gnnpe_pge_device_ptr(gnnpe_ctx *c, void **dev_path_group, void **dev_path_label_group)
+{
+    GNNPE_REQUIRE(c && c->have_pge, GNNPE_ERR_ARG, "gnnpe_pge_device_ptr: call gnnpe_pge_groups first");
+    if (dev_path_group) *dev_path_group = c->pge_pg.p;
+    if (dev_path_label_group) *dev_path_label_group = c->pge_plg.p;
     return GNNPE_OK;
 }
 

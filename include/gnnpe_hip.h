@@ -278,6 +278,9 @@ int gnnpe_build_box_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t dim, con
  * [vde[v], vde[u]] / [x[v], x[u]] of its 1-hop paths (v, u); n x 4e doubles each, laid out
  * (lo0, hi0, lo1, hi1, ...).  Needs gnnpe_vde.  Host outputs may be NULL. */
 int gnnpe_pge_groups(gnnpe_ctx *ctx, double *host_path_group, double *host_path_label_group);
+/* Device addresses of the two arrays gnnpe_pge_groups computed (n x 4e doubles each; vertex-id indexed): what a caller that
+ * keeps working on the device reads instead of the host copies (GNN-PGE/src/main.cpp:141-176 fills the same values). */
+int gnnpe_pge_device_ptr(gnnpe_ctx *ctx, void **dev_path_group, void **dev_path_label_group);
 /* R-tree of one GNN-PGE partition (GNN-PGE/include/custom.h:141-195): entry i = path_group of
  * host_vertices[i] (the partition's vertices in membership.txt order), son = i; written to `path`
  * (<f>gnn-pge/partitions/partition-i/index.dat). */
