@@ -258,6 +258,14 @@ def config5_leg(torch, stream, local_rank, labels, seed):
     torch.cuda.synchronize()
     t_count = time.perf_counter() - t0
     assert total2 == total
+    vms = []
+    for _ in range(3):  # gen_vde alone (k_x_from_labels + k_vde + k_vde_hubs): rows up to 3 000 entries long
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        eng.vde(want=False)
+        ev1.record()
+        torch.cuda.synchronize()
+        vms.append(ev0.elapsed_time(ev1))
     bpp = bytes_per_path(L, e)
     samples = []
     for log2_chunk in (24, 26):  # 2^24 paths = a few hundred work units (a starved chip); 2^26 = what a bulk emission queues
@@ -282,7 +290,7 @@ def config5_leg(torch, stream, local_rank, labels, seed):
     eng.close()
     deg = np.diff(g["offsets"].astype(np.int64))
     return dict(workload=f"config 5: power-law n=4000000 m=64000000 (max degree {int(deg.max())}), l=3, e=8, one GPU", paths=total,
-                vde_count_s=t_count, count_paths_per_s=total / t_count, kernel="k_deep3_slices", bytes_per_path=bpp, emit_samples=samples,
+                vde_count_s=t_count, vde_ms=min(vms), count_paths_per_s=total / t_count, kernel="k_deep3_slices", bytes_per_path=bpp, emit_samples=samples,
                 emit_frac=float(np.mean([x["frac"] for x in samples if x["paths"] >= 1 << 26] or [x["frac"] for x in samples])),
                 emit_frac_note="mean over the 2^26-path ranges (18 GB of output each); the 2^24-path ranges are listed too",
                 host_graph_generation_s=t_gen,

@@ -310,6 +310,28 @@ static int finish_rows(gnnpe_ctx *c, uint64_t n_new, const uint32_t *dev_new_row
                                c->hub_rows.as<uint32_t>(), c->hub_beg.as<uint32_t>(), c->hub_end.as<uint32_t>());
             GNNPE_HIP_TRY(hipGetLastError());
             c->n_hub = (uint32_t)nh;
+            // longest rows first (and a deterministic order: the list was filled through an atomic counter): the kernels that
+            // give a hub row to a lane or a wave then work on rows of similar length side by side
+            const uint32_t nhub = (uint32_t)nh;
+            if ((rc = c->scratch.reserve((size_t)nhub * 16 + 64))) return rc;
+            uint32_t *k_in = c->scratch.as<uint32_t>(), *k_out = k_in + nhub, *v_out = k_out + nhub;
+            hipLaunchKernelGGL(k_hub_sort_keys, dim3(grid_for(nhub)), dim3(kBlock), 0, c->stream, nhub, c->hub_rows.as<uint32_t>(),
+                               c->adj_deg.as<uint32_t>(), k_in);
+            // two passes: by row id ascending, then (stable) by degree descending
+            size_t tb = 0;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, c->hub_rows.as<uint32_t>(), v_out, (int)nhub, 0, 32, c->stream));
+            if ((rc = c->cub_tmp.reserve(tb))) return rc;
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->cub_tmp.p, tb, c->hub_rows.as<uint32_t>(), v_out, (int)nhub, 0, 32, c->stream));
+            hipLaunchKernelGGL(k_hub_sort_keys, dim3(grid_for(nhub)), dim3(kBlock), 0, c->stream, nhub, v_out, c->adj_deg.as<uint32_t>(), k_in);
+            tb = 0;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tb, k_in, k_out, v_out, c->hub_rows.as<uint32_t>(), (int)nhub, 0, 32, c->stream));
+            if ((rc = c->cub_tmp.reserve(tb))) return rc;
+            tb = c->cub_tmp.bytes;
+            GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->cub_tmp.p, tb, k_in, k_out, v_out, c->hub_rows.as<uint32_t>(), (int)nhub, 0, 32, c->stream));
+            hipLaunchKernelGGL(k_hub_bounds, dim3(grid_for(nhub)), dim3(kBlock), 0, c->stream, nhub, c->hub_rows.as<uint32_t>(),
+                               c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->hub_beg.as<uint32_t>(), c->hub_end.as<uint32_t>());
+            GNNPE_HIP_TRY(hipGetLastError());
         }
     }
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));

@@ -120,29 +120,35 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
     for (int k = 0; k < (E ? E : 32); k++) acc[k] = 0.0;
 
     __syncthreads();
-    for (uint32_t c0 = q_begin; c0 < q_end; c0 += kVdeStage) {
-        const uint32_t c1 = min(c0 + (uint32_t)kVdeStage, q_end);
-        for (uint32_t q = c0 + threadIdx.x; q < c1; q += blockDim.x) s_lab[q - c0] = nbr_label[q];
-        __syncthreads();
-        const uint32_t lo = max(my_b, c0), hi = min(my_e, c1);
-        for (uint32_t q = lo; q < hi; q++) {
-            const uint32_t lb = s_lab[q - c0];
-            if (E) {
+    // (one loop per address space of the table: a pointer that may be LDS or global makes every lookup a flat load)
+    auto sum_rows = [&](auto tab) {
+        for (uint32_t c0 = q_begin; c0 < q_end; c0 += kVdeStage) {
+            const uint32_t c1 = min(c0 + (uint32_t)kVdeStage, q_end);
+            for (uint32_t q = c0 + threadIdx.x; q < c1; q += blockDim.x) s_lab[q - c0] = nbr_label[q];
+            __syncthreads();
+            const uint32_t lo = max(my_b, c0), hi = min(my_e, c1);
+            for (uint32_t q = lo; q < hi; q++) {
+                const uint32_t lb = s_lab[q - c0];
+                if (E) {
 #pragma unroll
-                for (int k = 0; k < E; k++) acc[k] += tab_in_lds ? s_tab[lb * E + k] : xtab[(uint64_t)lb * E + k];
-            } else {
-                for (int k = 0; k < e; k++) acc[k] += tab_in_lds ? s_tab[lb * e + k] : xtab[(uint64_t)lb * e + k];
+                    for (int k = 0; k < E; k++) acc[k] += tab[lb * E + k];
+                } else {
+                    for (int k = 0; k < e; k++) acc[k] += tab[lb * e + k];
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
+    if (tab_in_lds) sum_rows(s_tab); else sum_rows(xtab);
     if (r < n_rows && !hub) {
         const uint32_t lv = labels[v];
-        for (int k = 0; k < e; k++) {
-            const double xv = tab_in_lds ? s_tab[lv * e + k] : xtab[(uint64_t)lv * e + k];
-            nx[(uint64_t)v * e + k] = acc[k];
-            vde[(uint64_t)v * e + k] = xv + acc[k];
-        }
+        auto finish = [&](auto tab) {
+            for (int k = 0; k < e; k++) {
+                nx[(uint64_t)v * e + k] = acc[k];
+                vde[(uint64_t)v * e + k] = tab[lv * e + k] + acc[k];
+            }
+        };
+        if (tab_in_lds) finish(s_tab); else finish(xtab);
     }
 }
 
@@ -174,20 +180,35 @@ __global__ __launch_bounds__(256) void k_vde_hubs(uint32_t n_hub, const uint32_t
         const uint32_t v = hub_rows[h];
         if (owned && !owned[v]) continue;  // halo rows are summed by their owners (their labels are not held here)
         const uint32_t st = adj_start[v], d = adj_deg[v];
-        const double *tab = tab_in_lds ? s_tab : xtab;
         double acc = 0.0;
-        uint32_t j = 0;
-        for (; j + 4 <= d; j += 4) {
-            const uint32_t l0 = nbr_label[st + j], l1 = nbr_label[st + j + 1], l2 = nbr_label[st + j + 2], l3 = nbr_label[st + j + 3];
-            const double a0 = tab[(uint64_t)l0 * E + k], a1 = tab[(uint64_t)l1 * E + k], a2 = tab[(uint64_t)l2 * E + k], a3 = tab[(uint64_t)l3 * E + k];
-            acc += a0;
-            acc += a1;
-            acc += a2;
-            acc += a3;
-        }
-        for (; j < d; j++) acc += tab[(uint64_t)nbr_label[st + j] * E + k];
+        // (two loops, one per address space of the table: a pointer that may be either makes every lookup a flat load)
+        auto sum_row = [&](auto tab) {
+            // the next four labels are in flight while this group's table values are added
+            const uint32_t *lp = nbr_label + st;
+            uint32_t j = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+            if (d >= 4) l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
+            for (; j + 8 <= d; j += 4) {
+                const uint32_t n0 = lp[j + 4], n1 = lp[j + 5], n2 = lp[j + 6], n3 = lp[j + 7];
+                const double a0 = tab[l0 * E + k], a1 = tab[l1 * E + k], a2 = tab[l2 * E + k], a3 = tab[l3 * E + k];
+                acc += a0;
+                acc += a1;
+                acc += a2;
+                acc += a3;
+                l0 = n0, l1 = n1, l2 = n2, l3 = n3;
+            }
+            if (j + 4 <= d) {
+                acc += tab[l0 * E + k];
+                acc += tab[l1 * E + k];
+                acc += tab[l2 * E + k];
+                acc += tab[l3 * E + k];
+                j += 4;
+            }
+            for (; j < d; j++) acc += tab[lp[j] * E + k];
+            return tab[labels[v] * E + k];
+        };
+        const double xv = tab_in_lds ? sum_row(s_tab) : sum_row(xtab);
         nx[(uint64_t)v * E + k] = acc;
-        vde[(uint64_t)v * E + k] = tab[(uint64_t)labels[v] * E + k] + acc;
+        vde[(uint64_t)v * E + k] = xv + acc;
     }
 }
 
@@ -344,6 +365,22 @@ __global__ void k_hub_list(uint64_t n_rows, const uint32_t *__restrict__ rows, c
                 hub_end[k] = adj_start[b] + d;
             }
         }
+    }
+}
+
+__global__ void k_hub_sort_keys(uint32_t n_hub, const uint32_t *__restrict__ hub_rows, const uint32_t *__restrict__ adj_deg,
+                                uint32_t *__restrict__ keys)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_hub; k += (uint64_t)gridDim.x * blockDim.x)
+        keys[k] = adj_deg[hub_rows[k]];
+}
+__global__ void k_hub_bounds(uint32_t n_hub, const uint32_t *__restrict__ hub_rows, const uint32_t *__restrict__ adj_start,
+                             const uint32_t *__restrict__ adj_deg, uint32_t *__restrict__ hub_beg, uint32_t *__restrict__ hub_end)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_hub; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = hub_rows[k];
+        hub_beg[k] = adj_start[b];
+        hub_end[k] = adj_start[b] + adj_deg[b];
     }
 }
 
