@@ -358,6 +358,9 @@ def main():
                     help="candidate allocations the library's output pool draws (gnnpe_output_pool_create: the one the emit kernel "
                          "writes fastest is kept, the others freed); 1 (default) = one allocation that takes what comes -- the "
                          "pool then only measures which of the two emit shapes is faster into it")
+    ap.add_argument("--compare-pool", type=int, default=3,
+                    help="with --placements 1: also time the steps into the kept one of this many candidate allocations (rounds 2-3 "
+                         "reported that as the headline); reported as roofline.drawn_pool, never as `value`; 0 = skip")
     ap.add_argument("--equal-paths", action="store_true",
                     help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
     args = ap.parse_args()
@@ -514,6 +517,25 @@ def main():
     else:
         assert sb.local_total == total
 
+    # for comparison with rounds 2-3, whose headline was the best of 12 (5) candidate allocations: the same steps into the
+    # kept one of `--compare-pool` candidates (transient memory: that many outputs; 0 = skip)
+    drawn = None
+    if not multi and args.placements == 1 and args.compare_pool > 1 and args.fill_variant == 4 and total >= (1 << 24):
+        pool2 = binding.OutputPool(eng, max(total, 1), L, D_out, candidates=args.compare_pool)
+        d_ev = []
+        one_step(False, pool2.ids, pool2.pde if D_out else None)
+        barrier()
+        for _ in range(max(3, args.steps // 2)):
+            one_step(True, pool2.ids, pool2.pde if D_out else None, d_ev)
+        barrier()
+        rep2 = pool2.report()
+        d_ms = float(np.mean([a.elapsed_time(b) for a, b in d_ev]))
+        drawn = dict(candidates=args.compare_pool, candidates_fill_ms=[round(x, 3) for x in rep2["candidates_ms"]], kept=rep2["kept"],
+                     launch_ms=d_ms, kernel=eng.emit_kernel_name())
+        pool2.close()
+        eng.fill_paths_capped_device(cap_rows, out_ids, out_pde)  # the last fill decides what emit_kernel_name() reports below
+        torch.cuda.synchronize()
+
     # the same steps into ONE plain allocation that takes what comes (what a caller without the pool gets)
     plain = None
     if not multi and args.placements > 1:
@@ -595,7 +617,7 @@ def main():
                         starts_ms=round(shapes["starts_ms"], 3), tiles_ms=round(shapes["tiles_ms"], 3), kept=shapes["kept"],
                         note="gnnpe_emit_calibrate_device: both emit kernels timed into the output buffer (host clock around stream "
                              "synchronisations, best of two after a first touch), the faster kept for it: k_fill_ranked = one wave per "
-                             "start vertex, resident grid; k_fill_tiles = one wave per 128-row output tile, launch order"),
+                             "start vertex, resident grid; k_fill_tiles = one wave per 64-row output tile, launch order"),
                     output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],
                                      probe=pool_rep["probe"],
                                      frac_median_candidate=(peak_bytes / (med_ms / 1e3) / HBM_PEAK_GBS) if med_ms else None,
@@ -604,6 +626,10 @@ def main():
                                      note="gnnpe_output_pool_create (product API, also behind gnnpe_main and offline.py); with --placements 1 (default "
                                           "since round 4) ONE allocation that takes what comes; with N > 1 independent candidate allocations, the emit "
                                           "kernel timed into each, the fastest kept and the others freed. `frac` is the kept buffer timed live over the steps"),
+                    drawn_pool=None if drawn is None else dict(
+                        drawn, frac=peak_bytes / (drawn["launch_ms"] / 1e3) / HBM_PEAK_GBS,
+                        note="NOT the headline: the same steps into the fastest of `candidates` independent allocations (what rounds 2-3 "
+                             "reported, with 5 and 12 candidates), for comparison with `frac`, which is one allocation as it came"),
                     plain_allocation=None if plain is None else dict(
                         launch_ms=plain["fill_ms"], frac=peak_bytes / (plain["fill_ms"] / 1e3) / HBM_PEAK_GBS, ms_per_step=plain["ms_per_step"],
                         value=global_total / (plain["ms_per_step"] / 1e3),

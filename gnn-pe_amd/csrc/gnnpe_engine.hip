@@ -1226,8 +1226,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         const bool tiles = c->n_hub == 0 && shape == 2 && c->n_edges != 0;
         if (tiles && (P.out_ids || d_pde)) {
             // rows per tile in units of 64 (GNNPE_TILE_SHAPE=<units> for A/B runs)
-            int kt = 2;
-            if (const char *ev = getenv("GNNPE_TILE_SHAPE")) kt = atoi(ev) == 1 ? 1 : 2;
+            int kt = 1;
+            if (const char *ev = getenv("GNNPE_TILE_SHAPE")) kt = atoi(ev) == 2 ? 2 : 1;
             if (e > 2) kt = 1;
             const uint32_t ts = 64u * (uint32_t)kt;
             if ((rc = ensure_tile_table(c, end, ts))) return rc;

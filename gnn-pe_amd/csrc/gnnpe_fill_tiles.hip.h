@@ -128,7 +128,9 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
         }
     };
     stamp(-1, false);
-    const uint64_t t = tile_lo + (uint64_t)blockIdx.x * WPB + wv;  // wave-uniform
+    // the tile index is wave-uniform, and the compiler must know it: the table entries then come through the scalar cache, past
+    // the vector memory pipeline in which this CU's loads and stores queue (stamps: 2 500 cycles for the table hop through it)
+    const uint64_t t = tile_lo + (uint64_t)blockIdx.x * WPB + (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
     if (t >= tile_hi) return;
     const uint64_t total = total_arg != ~0ull ? total_arg : P.eoff[P.n_edges];
     const uint64_t slot0 = t * TS;

@@ -374,7 +374,7 @@ int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
  *        calibrated (default)
  *   1    one wave per start vertex, resident grid (k_fill_ranked): 3.1 / 3.6 ms at BASELINE config 3 into a fast / slow
  *        allocation (profiles/r04_emit_ab.txt)
- *   2    one wave per output tile of 128 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.25 /
+ *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.25 /
  *        3.4 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
  * The environment variable GNNPE_EMIT=tiles|starts overrides the context's setting (same-process A/B runs). */
 int gnnpe_set_emit_shape(gnnpe_ctx *ctx, int shape);
