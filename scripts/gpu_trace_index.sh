@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${1:-r03}
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_idx_trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --placements 1 > gpurun_out/${R}_idx_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_idx_trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-config5 --compare-pool 0 > gpurun_out/${R}_idx_trace.log 2>&1
 echo "rc=$?"
 python3 - "$R" <<'PY'
 import csv, glob, sys
