@@ -714,16 +714,17 @@ __global__ void k_px_leaf_first(uint64_t n_leaves, uint32_t F, uint64_t r0, uint
     }
 }
 
-// {degree, label} words beside the row blocks, for the leaves' auxiliary index: word 0 of a block's strip = the row's
-// vertex b, word 1 + r = the vertex of the block's record r.  The strip of the block at unit `blk` starts at word
-// blk * kRauxPerUnit; a block of d records spans at least (8E + 12 d) / 128 units, so 16 words per unit always hold its
-// 1 + d words.  One wave per held row, once per count (the record order is the count's): 2m gathers from an n x 8 byte table.
-constexpr uint32_t kRauxPerUnit = kRowAlign / 8;
+// The row blocks once more, with every vertex' {degree, label} word inside the lines the leaf kernel reads anyway (round 4;
+// round 3 kept the words in strips of their own beside the blocks: one more line per pair, 2.5 ms on a 5.1 ms kernel).
+// Aux block of the row at unit `blk` = kAuxScale units from unit kAuxScale * blk: header {vde[b], word of b}, then per record
+// the record itself followed by the word of its vertex -- it always fits: 8E + 8 + d (R + 8) <= 2 (8E + d R) for R >= 8.
+// One wave per held row, once per count (the record order is the count's): 2m gathers from an n x 8 byte table.
+constexpr uint32_t kAuxScale = 2;
 template <int E, bool PACKED>
-__global__ __launch_bounds__(256) void k_px_raux(uint32_t n_held, const uint32_t *__restrict__ held,
-                                                 const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rblock,
-                                                 const char *__restrict__ recs, const uint64_t *__restrict__ vdl,
-                                                 uint64_t *__restrict__ raux)
+__global__ __launch_bounds__(256) void k_px_aux_blocks(uint32_t n_held, const uint32_t *__restrict__ held,
+                                                       const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rblock,
+                                                       const char *__restrict__ recs, const uint64_t *__restrict__ vdl,
+                                                       char *__restrict__ aux)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     const unsigned lane = threadIdx.x & 63u;
@@ -734,19 +735,24 @@ __global__ __launch_bounds__(256) void k_px_raux(uint32_t n_held, const uint32_t
         const uint32_t d = adj_deg[b];
         if (d == 0) continue;
         const uint32_t blk = rblock[b];
-        const char *base = recs + (uint64_t)blk * kRowAlign + 8 * E;
-        uint64_t *out = raux + (uint64_t)blk * kRauxPerUnit;
-        if (lane == 0) out[0] = vdl[b];
+        const char *src = recs + (uint64_t)blk * kRowAlign;
+        char *dst = aux + (uint64_t)blk * kAuxScale * kRowAlign;
+        if (lane < (unsigned)(2 * E)) reinterpret_cast<uint32_t *>(dst)[lane] = reinterpret_cast<const uint32_t *>(src)[lane];
+        if (lane == 0) {
+            const uint64_t wv = vdl[b];
+            reinterpret_cast<uint32_t *>(dst + 8 * E)[0] = (uint32_t)wv;
+            reinterpret_cast<uint32_t *>(dst + 8 * E)[1] = (uint32_t)(wv >> 32);
+        }
+        const uint32_t rw = d > kHubDegree ? (uint32_t)(sizeof(RecWide<E>) / 4) : (uint32_t)(sizeof(Rec) / 4);  // dwords per record
         for (uint32_t r = lane; r < d; r += 64) {
-            uint32_t id;
-            if (d > kHubDegree) {
-                id = reinterpret_cast<const RecWide<E> *>(base)[r].id;
-            } else if constexpr (PACKED) {
-                id = reinterpret_cast<const Rec *>(base)[r].idp & ((1u << kPackedIdBits) - 1u);
-            } else {
-                id = reinterpret_cast<const Rec *>(base)[r].id;
-            }
-            out[1 + r] = vdl[id];
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(src + 8 * E) + (uint64_t)r * rw;
+            uint32_t *o = reinterpret_cast<uint32_t *>(dst + 8 * E + 8) + (uint64_t)r * (rw + 2);
+            const uint32_t first = q[0];
+            const uint32_t id = (d > kHubDegree || !PACKED) ? first : (first & ((1u << kPackedIdBits) - 1u));
+            const uint64_t wv = vdl[id];
+            for (uint32_t z = 0; z < rw; z++) o[z] = q[z];
+            o[rw] = (uint32_t)wv;
+            o[rw + 1] = (uint32_t)(wv >> 32);
         }
     }
 }
@@ -771,12 +777,12 @@ __global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint3
 // the label features from the label table, the L + 2D reductions run side by side on DPP -- what round 2 computed in a
 // second pass that re-read the whole image and gathered every path's tuple (7.6 ms at config 3).
 // Stores: a leaf's used prefix only (kStoreU4 16-byte pieces); the image's tails are zeroed once per buffer (k_scrub_tails).
-template <int E, bool PACKED>
+template <int E, bool PACKED, bool AUX>
 __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint64_t r0, uint64_t r1,
                                                                         const uint64_t *__restrict__ pref,
                                                                         const uint32_t *__restrict__ first,
-                                                                        const PairXE<E> *__restrict__ px, const char *__restrict__ recs,
-                                                                        const uint64_t *__restrict__ raux,
+                                                                        const PairXE<E> *__restrict__ px, const char *__restrict__ recs_plain,
+                                                                        const char *__restrict__ recs_aux,
                                                                         const uint16_t *__restrict__ xrank,
                                                                         const double *__restrict__ xsorted, uint32_t n_labels,
                                                                         uint32_t xrank_lds, char *__restrict__ image,
@@ -796,11 +802,16 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // the 16-bit ranks in LDS when the table is small (xrank_lds entries; 64 labels x e = 2: 256 bytes), global otherwise
     extern __shared__ uint16_t s_xrank[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (adeg && xrank_lds) {
+    // with the auxiliary index the records come from the aux blocks (k_px_aux_blocks): header and every record carry the
+    // {degree, label} word of their vertex behind them
+    constexpr uint32_t kXW = AUX ? 8u : 0u;                        // bytes of that word
+    constexpr uint32_t kUnitBytes = AUX ? kAuxScale * kRowAlign : kRowAlign;
+    const char *const recs = AUX ? recs_aux : recs_plain;
+    if (AUX && xrank_lds) {
         for (uint32_t i = threadIdx.x; i < xrank_lds; i += 64 * kLeafWaves) s_xrank[i] = xrank[i];
         __syncthreads();
     }
-    const uint16_t *const xr = (adeg && xrank_lds) ? s_xrank : xrank;
+    const uint16_t *const xr = (AUX && xrank_lds) ? s_xrank : xrank;
     uint32_t *w = s_win[wv];
     const uint64_t pbase = pref[r0];
     // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
         for (int k = 0; k < E; k++) vs[k] = __shfl(x_cur.vs[k], (int)a);
         uint32_t e_ds = 0, e_ls = 0;
-        if (adeg) {
+        if constexpr (AUX) {
             e_ds = (uint32_t)__shfl((int)x_cur.ds, (int)a);
             e_ls = (uint32_t)__shfl((int)x_cur.ls, (int)a);
         }
@@ -885,9 +896,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         for (int k = 0; k < kRk; k++) rk[k] = 0u;
         if (act) {
             const uint32_t r = (uint32_t)lane - e_pp + (uint32_t)(sw & 0xFFu);  // point inside the unit
-            const char *const blk = recs + (uint64_t)e_blk * kRowAlign;
+            const char *const blk = recs + (uint64_t)e_blk * kUnitBytes;
             double vc[E];
-            uint32_t son, rec_at;
+            uint32_t son;
+            uint64_t wc = 0;  // {degree, label} of the entry's third vertex (AUX)
             if (fh & kUnitHub) {
                 // hub unit: the r-th entry ranked after s = the r-th set bit of the mask; paths follow in id order
                 uint64_t m = e_G;
@@ -901,8 +913,17 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                         pos += sh;
                     }
                 }
-                rec_at = (fh & ~kUnitHub) + pos;
-                const RecWide<E> rec = reinterpret_cast<const RecWide<E> *>(blk + 8 * E)[rec_at];
+                const uint32_t rec_at = (fh & ~kUnitHub) + pos;
+                RecWide<E> rec;
+                {
+                    constexpr int RWd = (int)(sizeof(RecWide<E>) / 4);
+                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kXW) + (uint64_t)rec_at * (RWd + kXW / 4);
+                    uint32_t wq[RWd + 2];
+#pragma unroll
+                    for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = rq[z];
+                    __builtin_memcpy(&rec, wq, sizeof(rec));
+                    if constexpr (AUX) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
+                }
 #pragma unroll
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
                 son = (uint32_t)(sw >> 8) + r;
@@ -910,18 +931,19 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 // read once by this leaf: non-temporal (round 2 A/B: 6.80 -> 6.63 ms per further partition)
                 Rec rec;
                 {
-                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E) + (uint64_t)r * (sizeof(Rec) / 4);
-                    uint32_t wq[sizeof(Rec) / 4];
+                    constexpr int RWd = (int)(sizeof(Rec) / 4);
+                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kXW) + (uint64_t)r * (RWd + kXW / 4);
+                    uint32_t wq[RWd + 2];
 #pragma unroll
-                    for (int z = 0; z < (int)(sizeof(Rec) / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);  // (dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower, 5.43 -> 5.69 ms)
+                    for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);  // (dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower, 5.43 -> 5.69 ms)
                     __builtin_memcpy(&rec, wq, sizeof(Rec));
+                    if constexpr (AUX) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
                 }
                 uint32_t ip;
                 if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
 #pragma unroll
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
                 son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(e_G & ((1ull << ip) - 1ull)));
-                rec_at = r;
             }
             const double *vb = reinterpret_cast<const double *>(blk);
             uint32_t *ent = w + 2 + lane * kEnt;
@@ -936,9 +958,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 ent[4 * k + 3] = y;
             }
             ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
-            if (adeg) {
-                const uint64_t *strip = raux + (uint64_t)e_blk * kRauxPerUnit;
-                const uint64_t wb = strip[0], wc = strip[1 + rec_at];
+            if constexpr (AUX) {
+                const uint32_t *hw = reinterpret_cast<const uint32_t *>(blk + 8 * E);
+                const uint64_t wb = ((uint64_t)hw[1] << 32) | hw[0];
                 dg[0] = e_ds;
                 dg[1] = (uint32_t)wb;
                 dg[2] = (uint32_t)wc;
@@ -958,7 +980,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (adeg) {  // wave-uniform
+        if constexpr (AUX) {
 #pragma unroll
             for (int q = 0; q < 3; q++) dg[q] = dpp_max_u32(dg[q]);
 #pragma unroll
@@ -1687,16 +1709,16 @@ template <int E> static int build_raux(gnnpe_ctx *c)
     GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
                   "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
     if ((rc = ensure_vertex_words(c))) return rc;
-    if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kRowAlign))) return rc;
+    if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kAuxScale * kRowAlign))) return rc;
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
     if (c->n_held) {
         if (c->n <= (1u << kPackedIdBits))
-            hipLaunchKernelGGL((k_px_raux<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+            hipLaunchKernelGGL((k_px_aux_blocks<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<char>());
         else
-            hipLaunchKernelGGL((k_px_raux<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<uint64_t>());
+            hipLaunchKernelGGL((k_px_aux_blocks<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
+                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<char>());
     }
     GNNPE_HIP_TRY(hipGetLastError());
     c->px_raux_valid = true;
@@ -1788,14 +1810,18 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
     // the label ranks ride in LDS when they fit beside the windows without costing a wave of occupancy (<= 4 KB)
     const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 2048) ? c->n_labels * e : 0u;
-#define GNNPE_PXL(EE, PK)                                                                                               \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 2, c->stream, cnt, nl, r0, r1, \
+#define GNNPE_PXL(EE, PK, AX)                                                                                           \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 2, c->stream, cnt, nl, r0, r1, \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
-                       c->px_raux.as<uint64_t>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds, image, \
+                       c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds, image, \
                        mbr_a, adeg, ambr)
-#define GNNPE_PXE(EE)                                          \
-    do {                                                       \
-        if (packed) GNNPE_PXL(EE, true); else GNNPE_PXL(EE, false); \
+#define GNNPE_PXE(EE)                                                           \
+    do {                                                                        \
+        if (with_aux) {                                                         \
+            if (packed) GNNPE_PXL(EE, true, true); else GNNPE_PXL(EE, false, true);   \
+        } else {                                                                \
+            if (packed) GNNPE_PXL(EE, true, false); else GNNPE_PXL(EE, false, false); \
+        }                                                                       \
     } while (0)
     switch (e) {
     case 1: GNNPE_PXE(1); break;

@@ -1,20042 +1,356 @@
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-U    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-U    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-U    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-H    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-@    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-!    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-@    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-%    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-~    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-@    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-H    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-@    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-U    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-@    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-M    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-Y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-6    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-%    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-*    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-Y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-Y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
->    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-X    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-P    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-Y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-F    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-S    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-`    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-K    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-5    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-B    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-G    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-O    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-7    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-k    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-C    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-I    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-D    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-E    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-V    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-U    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-L    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-8    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-9    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-z    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-j    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-{    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-}    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-<    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-/    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-q    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-4    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-x    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-3    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-0    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-R    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
--    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-T    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-#    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-v    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-y    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-'    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-l    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-i    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-c    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-h    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-A    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-N    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-:    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-\    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-+    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-,    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-d    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-t    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-.    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-g    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-o    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-p    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-(    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-1    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-)    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-f    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-[    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-a    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-s    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-w    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-_    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-n    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-u    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-m    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-b    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-e    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-r    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-"    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-]    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-=    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-     full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-2    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
-
-    full = set(range(p))  # every partition (22 GB through the host validator at the larger size: under a minute on the GPU box's host)
+"""GPU tests of R6: the bulk-loaded index.dat must satisfy every constraint of the reference's online
+consumer (oracle validator restating rtree.cpp / rtnode.cpp / entry.cpp / blk_file.cpp), hold exactly
+the partition's points, and make the UNTOUCHED reference `main -m online` print the known answer."""
+import json
+import os
+import re
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gnnpe_amd import synth
+from oracle import ref_main_path
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+
+
+def _engine(binding, g, sn, mem, p, e):
+    eng = binding.Engine(0)
+    eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+    eng.set_order(sn, mem, p)
+    eng.set_label_table(binding.host_label_table(int(g["labels"].max()) + 1, e))
+    return eng
+
+
+@pytest.mark.parametrize("e", [1, 2, 3, 5, 8])
+def test_index_image_structure_and_contents(oracle, test_graph, e):
+    import torch
+    from gnnpe_amd import binding
+    eng = _engine(binding, test_graph, test_graph["sorted_nodes"], test_graph["membership"], 1, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(ids.view(np.int32)).to(dev)
+    img_ptr, nbytes, hdr = eng.build_index_device(total, 3, t)
+    img = eng.copy_to_host(img_ptr, nbytes).tobytes()
+    d = oracle.index_validate(img)  # raises on any violated consumer constraint
+    D = 3 * e
+    cap = (4096 - 5) // (16 * D + 4)
+    assert d["dim"] == D and d["num_data"] == total and d["root_is_data"] == 0
+    assert d["n_blocks"] == d["dnodes"] + d["inodes"] == hdr[1] and len(img) == (hdr[1] + 1) * 4096
+    assert d["dnodes"] == -(-total // min(cap - 2, 64))
+    order = np.argsort(d["leaf_son"], kind="stable")
+    assert np.array_equal(d["leaf_son"][order], np.arange(total))  # every path exactly once
+    assert np.array_equal(d["leaf_pt"][order], vde[ids].reshape(total, D))  # lo = hi = pde row, bit exact
+    eng.close()
+
+
+def test_index_leaves_are_label_major(oracle, test_graph):
+    """Bulk-load order: paths sorted by their label triple first (the online traversal prunes on the label
+    MBR, custom.h:441-451), so left-to-right leaf entries carry non-decreasing label triples and all but a
+    few leaves hold a single triple."""
+    import torch
+    from gnnpe_amd import binding
+    g = test_graph
+    eng = _engine(binding, g, g["sorted_nodes"], g["membership"], 1, 2)
+    eng.vde(want=False)
+    total = eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    t = torch.from_numpy(ids.view(np.int32)).to(torch.device("cuda:0"))
+    p, nb, hdr = eng.build_index_device(total, 3, t)
+    d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+    lab = g["labels"].astype(np.int64)[ids[d["leaf_son"]]]  # tree walk = left-to-right leaf order
+    n_labels = int(g["labels"].max()) + 1
+    triple = (lab[:, 0] * n_labels + lab[:, 1]) * n_labels + lab[:, 2]
+    assert np.all(np.diff(triple) >= 0)
+    F = (4096 - 5) // (16 * 6 + 4) - 2
+    n_leaves = -(-total // F)
+    mixed = sum(1 for j in range(n_leaves) if triple[j * F] != triple[min(total, (j + 1) * F) - 1])
+    assert mixed <= len(np.unique(triple))  # at most one straddling leaf per label triple
+    eng.close()
+
+
+def test_index_small_and_empty_partitions(oracle):
+    import torch
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(200, 700, n_labels=4, seed=8)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, np.zeros(200, np.uint32), 1, 2)
+    x, nx, vde = eng.vde()
+    eng.count_paths(2)
+    ids, _, _ = eng.fill_paths(pde=False)
+    dev = torch.device("cuda:0")
+    for cnt in (1, 2, 37, 38, 39, 76, 77, 1445):
+        sub = np.ascontiguousarray(ids[:cnt])
+        t = torch.from_numpy(sub.view(np.int32)).to(dev)
+        p, nb, hdr = eng.build_index_device(cnt, 3, t)
+        d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+        assert d["num_data"] == cnt and d["root_is_data"] == 0 and d["inodes"] >= 1
+        o = np.argsort(d["leaf_son"])
+        assert np.array_equal(d["leaf_pt"][o], vde[sub].reshape(cnt, 6))
+    # empty partition: the reference's own empty tree (one empty leaf that is the root)
+    p, nb, hdr = eng.build_index_device(0, 3, None)
+    img = eng.copy_to_host(p, nb).tobytes()
+    assert nb == 2 * 4096 and hdr == [4096, 1, 6, 0, 1, 0, 1, 0]
+    assert img[24] == 1 and img[4096] == 0 and img[4097:4101] == b"\0\0\0\0"
+    eng.close()
+
+
+@pytest.mark.parametrize("p", [1, 2])
+def test_reference_online_consumes_prebuilt_index(tmp_path, oracle, p):
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    gold = json.load(open(os.path.join(GOLDEN, "test_graph", "golden.json")))[f"p{p}"]
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    deg = np.array([int(l.split()[3]) for l in open(graph) if l.startswith("v")])
+    sn = np.argsort(deg, kind="stable").astype(np.uint32)
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, p)
+    mem = np.zeros(len(deg), np.uint32) if p == 1 else (np.arange(len(deg)) % 2).astype(np.uint32)
+    synth.write_membership(os.path.join(tmp, "gnn-pe", "membership.txt"), sn, mem)
+    r = subprocess.run([CLI, "-f", tmp + "/", "-d", graph, "-p", str(p), "--index", "--timing"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for i in range(p):
+        img = open(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "index.dat"), "rb").read()
+        d = oracle.index_validate(img)
+        assert d["num_data"] == (gold["index"][i]["num_data"])
+    t0 = time.time()
+    out = subprocess.check_output([ref_main_path(), "-f", tmp + "/", "-d", graph, "-q",
+                                   os.path.join(GOLDEN, "test_graph", "query_graph.graph"), "-m", "online", "-p", str(p)],
+                                  text=True)
+    dt = time.time() - t0
+    assert int(re.search(r"Answer Number: (\d+)", out).group(1)) == gold["answer_number"] == 45426
+    # the reference skipped its ~40 s insert loop because index.dat already existed (custom.h:222-235)
+    assert dt < 25, dt
+
+
+# ---- pair-major build: the partition's image straight from the enumeration state (no tuple array) ---------------------
+def _partition_paths(ref, mem, pid):
+    sel = np.flatnonzero(mem[ref[:, 0]] == pid)
+    return ref[sel]
+
+
+@pytest.mark.parametrize("e,p", [(2, 1), (2, 3), (1, 2), (3, 1), (4, 2), (8, 1)])
+def test_pair_major_partition_images(oracle, e, p):
+    """Hub-free graph (every row <= 64): gnnpe_build_index_partition_device sorts the (s, b) pairs and reads the points out
+    of the row blocks.  Every consumer constraint holds, every path of the partition is a leaf entry exactly once with
+    son = its index inside the partition (the line number in partition_paths.txt, custom.h:205-216,243) and
+    lo = hi = its pde row, bit for bit."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(4000, 36000, n_labels=7, seed=5 + e)
+    assert np.diff(g["offsets"].astype(np.int64)).max() <= 64
+    rng = np.random.default_rng(e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)          # arbitrary processing order
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)  # arbitrary partition of the vertices
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    assert total == len(ref)
+    D = 3 * e
+    F = min((4096 - 5) // (16 * D + 4) - 1, 64)  # pair-major leaves: capacity - 1 entries (the tuple-array build keeps capacity - 2)
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["dim"] == D and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
+        assert d["dnodes"] == -(-len(mine) // F)
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), D))
+    # leaves are pair-major: left to right, the (label s, label b) of the entries never decreases
+    mine = _partition_paths(ref, mem, 0)
+    d = oracle.index_validate(eng.copy_to_host(*eng.build_index_partition_device(0)[:2]).tobytes())
+    lab = g["labels"].astype(np.int64)[mine[d["leaf_son"]]]
+    assert np.all(np.diff(lab[:, 0] * 7 + lab[:, 1]) >= 0)
+    eng.close()
+
+
+def test_pair_major_with_hub_rows(oracle, test_graph):
+    """Test/data_graph.graph has a row of degree 168: its pairs are cut into units of 64 row entries with a kept mask, and
+    sorted with the ordinary pairs.  Same contract: every path once, son = its index, lo = hi = its pde row."""
+    from gnnpe_amd import binding
+    g = test_graph
+    eng = _engine(binding, g, g["sorted_nodes"], g["membership"], 1, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    assert eng.rows_held()[2] >= 1  # hub rows present
+    ids, _, _ = eng.fill_paths(pde=False)
+    p, nb, hdr = eng.build_index_partition_device(0)
+    d = oracle.index_validate(eng.copy_to_host(p, nb).tobytes())
+    o = np.argsort(d["leaf_son"], kind="stable")
+    assert d["num_data"] == total and np.array_equal(d["leaf_son"][o], np.arange(total))
+    assert np.array_equal(d["leaf_pt"][o], vde[ids].reshape(total, 6))
+    eng.close()
+
+
+@pytest.mark.parametrize("e,p", [(2, 3), (8, 2)])
+def test_pair_major_power_law_partitions(oracle, e, p):
+    """Power-law graph (hubs of several hundred entries: hub pairs spanning many units and many leaves), arbitrary order
+    and partition: per partition the leaf entries are exactly its paths."""
+    from gnnpe_amd import binding
+    g = synth.powerlaw_graph(3000, 20000, exponent=2.1, max_degree=700, n_labels=6, seed=3)
+    assert np.diff(g["offsets"].astype(np.int64)).max() > 200
+    rng = np.random.default_rng(e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    assert total == len(ref)
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert d["num_data"] == len(mine) and np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), 3 * e))
+    eng.close()
+
+
+def test_reference_online_consumes_pair_major_index(tmp_path):
+    """The untouched reference online binary on a hub-free graph: same Answer Number from the trees it inserts itself and
+    from the pair-major index.dat files of `gnnpe_main --index` (p = 3, arbitrary membership)."""
+    if not os.path.exists(ref_main_path()):
+        pytest.skip("oracle/_ref/ref_main not built")
+    g = synth.gnm_graph(1500, 9000, n_labels=5, seed=21)
+    sn = synth.degree_order(g["offsets"])
+    rng = np.random.default_rng(21)
+    mem = rng.integers(0, 3, size=g["n"]).astype(np.uint32)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    q = os.path.join(GOLDEN, "test_graph", "query_graph.graph")
+    ans = []
+    for name in ("ref", "ours"):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        synth.make_dataset_dir(d, 3)
+        synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+        if name == "ref":
+            subprocess.check_call([ref_main_path(), "-f", d + "/", "-d", gp, "-m", "offline", "-p", "3"], stdout=subprocess.DEVNULL)
+        else:
+            r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "3", "--index"], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+        out = subprocess.check_output([ref_main_path(), "-f", d + "/", "-d", gp, "-q", q, "-m", "online", "-p", "3"], text=True)
+        ans.append(int(re.search(r"Answer Number: (\d+)", out).group(1)))
+    assert ans[0] == ans[1]
+
+
+@pytest.mark.parametrize("n,m,p", [(100_000, 1_000_000, 4), (1_000_000, 10_000_000, 8)])
+def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
+    """BASELINE config 2 (100K / 1M, 2.0e7 paths, p = 4) and configs 3 / 4 (1M / 10M, 2.0e8 paths, p = 8: 22 GB of
+    index.dat): every partition's image passes the oracle's
+    validator of the consumer's constraints, holds every path of the partition exactly once with son = its index inside the partition, and lo = hi = its pde row, bit for bit
+    (paths and vde from the oracle's all-core pass)."""
+    from gnnpe_amd import binding
+    if n >= 1_000_000:
+        avail = [int(ln.split()[1]) >> 20 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:")][0]
+        if avail < 64:
+            pytest.skip(f"{avail} GiB of host memory available, 64 needed")
+    g = synth.gnm_graph(n, m)
+    sn = synth.degree_order(g["offsets"])
+    mem = synth.block_membership(g["n"], p)
+    eng = _engine(binding, g, sn, mem, p, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    P, ovde, so, ref, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
+    assert total == P and np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
+    seen = 0
+    full = set(range(p))  # every partition: 22 GB through the host validator takes under a minute on the GPU box's host
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        if pid not in full:  # the other partitions: header only (entry count, node counts, file size)
+            assert hdr[3] == len(mine) and nbytes == (hdr[1] + 1) * 4096 and hdr[4] == -(-len(mine) // 39)
+            seen += len(mine)
+            continue
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["dim"] == 6 and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order].view(np.uint64), ovde[mine].reshape(len(mine), 6).view(np.uint64))
+        seen += len(mine)
+    assert seen == total
+    eng.close()
+
+
+def test_index_files_in_memory_budgeted_waves(tmp_path, monkeypatch):
+    """gnnpe_build_index_files keeps device copies of the images only as far as memory allows: with the kept
+    bytes capped (GNNPE_INDEX_KEEP_BYTES, testing aid) the partitions go out in several waves, or one by one straight from
+    the build buffer, and every file -- index.dat AND aux_index.bin -- equals the unconstrained run's.  Files appear under
+    their names only when complete (no .tmp left behind)."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(20000, 160000, n_labels=9, seed=8)
+    sn = synth.degree_order(g["offsets"])
+    p = 5
+    mem = (np.arange(g["n"]) % p).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, 2)
+    eng.vde(want=False)
+    eng.count_paths(2)
+    outs = {}
+    for name, cap in (("all", None), ("two", str(2 * 28 << 20)), ("none", "1")):
+        d = tmp_path / name
+        d.mkdir()
+        if cap is None:
+            monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("GNNPE_INDEX_KEEP_BYTES", cap)
+        paths = [str(d / f"index{i}.dat") for i in range(p)]
+        aux = [str(d / f"aux{i}.bin") for i in range(p)]
+        eng.build_index_files(paths, aux)
+        assert sorted(os.listdir(d)) == sorted([f"index{i}.dat" for i in range(p)] + [f"aux{i}.bin" for i in range(p)])
+        outs[name] = [open(x, "rb").read() for x in paths + aux]
+        assert all(len(b) >= 8192 for b in outs[name][:p])
+    assert outs["two"] == outs["all"] and outs["none"] == outs["all"]
+    # a path that cannot be written leaves nothing behind, not a truncated file
+    monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+    bad = [str(tmp_path / "missing_dir" / f"index{i}.dat") for i in range(p)]
+    with pytest.raises(binding.GnnpeError):
+        eng.build_index_files(bad)
+    assert not (tmp_path / "missing_dir").exists()
+    eng.close()
+
+
+def test_index_size_guard_and_every_partition_through_the_reference(tmp_path):
+    """VERDICT r3 item 5.  (1) `gnnpe_main --index` refuses BEFORE writing anything when a partition's index.dat would reach
+    2 GiB -- the untouched consumer seeks with 32-bit arithmetic (include/blockfile/blk_file.h:32-33) -- and names the smallest
+    -p that fits (BASELINE config 2 with p = 1: 2.1 GB, the size at which the reference's own tree crashes its own reader,
+    tests/golden/large_index/reference_config2_p1_crash.json).  (2) At a p for which every file is consumable, ALL
+    partitions go through `ref_main -m online` and the answer equals the one the reference printed from the trees it
+    inserted itself (G(70K, 700K), p = 4: tests/golden/large_index/reference_p4.json, a 33-minute run of the reference)."""
+    g = synth.gnm_graph(100_000, 1_000_000)
+    gp = str(tmp_path / "c2.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "c2")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 1)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), np.zeros(g["n"], np.uint32))
+    r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-m", "offline", "-p", "1", "--index"], capture_output=True, text=True)
+    assert r.returncode == 1, r.stderr[-500:]
+    assert "2 GiB" in r.stderr and "blk_file.h:33" in r.stderr and "from -p 2" in r.stderr and "--allow-large" in r.stderr
+    assert not os.path.exists(os.path.join(d, "gnn-pe", "all_paths.txt"))
+    assert not os.path.exists(os.path.join(d, "gnn-pe", "partitions", "partition-0", "index.dat"))
+
+    ref = json.load(open(os.path.join(GOLDEN, "large_index", "reference_p4.json")))
+    query = os.path.join(GOLDEN, "large_index", "query.graph")
+    g = synth.gnm_graph(70_000, 700_000)
+    gp = str(tmp_path / "g70.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "g70")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, 4)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), synth.degree_order(g["offsets"]), synth.block_membership(g["n"], 4))
+    subprocess.check_call([CLI, "-f", d + "/", "-d", gp, "-m", "offline", "-p", "4", "--index"], stdout=subprocess.DEVNULL)
+    assert int(open(os.path.join(d, "gnn-pe", "all_paths.txt")).readline()) == ref["paths"]
+    for i in range(4):
+        assert 8192 <= os.path.getsize(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) < (1 << 31)
+    out = subprocess.run([ref_main_path(), "-f", d + "/", "-d", gp, "-q", query, "-m", "online", "-p", "4"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-300:]
+    assert "This R-Tree contains" not in out.stdout  # it inserted nothing: every partition's tree came from our files
+    assert int(re.search(r"Answer Number: (\d+)", out.stdout).group(1)) == ref["answer_number"] == 2
