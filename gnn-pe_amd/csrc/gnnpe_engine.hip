@@ -794,6 +794,24 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         GNNPE_BY_E(e, GNNPE_RR)
 #undef GNNPE_RR
 #undef GNNPE_RRK
+        // diagnostic launches beside the real one (GNNPE_ROWS_PROBE, scripts/count_ab.py): pieces of the kernel on their own,
+        // into scratch copies of its outputs; whole graph on one device, e = 2, packed ids only
+        if (const char *ev = getenv("GNNPE_ROWS_PROBE")) {
+            const int mode = atoi(ev);
+            if (mode >= 1 && mode <= 3 && c->rows_identity && e == 2 && packed && c->slab_begin == 0 && c->slab_end == c->n) {
+                DevBuf probe_recs, probe_pairs;  // freed on return (a diagnostic path may allocate)
+                if ((rc = probe_recs.reserve((c->rblock_units + 1) * kRowAlign)) || (rc = probe_pairs.reserve((ne + 1) * sizeof(RankedPair)))) return rc;
+#define GNNPE_RP(MM)                                                                                                    \
+    hipLaunchKernelGGL((k_rows_rank_probe<2, true, MM>), grid, block, 0, c->stream, c->n_held, c->adj_start.as<uint32_t>(), \
+                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), vde, c->poffs.as<uint32_t>(), \
+                       c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(), probe_recs.as<char>(), probe_pairs.as<RankedPair>())
+                for (int rep = 0; rep < 3; rep++) {
+                    if (mode == 1) GNNPE_RP(1); else if (mode == 2) GNNPE_RP(2); else GNNPE_RP(3);
+                }
+#undef GNNPE_RP
+                GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+        }
         GNNPE_HIP_TRY(hipGetLastError());
     }
     if (c->n_hub) {

@@ -142,6 +142,60 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
     }
 }
 
+// DIAGNOSTIC (GNNPE_ROWS_PROBE=1|2|3, scripts/count_ab.py; never launched by the product, its outputs are not the
+// enumeration's): what the pieces of k_rows_rank cost on their own, for the question whether a split into a rank-only pass
+// over an L2-sized table and a payload pass would beat the fused kernel.
+//   MODE 1  the G pass alone: one 4-byte gather per entry from the 4 MB rank table, G, the pair scatter; no payload, no records
+//   MODE 2  MODE 1 without the pair scatter (the pairs go to the entries' own, coalesced positions)
+//   MODE 3  the payload pass alone: one 16-byte vde gather per entry, the record written at the entry's id position
+template <int E, bool PACKED, int MODE>
+__global__ __launch_bounds__(256) void k_rows_rank_probe(uint32_t n_held, const uint32_t *__restrict__ adj_start,
+                                                         const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ nbrs,
+                                                         const uint32_t *__restrict__ rank, const double *__restrict__ vde,
+                                                         const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ revpos,
+                                                         const uint32_t *__restrict__ rblock, char *__restrict__ recs,
+                                                         RankedPair *__restrict__ pairs)
+{
+    typedef typename RecOf<E, PACKED>::type Rec;
+    const unsigned lane = lane_id();
+    const uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_held) return;
+    const uint32_t b = (uint32_t)w, st = adj_start[b], d = adj_deg[b];
+    if (d == 0 || d > kHubDegree) return;
+    const uint32_t blk = rblock[b];
+    char *const base = recs + (uint64_t)blk * kRowAlign;
+    if constexpr (MODE == 3) {
+        if (lane < d) {
+            const uint32_t u = nbrs[st + lane];
+            Rec rec;
+            if constexpr (PACKED) rec.idp = u | (lane << kPackedIdBits); else { rec.id = u; rec.aux = lane; }
+#pragma unroll
+            for (int k = 0; k < E; k++) rec.vde[k] = vde[(uint64_t)u * E + k];
+            reinterpret_cast<Rec *>(base + 8 * E)[lane] = rec;
+        }
+        return;
+    }
+    uint32_t r = 0, u = 0, rp = kNoEdge;
+    if (lane < d) {
+        u = nbrs[st + lane];
+        r = rank[u];
+        rp = revpos[st + lane];
+    }
+    const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    uint32_t Glo = 0, Ghi = 0;
+    for (uint32_t i = 0; i < du; i++) {
+        const uint64_t m = __ballot(r > rl32(r, (int)i));
+        Glo = writelane32((uint32_t)m, i, Glo);
+        if (du > 32) Ghi = writelane32((uint32_t)(m >> 32), i, Ghi);
+    }
+    const uint64_t G = ((uint64_t)Ghi << 32) | Glo;
+    if (lane < d && rp != kNoEdge) {
+        RankedPair pr = {blk, (uint32_t)__popcll(G), G};
+        if constexpr (MODE == 1) pairs[poffs[r] + rp] = pr;  // (whole graph = one slab: the start's first pair slot is poffs[rank])
+        else pairs[st + lane] = pr;
+    }
+}
+
 // Hub rows, pass 1 (one wave per hub row): header + records {id, rank, vde} in id order, and the row's neighbour ranks
 // as a stream for the per-row sort.
 template <int E>
