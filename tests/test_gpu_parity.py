@@ -465,16 +465,20 @@ def test_two_slabs_with_halo_exchange_on_one_gpu(binding, oracle, variant):
             bufs.append(buf)
         for r in range(2):
             engs[r].vde_unpack_slab(int(bounds[1 - r]), int(bounds[2 - r]), bufs[1 - r])
-        out_ids, out_pde = [], []
-        for r in range(2):
-            total = engs[r].count_paths(2)
-            i, p, _ = engs[r].fill_paths(0, total)
-            out_ids.append(i)
-            out_pde.append(p)
-        ids = np.concatenate(out_ids)
-        pde = np.concatenate(out_pde)
-        assert np.array_equal(ids, ref_ids)
-        assert np.array_equal(pde, ovde[ref_ids].reshape(len(ref_ids), 6))
+        for shape in ((1, 2) if variant == 4 else (1,)):  # both emit shapes on slab contexts with halo rows (no hub rows here)
+            out_ids, out_pde = [], []
+            for r in range(2):
+                engs[r].set_emit_shape(shape)
+                total = engs[r].count_paths(2)
+                i, p, _ = engs[r].fill_paths(0, total)
+                if variant == 4 and total:
+                    assert engs[r].emit_kernel_name() == ("k_fill_ranked", "k_fill_tiles")[shape - 1]
+                out_ids.append(i)
+                out_pde.append(p)
+            ids = np.concatenate(out_ids)
+            pde = np.concatenate(out_pde)
+            assert np.array_equal(ids, ref_ids)
+            assert np.array_equal(pde, ovde[ref_ids].reshape(len(ref_ids), 6))
     for e in engs:
         e.close()
 
