@@ -60,6 +60,14 @@ with open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.csv"), "w") as f:
         ms = timed[0][2]
         f.write(f"# timed steps ({timed[0][0].split('<')[0]}): {ms:.3f} ms per launch -> {PATHS} paths x {BPP} B / {ms:.3f} ms = {PATHS * BPP / ms / 1e6:.0f} GB/s = "
                 f"{PATHS * BPP / ms / 1e6 / HBM:.3f} of the {HBM / 1000:.0f} TB/s spec (one allocation as it came; the faster emit shape for it)\n")
+    try:  # the bench's own event timing of the SAME run (the JSON line the traced command printed)
+        import json
+        line = [l for l in open(os.path.join(ROOT, "gpurun_out", f"{rnd}_trace.log")) if l.startswith('{"metric"')][-1]
+        rf = json.loads(line)["roofline"]
+        f.write(f"# bench.py's own timing of the same run: roofline.launch_ms {rf['launch_ms']:.3f} ms, frac {rf['frac']:.3f}, kernel {rf['kernel']}, "
+                f"emit_shapes {rf['emit_shapes']['starts_ms']} / {rf['emit_shapes']['tiles_ms']} ms kept {rf['emit_shapes']['kept']}\n")
+    except Exception as ex:  # the log is optional
+        f.write(f"# (bench line of the traced run not found: {ex})\n")
     f.write("Name,Calls,AverageMs,TotalMs\n")
     for name, n, avg, tot in sorted(lines, key=lambda l: -l[3]):
         f.write(f'"{name}",{n},{avg:.4f},{tot:.3f}\n')
