@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
     constexpr int NP = KT + 1;            // record passes every tile makes; a tile's pairs hold at most TS + 2 * 62 records, so
     constexpr int NMARK = 64 * (KT + 2);  // one more pass exists for the few that hold more than 64 NP (record slots: NMARK)
     static_assert(SP <= 64 && (SP & (SP - 1)) == 0, "one lane per pair of the strip");
-    __shared__ uint32_t s_cs[WPB][SP + 1], s_blk[WPB][SP], s_b[WPB][SP], s_s[WPB][SP];
+    __shared__ uint32_t s_cs[WPB][SP], s_blk[WPB][SP], s_b[WPB][SP], s_s[WPB][SP];  // (s_cs without a sentinel: 20 480 B per workgroup at e = 2 = eight per CU)
     __shared__ uint64_t s_G[WPB][SP];
     __shared__ __attribute__((aligned(16))) double s_vb[WPB][SP * EP];
     __shared__ __attribute__((aligned(16))) double s_vs[WPB][SP * EP];
@@ -238,7 +238,6 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
             sG[lane] = G;
         }
         if (mine) smark[excl] = (uint8_t)(lane + 1);  // excl < TS + 62 <= NMARK for a pair that reaches the tile
-        if (lane == 0) cs[SP] = C;
         // the pairs that own rows fetch their start vertex' embedding and their row block's header (vde[b]: the line the
         // pair's first records sit in) now; both land in the strip after the record loop, so neither load is a hop of its
         // own.  Nothing loaded before is used after this point: the compiler's wait for an older load would wait for these
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (rel != 0) {
             const uint32_t a_hi = 63u - (uint32_t)__clzll(rel);
-            const uint32_t f_hi = cs[a_hi + 1];  // one past the last record of the last pair that reaches the tile
+            const uint32_t f_hi = a_hi + 1 < (uint32_t)SP ? cs[a_hi + 1] : C;  // one past the last record of the last pair that reaches the tile
             // every record of those pairs: all loads of the tile first, then the rows
             constexpr int RW = (int)(sizeof(Rec) / 4), VW = RW - 2 * E;  // dwords per record / in front of its vde
             uint32_t rw[NP][RW];
