@@ -780,10 +780,27 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         // one row per wave, workgroups in launch order (the kernel's loop is then a single pass): the blocks are written as one
         // dense front; against the resident grid 1.063 -> 1.050 ms for the count phase at config 3 (scripts/count_ab.py)
         const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 3) / 4, 1u << 30)), block(kBlock);
+        // rows per wave: 1 (one wave per row) or 4 with the rows' loads batched (GNNPE_ROWS_ILP=1|4 overrides; default below)
+        int rows_ilp = 4;
+        if (const char *ev = getenv("GNNPE_ROWS_ILP")) rows_ilp = atoi(ev);
+        if (rows_ilp != 1 && rows_ilp != 2 && rows_ilp != 8) rows_ilp = 4;
+        const dim3 gridk((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 4 * rows_ilp - 1) / (4 * rows_ilp), 1u << 30));
+#define GNNPE_RRM(EE, PK, KK)                                                                                       \
+    hipLaunchKernelGGL((k_rows_rank_multi<EE, PK, KK>), gridk, block, 0, c->stream, c->n_held, held,                \
+                       c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),              \
+                       c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),                   \
+                       c->rrecs.as<char>(), c->rpairs.as<RankedPair>())
 #define GNNPE_RRK(EE, PK)                                                                                           \
-    hipLaunchKernelGGL((k_rows_rank<EE, PK>), grid, block, 0, c->stream, c->n_held, held, c->adj_start.as<uint32_t>(), \
-                       c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->vinfo.as<double>(),                     \
-                       c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->rpairs.as<RankedPair>())
+    do {                                                                                                            \
+        if (rows_ilp == 8) GNNPE_RRM(EE, PK, 8);                                                                    \
+        else if (rows_ilp == 4) GNNPE_RRM(EE, PK, 4);                                                               \
+        else if (rows_ilp == 2) GNNPE_RRM(EE, PK, 2);                                                               \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_rows_rank<EE, PK>), grid, block, 0, c->stream, c->n_held, held,                   \
+                               c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),      \
+                               c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),           \
+                               c->rrecs.as<char>(), c->rpairs.as<RankedPair>());                                    \
+    } while (0)
 #define GNNPE_RR(EE)                                                                                               \
     do {                                                                                                           \
         hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
@@ -794,6 +811,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         GNNPE_BY_E(e, GNNPE_RR)
 #undef GNNPE_RR
 #undef GNNPE_RRK
+#undef GNNPE_RRM
         // diagnostic launches beside the real one (GNNPE_ROWS_PROBE, scripts/count_ab.py): pieces of the kernel on their own,
         // into scratch copies of its outputs; whole graph on one device, e = 2, packed ids only
         if (const char *ev = getenv("GNNPE_ROWS_PROBE")) {

@@ -142,6 +142,87 @@ __global__ __launch_bounds__(256) void k_rows_rank(uint32_t n_held, const uint32
     }
 }
 
+// The same computation with K rows per wave, one after the other, but with the K rows' loads batched: the descriptors of all K
+// rows, then their neighbour / reverse-position loads, then their vinfo gathers, then K times {G, record, pair}.  A wave per
+// row spends its life in three dependent round trips (row -> neighbours -> vinfo) for ~20 useful lanes; the trace of the
+// per-rank steps (scripts/emulate_rank.py) fits 0.40 ms per million ROWS + 0.005 per million entries + 0.02 per million
+// scattered pairs -- per rank the kernel is bound by the number of waves, not by the entries.  No load sits under a lane
+// mask (idle lanes re-read the row's last entry): hipcc would wait for it at the join.
+template <int E, bool PACKED, int K>
+__global__ __launch_bounds__(256) void k_rows_rank_multi(uint32_t n_held, const uint32_t *__restrict__ held,
+                                                         const uint32_t *__restrict__ adj_start,
+                                                         const uint32_t *__restrict__ adj_deg,
+                                                         const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
+                                                         const uint32_t *__restrict__ revpos,
+                                                         const uint32_t *__restrict__ rblock, char *__restrict__ recs,
+                                                         RankedPair *__restrict__ pairs)
+{
+    typedef typename RecOf<E, PACKED>::type Rec;
+    constexpr int S = GNNPE_VINFO_STRIDE(E);
+    const unsigned lane = lane_id();
+    const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    uint32_t b[K], st[K], d[K], blk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint64_t idx = w * K + k;
+        const bool ok = idx < n_held;
+        b[k] = ok ? (held ? held[idx] : (uint32_t)idx) : 0u;
+        st[k] = adj_start[b[k]];
+        d[k] = ok ? adj_deg[b[k]] : 0u;
+        if (d[k] > kHubDegree) d[k] = 0;  // hub rows: k_hub_records / k_hub_pairs
+        blk[k] = rblock[b[k]];
+    }
+    uint32_t u[K], rp[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t q = d[k] ? st[k] + min(lane, d[k] - 1u) : 0u;
+        u[k] = nbrs[q];
+        rp[k] = revpos[q];
+    }
+    double vu[K][E], hb[K];
+    uint64_t rw[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const double *vi = vinfo + (uint64_t)u[k] * S;
+#pragma unroll
+        for (int j = 0; j < E; j++) vu[k][j] = vi[j];
+        rw[k] = reinterpret_cast<const uint64_t *>(vi)[E];
+        hb[k] = vinfo[(uint64_t)b[k] * S + min(lane, (unsigned)(E - 1))];  // header: vde of the row's vertex
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[k]);
+        if (du == 0) continue;
+        char *const base = recs + (uint64_t)blk[k] * kRowAlign;
+        const uint32_t r = lane < du ? (uint32_t)rw[k] : 0u, po = (uint32_t)(rw[k] >> 32);
+        if (lane < (unsigned)E) reinterpret_cast<double *>(base)[lane] = hb[k];
+        uint32_t Glo = 0, Ghi = 0;
+        for (uint32_t i = 0; i < du; i++) {
+            const uint64_t m = __ballot(r > rl32(r, (int)i));
+            Glo = writelane32((uint32_t)m, i, Glo);
+            if (du > 32) Ghi = writelane32((uint32_t)(m >> 32), i, Ghi);
+        }
+        const uint64_t G = ((uint64_t)Ghi << 32) | Glo;
+        if (lane < du) {
+            const uint32_t cnt = (uint32_t)__popcll(G);
+            Rec rec;
+            if constexpr (PACKED) {
+                rec.idp = u[k] | (lane << kPackedIdBits);
+            } else {
+                rec.id = u[k];
+                rec.aux = lane;
+            }
+#pragma unroll
+            for (int j = 0; j < E; j++) rec.vde[j] = vu[k][j];
+            reinterpret_cast<Rec *>(base + 8 * E)[cnt] = rec;
+            if (rp[k] != kNoEdge && po != kNoEdge) {
+                RankedPair pr = {blk[k], cnt, G};
+                pairs[po + rp[k]] = pr;
+            }
+        }
+    }
+}
+
 // DIAGNOSTIC (GNNPE_ROWS_PROBE=1|2|3, scripts/count_ab.py; never launched by the product, its outputs are not the
 // enumeration's): what the pieces of k_rows_rank cost on their own, for the question whether a split into a rank-only pass
 // over an L2-sized table and a payload pass would beat the fused kernel.
