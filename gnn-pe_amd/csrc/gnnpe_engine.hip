@@ -820,7 +820,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
                 DevBuf probe_recs, probe_pairs;  // freed on return (a diagnostic path may allocate)
                 if ((rc = probe_recs.reserve((c->rblock_units + 1) * kRowAlign)) || (rc = probe_pairs.reserve((ne + 1) * sizeof(RankedPair)))) return rc;
 #define GNNPE_RP(MM)                                                                                                    \
-    hipLaunchKernelGGL((k_rows_rank_probe<2, true, MM>), grid, block, 0, c->stream, c->n_held, c->adj_start.as<uint32_t>(), \
+    hipLaunchKernelGGL((k_rows_rank_probe<2, true, MM>), dim3((c->n_held + 15) / 16), block, 0, c->stream, c->n_held, c->adj_start.as<uint32_t>(), \
                        c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->rank.as<uint32_t>(), vde, c->poffs.as<uint32_t>(), \
                        c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(), probe_recs.as<char>(), probe_pairs.as<RankedPair>())
                 for (int rep = 0; rep < 3; rep++) {

@@ -237,43 +237,68 @@ __global__ __launch_bounds__(256) void k_rows_rank_probe(uint32_t n_held, const 
                                                          const uint32_t *__restrict__ rblock, char *__restrict__ recs,
                                                          RankedPair *__restrict__ pairs)
 {
+    // four rows per wave with their loads batched, like k_rows_rank_multi: the pieces are compared at the product's shape
     typedef typename RecOf<E, PACKED>::type Rec;
+    constexpr int K = 4;
     const unsigned lane = lane_id();
-    const uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    if (w >= n_held) return;
-    const uint32_t b = (uint32_t)w, st = adj_start[b], d = adj_deg[b];
-    if (d == 0 || d > kHubDegree) return;
-    const uint32_t blk = rblock[b];
-    char *const base = recs + (uint64_t)blk * kRowAlign;
-    if constexpr (MODE == 3) {
-        if (lane < d) {
-            const uint32_t u = nbrs[st + lane];
-            Rec rec;
-            if constexpr (PACKED) rec.idp = u | (lane << kPackedIdBits); else { rec.id = u; rec.aux = lane; }
+    const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    uint32_t st[K], d[K], blk[K];
 #pragma unroll
-            for (int k = 0; k < E; k++) rec.vde[k] = vde[(uint64_t)u * E + k];
-            reinterpret_cast<Rec *>(base + 8 * E)[lane] = rec;
+    for (int k = 0; k < K; k++) {
+        const uint64_t idx = w * K + k;
+        const uint32_t b = idx < n_held ? (uint32_t)idx : 0u;
+        st[k] = adj_start[b];
+        d[k] = idx < n_held ? adj_deg[b] : 0u;
+        if (d[k] > kHubDegree) d[k] = 0;
+        blk[k] = rblock[b];
+    }
+    uint32_t u[K], rp[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t q = d[k] ? st[k] + min(lane, d[k] - 1u) : 0u;
+        u[k] = nbrs[q];
+        rp[k] = MODE == 3 ? 0u : revpos[q];
+    }
+    if constexpr (MODE == 3) {
+        double v[K][E];
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int j = 0; j < E; j++) v[k][j] = vde[(uint64_t)u[k] * E + j];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (lane < d[k]) {
+                Rec rec;
+                if constexpr (PACKED) rec.idp = u[k] | (lane << kPackedIdBits); else { rec.id = u[k]; rec.aux = lane; }
+#pragma unroll
+                for (int j = 0; j < E; j++) rec.vde[j] = v[k][j];
+                reinterpret_cast<Rec *>(recs + (uint64_t)blk[k] * kRowAlign + 8 * E)[lane] = rec;
+            }
         }
         return;
     }
-    uint32_t r = 0, u = 0, rp = kNoEdge;
-    if (lane < d) {
-        u = nbrs[st + lane];
-        r = rank[u];
-        rp = revpos[st + lane];
-    }
-    const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-    uint32_t Glo = 0, Ghi = 0;
-    for (uint32_t i = 0; i < du; i++) {
-        const uint64_t m = __ballot(r > rl32(r, (int)i));
-        Glo = writelane32((uint32_t)m, i, Glo);
-        if (du > 32) Ghi = writelane32((uint32_t)(m >> 32), i, Ghi);
-    }
-    const uint64_t G = ((uint64_t)Ghi << 32) | Glo;
-    if (lane < d && rp != kNoEdge) {
-        RankedPair pr = {blk, (uint32_t)__popcll(G), G};
-        if constexpr (MODE == 1) pairs[poffs[r] + rp] = pr;  // (whole graph = one slab: the start's first pair slot is poffs[rank])
-        else pairs[st + lane] = pr;
+    uint32_t rk[K], po[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) rk[k] = rank[u[k]];
+#pragma unroll
+    for (int k = 0; k < K; k++) po[k] = MODE == 1 ? poffs[rk[k]] : 0u;  // (whole graph = one slab: a start's first pair slot is poffs[rank])
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[k]);
+        if (du == 0) continue;
+        const uint32_t r = lane < du ? rk[k] : 0u;
+        uint32_t Glo = 0, Ghi = 0;
+        for (uint32_t i = 0; i < du; i++) {
+            const uint64_t m = __ballot(r > rl32(r, (int)i));
+            Glo = writelane32((uint32_t)m, i, Glo);
+            if (du > 32) Ghi = writelane32((uint32_t)(m >> 32), i, Ghi);
+        }
+        const uint64_t G = ((uint64_t)Ghi << 32) | Glo;
+        if (lane < du && rp[k] != kNoEdge) {
+            RankedPair pr = {blk[k], (uint32_t)__popcll(G), G};
+            if constexpr (MODE == 1) pairs[po[k] + rp[k]] = pr;
+            else pairs[st[k] + lane] = pr;
+        }
     }
 }
 

@@ -14,7 +14,7 @@ for f in glob.glob("gpurun_out/rows_probe_trace/*/*_kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "k_rows_rank" in n:
-            m = re.search(r"k_rows_rank(_probe)?<[^>]*>", n)
+            m = re.search(r"k_rows_rank(_probe|_multi)?<[^>]*>", n)
             per.setdefault(m.group(0), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for k, v in sorted(per.items()):
     print(f"{k:40s} launches {len(v):2d}  min {min(v):.3f} ms  median {sorted(v)[len(v) // 2]:.3f} ms")
@@ -32,7 +32,7 @@ for f in glob.glob(f"gpurun_out/rows_probe_pmc_{i}/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "k_rows_rank" in n:
-            k = re.search(r"k_rows_rank(_probe)?<[^>]*>", n).group(0)
+            k = re.search(r"k_rows_rank(_probe|_multi)?<[^>]*>", n).group(0)
             per.setdefault((r["Counter_Name"], k), {}).setdefault(r["Dispatch_Id"], 0.0)
             per[(r["Counter_Name"], k)][r["Dispatch_Id"]] += float(r["Counter_Value"])
 for (c, k), v in sorted(per.items()):
