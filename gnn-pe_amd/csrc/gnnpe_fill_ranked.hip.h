@@ -396,7 +396,7 @@ struct __attribute__((packed, aligned(4))) IdRow {
 };
 
 template <int E, bool PACKED, int kBatch>
-__global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
+__global__ __launch_bounds__(256, (E <= 2 ? 7 : 1)) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
                                                      const RankedPair *__restrict__ pairs,
                                                      const char *__restrict__ recs, uint32_t slab_len)
 {
@@ -479,10 +479,11 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
         if (k < sr.ds) {
             // read once, never again: non-temporal (same-process A/B at config 3: 3.085 -> 3.036 ms; the RECORD loads must
             // stay cached -- a pair's header and first records share lines across load instructions: 4.02 -> 4.37 ms)
-            const uint32_t *pq = reinterpret_cast<const uint32_t *>(&pairs[sr.e0 + k]);
-            pr.block = __builtin_nontemporal_load(pq);
-            pr.cnt = __builtin_nontemporal_load(pq + 1);
-            pr.G = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(pq + 2));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 pw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&pairs[sr.e0 + k]));  // one 16-byte load
+            pr.block = pw.x;
+            pr.cnt = pw.y;
+            pr.G = ((uint64_t)pw.w << 32) | pw.z;
             bk = __builtin_nontemporal_load(&P.nbrs[sr.a_s + k]);  // the k-th neighbour of s is the pair's middle vertex
         }
     };
@@ -564,34 +565,58 @@ __global__ __launch_bounds__(256) void k_fill_ranked(FillParams P, const StartRe
                         const uint64_t m = __ballot(fits);
                         const uint32_t ke = 64u - (uint32_t)__clzll(m);  // m != 0: ke = kb + 1 always fits (<= 63 records)
                         const uint32_t hi = cs[ke];
-#pragma unroll 1
-                        for (uint32_t f = lo + lane; f < hi; f += 64) {
-                            uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= f
+                        {
+                            // a batch holds at most kBatch = 64 records: one record per lane.  The record and its pair's header
+                            // (vde[b], same line) are loaded as raw dwords by EVERY lane (idle lanes re-read the batch's last
+                            // record: no load under a lane mask) and pinned by an empty asm statement, so that both loads are
+                            // issued back to back -- hipcc otherwise sinks the payload load below the first use of the id
+                            // word and the header load into its branch: three dependent round trips per batch instead of one
+                            static_assert(kBatch == 64, "one record per lane and batch");
+                            const uint32_t f = lo + lane, fc = min(f, hi - 1u);
+                            uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= fc
                             while (bnd - a > 1) {
                                 const uint32_t mid = (a + bnd) >> 1;
-                                if (cs[mid] <= f) a = mid; else bnd = mid;
+                                if (cs[mid] <= fc) a = mid; else bnd = mid;
                             }
                             const uint32_t ca = cs[a];
                             const char *const base = recs + (uint64_t)sblk[a] * kRowAlign;
-                            const Rec rec = reinterpret_cast<const Rec *>(base + 8 * E)[f - ca];
-                            uint32_t id, ip;
-                            if constexpr (PACKED) {
-                                id = rec.idp & ((1u << kPackedIdBits) - 1u);
-                                ip = rec.idp >> kPackedIdBits;
-                            } else {
-                                id = rec.id;
-                                ip = rec.aux;
-                            }
-                            const uint64_t below = sG[a] & ((1ull << ip) - 1ull);
-                            const uint32_t row = (ca - lo) + (uint32_t)__popcll(below);
-                            sid[row] = id;
-                            sa[row] = (uint8_t)a;
+                            constexpr int RW = (int)(sizeof(Rec) / 4), VW = RW - 2 * E;
+                            const uint32_t *rq = reinterpret_cast<const uint32_t *>(base + 8 * E) + (uint64_t)(fc - ca) * RW;
+                            uint32_t rw[RW], hw[2 * E];
+#pragma unroll
+                            for (int z = 0; z < RW; z++) rw[z] = rq[z];
                             if (want_pde) {
 #pragma unroll
-                                for (int k2 = 0; k2 < E; k2++) sv[row * EP + k2] = rec.vde[k2];
-                                if (f == ca) {  // first record of the pair: the header (vde[b]) is in the same line
+                                for (int z = 0; z < 2 * E; z++) hw[z] = reinterpret_cast<const uint32_t *>(base)[z];
+                            }
 #pragma unroll
-                                    for (int k2 = 0; k2 < E; k2++) svb[a * EP + k2] = reinterpret_cast<const double *>(base)[k2];
+                            for (int z = 0; z < RW; z++) asm volatile("" : "+v"(rw[z]));
+                            if (want_pde) {
+#pragma unroll
+                                for (int z = 0; z < 2 * E; z++) asm volatile("" : "+v"(hw[z]));
+                            }
+                            if (f < hi) {
+                                uint32_t id, ip;
+                                if constexpr (PACKED) {
+                                    id = rw[0] & ((1u << kPackedIdBits) - 1u);
+                                    ip = rw[0] >> kPackedIdBits;
+                                } else {
+                                    id = rw[0];
+                                    ip = rw[1];
+                                }
+                                const uint64_t below = sG[a] & ((1ull << ip) - 1ull);
+                                const uint32_t row = (ca - lo) + (uint32_t)__popcll(below);
+                                sid[row] = id;
+                                sa[row] = (uint8_t)a;
+                                if (want_pde) {
+                                    uint32_t *q = reinterpret_cast<uint32_t *>(sv + row * EP);
+#pragma unroll
+                                    for (int z = 0; z < 2 * E; z++) q[z] = rw[VW + z];
+                                    if (f == ca) {  // first record of the pair: its lane parks the header
+                                        uint32_t *qh = reinterpret_cast<uint32_t *>(svb + a * EP);
+#pragma unroll
+                                        for (int z = 0; z < 2 * E; z++) qh[z] = hw[z];
+                                    }
                                 }
                             }
                         }
