@@ -87,4 +87,31 @@ __device__ __forceinline__ double wave_min(double v) { return lane63(dpp_min_f64
 __device__ __forceinline__ double wave_max(double v) { return lane63(dpp_max_f64(v)); }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)dpp_max_u32(v), 63); }
 
+// wave-wide inclusive scans on DPP (row shifts inside rows of 16, then the two row broadcasts): no LDS crossbar, so the
+// six steps cost VALU issue only -- __shfl_up is ds_bpermute, one LDS round trip per step on the kernel's critical path
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_shift0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);  // lanes without a source read 0
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += dpp_shift0<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_shift0<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_shift0<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_shift0<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_shift0<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_shift0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
+{
+    v = max(v, dpp_shift0<0x111, 0xF>(v));
+    v = max(v, dpp_shift0<0x112, 0xF>(v));
+    v = max(v, dpp_shift0<0x114, 0xF>(v));
+    v = max(v, dpp_shift0<0x118, 0xF>(v));
+    v = max(v, dpp_shift0<0x142, 0xA>(v));
+    v = max(v, dpp_shift0<0x143, 0xC>(v));
+    return v;
+}
+
 }  // namespace gnnpe

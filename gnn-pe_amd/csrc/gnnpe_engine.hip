@@ -1233,12 +1233,19 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         // write one moving window of the output
         const StartRec *sr = c->srec.as<StartRec>();
         const bool packed = packed_ids(c);
+        // Occupancy cap: dynamic LDS the kernel never touches, sized so that FIVE workgroups fit a CU at e <= 2 (14 688 B static
+        // + 13 000 B = 27 688 B).  With the start's loads batched (round 4) a wave keeps more bytes in flight, and fewer
+        // resident waves write faster -- same process, same buffers (scripts/emit_ab_libs.py): 8 / 7 / 6 / 5 / 4 workgroups
+        // per CU 3.37 / 3.05 / 2.95 / 2.93 / 3.00 ms in a fast allocation (the registers alone would admit 8); 128 staged rows
+        // per wave at 6 / 5 / 4 workgroups: 3.13 / 3.18 / 3.70 ms against 2.98 with 64.
+        size_t lds_pad = e <= 2 ? 13000 : 0;
+        if (const char *ev = getenv("GNNPE_FILL_LDS_PAD")) lds_pad = (size_t)atoi(ev);
 #define GNNPE_LK(KERN)                                                                                                  \
     do {                                                                                                                \
         auto kern = KERN;                                                                                               \
-        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)blocks_per_cu(kern) * c->num_cus; \
+        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)(lds_pad ? std::min<int>(blocks_per_cu(kern), (int)(160 * 1024 / (14688 + lds_pad))) : blocks_per_cu(kern)) * c->num_cus; \
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, fit))), block(kBlock);                           \
-        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len); \
+        hipLaunchKernelGGL(kern, grid, block, lds_pad, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len); \
     } while (0)
 #define GNNPE_L(EE)                                                                                                     \
     do {                                                                                                                \

@@ -14,6 +14,7 @@
 // emit kernel streams them with a ballot compaction -- in the same launch, pair by pair, so one graph may mix both.
 #pragma once
 
+#include "gnnpe_dpp.hip.h"
 #include "gnnpe_kernels.hip.h"
 #include "gnnpe_records.h"
 
@@ -396,7 +397,7 @@ struct __attribute__((packed, aligned(4))) IdRow {
 };
 
 template <int E, bool PACKED, int kBatch>
-__global__ __launch_bounds__(256, (E <= 2 ? 7 : 1)) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
+__global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
                                                      const RankedPair *__restrict__ pairs,
                                                      const char *__restrict__ recs, uint32_t slab_len)
 {
@@ -470,43 +471,44 @@ __global__ __launch_bounds__(256, (E <= 2 ? 7 : 1)) void k_fill_ranked(FillParam
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
+    // the strip's pairs, one per lane.  Every lane loads (lanes past the start's last pair re-read it and are zeroed after):
+    // a load under a lane mask makes hipcc wait for every outstanding access at the join
     auto load_pairs = [&](const StartRec &sr, uint32_t k0, RankedPair &pr, uint32_t &bk) {
-        pr.block = 0;
-        pr.cnt = 0;
-        pr.G = 0;
-        bk = 0;
-        const uint32_t k = k0 + lane;
-        if (k < sr.ds) {
-            // read once, never again: non-temporal (same-process A/B at config 3: 3.085 -> 3.036 ms; the RECORD loads must
-            // stay cached -- a pair's header and first records share lines across load instructions: 4.02 -> 4.37 ms)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 pw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&pairs[sr.e0 + k]));  // one 16-byte load
-            pr.block = pw.x;
-            pr.cnt = pw.y;
-            pr.G = ((uint64_t)pw.w << 32) | pw.z;
-            bk = __builtin_nontemporal_load(&P.nbrs[sr.a_s + k]);  // the k-th neighbour of s is the pair's middle vertex
-        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t k = k0 + lane, kc = min(k, sr.ds - 1u);  // (sr.ds >= 1 for a start vertex with paths)
+        // read once, never again: non-temporal (same-process A/B at config 3: 3.085 -> 3.036 ms; the RECORD loads must
+        // stay cached -- a pair's header and first records share lines across load instructions: 4.02 -> 4.37 ms)
+        const u32x4 pw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&pairs[sr.e0 + kc]));  // one 16-byte load
+        const uint32_t bq = __builtin_nontemporal_load(&P.nbrs[sr.a_s + kc]);  // the k-th neighbour of s is the pair's middle vertex
+        const bool in = k < sr.ds;
+        pr.block = in ? pw.x : 0u;
+        pr.cnt = in ? pw.y : 0u;
+        pr.G = in ? (((uint64_t)pw.w << 32) | pw.z) : 0ull;
+        bk = in ? bq : 0u;
     };
 
-    // a wave's start vertices: w, w + nw, ... (wave-uniform, so the start record arrives through the scalar cache)
-    for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); w < slab_len;
-         w += nw) {
-        const StartRec sr = srec[w];
+    // a wave's start vertices: w, w + nw, ... (wave-uniform, so the start record arrives through the scalar cache); the NEXT
+    // start's record is requested one start ahead
+    uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (w >= slab_len) return;
+    StartRec sr = srec[w];
+    for (; w < slab_len; w += nw) {
+        const StartRec sr_next = srec[min(w + nw, slab_len - 1u)];
         RankedPair pr;
         uint32_t bk;
         if (sr.end != sr.base && sr.base < P.end && sr.end > P.begin) {
             const uint32_t s = sr.s, ds = sr.ds, thr = P.slab_begin + w;
-            if (want_pde && lane < (unsigned)E) svs[lane] = P.vde[(uint64_t)s * E + lane];
+            // vde[s] and the first strip's pairs are in flight together (the LDS copy of vde[s] used to wait for its load
+            // BEFORE the pair loads were issued: one more round trip per start vertex)
+            double vs_val = 0.0;
+            if (want_pde) vs_val = P.vde[(uint64_t)s * E + min(lane, (unsigned)(E - 1))];
+            load_pairs(sr, 0, pr, bk);
+            if (want_pde && lane < (unsigned)E) svs[lane] = vs_val;
             uint64_t chunk_base = sr.base;  // output slot of the strip's first row
             for (uint32_t k0 = 0; k0 < ds; k0 += 64) {
-                load_pairs(sr, k0, pr, bk);
+                if (k0) load_pairs(sr, k0, pr, bk);
                 const uint32_t pcnt = pr.cnt & ~kHubFlag;
-                uint32_t incl = pcnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t t = __shfl_up(incl, off);
-                    if (lane >= (unsigned)off) incl += t;
-                }
+                const uint32_t incl = wave_scan_add(pcnt);  // DPP: no LDS round trips (six ds_bpermute before)
                 const uint32_t C = rl32(incl, 63);
                 const uint64_t hubs = __ballot((pr.cnt & kHubFlag) != 0);
                 cs[lane] = incl - pcnt;
@@ -566,56 +568,69 @@ __global__ __launch_bounds__(256, (E <= 2 ? 7 : 1)) void k_fill_ranked(FillParam
                         const uint32_t ke = 64u - (uint32_t)__clzll(m);  // m != 0: ke = kb + 1 always fits (<= 63 records)
                         const uint32_t hi = cs[ke];
                         {
-                            // a batch holds at most kBatch = 64 records: one record per lane.  The record and its pair's header
+                            // a batch holds at most kBatch records: kBatch / 64 per lane.  The records and their pairs' headers
                             // (vde[b], same line) are loaded as raw dwords by EVERY lane (idle lanes re-read the batch's last
-                            // record: no load under a lane mask) and pinned by an empty asm statement, so that both loads are
+                            // record: no load under a lane mask) and pinned by an empty asm statement, so that all loads are
                             // issued back to back -- hipcc otherwise sinks the payload load below the first use of the id
                             // word and the header load into its branch: three dependent round trips per batch instead of one
-                            static_assert(kBatch == 64, "one record per lane and batch");
-                            const uint32_t f = lo + lane, fc = min(f, hi - 1u);
-                            uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= fc
-                            while (bnd - a > 1) {
-                                const uint32_t mid = (a + bnd) >> 1;
-                                if (cs[mid] <= fc) a = mid; else bnd = mid;
-                            }
-                            const uint32_t ca = cs[a];
-                            const char *const base = recs + (uint64_t)sblk[a] * kRowAlign;
+                            constexpr int NB = kBatch / 64;
                             constexpr int RW = (int)(sizeof(Rec) / 4), VW = RW - 2 * E;
-                            const uint32_t *rq = reinterpret_cast<const uint32_t *>(base + 8 * E) + (uint64_t)(fc - ca) * RW;
-                            uint32_t rw[RW], hw[2 * E];
+                            uint32_t rw[NB][RW], hw[NB][2 * E], pa[NB], pca[NB];
 #pragma unroll
-                            for (int z = 0; z < RW; z++) rw[z] = rq[z];
-                            if (want_pde) {
-#pragma unroll
-                                for (int z = 0; z < 2 * E; z++) hw[z] = reinterpret_cast<const uint32_t *>(base)[z];
-                            }
-#pragma unroll
-                            for (int z = 0; z < RW; z++) asm volatile("" : "+v"(rw[z]));
-                            if (want_pde) {
-#pragma unroll
-                                for (int z = 0; z < 2 * E; z++) asm volatile("" : "+v"(hw[z]));
-                            }
-                            if (f < hi) {
-                                uint32_t id, ip;
-                                if constexpr (PACKED) {
-                                    id = rw[0] & ((1u << kPackedIdBits) - 1u);
-                                    ip = rw[0] >> kPackedIdBits;
-                                } else {
-                                    id = rw[0];
-                                    ip = rw[1];
+                            for (int p = 0; p < NB; p++) {
+                                const uint32_t fc = min(lo + lane + 64u * p, hi - 1u);
+                                uint32_t a = kb, bnd = ke;  // largest a in [kb, ke) with cs[a] <= fc
+                                while (bnd - a > 1) {
+                                    const uint32_t mid = (a + bnd) >> 1;
+                                    if (cs[mid] <= fc) a = mid; else bnd = mid;
                                 }
-                                const uint64_t below = sG[a] & ((1ull << ip) - 1ull);
-                                const uint32_t row = (ca - lo) + (uint32_t)__popcll(below);
-                                sid[row] = id;
-                                sa[row] = (uint8_t)a;
+                                const uint32_t ca = cs[a];
+                                pa[p] = a;
+                                pca[p] = ca;
+                                const char *const base = recs + (uint64_t)sblk[a] * kRowAlign;
+                                const uint32_t *rq = reinterpret_cast<const uint32_t *>(base + 8 * E) + (uint64_t)(fc - ca) * RW;
+#pragma unroll
+                                for (int z = 0; z < RW; z++) rw[p][z] = rq[z];
                                 if (want_pde) {
-                                    uint32_t *q = reinterpret_cast<uint32_t *>(sv + row * EP);
 #pragma unroll
-                                    for (int z = 0; z < 2 * E; z++) q[z] = rw[VW + z];
-                                    if (f == ca) {  // first record of the pair: its lane parks the header
-                                        uint32_t *qh = reinterpret_cast<uint32_t *>(svb + a * EP);
+                                    for (int z = 0; z < 2 * E; z++) hw[p][z] = reinterpret_cast<const uint32_t *>(base)[z];
+                                }
+                            }
 #pragma unroll
-                                        for (int z = 0; z < 2 * E; z++) qh[z] = hw[z];
+                            for (int p = 0; p < NB; p++) {
+#pragma unroll
+                                for (int z = 0; z < RW; z++) asm volatile("" : "+v"(rw[p][z]));
+                                if (want_pde) {
+#pragma unroll
+                                    for (int z = 0; z < 2 * E; z++) asm volatile("" : "+v"(hw[p][z]));
+                                }
+                            }
+#pragma unroll
+                            for (int p = 0; p < NB; p++) {
+                                const uint32_t f = lo + lane + 64u * p;
+                                if (f < hi) {
+                                    const uint32_t a = pa[p], ca = pca[p];
+                                    uint32_t id, ip;
+                                    if constexpr (PACKED) {
+                                        id = rw[p][0] & ((1u << kPackedIdBits) - 1u);
+                                        ip = rw[p][0] >> kPackedIdBits;
+                                    } else {
+                                        id = rw[p][0];
+                                        ip = rw[p][1];
+                                    }
+                                    const uint64_t below = sG[a] & ((1ull << ip) - 1ull);
+                                    const uint32_t row = (ca - lo) + (uint32_t)__popcll(below);
+                                    sid[row] = id;
+                                    sa[row] = (uint8_t)a;
+                                    if (want_pde) {
+                                        uint32_t *q = reinterpret_cast<uint32_t *>(sv + row * EP);
+#pragma unroll
+                                        for (int z = 0; z < 2 * E; z++) q[z] = rw[p][VW + z];
+                                        if (f == ca) {  // first record of the pair: its lane parks the header
+                                            uint32_t *qh = reinterpret_cast<uint32_t *>(svb + a * EP);
+#pragma unroll
+                                            for (int z = 0; z < 2 * E; z++) qh[z] = hw[p][z];
+                                        }
                                     }
                                 }
                             }
@@ -629,6 +644,7 @@ __global__ __launch_bounds__(256, (E <= 2 ? 7 : 1)) void k_fill_ranked(FillParam
                 chunk_base += C;
             }
         }
+        sr = sr_next;
     }
 }
 

@@ -53,33 +53,6 @@ __global__ void k_tile_first(uint64_t n_pairs, const uint64_t *__restrict__ eoff
     }
 }
 
-// wave-wide inclusive scans on DPP (row shifts inside rows of 16, then the two row broadcasts): no LDS crossbar, so the
-// six steps cost VALU issue only -- __shfl_up is ds_bpermute, one LDS round trip per step on the kernel's critical path
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_shift0(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);  // lanes without a source read 0
-}
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
-{
-    v += dpp_shift0<0x111, 0xF>(v);  // row_shr:1
-    v += dpp_shift0<0x112, 0xF>(v);  // row_shr:2
-    v += dpp_shift0<0x114, 0xF>(v);  // row_shr:4
-    v += dpp_shift0<0x118, 0xF>(v);  // row_shr:8
-    v += dpp_shift0<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_shift0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
-{
-    v = max(v, dpp_shift0<0x111, 0xF>(v));
-    v = max(v, dpp_shift0<0x112, 0xF>(v));
-    v = max(v, dpp_shift0<0x114, 0xF>(v));
-    v = max(v, dpp_shift0<0x118, 0xF>(v));
-    v = max(v, dpp_shift0<0x142, 0xA>(v));
-    v = max(v, dpp_shift0<0x143, 0xC>(v));
-    return v;
-}
-
 // One wave per output tile of TS = 64 KT rows.  SP = pairs per strip (one lane each); a tile whose pairs do not fit one
 // strip (runs of empty pairs behind high-ranked start vertices) takes several, flushing the rows of each.  A wave lives
 // for three dependent memory round trips and nothing else, so everything between them is kept off LDS round trips:
