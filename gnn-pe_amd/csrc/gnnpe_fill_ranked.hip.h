@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParam
                         const uint64_t m = __ballot(fits);
                         const uint32_t ke = 64u - (uint32_t)__clzll(m);  // m != 0: ke = kb + 1 always fits (<= 63 records)
                         const uint32_t hi = cs[ke];
-                        {
+                        if (hi > lo) {  // (wave-uniform; empty when the pairs in front of a hub pair hold no path)
                             // a batch holds at most kBatch records: kBatch / 64 per lane.  The records and their pairs' headers
                             // (vde[b], same line) are loaded as raw dwords by EVERY lane (idle lanes re-read the batch's last
                             // record: no load under a lane mask) and pinned by an empty asm statement, so that all loads are

@@ -556,3 +556,27 @@ def test_load_rejects_rows_the_kernels_cannot_handle(binding):
     eng.set_order(np.arange(4, dtype=np.uint32), lab, 1)
     assert eng.count_paths(2) == 1  # 1-0-2
     eng.close()
+
+
+def test_empty_pairs_in_front_of_a_hub_pair(binding, oracle):
+    """A start vertex whose first pair holds no path and whose second pair has a hub row (> 64 entries) as its middle vertex:
+    the start-vertex emit kernel's plain batch in front of the hub pair is EMPTY (round 4: its clamped record loads must not run
+    -- they indexed past the pair's block)."""
+    n_leaf = 69
+    x, a, s, h = 0, 1, 2, 3
+    eu = [x, a, s] + [h] * n_leaf
+    ev = [a, s, h] + list(range(4, 4 + n_leaf))
+    from gnnpe_amd import synth
+    n = 4 + n_leaf
+    offs, nbrs = synth._csr_from_edges(n, np.array(eu, np.int64), np.array(ev, np.int64))
+    assert offs[h + 1] - offs[h] == n_leaf + 1 > 64
+    g = dict(offsets=offs, nbrs=nbrs, labels=(np.arange(n) % 3).astype(np.uint32))
+    sn = np.array([x, s, a, h] + list(range(4, n)), np.uint32)  # rank[x] < rank[s]: the pair (s, a) keeps nothing
+    eng = _engine(binding, g, sn, np.zeros(n, np.uint32), 1, 2)
+    xx, nx, vde = eng.vde()
+    total = eng.count_paths(2)
+    ref = oracle.enumerate_closed(offs, nbrs, sn, 3)
+    assert total == len(ref) and [s, h, 4] in ref.tolist() and not any(r[0] == s and r[1] == a for r in ref.tolist())
+    ids, pde, _ = eng.fill_paths()
+    assert np.array_equal(ids, ref) and np.array_equal(pde, vde[ref].reshape(len(ref), 6))
+    eng.close()
