@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void k_rows_rank_multi(uint32_t n_held, const 
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const uint32_t q = d[k] ? st[k] + min(lane, d[k] - 1u) : 0u;
-        u[k] = nbrs[q];
+        const uint32_t uq = nbrs[q];
+        u[k] = d[k] ? uq : 0u;  // (a row without entries gathers vertex 0's record: entry 0 may not exist)
         rp[k] = revpos[q];
     }
     double vu[K][E], hb[K];
