@@ -897,6 +897,12 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         if (act) {
             const uint32_t r = (uint32_t)lane - e_pp + (uint32_t)(sw & 0xFFu);  // point inside the unit
             const char *const blk = recs + (uint64_t)e_blk * kUnitBytes;
+            // the block's header (vde[b] and, with AUX, b's {degree, label} word) is requested BEFORE the record: hipcc sinks a
+            // load to its first use, which put this one behind the wait for the record -- a fourth dependent round trip per leaf
+            constexpr int kHdrW = 2 * E + (int)(kXW / 4);
+            uint32_t hv[kHdrW];
+#pragma unroll
+            for (int z = 0; z < kHdrW; z++) hv[z] = reinterpret_cast<const uint32_t *>(blk)[z];
             double vc[E];
             uint32_t son;
             uint64_t wc = 0;  // {degree, label} of the entry's third vertex (AUX)
@@ -945,7 +951,11 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
                 son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(e_G & ((1ull << ip) - 1ull)));
             }
-            const double *vb = reinterpret_cast<const double *>(blk);
+#pragma unroll
+            for (int z = 0; z < kHdrW; z++) asm volatile("" : "+v"(hv[z]));  // (keeps the header load where it was issued)
+            double vb[E];
+#pragma unroll
+            for (int k = 0; k < E; k++) vb[k] = __longlong_as_double((long long)(((uint64_t)hv[2 * k + 1] << 32) | hv[2 * k]));
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
             for (int k = 0; k < D; k++) {
@@ -959,8 +969,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             }
             ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
             if constexpr (AUX) {
-                const uint32_t *hw = reinterpret_cast<const uint32_t *>(blk + 8 * E);
-                const uint64_t wb = ((uint64_t)hw[1] << 32) | hw[0];
+                const uint64_t wb = ((uint64_t)hv[2 * E + 1] << 32) | hv[2 * E];
                 dg[0] = e_ds;
                 dg[1] = (uint32_t)wb;
                 dg[2] = (uint32_t)wc;
