@@ -237,23 +237,33 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
                                                unsigned lane)
 {
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
-    if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
-        const uint32_t r = r_lo + lane;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 v;
-        v.x = s;
-        v.y = b;
-        v.z = kc[r];
-        v.w = kd[r];
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(P.out_ids) + (o0 + lane));
-    }
+    if (rows == 0) return;  // (wave-uniform; the clamped loads below index row rows - 1)
+    // Order matters on this hardware (one vmcnt counter for loads AND stores, completed in issue order): a load issued
+    // after a store cannot be waited for without waiting for that store's acknowledgement, and hipcc places a wait in front
+    // of each use of a loaded value -- with the uses between the stores that made every store pair wait for the stores
+    // before it (`global_store; s_waitcnt vmcnt(1); global_store`, round 3's binary).  So: ALL loads of the step first, by
+    // every lane (rows past the step's last re-read it: no load under a lane mask), pinned by an empty asm statement = one
+    // wait; then the id rows and the embedding rows, stores only.
+    auto store_ids = [&]() {
+        if (P.out_ids && lane < rows) {  // one 16-byte row per lane, consecutive lanes on consecutive rows
+            const uint32_t r = r_lo + lane;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v;
+            v.x = s;
+            v.y = b;
+            v.z = kc[r];
+            v.w = kd[r];
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(P.out_ids) + (o0 + lane));
+        }
+    };
+    if (!P.out_pde || !(E == 2 || E == 4 || E == 8)) store_ids();
     if (P.out_pde) {
         // rows are D = 4e doubles: always an even count, and o0 * D * 8 is a multiple of 16 bytes
         dbl2 *dst = reinterpret_cast<dbl2 *>(P.out_pde + o0 * D);
         if constexpr (E == 4 || E == 8) {
             // half a row (s | b, then c | d) is 2H pieces: the wave takes 64 / 2H rows per pass, every lane one piece of the
-            // c | d half -- ALL of the step's loads first (2H per lane), then the stores: the lane's fixed piece into the
-            // first half of its rows, the loaded pieces into the second (e = 8: 128-byte halves, whole lines per store)
+            // c | d half: the lane's fixed piece goes into the first half of its rows, the loaded pieces into the second
+            // (e = 8: 128-byte halves, whole lines per store)
             constexpr uint32_t H = E / 2, HP = 2 * H, RP = 64 / HP;
             const uint32_t piece = lane % HP, rsub = lane / HP, cp = piece % H;
             const bool is_d = piece >= H;
@@ -261,10 +271,13 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
             dbl2 v[HP];
 #pragma unroll
             for (uint32_t j = 0; j < HP; j++) {
-                const uint32_t r = j * RP + rsub;
-                v[j] = fixed;
-                if (r < rows) v[j] = is_d ? nv2[(uint64_t)kp[r_lo + r] * H + cp] : vde2[(uint64_t)kc[r_lo + r] * H + cp];
+                const uint32_t rc = r_lo + min(j * RP + rsub, rows - 1u);
+                const dbl2 *src = is_d ? nv2 + (uint64_t)kp[rc] * H + cp : vde2 + (uint64_t)kc[rc] * H + cp;
+                v[j] = *src;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < HP; j++) asm volatile("" : "+v"(v[j]));
+            store_ids();
 #pragma unroll
             for (uint32_t j = 0; j < HP; j++) {
                 const uint32_t r = j * RP + rsub;
@@ -280,10 +293,14 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
             dbl2 v[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t r = j * 16 + rsub;
-                v[j] = fixed;
-                if (col >= 2 && r < rows) v[j] = col == 2 ? vde2[kc[r_lo + r]] : nv2[kp[r_lo + r]];
+                const uint32_t rc = r_lo + min(j * 16 + rsub, rows - 1u);
+                const dbl2 *src = col == 3 ? nv2 + kp[rc] : vde2 + kc[rc];  // (columns 0 and 1 load too and keep `fixed`)
+                const dbl2 got = *src;
+                v[j] = col >= 2 ? got : fixed;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) asm volatile("" : "+v"(v[j]));
+            store_ids();
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
                 const uint32_t r = j * 16 + rsub;
