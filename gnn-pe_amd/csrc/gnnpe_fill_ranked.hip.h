@@ -191,6 +191,14 @@ __global__ __launch_bounds__(256) void k_rows_rank_multi(uint32_t n_held, const 
         rw[k] = reinterpret_cast<const uint64_t *>(vi)[E];
         hb[k] = vinfo[(uint64_t)b[k] * S + min(lane, (unsigned)(E - 1))];  // header: vde of the row's vertex
     }
+    // every gathered value is waited for HERE, once: hipcc otherwise waits in front of each row's first use, between the
+    // stores of the rows before it -- and with one counter for loads and stores that means waiting for those stores
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        asm volatile("" : "+v"(rw[k]), "+v"(hb[k]), "+v"(rp[k]));
+#pragma unroll
+        for (int j = 0; j < E; j++) asm volatile("" : "+v"(vu[k][j]));
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const uint32_t du = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[k]);

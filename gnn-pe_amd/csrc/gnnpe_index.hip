@@ -995,12 +995,22 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
             for (int k = 0; k < kRk; k++) rk[k] = dpp_max_pk_u16(rk[k]);
             if (lane == 63) {  // the reductions end in the last lane: ranks back to the table's doubles
+                // (all 2D table loads first, pinned, then the stores: a load -> store -> load chain waits for every store's
+                // acknowledgement before the next load's value can be used -- one counter for loads and stores)
+                double lo_v[D], hi_v[D];
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     const uint32_t word = rk[k];  // dword k holds {rank max, complemented rank max} of dimension k
                     const uint32_t hi_r = word & 0xFFFFu, lo_r = (~(word >> 16)) & 0xFFFFu;
-                    ambr[(j * D + k) * 2] = xsorted[(uint64_t)(k % E) * n_labels + lo_r];
-                    ambr[(j * D + k) * 2 + 1] = xsorted[(uint64_t)(k % E) * n_labels + hi_r];
+                    lo_v[k] = xsorted[(uint64_t)(k % E) * n_labels + lo_r];
+                    hi_v[k] = xsorted[(uint64_t)(k % E) * n_labels + hi_r];
+                }
+#pragma unroll
+                for (int k = 0; k < D; k++) asm volatile("" : "+v"(lo_v[k]), "+v"(hi_v[k]));
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    ambr[(j * D + k) * 2] = lo_v[k];
+                    ambr[(j * D + k) * 2 + 1] = hi_v[k];
                 }
 #pragma unroll
                 for (int q = 0; q < 3; q++) adeg[j * 3 + q] = dg[q];
