@@ -43,11 +43,23 @@ __device__ __forceinline__ void aux_fail(uint32_t *err, uint32_t code, uint32_t 
 
 // {degree, label} of every vertex side by side: one 8-byte gather per path vertex instead of two 4-byte ones (the leaf
 // level issues 1.2e9 of them at config 3 and is bound by their number)
+// vmax[0..1]: the largest degree and the largest label (the pair-major build packs both into a record's id bits when they fit)
 __global__ void k_aux_pack_vertex(uint32_t n, const uint32_t *__restrict__ degree, const uint32_t *__restrict__ labels,
-                                  uint64_t *__restrict__ vdl)
+                                  uint64_t *__restrict__ vdl, uint32_t *__restrict__ vmax)
 {
-    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x)
-        vdl[v] = (uint64_t)degree[v] | ((uint64_t)labels[v] << 32);
+    uint32_t md = 0, ml = 0;
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = degree[v], lab = labels[v];
+        vdl[v] = (uint64_t)d | ((uint64_t)lab << 32);
+        md = max(md, d);
+        ml = max(ml, lab);
+    }
+    md = dpp_max_u32(md);
+    ml = dpp_max_u32(ml);
+    if ((threadIdx.x & 63u) == 63u) {  // the reductions end in the last lane
+        atomicMax(vmax, md);
+        atomicMax(vmax + 1, ml);
+    }
 }
 
 // The leaf level for any path length and embedding width, one wave per node block: entry -> son = index of a path of the
@@ -317,11 +329,13 @@ int ensure_vertex_words(gnnpe_ctx *c)
     GNNPE_REQUIRE(c->rows_identity || c->have_deg_all, GNNPE_ERR_UNSUPPORTED,
                   "the auxiliary index needs every vertex' degree: load the whole graph (gnnpe_load_csr) or call gnnpe_set_degrees");
     int rc;
-    if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8))) return rc;
+    if ((rc = c->aux_vdl.reserve(((size_t)c->n + 1) * 8 + 8))) return rc;
     const uint32_t *deg = c->have_deg_all ? c->deg_all.as<uint32_t>() : c->adj_deg.as<uint32_t>();
+    uint32_t *vmax = reinterpret_cast<uint32_t *>(c->aux_vdl.as<uint64_t>() + c->n);  // {largest degree, largest label} behind the table
+    GNNPE_HIP_TRY(hipMemsetAsync(vmax, 0, 8, c->stream));
     if (c->n)
         hipLaunchKernelGGL(k_aux_pack_vertex, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, deg, c->labels.as<uint32_t>(),
-                           c->aux_vdl.as<uint64_t>());
+                           c->aux_vdl.as<uint64_t>(), vmax);
     GNNPE_HIP_TRY(hipGetLastError());
     return GNNPE_OK;
 }

@@ -124,6 +124,8 @@ struct gnnpe_ctx {
     bool px_valid = false;  // R6 scratch + the assembled index.dat image
     gnnpe::DevBuf px_raux;  // {degree, label} strips beside the row blocks (k_px_raux), valid for one count like the pair order
     bool px_raux_valid = false;
+    bool px_raux_compact = false;  // the word rides in the records' id bits (degree | label << px_raux_dbits)
+    uint32_t px_raux_dbits = 0;
     // the pair-major leaf kernel stores used prefixes only: which buffer's block tails are known to be zero, and from which byte
     const void *img_scrub_ptr = nullptr;
     size_t img_scrub_bytes = 0;

@@ -717,14 +717,18 @@ __global__ void k_px_leaf_first(uint64_t n_leaves, uint32_t F, uint64_t r0, uint
 // The row blocks once more, with every vertex' {degree, label} word inside the lines the leaf kernel reads anyway (round 4;
 // round 3 kept the words in strips of their own beside the blocks: one more line per pair, 2.5 ms on a 5.1 ms kernel).
 // Aux block of the row at unit `blk` = kAuxScale units from unit kAuxScale * blk: header {vde[b], word of b}, then per record
-// the record itself followed by the word of its vertex -- it always fits: 8E + 8 + d (R + 8) <= 2 (8E + d R) for R >= 8.
+//   COMPACT  the record with its vertex ID REPLACED by the word degree | label << dbits (the leaf kernel never needs the id of
+//            the third vertex: the path's index comes from the id-POSITION, which stays): records keep their size, so the
+//            auxiliary rows cost the leaves no line at all.  Needs dbits + bits(label) <= kPackedIdBits (build_raux).
+//   else     the record itself followed by the 8-byte word -- it always fits: 8E + 8 + d (R + 8) <= 2 (8E + d R) for R >= 8;
+//            records of 28 instead of 20 bytes: one more line per pair on average (+1.9 ms at config 3).
 // One wave per held row, once per count (the record order is the count's): 2m gathers from an n x 8 byte table.
 constexpr uint32_t kAuxScale = 2;
-template <int E, bool PACKED>
+template <int E, bool PACKED, bool COMPACT>
 __global__ __launch_bounds__(256) void k_px_aux_blocks(uint32_t n_held, const uint32_t *__restrict__ held,
                                                        const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rblock,
                                                        const char *__restrict__ recs, const uint64_t *__restrict__ vdl,
-                                                       char *__restrict__ aux)
+                                                       uint32_t dbits, char *__restrict__ aux)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     const unsigned lane = threadIdx.x & 63u;
@@ -743,16 +747,24 @@ __global__ __launch_bounds__(256) void k_px_aux_blocks(uint32_t n_held, const ui
             reinterpret_cast<uint32_t *>(dst + 8 * E)[0] = (uint32_t)wv;
             reinterpret_cast<uint32_t *>(dst + 8 * E)[1] = (uint32_t)(wv >> 32);
         }
+        const bool wide = d > kHubDegree || !PACKED;
         const uint32_t rw = d > kHubDegree ? (uint32_t)(sizeof(RecWide<E>) / 4) : (uint32_t)(sizeof(Rec) / 4);  // dwords per record
+        const uint32_t ow = COMPACT ? rw : rw + 2;
         for (uint32_t r = lane; r < d; r += 64) {
             const uint32_t *q = reinterpret_cast<const uint32_t *>(src + 8 * E) + (uint64_t)r * rw;
-            uint32_t *o = reinterpret_cast<uint32_t *>(dst + 8 * E + 8) + (uint64_t)r * (rw + 2);
+            uint32_t *o = reinterpret_cast<uint32_t *>(dst + 8 * E + 8) + (uint64_t)r * ow;
             const uint32_t first = q[0];
-            const uint32_t id = (d > kHubDegree || !PACKED) ? first : (first & ((1u << kPackedIdBits) - 1u));
+            const uint32_t id = wide ? first : (first & ((1u << kPackedIdBits) - 1u));
             const uint64_t wv = vdl[id];
-            for (uint32_t z = 0; z < rw; z++) o[z] = q[z];
-            o[rw] = (uint32_t)wv;
-            o[rw + 1] = (uint32_t)(wv >> 32);
+            if constexpr (COMPACT) {
+                const uint32_t cw = (uint32_t)wv | ((uint32_t)(wv >> 32) << dbits);
+                o[0] = wide ? cw : (cw | (first & ~((1u << kPackedIdBits) - 1u)));
+                for (uint32_t z = 1; z < rw; z++) o[z] = q[z];
+            } else {
+                for (uint32_t z = 0; z < rw; z++) o[z] = q[z];
+                o[rw] = (uint32_t)wv;
+                o[rw + 1] = (uint32_t)(wv >> 32);
+            }
         }
     }
 }
@@ -777,7 +789,7 @@ __global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint3
 // the label features from the label table, the L + 2D reductions run side by side on DPP -- what round 2 computed in a
 // second pass that re-read the whole image and gathered every path's tuple (7.6 ms at config 3).
 // Stores: a leaf's used prefix only (kStoreU4 16-byte pieces); the image's tails are zeroed once per buffer (k_scrub_tails).
-template <int E, bool PACKED, bool AUX>
+template <int E, bool PACKED, int AUX>  // AUX: 0 = image only; 1 = aux blocks with 8-byte words behind the records; 2 = compact
 __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint64_t r0, uint64_t r1,
                                                                         const uint64_t *__restrict__ pref,
                                                                         const uint32_t *__restrict__ first,
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                                                                         const char *__restrict__ recs_aux,
                                                                         const uint16_t *__restrict__ xrank,
                                                                         const double *__restrict__ xsorted, uint32_t n_labels,
-                                                                        uint32_t xrank_lds, char *__restrict__ image,
+                                                                        uint32_t xrank_lds, uint32_t dbits, char *__restrict__ image,
                                                                         double *__restrict__ node_mbr, uint32_t *__restrict__ adeg,
                                                                         double *__restrict__ ambr)
 {
@@ -800,18 +812,21 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     __shared__ uint8_t s_pp[kLeafWaves][kStrip];
     // the label table by rank (gen_vde_x rows, custom.h:492-511; gnnpe_common.h: xrank / xsorted) for the leaves' label MBR:
     // the 16-bit ranks in LDS when the table is small (xrank_lds entries; 64 labels x e = 2: 256 bytes), global otherwise
-    extern __shared__ uint16_t s_xrank[];
+    // (round 4: and the table's doubles by rank, xsorted, in front of them -- the aux epilogue's 2D lookups were global loads
+    // between the leaf's last record and its stores: one more dependent round trip in a wave that lives for three)
+    extern __shared__ __attribute__((aligned(8))) unsigned char s_dyn[];
+    double *const s_xsorted = reinterpret_cast<double *>(s_dyn);
+    uint16_t *const s_xrank = reinterpret_cast<uint16_t *>(s_dyn + (size_t)xrank_lds * 8);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // with the auxiliary index the records come from the aux blocks (k_px_aux_blocks): header and every record carry the
     // {degree, label} word of their vertex behind them
-    constexpr uint32_t kXW = AUX ? 8u : 0u;                        // bytes of that word
+    // (AUX = 2: the record's id bits ARE the word, k_px_aux_blocks<.., COMPACT>: records as long as the plain ones)
+    constexpr uint32_t kHX = AUX ? 8u : 0u;       // bytes of b's word behind the header
+    constexpr uint32_t kXW = AUX == 1 ? 8u : 0u;  // bytes of the word behind every record
     constexpr uint32_t kUnitBytes = AUX ? kAuxScale * kRowAlign : kRowAlign;
     const char *const recs = AUX ? recs_aux : recs_plain;
-    if (AUX && xrank_lds) {
-        for (uint32_t i = threadIdx.x; i < xrank_lds; i += 64 * kLeafWaves) s_xrank[i] = xrank[i];
-        __syncthreads();
-    }
     const uint16_t *const xr = (AUX && xrank_lds) ? s_xrank : xrank;
+    const double *const xs = (AUX && xrank_lds) ? s_xsorted : xsorted;
     uint32_t *w = s_win[wv];
     const uint64_t pbase = pref[r0];
     // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
@@ -826,22 +841,35 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // 16 384 leaves on, to leave them in the L2 -- cost 0.5 ms at every distance (scripts/index_ab.py: 5.95 -> 6.43-6.53 ms per
     // further partition): the kernel is short of request slots, not of patience.
     const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
-    if (j < n_leaves) {
-        const uint64_t g0 = j * F;
-        const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - g0);
+    const bool have_leaf = j < n_leaves;  // (wave-uniform; false only in the last workgroup)
+    const uint64_t g0 = j * F;
+    const uint32_t ne = have_leaf ? (uint32_t)min((uint64_t)F, n_pts - g0) : 0u;
+    uint64_t rel_cur = ~0ull;
+    PairXE<E> x_cur;
+    x_cur.block = x_cur.cnt = x_cur.ds = x_cur.ls = 0;
+    x_cur.G = x_cur.son0 = 0;
+#pragma unroll
+    for (int k = 0; k < E; k++) x_cur.vs[k] = 0.0;
+    if (have_leaf) {
         // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
         const uint64_t f_end = j + 1 < n_leaves ? (uint64_t)first[j + 1] : r1;
         const uint64_t kk = (uint64_t)first[j] + lane;
-        uint64_t rel_cur = ~0ull;
-        PairXE<E> x_cur;
-        x_cur.block = x_cur.cnt = x_cur.ds = x_cur.ls = 0;
-        x_cur.G = x_cur.son0 = 0;
-#pragma unroll
-        for (int k = 0; k < E; k++) x_cur.vs[k] = 0.0;
         if (kk < r1 && kk <= f_end) {
             rel_cur = pref[kk] - pbase;
             x_cur = px[kk];
         }
+    }
+    // the label tables go into LDS BEHIND the pairs' loads (round 4): filled and fenced by a workgroup barrier at the kernel's
+    // start they were a round trip of their own in front of everything (the auxiliary rows cost 2.0 ms on a 5.8 ms kernel, the
+    // same with and without their extra line per pair); here their wait is the wait for the pairs
+    if (AUX && xrank_lds) {
+        for (uint32_t i = threadIdx.x; i < xrank_lds; i += 64 * kLeafWaves) {
+            s_xrank[i] = xrank[i];
+            s_xsorted[i] = xsorted[i];
+        }
+        __syncthreads();
+    }
+    if (have_leaf) {
         // this lane's pair as the entry lanes will ask for it
         uint32_t pp = 0xFFu;
         uint32_t p_first = 0;
@@ -899,7 +927,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             const char *const blk = recs + (uint64_t)e_blk * kUnitBytes;
             // the block's header (vde[b] and, with AUX, b's {degree, label} word) is requested BEFORE the record: hipcc sinks a
             // load to its first use, which put this one behind the wait for the record -- a fourth dependent round trip per leaf
-            constexpr int kHdrW = 2 * E + (int)(kXW / 4);
+            constexpr int kHdrW = 2 * E + (int)(kHX / 4);
             uint32_t hv[kHdrW];
 #pragma unroll
             for (int z = 0; z < kHdrW; z++) hv[z] = reinterpret_cast<const uint32_t *>(blk)[z];
@@ -923,12 +951,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 RecWide<E> rec;
                 {
                     constexpr int RWd = (int)(sizeof(RecWide<E>) / 4);
-                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kXW) + (uint64_t)rec_at * (RWd + kXW / 4);
+                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)rec_at * (RWd + kXW / 4);
                     uint32_t wq[RWd + 2];
 #pragma unroll
                     for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = rq[z];
                     __builtin_memcpy(&rec, wq, sizeof(rec));
-                    if constexpr (AUX) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
+                    if constexpr (AUX == 1) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
+                    if constexpr (AUX == 2) wc = (uint64_t)(wq[0] & ((1u << dbits) - 1u)) | ((uint64_t)(wq[0] >> dbits) << 32);
                 }
 #pragma unroll
                 for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
@@ -938,12 +967,16 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 Rec rec;
                 {
                     constexpr int RWd = (int)(sizeof(Rec) / 4);
-                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kXW) + (uint64_t)r * (RWd + kXW / 4);
+                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)r * (RWd + kXW / 4);
                     uint32_t wq[RWd + 2];
 #pragma unroll
                     for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);  // (dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower, 5.43 -> 5.69 ms)
                     __builtin_memcpy(&rec, wq, sizeof(Rec));
-                    if constexpr (AUX) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
+                    if constexpr (AUX == 1) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
+                    if constexpr (AUX == 2) {
+                        const uint32_t cw = PACKED ? (wq[0] & ((1u << kPackedIdBits) - 1u)) : wq[0];
+                        wc = (uint64_t)(cw & ((1u << dbits) - 1u)) | ((uint64_t)(cw >> dbits) << 32);
+                    }
                 }
                 uint32_t ip;
                 if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
@@ -994,27 +1027,27 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             for (int q = 0; q < 3; q++) dg[q] = dpp_max_u32(dg[q]);
 #pragma unroll
             for (int k = 0; k < kRk; k++) rk[k] = dpp_max_pk_u16(rk[k]);
-            if (lane == 63) {  // the reductions end in the last lane: ranks back to the table's doubles
-                // (all 2D table loads first, pinned, then the stores: a load -> store -> load chain waits for every store's
-                // acknowledgement before the next load's value can be used -- one counter for loads and stores)
-                double lo_v[D], hi_v[D];
+            // The reductions end in the last lane.  Its values go out as ONE store per array, consecutive lanes on consecutive
+            // words (readlane + select): the last lane storing its 2D doubles and three degrees itself was 2D + 3 single-lane
+            // store instructions = 27 write requests per leaf beside the image's 62 -- the 2.0 ms the auxiliary rows cost a
+            // 5.8 ms kernel (round 4; not their extra line per pair: 28- and 20-byte records timed alike).
+            uint32_t word = 0, dgv = 0;
 #pragma unroll
-                for (int k = 0; k < D; k++) {
-                    const uint32_t word = rk[k];  // dword k holds {rank max, complemented rank max} of dimension k
-                    const uint32_t hi_r = word & 0xFFFFu, lo_r = (~(word >> 16)) & 0xFFFFu;
-                    lo_v[k] = xsorted[(uint64_t)(k % E) * n_labels + lo_r];
-                    hi_v[k] = xsorted[(uint64_t)(k % E) * n_labels + hi_r];
-                }
-#pragma unroll
-                for (int k = 0; k < D; k++) asm volatile("" : "+v"(lo_v[k]), "+v"(hi_v[k]));
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    ambr[(j * D + k) * 2] = lo_v[k];
-                    ambr[(j * D + k) * 2 + 1] = hi_v[k];
-                }
-#pragma unroll
-                for (int q = 0; q < 3; q++) adeg[j * 3 + q] = dg[q];
+            for (int k = 0; k < D; k++) {
+                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)rk[k], 63);  // {rank max, complemented rank max} of dimension k
+                if ((lane >> 1) == k) word = u;
             }
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)dg[q], 63);
+                if (lane == q) dgv = u;
+            }
+            static_assert(2 * D <= 64, "one lane per bound of the leaf's label MBR");
+            if (lane < 2 * D) {  // even lanes the lower bound, odd lanes the upper: ranks back to the table's doubles
+                const uint32_t r16 = (lane & 1) ? (word & 0xFFFFu) : ((~(word >> 16)) & 0xFFFFu);
+                ambr[j * (2 * D) + lane] = xs[(uint64_t)((lane >> 1) % E) * n_labels + r16];
+            }
+            if (lane < 3) adeg[j * 3 + lane] = dgv;
         }
         // node MBR for the parent level: kMbrParts lanes per dimension, each scanning every kMbrParts-th assembled entry,
         // then a butterfly over the dimension's lanes (one lane per dimension walking all entries was 0.6 of the
@@ -1035,9 +1068,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 lo = fmin(lo, __shfl_xor(lo, m));
                 hi = fmax(hi, __shfl_xor(hi, m));
             }
-            if (part == 0) {
-                node_mbr[(j * D + k) * 2] = lo;
-                node_mbr[(j * D + k) * 2 + 1] = hi;
+            if (part == 0) {  // {lo, hi}: one 16-byte store
+                typedef double dbl2v __attribute__((ext_vector_type(2)));
+                dbl2v lh = {lo, hi};
+                *reinterpret_cast<dbl2v *>(node_mbr + (j * D + k) * 2) = lh;
             }
         }
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1731,13 +1765,25 @@ template <int E> static int build_raux(gnnpe_ctx *c)
     if ((rc = c->px_raux.reserve((c->rblock_units + 1) * (uint64_t)kAuxScale * kRowAlign))) return rc;
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
+    // the largest degree and label decide the record form: both inside a record's id bits when they fit (once per count: one
+    // 8-byte copy and a stream synchronisation; GNNPE_AUX_WIDE=1 forces the 8-byte words for A/B runs and tests)
+    uint32_t vmax[2] = {0u, 0u};
+    GNNPE_HIP_TRY(hipMemcpyAsync(vmax, c->aux_vdl.as<uint64_t>() + c->n, 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t dbits = bits_for(vmax[0]), lbits = bits_for(vmax[1]);
+    const char *force_wide = getenv("GNNPE_AUX_WIDE");
+    c->px_raux_compact = dbits + lbits <= kPackedIdBits && dbits >= 1 && !(force_wide && atoi(force_wide));
+    c->px_raux_dbits = dbits;
     if (c->n_held) {
-        if (c->n <= (1u << kPackedIdBits))
-            hipLaunchKernelGGL((k_px_aux_blocks<E, true>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<char>());
-        else
-            hipLaunchKernelGGL((k_px_aux_blocks<E, false>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(),
-                               c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), c->px_raux.as<char>());
+#define GNNPE_AXB(PK, CP)                                                                                                  \
+    hipLaunchKernelGGL((k_px_aux_blocks<E, PK, CP>), grid, block, 0, c->stream, c->n_held, held, c->adj_deg.as<uint32_t>(), \
+                       c->rblock.as<uint32_t>(), c->rrecs.as<char>(), c->aux_vdl.as<uint64_t>(), dbits, c->px_raux.as<char>())
+        if (c->n <= (1u << kPackedIdBits)) {
+            if (c->px_raux_compact) GNNPE_AXB(true, true); else GNNPE_AXB(true, false);
+        } else {
+            if (c->px_raux_compact) GNNPE_AXB(false, true); else GNNPE_AXB(false, false);
+        }
+#undef GNNPE_AXB
     }
     GNNPE_HIP_TRY(hipGetLastError());
     c->px_raux_valid = true;
@@ -1827,19 +1873,22 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     const bool packed = c->n <= (1u << kPackedIdBits);
     GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
     const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
-    // the label ranks ride in LDS when they fit beside the windows without costing a wave of occupancy (<= 4 KB)
-    const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 2048) ? c->n_labels * e : 0u;
+    // the label tables (16-bit ranks and the doubles by rank: 10 bytes per entry) ride in LDS when they fit beside the windows
+    // without costing a wave of occupancy (eight workgroups of 15 904 + 4 480 bytes fill a CU's 160 KB)
+    const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 448) ? c->n_labels * e : 0u;
 #define GNNPE_PXL(EE, PK, AX)                                                                                           \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 2, c->stream, cnt, nl, r0, r1, \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10, c->stream, cnt, nl, r0, r1, \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
-                       c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds, image, \
-                       mbr_a, adeg, ambr)
+                       c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds,        \
+                       c->px_raux_dbits, image, mbr_a, adeg, ambr)
 #define GNNPE_PXE(EE)                                                           \
     do {                                                                        \
-        if (with_aux) {                                                         \
-            if (packed) GNNPE_PXL(EE, true, true); else GNNPE_PXL(EE, false, true);   \
+        if (with_aux && c->px_raux_compact) {                                   \
+            if (packed) GNNPE_PXL(EE, true, 2); else GNNPE_PXL(EE, false, 2);   \
+        } else if (with_aux) {                                                  \
+            if (packed) GNNPE_PXL(EE, true, 1); else GNNPE_PXL(EE, false, 1);   \
         } else {                                                                \
-            if (packed) GNNPE_PXL(EE, true, false); else GNNPE_PXL(EE, false, false); \
+            if (packed) GNNPE_PXL(EE, true, 0); else GNNPE_PXL(EE, false, 0);   \
         }                                                                       \
     } while (0)
     switch (e) {

@@ -264,13 +264,16 @@ def test_aux_index_of_a_large_partition_by_properties(oracle, source):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["compact", "wide"])
 @pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1)])
-def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, kind, e, p):
+def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, monkeypatch, kind, e, p, form):
     """gnnpe_build_index_partition_aux_device: the auxiliary index the pair-major LEAF KERNEL computes while it assembles
     the leaves (+ the upper levels) must equal, bit for bit, the generic pass over the finished image with the partition's
     tuples (gnnpe_aux_index_device) -- which the tests above pin to the reference's constructor.  Hub rows (power-law, Test/),
-    several partitions, every specialised embedding width."""
+    several partitions, every specialised embedding width; both forms of the aux row blocks (the {degree, label} word
+    inside a record's id bits -- the default wherever it fits -- and as 8 bytes behind every record)."""
     import torch
+    monkeypatch.setenv("GNNPE_AUX_WIDE", "1" if form == "wide" else "0")  # read once per count by build_raux
     if kind == "gnm":
         g = synth.gnm_graph(6000, 48000, n_labels=11, seed=5)
     elif kind == "powerlaw":
