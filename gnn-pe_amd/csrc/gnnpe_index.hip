@@ -789,7 +789,7 @@ __global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint3
 // the label features from the label table, the L + 2D reductions run side by side on DPP -- what round 2 computed in a
 // second pass that re-read the whole image and gathered every path's tuple (7.6 ms at config 3).
 // Stores: a leaf's used prefix only (kStoreU4 16-byte pieces); the image's tails are zeroed once per buffer (k_scrub_tails).
-template <int E, bool PACKED, int AUX>  // AUX: 0 = image only; 1 = aux blocks with 8-byte words behind the records; 2 = compact
+template <int E, bool PACKED, int AUX, int NL>  // AUX: 0 = image only; 1 = aux blocks with 8-byte words behind the records; 2 = compact
 __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint64_t r0, uint64_t r1,
                                                                         const uint64_t *__restrict__ pref,
                                                                         const uint32_t *__restrict__ first,
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     constexpr int kStrip = F + 1 < 64 ? (F + 1 + 7) / 8 * 8 : 64;
     constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;  // 16-byte pieces of a full leaf's used prefix
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
-    __shared__ uint8_t s_pp[kLeafWaves][kStrip];
+    __shared__ uint8_t s_pp[kLeafWaves][NL][kStrip];
     // the label table by rank (gen_vde_x rows, custom.h:492-511; gnnpe_common.h: xrank / xsorted) for the leaves' label MBR:
     // the 16-bit ranks in LDS when the table is small (xrank_lds entries; 64 labels x e = 2: 256 bytes), global otherwise
     // (round 4: and the table's doubles by rank, xsorted, in front of them -- the aux epilogue's 2D lookups were global loads
@@ -829,8 +829,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     const double *const xs = (AUX && xrank_lds) ? s_xsorted : xsorted;
     uint32_t *w = s_win[wv];
     const uint64_t pbase = pref[r0];
-    // One leaf per wave, no grid-stride loop: the leaves in flight are then one contiguous window of the image and of the
-    // sorted pairs, and the block scheduler balances the tail (round 2, scripts/index_ab.py: 2048 resident-sized blocks
+    // One leaf per wave (NL = 1), no grid-stride loop: the leaves in flight are then one contiguous window of the image and of
+    // the sorted pairs, and the block scheduler balances the tail (round 2, scripts/index_ab.py: 2048 resident-sized blocks
     // walking strided leaves 8.34 ms, 24576 blocks 7.42, one leaf per wave 7.11).
     // Round 3 tried the resident grid again WITH the next leaf's pairs and the bounds of the one after it fetched ahead (two of
     // a leaf's three dependent round trips hidden): 64 VGPRs with 7 spilled at 8 waves per SIMD, 6.2 ms against 5.1 -- in a loop
@@ -840,28 +840,67 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // Touching ahead -- every wave also loading a word of the pairs and of the row blocks' first lines of the leaf 2 048 ...
     // 16 384 leaves on, to leave them in the L2 -- cost 0.5 ms at every distance (scripts/index_ab.py: 5.95 -> 6.43-6.53 ms per
     // further partition): the kernel is short of request slots, not of patience.
-    const uint64_t j = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv));
-    const bool have_leaf = j < n_leaves;  // (wave-uniform; false only in the last workgroup)
-    const uint64_t g0 = j * F;
-    const uint32_t ne = have_leaf ? (uint32_t)min((uint64_t)F, n_pts - g0) : 0u;
-    uint64_t rel_cur = ~0ull;
-    PairXE<E> x_cur;
-    x_cur.block = x_cur.cnt = x_cur.ds = x_cur.ls = 0;
-    x_cur.G = x_cur.son0 = 0;
+    // NL = 2 (round 4, measured and NOT used): a wave takes TWO consecutive leaves and walks their three round trips side by
+    // side -- both leaves' bounds, then both leaves' pairs, then both leaves' records, every load of both before the first
+    // store of either (checked in the ISA) -- and assembles them one after the other in the same LDS window: twice the useful
+    // requests in flight per wave at the hardware's eight waves per SIMD.  Same process, same buffers (scripts/
+    // index_aux_ab.py): image 5.27-5.29 ms against 5.17-5.18 with one leaf per wave, with the auxiliary rows 6.57 against
+    // 6.39.  So the kernel does not wait for latency at eight waves per SIMD: it moves the lines it touches (29.6 GB by the
+    // counters) at 5.7 TB/s, above what a plain 71 % write / 29 % read stream reaches on these boxes (4.9-5.2 TB/s).
+    const uint64_t jw = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv)) * NL;
+    bool have_leaf[NL];
+    uint64_t g0[NL], rel_cur[NL];
+    uint32_t ne[NL];
+    PairXE<E> x_cur[NL];
+    // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
+    uint32_t fj[NL + 1];
 #pragma unroll
-    for (int k = 0; k < E; k++) x_cur.vs[k] = 0.0;
-    if (have_leaf) {
-        // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
-        const uint64_t f_end = j + 1 < n_leaves ? (uint64_t)first[j + 1] : r1;
-        const uint64_t kk = (uint64_t)first[j] + lane;
-        if (kk < r1 && kk <= f_end) {
-            rel_cur = pref[kk] - pbase;
-            x_cur = px[kk];
-        }
+    for (int q = 0; q <= NL; q++) fj[q] = jw + q < n_leaves ? first[jw + q] : (uint32_t)r1;
+    // (no load under a lane mask, and both leaves' loads issued before either's values are touched -- hipcc had put leaf 0's
+    // `pref - pbase` in front of leaf 1's loads: a lane without a pair of its own asks for the leaf's first pair again, the
+    // very address lane 0 asks for)
+    bool have_pair[NL];
+    constexpr int kPxW = (int)(sizeof(PairXE<E>) / 4);
+    uint32_t xw[NL][kPxW];
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+        const uint64_t j = jw + q;
+        have_leaf[q] = j < n_leaves;  // (wave-uniform; false only in the last workgroup)
+        g0[q] = j * F;
+        ne[q] = have_leaf[q] ? (uint32_t)min((uint64_t)F, n_pts - g0[q]) : 0u;
+        const uint64_t f_end = (uint64_t)fj[q + 1];
+        const uint64_t kk = (uint64_t)fj[q] + lane;
+        have_pair[q] = have_leaf[q] && kk < r1 && kk <= f_end;
+        const uint64_t kc = have_pair[q] ? kk : (have_leaf[q] ? (uint64_t)fj[q] : r0);
+        rel_cur[q] = pref[kc];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(px + kc);
+#pragma unroll
+        for (int z = 0; z < kPxW; z++) xw[q][z] = src[z];
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+        asm volatile("" : "+v"(rel_cur[q]));
+#pragma unroll
+        for (int z = 0; z < kPxW; z++) asm volatile("" : "+v"(xw[q][z]));
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+        rel_cur[q] = have_pair[q] ? rel_cur[q] - pbase : ~0ull;
+#pragma unroll
+        for (int z = 0; z < kPxW; z++)
+            if (!have_pair[q]) xw[q][z] = 0u;
+        // PairXE<E>: {block, cnt, G, son0, ds, ls, vs[E]} (dwords 0, 1, 2-3, 4-5, 6, 7, 8 ...)
+        x_cur[q].block = xw[q][0];
+        x_cur[q].cnt = xw[q][1];
+        x_cur[q].G = ((uint64_t)xw[q][3] << 32) | xw[q][2];
+        x_cur[q].son0 = ((uint64_t)xw[q][5] << 32) | xw[q][4];
+        x_cur[q].ds = xw[q][6];
+        x_cur[q].ls = xw[q][7];
+#pragma unroll
+        for (int k = 0; k < E; k++) x_cur[q].vs[k] = __longlong_as_double((long long)(((uint64_t)xw[q][9 + 2 * k] << 32) | xw[q][8 + 2 * k]));
     }
     // the label tables go into LDS BEHIND the pairs' loads (round 4): filled and fenced by a workgroup barrier at the kernel's
-    // start they were a round trip of their own in front of everything (the auxiliary rows cost 2.0 ms on a 5.8 ms kernel, the
-    // same with and without their extra line per pair); here their wait is the wait for the pairs
+    // start they were a round trip of their own in front of everything; here their wait is the wait for the pairs
     if (AUX && xrank_lds) {
         for (uint32_t i = threadIdx.x; i < xrank_lds; i += 64 * kLeafWaves) {
             s_xrank[i] = xrank[i];
@@ -869,51 +908,113 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         }
         __syncthreads();
     }
-    if (have_leaf) {
+    // ---- per entry of either leaf: its pair (from the lane that holds it), then the loads of its row block's header and of
+    // its record -- issued for every leaf of the wave before any of them is used
+    constexpr int kHdrW = 2 * E + (int)(kHX / 4);
+    constexpr int RWd = (int)(sizeof(Rec) / 4), RWw = (int)(sizeof(RecWide<E>) / 4);
+    constexpr int kRecW = RWw + (int)(kXW / 4);  // dwords of the longest record (a hub unit's) with its word
+    uint32_t e_pp[NL], fh[NL], e_ds[NL], e_ls[NL], rr_[NL];
+    uint64_t e_G[NL], sw[NL];
+    double vs[NL][E];
+    uint32_t hv[NL][kHdrW], wq[NL][kRecW];
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
         // this lane's pair as the entry lanes will ask for it
         uint32_t pp = 0xFFu;
         uint32_t p_first = 0;
         uint64_t p_son = 0;
-        if (rel_cur < g0 + ne && lane < kStrip) {
-            pp = (uint32_t)(rel_cur >= g0 ? rel_cur - g0 : 0u);  // first entry of the pair inside this leaf
+        if (rel_cur[q] < g0[q] + ne[q] && lane < kStrip) {
+            pp = (uint32_t)(rel_cur[q] >= g0[q] ? rel_cur[q] - g0[q] : 0u);  // first entry of the pair inside this leaf
             // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
-            p_first = (x_cur.cnt & kUnitHub) ? ((uint32_t)(x_cur.son0 >> 32) | kUnitHub) : 0u;
+            p_first = (x_cur[q].cnt & kUnitHub) ? ((uint32_t)(x_cur[q].son0 >> 32) | kUnitHub) : 0u;
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
-            p_son = ((x_cur.son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur >= g0 ? 0u : (uint32_t)(g0 - rel_cur));
+            p_son = ((x_cur[q].son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur[q] >= g0[q] ? 0u : (uint32_t)(g0[q] - rel_cur[q]));
         }
-        if (lane < kStrip) s_pp[wv][lane] = (uint8_t)pp;
-        if (lane == 0) {
-            w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
-            w[1] = ne;
-        }
-        for (uint32_t i = 2 + ne * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero the window's tail
+        if (lane < kStrip) s_pp[wv][q][lane] = (uint8_t)pp;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool act = (uint32_t)lane < ne;
-        uint32_t a = 0;  // largest a with s_pp[a] <= lane (unused slots hold 0xFF)
-        if (act) {
+        // No load below sits under a lane mask (hipcc may wait for such a load where the lanes join, and a wait between the two
+        // leaves' loads is what this kernel must not have): an idle lane acts as entry 0 -- the very addresses lane 0 asks for
+        const uint32_t le = (uint32_t)lane < ne[q] ? (uint32_t)lane : 0u;
+        uint32_t a = 0;  // largest a with s_pp[a] <= le (unused slots hold 0xFF)
+        {
             uint32_t bnd = kStrip;
 #pragma unroll
             for (int it = 0; it < 6; it++) {
                 const uint32_t mid = (a + bnd) >> 1;
-                if ((uint32_t)s_pp[wv][mid] <= (uint32_t)lane) a = mid; else bnd = mid;
+                if ((uint32_t)s_pp[wv][q][mid] <= le) a = mid; else bnd = mid;
             }
         }
         // the pair's fields from lane a (wave-wide shuffles: every lane takes part, idle lanes read lane 0)
-        const uint32_t e_pp = (uint32_t)__shfl((int)pp, (int)a);
-        const uint32_t e_blk = (uint32_t)__shfl((int)x_cur.block, (int)a);
-        const uint32_t fh = (uint32_t)__shfl((int)p_first, (int)a);
-        const uint64_t e_G = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x_cur.G >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)x_cur.G, (int)a);
-        const uint64_t sw = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(p_son >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)p_son, (int)a);
-        double vs[E];
+        e_pp[q] = (uint32_t)__shfl((int)pp, (int)a);
+        const uint32_t e_blk = (uint32_t)__shfl((int)x_cur[q].block, (int)a);
+        fh[q] = (uint32_t)__shfl((int)p_first, (int)a);
+        e_G[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x_cur[q].G >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)x_cur[q].G, (int)a);
+        sw[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(p_son >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)p_son, (int)a);
 #pragma unroll
-        for (int k = 0; k < E; k++) vs[k] = __shfl(x_cur.vs[k], (int)a);
-        uint32_t e_ds = 0, e_ls = 0;
-        if constexpr (AUX) {
-            e_ds = (uint32_t)__shfl((int)x_cur.ds, (int)a);
-            e_ls = (uint32_t)__shfl((int)x_cur.ls, (int)a);
+        for (int k = 0; k < E; k++) vs[q][k] = __shfl(x_cur[q].vs[k], (int)a);
+        e_ds[q] = e_ls[q] = 0;
+        if constexpr (AUX != 0) {
+            e_ds[q] = (uint32_t)__shfl((int)x_cur[q].ds, (int)a);
+            e_ls[q] = (uint32_t)__shfl((int)x_cur[q].ls, (int)a);
         }
+        // (a wave's missing leaf: the first record of the buffer's first block)
+        const uint32_t r = have_leaf[q] ? le - e_pp[q] + (uint32_t)(sw[q] & 0xFFu) : 0u;  // point inside the unit
+        rr_[q] = r;
+        const char *const blk = recs + (uint64_t)(have_leaf[q] ? e_blk : 0u) * kUnitBytes;
+        // the block's header (vde[b] and, with AUX, b's {degree, label} word) is requested BEFORE the record: hipcc sinks a
+        // load to its first use, which put this one behind the wait for the record -- a fourth dependent round trip per leaf
+#pragma unroll
+        for (int z = 0; z < kHdrW; z++) hv[q][z] = reinterpret_cast<const uint32_t *>(blk)[z];
+        const bool hub = have_leaf[q] && (fh[q] & kUnitHub);
+        uint32_t rec_at = r;
+        if (hub) {
+            // hub unit: the r-th entry ranked after s = the r-th set bit of the mask; paths follow in id order
+            uint64_t m = e_G[q];
+            uint32_t rr = r, pos = 0;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) {
+                const uint32_t cbits = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
+                if (rr >= cbits) {
+                    rr -= cbits;
+                    m >>= sh;
+                    pos += sh;
+                }
+            }
+            rec_at = (fh[q] & ~kUnitHub) + pos;
+        }
+        // a hub row's records are wide ones {id, rank, vde}; read once by this leaf: non-temporal (round 2 A/B: 6.80 -> 6.63 ms
+        // per further partition).  Dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower.
+        const uint32_t stride = (hub ? (uint32_t)RWw : (uint32_t)RWd) + kXW / 4;
+        const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)rec_at * stride;
+#pragma unroll
+        for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[q][z] = __builtin_nontemporal_load(rq + z);
+        if constexpr (RWw > RWd) {  // (packed ids: a hub unit's record is one dword longer; a wave-uniform branch)
+            static_assert(RWw - RWd <= 1, "one dword more");
+            uint32_t extra = 0u;
+            if (__ballot(hub)) extra = rq[hub ? kRecW - 1 : 0];
+            wq[q][kRecW - 1] = extra;
+        }
+    }
+    // every load of the wave is in flight: ONE wait, in front of the first leaf's assembly
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+#pragma unroll
+        for (int z = 0; z < kHdrW; z++) asm volatile("" : "+v"(hv[q][z]));
+#pragma unroll
+        for (int z = 0; z < kRecW; z++) asm volatile("" : "+v"(wq[q][z]));
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+        if (!have_leaf[q]) continue;  // (wave-uniform)
+        const uint64_t j = jw + q;
+        const bool act = (uint32_t)lane < ne[q];
+        if (lane == 0) {
+            w[0] = 0u;  // level 0 = leaf (byte 3 of the window)
+            w[1] = ne[q];
+        }
+        for (uint32_t i = 2 + ne[q] * kEnt + lane; i < (uint32_t)kWin; i += 64) w[i] = 0u;  // zero the window's tail
         // per entry: degrees of its three vertices, and per dimension the rank of its label feature twice -- as it is (the
         // wave's max gives the MBR's upper bound) and complemented (max of the complement = the lower bound); idle lanes
         // hold zeros, the identity of max
@@ -923,76 +1024,37 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
         for (int k = 0; k < kRk; k++) rk[k] = 0u;
         if (act) {
-            const uint32_t r = (uint32_t)lane - e_pp + (uint32_t)(sw & 0xFFu);  // point inside the unit
-            const char *const blk = recs + (uint64_t)e_blk * kUnitBytes;
-            // the block's header (vde[b] and, with AUX, b's {degree, label} word) is requested BEFORE the record: hipcc sinks a
-            // load to its first use, which put this one behind the wait for the record -- a fourth dependent round trip per leaf
-            constexpr int kHdrW = 2 * E + (int)(kHX / 4);
-            uint32_t hv[kHdrW];
-#pragma unroll
-            for (int z = 0; z < kHdrW; z++) hv[z] = reinterpret_cast<const uint32_t *>(blk)[z];
+            const bool hub = (fh[q] & kUnitHub) != 0u;
             double vc[E];
             uint32_t son;
             uint64_t wc = 0;  // {degree, label} of the entry's third vertex (AUX)
-            if (fh & kUnitHub) {
-                // hub unit: the r-th entry ranked after s = the r-th set bit of the mask; paths follow in id order
-                uint64_t m = e_G;
-                uint32_t rr = r, pos = 0;
+            uint32_t first_dw = wq[q][0];
+            // (records decoded dword by dword, by selects -- an index that depends on the lane would put the array into scratch:
+            // wide {id, aux, vde}, packed {id | id-position << 26, vde} -- gnnpe_records.h)
+            constexpr int kV = PACKED ? 1 : 2;  // first dword of an ordinary record's vde (a hub unit's: 2)
 #pragma unroll
-                for (int sh = 32; sh > 0; sh >>= 1) {
-                    const uint32_t cbits = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
-                    if (rr >= cbits) {
-                        rr -= cbits;
-                        m >>= sh;
-                        pos += sh;
-                    }
-                }
-                const uint32_t rec_at = (fh & ~kUnitHub) + pos;
-                RecWide<E> rec;
-                {
-                    constexpr int RWd = (int)(sizeof(RecWide<E>) / 4);
-                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)rec_at * (RWd + kXW / 4);
-                    uint32_t wq[RWd + 2];
-#pragma unroll
-                    for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = rq[z];
-                    __builtin_memcpy(&rec, wq, sizeof(rec));
-                    if constexpr (AUX == 1) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
-                    if constexpr (AUX == 2) wc = (uint64_t)(wq[0] & ((1u << dbits) - 1u)) | ((uint64_t)(wq[0] >> dbits) << 32);
-                }
-#pragma unroll
-                for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
-                son = (uint32_t)(sw >> 8) + r;
-            } else {
-                // read once by this leaf: non-temporal (round 2 A/B: 6.80 -> 6.63 ms per further partition)
-                Rec rec;
-                {
-                    constexpr int RWd = (int)(sizeof(Rec) / 4);
-                    const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)r * (RWd + kXW / 4);
-                    uint32_t wq[RWd + 2];
-#pragma unroll
-                    for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[z] = __builtin_nontemporal_load(rq + z);  // (dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower, 5.43 -> 5.69 ms)
-                    __builtin_memcpy(&rec, wq, sizeof(Rec));
-                    if constexpr (AUX == 1) wc = ((uint64_t)wq[RWd + 1] << 32) | wq[RWd];
-                    if constexpr (AUX == 2) {
-                        const uint32_t cw = PACKED ? (wq[0] & ((1u << kPackedIdBits) - 1u)) : wq[0];
-                        wc = (uint64_t)(cw & ((1u << dbits) - 1u)) | ((uint64_t)(cw >> dbits) << 32);
-                    }
-                }
-                uint32_t ip;
-                if constexpr (PACKED) ip = rec.idp >> kPackedIdBits; else ip = rec.aux;
-#pragma unroll
-                for (int k = 0; k < E; k++) vc[k] = rec.vde[k];
-                son = (uint32_t)((sw >> 8) + (uint64_t)__popcll(e_G & ((1ull << ip) - 1ull)));
+            for (int k = 0; k < E; k++) {
+                const uint32_t lo32 = hub ? wq[q][2 + 2 * k] : wq[q][kV + 2 * k];
+                const uint32_t hi32 = hub ? wq[q][2 + 2 * k + 1] : wq[q][kV + 2 * k + 1];
+                vc[k] = __longlong_as_double((long long)(((uint64_t)hi32 << 32) | lo32));
             }
-#pragma unroll
-            for (int z = 0; z < kHdrW; z++) asm volatile("" : "+v"(hv[z]));  // (keeps the header load where it was issued)
+            if constexpr (AUX == 1) {
+                const uint32_t w0 = hub ? wq[q][RWw] : wq[q][RWd], w1 = hub ? wq[q][RWw + 1] : wq[q][RWd + 1];
+                wc = ((uint64_t)w1 << 32) | w0;
+            }
+            uint32_t ip;
+            if constexpr (PACKED) ip = first_dw >> kPackedIdBits; else ip = wq[q][1];
+            if (PACKED && !hub) first_dw &= (1u << kPackedIdBits) - 1u;
+            son = hub ? (uint32_t)(sw[q] >> 8) + rr_[q]
+                      : (uint32_t)((sw[q] >> 8) + (uint64_t)__popcll(e_G[q] & ((1ull << (ip & 63u)) - 1ull)));
+            if constexpr (AUX == 2) wc = (uint64_t)(first_dw & ((1u << dbits) - 1u)) | ((uint64_t)(first_dw >> dbits) << 32);
             double vb[E];
 #pragma unroll
-            for (int k = 0; k < E; k++) vb[k] = __longlong_as_double((long long)(((uint64_t)hv[2 * k + 1] << 32) | hv[2 * k]));
+            for (int k = 0; k < E; k++) vb[k] = __longlong_as_double((long long)(((uint64_t)hv[q][2 * k + 1] << 32) | hv[q][2 * k]));
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double val = k < E ? vs[k] : (k < 2 * E ? vb[k - E] : vc[k - 2 * E]);
+                const double val = k < E ? vs[q][k] : (k < 2 * E ? vb[k - E] : vc[k - 2 * E]);
                 const uint64_t bits64 = (uint64_t)__double_as_longlong(val);
                 const uint32_t x = (uint32_t)bits64, y = (uint32_t)(bits64 >> 32);
                 ent[4 * k] = x;      // bounces[2k]   (custom.h:246)
@@ -1001,12 +1063,12 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 ent[4 * k + 3] = y;
             }
             ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
-            if constexpr (AUX) {
-                const uint64_t wb = ((uint64_t)hv[2 * E + 1] << 32) | hv[2 * E];
-                dg[0] = e_ds;
+            if constexpr (AUX != 0) {
+                const uint64_t wb = ((uint64_t)hv[q][2 * E + 1] << 32) | hv[q][2 * E];
+                dg[0] = e_ds[q];
                 dg[1] = (uint32_t)wb;
                 dg[2] = (uint32_t)wc;
-                const uint32_t lab[3] = {e_ls, (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
+                const uint32_t lab[3] = {e_ls[q], (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
                 uint16_t h[2 * D + 1];
                 h[2 * D] = 0;
 #pragma unroll
@@ -1022,9 +1084,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if constexpr (AUX) {
+        if constexpr (AUX != 0) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) dg[q] = dpp_max_u32(dg[q]);
+            for (int t = 0; t < 3; t++) dg[t] = dpp_max_u32(dg[t]);
 #pragma unroll
             for (int k = 0; k < kRk; k++) rk[k] = dpp_max_pk_u16(rk[k]);
             // The reductions end in the last lane.  Its values go out as ONE store per array, consecutive lanes on consecutive
@@ -1038,9 +1100,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 if ((lane >> 1) == k) word = u;
             }
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)dg[q], 63);
-                if (lane == q) dgv = u;
+            for (int t = 0; t < 3; t++) {
+                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)dg[t], 63);
+                if (lane == t) dgv = u;
             }
             static_assert(2 * D <= 64, "one lane per bound of the leaf's label MBR");
             if (lane < 2 * D) {  // even lanes the lower bound, odd lanes the upper: ranks back to the table's doubles
@@ -1057,9 +1119,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         if (lane < D * kMbrParts) {
             const int k = lane / kMbrParts, part = lane % kMbrParts;
             double lo = 1e300, hi = -1e300;
-            for (uint32_t i = (uint32_t)part; i < ne; i += kMbrParts) {
-                const uint32_t *q = w + 2 + i * kEnt + 4 * k;
-                const double x = __longlong_as_double((long long)(((uint64_t)q[1] << 32) | q[0]));
+            for (uint32_t i = (uint32_t)part; i < ne[q]; i += kMbrParts) {
+                const uint32_t *e4 = w + 2 + i * kEnt + 4 * k;
+                const double x = __longlong_as_double((long long)(((uint64_t)e4[1] << 32) | e4[0]));
                 lo = fmin(lo, x);
                 hi = fmax(hi, x);
             }
@@ -1091,6 +1153,11 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 }
                 __builtin_nontemporal_store(o, dst + c);  // (one 16-byte store or four dword stores: the same time)
             }
+        }
+        if (q + 1 < NL) {  // the window is reused by the wave's next leaf
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }
@@ -1872,12 +1939,14 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
                        c->px_first.as<uint32_t>());
     const bool packed = c->n <= (1u << kPackedIdBits);
     GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
-    const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);  // one leaf per wave
+    // one leaf per wave (the kernel's NL = 2 form, two leaves per wave, is not instantiated: see its comment)
+    const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);
     // the label tables (16-bit ranks and the doubles by rank: 10 bytes per entry) ride in LDS when they fit beside the windows
     // without costing a wave of occupancy (eight workgroups of 15 904 + 4 480 bytes fill a CU's 160 KB)
     const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 448) ? c->n_labels * e : 0u;
-#define GNNPE_PXL(EE, PK, AX)                                                                                           \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10, c->stream, cnt, nl, r0, r1, \
+#define GNNPE_PXL(EE, PK, AX) GNNPE_PXN(EE, PK, AX, 1)
+#define GNNPE_PXN(EE, PK, AX, NN)                                                                                       \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX, NN>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10, c->stream, cnt, nl, r0, r1, \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
                        c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds,        \
                        c->px_raux_dbits, image, mbr_a, adeg, ambr)
@@ -1900,6 +1969,7 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     }
 #undef GNNPE_PXE
 #undef GNNPE_PXL
+#undef GNNPE_PXN
     GNNPE_HIP_TRY(hipGetLastError());
     // (with_aux: the upper levels' auxiliary rows and all keys come out of the same launches, bottom-up)
     if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b, 3, with_aux ? c->aux_key.as<double>() : nullptr, adeg, ambr))) return rc;
