@@ -1084,33 +1084,6 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if constexpr (AUX != 0) {
-#pragma unroll
-            for (int t = 0; t < 3; t++) dg[t] = dpp_max_u32(dg[t]);
-#pragma unroll
-            for (int k = 0; k < kRk; k++) rk[k] = dpp_max_pk_u16(rk[k]);
-            // The reductions end in the last lane.  Its values go out as ONE store per array, consecutive lanes on consecutive
-            // words (readlane + select): the last lane storing its 2D doubles and three degrees itself was 2D + 3 single-lane
-            // store instructions = 27 write requests per leaf beside the image's 62 -- the 2.0 ms the auxiliary rows cost a
-            // 5.8 ms kernel (round 4; not their extra line per pair: 28- and 20-byte records timed alike).
-            uint32_t word = 0, dgv = 0;
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)rk[k], 63);  // {rank max, complemented rank max} of dimension k
-                if ((lane >> 1) == k) word = u;
-            }
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)dg[t], 63);
-                if (lane == t) dgv = u;
-            }
-            static_assert(2 * D <= 64, "one lane per bound of the leaf's label MBR");
-            if (lane < 2 * D) {  // even lanes the lower bound, odd lanes the upper: ranks back to the table's doubles
-                const uint32_t r16 = (lane & 1) ? (word & 0xFFFFu) : ((~(word >> 16)) & 0xFFFFu);
-                ambr[j * (2 * D) + lane] = xs[(uint64_t)((lane >> 1) % E) * n_labels + r16];
-            }
-            if (lane < 3) adeg[j * 3 + lane] = dgv;
-        }
         // node MBR for the parent level: kMbrParts lanes per dimension, each scanning every kMbrParts-th assembled entry,
         // then a butterfly over the dimension's lanes (one lane per dimension walking all entries was 0.6 of the
         // kernel's time)
@@ -1153,6 +1126,64 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 }
                 __builtin_nontemporal_store(o, dst + c);  // (one 16-byte store or four dword stores: the same time)
             }
+        }
+        if constexpr (AUX != 0) {
+            // The leaf's auxiliary rows: maxima over its entries of D rank words and three degrees.  Through the LDS window,
+            // which is free once the image's stores have read it: every entry lane parks its D + 3 dwords, kParts lanes per
+            // column scan the entries, a DPP step or two joins the parts, and the results go out as ONE store per array,
+            // consecutive lanes on consecutive words.  (Until round 4: nine full-wave DPP reductions -- 160 VALU instructions
+            // and 90 cycles of DPP hazard nops in a kernel whose budget is ~600 VALU instructions per leaf at config 3: the
+            // kernel runs out of instruction issue as well as of requests, 536 VALU instructions with the auxiliary rows
+            // against 272 without -- and the last lane stored its 2D doubles and three degrees itself: 27 single-lane store
+            // instructions = 27 write requests per leaf beside the image's 62.)
+            constexpr int kCols = D + 3;
+            constexpr int kParts = kCols * 8 <= 64 ? 8 : kCols * 4 <= 64 ? 4 : kCols * 2 <= 64 ? 2 : 1;
+            static_assert(kCols * kParts <= 64 && kRk == D, "one lane group per column");
+            static_assert((F + 1) * kCols <= F * kEnt, "the parked columns fit the window's entry area");
+            uint32_t *sc = w + 2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the stores' reads of the window are done
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < D; k++) sc[lane * kCols + k] = rk[k];
+#pragma unroll
+                for (int t = 0; t < 3; t++) sc[lane * kCols + D + t] = dg[t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int col = lane / kParts, part = lane % kParts;
+            const bool ranks = col < D;  // packed 16-bit maxima; the degree columns are whole dwords
+            uint32_t red = 0;
+            if (col < kCols)
+                for (uint32_t i = (uint32_t)part; i < ne[q]; i += kParts) {
+                    const uint32_t v = sc[i * kCols + col];
+                    red = ranks ? pk_max_u16(red, v) : max(red, v);
+                }
+            if constexpr (kParts >= 2) {
+                const uint32_t o = dpp_u32_zero<0xB1, 0xF>(red);  // quad_perm [1,0,3,2]
+                red = ranks ? pk_max_u16(red, o) : max(red, o);
+            }
+            if constexpr (kParts >= 4) {
+                const uint32_t o = dpp_u32_zero<0x4E, 0xF>(red);  // quad_perm [2,3,0,1]
+                red = ranks ? pk_max_u16(red, o) : max(red, o);
+            }
+            if constexpr (kParts >= 8) {
+                const uint32_t o = dpp_u32_zero<0x141, 0xF>(red);  // row_half_mirror
+                red = ranks ? pk_max_u16(red, o) : max(red, o);
+            }
+            if (col < kCols && part == 0) sc[F * kCols + col] = red;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            static_assert(2 * D <= 64, "one lane per bound of the leaf's label MBR");
+            if (lane < 2 * D) {  // even lanes the lower bound, odd lanes the upper: ranks back to the table's doubles
+                const uint32_t word = sc[F * kCols + (lane >> 1)];  // {rank max, complemented rank max} of dimension lane / 2
+                const uint32_t r16 = (lane & 1) ? (word & 0xFFFFu) : ((~(word >> 16)) & 0xFFFFu);
+                ambr[j * (2 * D) + lane] = xs[(uint64_t)((lane >> 1) % E) * n_labels + r16];
+            }
+            if (lane < 3) adeg[j * 3 + lane] = sc[F * kCols + D + lane];
         }
         if (q + 1 < NL) {  // the window is reused by the wave's next leaf
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
