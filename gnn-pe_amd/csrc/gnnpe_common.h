@@ -193,7 +193,8 @@ struct gnnpe_ctx {
     uint32_t rblock_e = 0;
     gnnpe::DevBuf slab_bounds;  // gnnpe_vde_unpack_all: the ranks' slab bounds on the device
     gnnpe::DevBuf aux_upper;  // inner node blocks listed by the leaf-level launch of the auxiliary index pass
-    gnnpe::DevBuf aux_vdl;  // {degree, label} per vertex for the auxiliary index pass
+    gnnpe::DevBuf aux_vdl;  // {degree, label} per vertex for the auxiliary index pass (+ the largest degree and label behind it)
+    bool aux_vdl_valid = false;
     gnnpe::DevBuf aux_key, aux_deg, aux_mbr;  // auxiliary index of the last gnnpe_aux_index_device call (gnnpe_aux.hip)
     // which partition's image index_image holds (set by gnnpe_build_index_partition_device, cleared by the other builds)
     bool img_valid = false;

@@ -259,6 +259,7 @@ static void invalidate_derived(gnnpe_ctx *c)
     c->halo_min_rank = 0;  // called by the loaders only: a freshly loaded graph has no halo rows
     c->have_vde = false;
     c->have_deg_all = false;
+    c->aux_vdl_valid = false;
     c->have_pge = false;
     c->nbr_vde_valid = false;
     c->counted = false;

@@ -112,6 +112,7 @@ int gnnpe_set_degrees(gnnpe_ctx *c, const uint32_t *host_degrees)
     GNNPE_HIP_TRY(hipMemcpyAsync(c->deg_all.p, host_degrees, (size_t)c->n * 4, hipMemcpyHostToDevice, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_deg_all = true;
+    c->aux_vdl_valid = false;
     return GNNPE_OK;
 }
 

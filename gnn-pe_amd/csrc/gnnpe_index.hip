@@ -546,6 +546,13 @@ __global__ void k_px_pbase(uint32_t len, const uint32_t *__restrict__ sorted_par
     }
 }
 
+__global__ void k_px_pbase_single(uint32_t len, const StartRec *__restrict__ srec, uint64_t *__restrict__ pbase)
+{
+    const uint64_t b0 = srec[0].base;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
+        pbase[i] = srec[i].base - b0;
+}
+
 // Sorted items are UNITS: a pair whose middle row has at most 64 entries is one unit (its records are addressed through
 // G), a hub pair is cut into units of 64 consecutive entries of the id-ordered hub row, each with the 64-bit mask of the
 // entries ranked after s (the r-th path of the unit is the r-th set bit).  PairXE.cnt bit 31 marks a hub unit, whose
@@ -670,8 +677,11 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
         }
     }
 }
+// cnt32[i] = paths of sorted unit i (cnt32[ne] = 0): the prefix scan then reads 4 bytes per unit instead of striding over
+// the 48-byte records (0.26 -> 0.1 ms at config 3)
 template <int E>
-__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairXE<E> *__restrict__ px, PairXE<E> *__restrict__ out)
+__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairXE<E> *__restrict__ px, PairXE<E> *__restrict__ out,
+                             uint32_t *__restrict__ cnt32)
 {
     // one 16-byte piece per thread: consecutive lanes store consecutive pieces (a record per thread stored its three pieces
     // 48 bytes apart: 0.70 ms for 2.0e7 records at config 3)
@@ -679,8 +689,12 @@ __global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, co
     static_assert(sizeof(PairXE<E>) % 16 == 0, "pair records are whole 16-byte pieces");
     const uint4 *src = reinterpret_cast<const uint4 *>(px);
     uint4 *dst = reinterpret_cast<uint4 *>(out);
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < ne * PC; t += (uint64_t)gridDim.x * blockDim.x)
-        dst[t] = src[(uint64_t)order[t / PC] * PC + t % PC];
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < ne * PC; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = src[(uint64_t)order[t / PC] * PC + t % PC];
+        dst[t] = v;
+        if (t % PC == 0) cnt32[t / PC] = v.y & 0x7FFFFFFFu;  // {block, cnt, G}: the record's first piece
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt32[ne] = 0u;
 }
 template <int E> struct CntOfPairX {
     __host__ __device__ uint64_t operator()(const PairXE<E> &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
@@ -1047,7 +1061,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             if (PACKED && !hub) first_dw &= (1u << kPackedIdBits) - 1u;
             son = hub ? (uint32_t)(sw[q] >> 8) + rr_[q]
                       : (uint32_t)((sw[q] >> 8) + (uint64_t)__popcll(e_G[q] & ((1ull << (ip & 63u)) - 1ull)));
-            if constexpr (AUX == 2) wc = (uint64_t)(first_dw & ((1u << dbits) - 1u)) | ((uint64_t)(first_dw >> dbits) << 32);
+            if constexpr (AUX == 2) wc = (uint64_t)(first_dw & ((1u << (dbits & 31u)) - 1u)) | ((uint64_t)(first_dw >> (dbits & 31u)) << 32);
             double vb[E];
 #pragma unroll
             for (int k = 0; k < E; k++) vb[k] = __longlong_as_double((long long)(((uint64_t)hv[q][2 * k + 1] << 32) | hv[q][2 * k]));
@@ -1092,11 +1106,24 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         if (lane < D * kMbrParts) {
             const int k = lane / kMbrParts, part = lane % kMbrParts;
             double lo = 1e300, hi = -1e300;
-            for (uint32_t i = (uint32_t)part; i < ne[q]; i += kMbrParts) {
-                const uint32_t *e4 = w + 2 + i * kEnt + 4 * k;
-                const double x = __longlong_as_double((long long)(((uint64_t)e4[1] << 32) | e4[0]));
-                lo = fmin(lo, x);
-                hi = fmax(hi, x);
+            {
+                // a fixed number of reads, all issued before the first is used (entries past the leaf's last are zeros of the
+                // window's tail and are skipped)
+                constexpr int kIt = (F + kMbrParts - 1) / kMbrParts;
+                uint32_t x0[kIt], x1[kIt];
+#pragma unroll
+                for (int it = 0; it < kIt; it++) {
+                    const uint32_t *e4 = w + 2 + min((uint32_t)(part + it * kMbrParts), (uint32_t)(F - 1)) * kEnt + 4 * k;
+                    x0[it] = e4[0];
+                    x1[it] = e4[1];
+                }
+#pragma unroll
+                for (int it = 0; it < kIt; it++) {
+                    const double x = __longlong_as_double((long long)(((uint64_t)x1[it] << 32) | x0[it]));
+                    const bool in = (uint32_t)(part + it * kMbrParts) < ne[q];
+                    lo = in ? fmin(lo, x) : lo;
+                    hi = in ? fmax(hi, x) : hi;
+                }
             }
 #pragma unroll
             for (int m = 1; m < kMbrParts; m <<= 1) {
@@ -1135,7 +1162,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             // and 90 cycles of DPP hazard nops in a kernel whose budget is ~600 VALU instructions per leaf at config 3: the
             // kernel runs out of instruction issue as well as of requests, 536 VALU instructions with the auxiliary rows
             // against 272 without -- and the last lane stored its 2D doubles and three degrees itself: 27 single-lane store
-            // instructions = 27 write requests per leaf beside the image's 62.)
+            // instructions = 27 write requests per leaf beside the image's 62.)  With this epilogue knocked out the build
+            // took 5.71 ms against 6.12 with it and 5.35 for the image alone (profiles/r04_index_aux_ab.txt).
             constexpr int kCols = D + 3;
             constexpr int kParts = kCols * 8 <= 64 ? 8 : kCols * 4 <= 64 ? 4 : kCols * 2 <= 64 ? 2 : 1;
             static_assert(kCols * kParts <= 64 && kRk == D, "one lane group per column");
@@ -1156,11 +1184,20 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             const int col = lane / kParts, part = lane % kParts;
             const bool ranks = col < D;  // packed 16-bit maxima; the degree columns are whole dwords
             uint32_t red = 0;
-            if (col < kCols)
-                for (uint32_t i = (uint32_t)part; i < ne[q]; i += kParts) {
-                    const uint32_t v = sc[i * kCols + col];
+            {
+                // a fixed number of reads, all issued before the first is used (entries past the leaf's last read parked
+                // columns of an earlier use of the window or entry bytes -- inside the window -- and count as zero)
+                constexpr int kIt = (F + kParts - 1) / kParts;
+                const uint32_t cc = min((uint32_t)col, (uint32_t)(kCols - 1));
+                uint32_t vv[kIt];
+#pragma unroll
+                for (int it = 0; it < kIt; it++) vv[it] = sc[min((uint32_t)(part + it * kParts), (uint32_t)(F - 1)) * kCols + cc];
+#pragma unroll
+                for (int it = 0; it < kIt; it++) {
+                    const uint32_t v = (uint32_t)(part + it * kParts) < ne[q] ? vv[it] : 0u;
                     red = ranks ? pk_max_u16(red, v) : max(red, v);
                 }
+            }
             if constexpr (kParts >= 2) {
                 const uint32_t o = dpp_u32_zero<0xB1, 0xF>(red);  // quad_perm [1,0,3,2]
                 red = ranks ? pk_max_u16(red, o) : max(red, o);
@@ -1781,7 +1818,11 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
     uint32_t *v_in = reinterpret_cast<uint32_t *>(tmp + o_vals), *v_out = v_in + nu + 1;
     uint64_t *d_bounds = reinterpret_cast<uint64_t *>(tmp + o_bnd);
     // 1. partition-local index of every start vertex' first path
-    if (len) {
+    if (len && p == 1) {
+        // one partition: the paths before a start vertex are its first output slot minus the slab's (no sort, no scan: 30
+        // launches less)
+        hipLaunchKernelGGL(k_px_pbase_single, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, srec, c->px_pbase.as<uint64_t>());
+    } else if (len) {
         hipLaunchKernelGGL(k_px_start_parts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, srec, part_in, idx_in);
         const int pb = (int)std::max(1u, bits_for(p));
         tb = 0;
@@ -1824,13 +1865,15 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
     } while (0)
     if (nu) {
         if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
-        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu * (sizeof(PairXE<E>) / 16))), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs);
+        // (the sort's input values are dead by now: their array takes the sorted units' counts)
+        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu * (sizeof(PairXE<E>) / 16))), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs, v_in);
     } else {
         GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(v_in, 0, 4, c->stream));
     }
 #undef GNNPE_PX_SORT
     {
-        hipcub::TransformInputIterator<uint64_t, CntOfPairX<E>, const PX *> it(pxs, CntOfPairX<E>());
+        hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t *> it(v_in, U32ToU64());
         tb = 0;
         GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
         if ((rc = c->cub_tmp.reserve(tb))) return rc;

@@ -27,10 +27,10 @@ for rnd in range(2):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(); build(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        if case.startswith("aux") and rnd == 0:
+        if case in ("aux compact", "aux wide") and rnd == 0:
             r = eng.build_index_partition_aux_device(0, fetch=True)
             keep[case] = (r[3].copy(), r[4].copy(), r[5].copy())
-        print(f"round {rnd} [{case:16s}]: first build of the count {first:.3f} ms, from the cached pair order min {min(ts):.3f} median {sorted(ts)[2]:.3f} ms", flush=True)
+        print(f"round {rnd} [{case:24s}]: first build of the count {first:.3f} ms, from the cached pair order min {min(ts):.3f} median {sorted(ts)[2]:.3f} ms", flush=True)
 a = keep["aux compact"]
 for other in ("aux wide",):
     print(f"auxiliary arrays of [{other}] identical to [aux compact]:", all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, keep[other])))
