@@ -265,7 +265,7 @@ def test_aux_index_of_a_large_partition_by_properties(oracle, source):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["compact", "wide"])
-@pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1)])
+@pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1), ("biglabels", 2, 2)])
 def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, monkeypatch, kind, e, p, form):
     """gnnpe_build_index_partition_aux_device: the auxiliary index the pair-major LEAF KERNEL computes while it assembles
     the leaves (+ the upper levels) must equal, bit for bit, the generic pass over the finished image with the partition's
@@ -278,6 +278,14 @@ def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, monkeyp
         g = synth.gnm_graph(6000, 48000, n_labels=11, seed=5)
     elif kind == "powerlaw":
         g = synth.powerlaw_graph(8000, 40000, exponent=2.1, max_degree=300, n_labels=9, seed=6)
+    elif kind == "biglabels":
+        # degrees past 1 024 (11 bits) and labels up to 65 535 (16 bits): the {degree, label} word does not fit a record's 26
+        # id bits, so the DATA chooses the 8-byte words whatever `form` asks for, and the label tables (131 072 entries) stay
+        # in global memory instead of the leaf kernel's LDS
+        g = synth.powerlaw_graph(8000, 80000, exponent=1.8, max_degree=3000, n_labels=9, seed=6)
+        assert int(np.diff(g["offsets"].astype(np.int64)).max()) >= 1024
+        g["labels"] = ((g["labels"].astype(np.uint64) * 8191 + np.arange(g["n"], dtype=np.uint64) * 7) % 65536).astype(np.uint32)
+        g["labels"][0] = 65535
     else:
         g = dict(n=test_graph["meta"]["n"], offsets=test_graph["offsets"], nbrs=test_graph["nbrs"], labels=test_graph["labels"])
     sn = synth.degree_order(g["offsets"])
