@@ -21,7 +21,6 @@ void set_error(const char *fmt, ...);
 // gnnpe_aux.hip: {degree, label} word of every vertex (c->aux_vdl)
 int ensure_vertex_words(gnnpe_ctx *c);
 int resolve_total(gnnpe_ctx *c);  // gnnpe_engine.hip: fetch the count's total if the last count was enqueue-only
-int ensure_pair_ends(gnnpe_ctx *c);  // gnnpe_engine.hip: c->pst = {start vertex, middle vertex} of every pair of the slab
 
 #define GNNPE_HIP_TRY(expr)                                                                       \
     do {                                                                                          \

@@ -87,23 +87,6 @@ int resolve_total(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-// {start vertex, middle vertex} of every pair of the slab in emission order (k_pair_ends): structure of (graph, order, slab),
-// built by the first caller after one of them changes -- the output-tile emit and the pair-major index build
-int ensure_pair_ends(gnnpe_ctx *c)
-{
-    if (c->pst_valid) return GNNPE_OK;
-    const uint32_t len = c->slab_end - c->slab_begin;
-    int rc;
-    if ((rc = c->pst.reserve(((size_t)c->n_edges + 1) * sizeof(uint2)))) return rc;
-    if (len)
-        hipLaunchKernelGGL(k_pair_ends, dim3(grid_for((uint64_t)len * 64)), dim3(kBlock), 0, c->stream, len, c->slab_begin,
-                           c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                           c->nbrs.as<uint32_t>(), c->pst.as<uint2>());
-    GNNPE_HIP_TRY(hipGetLastError());
-    c->pst_valid = true;
-    return GNNPE_OK;
-}
-
 // blocks of a kernel that fit one CU (occupancy query, once per instantiation)
 template <class K> static int blocks_per_cu(K kernel)
 {
@@ -908,9 +891,18 @@ static int ensure_slab_struct(gnnpe_ctx *c)
 // tile table of this count for the tiles of rows [0, rows_hi)
 static int ensure_tile_table(gnnpe_ctx *c, uint64_t rows_hi, uint32_t ts)
 {
+    const uint32_t len = c->slab_end - c->slab_begin;
     const uint64_t ne = c->n_edges;
     int rc;
-    if ((rc = ensure_pair_ends(c))) return rc;
+    if (!c->pst_valid) {
+        if ((rc = c->pst.reserve((ne + 1) * sizeof(uint2)))) return rc;
+        if (len)
+            hipLaunchKernelGGL(k_pair_ends, dim3(grid_for((uint64_t)len * 64)), dim3(kBlock), 0, c->stream, len, c->slab_begin,
+                               c->sorted.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                               c->nbrs.as<uint32_t>(), c->pst.as<uint2>());
+        GNNPE_HIP_TRY(hipGetLastError());
+        c->pst_valid = true;
+    }
     const uint64_t need = (rows_hi + ts - 1) / ts + 1;  // tiles + the sentinel entry
     if (c->tile_gen == c->count_gen && c->tile_cap >= need && c->tile_rows == ts) return GNNPE_OK;
     if ((rc = c->tfirst.reserve((need + 1) * 8))) return rc;

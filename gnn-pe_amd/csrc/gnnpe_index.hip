@@ -589,55 +589,43 @@ __device__ __forceinline__ uint64_t px_key(uint64_t part, uint64_t ks, uint64_t 
     return (lab << zbits) | z;
 }
 
-// a vertex' key word as the wide table holds it ({label << 32 | spread bits}); the narrow table (k_vkey_narrow) packs the
-// label above `nsb` spread bits of one dword: the per-pair gather of the middle vertex' word then goes to a table of 4 bytes per
-// vertex
-__device__ __forceinline__ uint64_t vkey_wide(uint64_t w, uint32_t) { return w; }
-__device__ __forceinline__ uint64_t vkey_wide(uint32_t w, uint32_t nsb)
+// one record + one sort key per ordinary pair, at the pair's unit slot; 16 lanes per start vertex
+template <int E, typename KeyT>
+__global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
+                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
+                           const double *__restrict__ vde, const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst,
+                           uint32_t lb, uint32_t sbits, uint32_t zbits, PairXE<E> *__restrict__ px, KeyT *__restrict__ keys,
+                           uint32_t *__restrict__ vals)
 {
-    return ((uint64_t)(w >> nsb) << 32) | (uint64_t)(w & ((1u << nsb) - 1u));
-}
-
-// one record + one sort key per ordinary pair, at the pair's unit slot.  One THREAD per pair (round 4; before: 16 lanes per
-// start vertex walking its pairs -- start record -> the start's words -> its pairs' words, three dependent round trips by a
-// quarter-filled wave, then a second trip of the loop for the 17th pair on: 0.80 ms at config 3 for 1.6 GB moved): the pair
-// names its start and middle vertex itself (pst, k_pair_ends: structure of graph, order and slab), so every word that
-// depends on the vertices alone is requested at once and only the start's record waits for its rank.
-template <int E, typename KeyT, typename WordT>
-__global__ __launch_bounds__(256) void k_px_pairs(uint64_t n_pairs, uint32_t n_parts, uint32_t slab_begin,
-                                                  const uint2 *__restrict__ pst, const uint32_t *__restrict__ rank,
-                                                  const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
-                                                  const uint64_t *__restrict__ eoff, const WordT *__restrict__ vkey, uint32_t nsb,
-                                                  const double *__restrict__ vde, const uint64_t *__restrict__ pbase,
-                                                  const uint64_t *__restrict__ ufirst, uint32_t lb, uint32_t sbits, uint32_t zbits,
-                                                  PairXE<E> *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    for (uint64_t q = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; q < n_pairs; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint2 sb = pst[q];
-        const RankedPair pr = pairs[q];
-        if (pr.cnt & kHubFlag) continue;  // k_px_hub_units
-        const uint32_t g = rank[sb.x] - slab_begin;
-        const uint64_t ks = vkey_wide(vkey[sb.x], nsb), kb = vkey_wide(vkey[sb.y], nsb);
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; g < len; g += ng) {
+        const StartRec sr = srec[g];
+        const uint64_t ks = vkey[sr.s];
         double vs[E];
 #pragma unroll
-        for (int k = 0; k < E; k++) vs[k] = vde[(uint64_t)sb.x * E + k];
-        const uint64_t eo = eoff[q];
-        const uint64_t at = ufirst ? ufirst[q] : q;
-        const uint64_t base = srec[g].base;
-        const uint32_t ds = srec[g].ds, part = srec[g].part;
-        PairXE<E> x;
-        x.block = pr.block;
-        x.cnt = pr.cnt;
-        x.G = pr.G;
-        x.son0 = pbase[g] + (eo - base);
-        x.ds = ds;
-        x.ls = (uint32_t)(ks >> 32);
+        for (int k = 0; k < E; k++) vs[k] = vde[(uint64_t)sr.s * E + k];
+        for (uint32_t k = sub; k < sr.ds; k += 16) {
+            const uint32_t q = sr.e0 + k;
+            const RankedPair pr = pairs[q];
+            if (pr.cnt & kHubFlag) continue;  // k_px_hub_units
+            const uint64_t at = ufirst ? ufirst[q] : (uint64_t)q;
+            const uint32_t b = nbrs[sr.a_s + k];
+            PairXE<E> x;
+            x.block = pr.block;
+            x.cnt = pr.cnt;
+            x.G = pr.G;
+            x.son0 = pbase[g] + (eoff[q] - sr.base);
+            x.ds = sr.ds;
+            x.ls = (uint32_t)(ks >> 32);
 #pragma unroll
-        for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vs[k2];
-        px[at] = x;
-        // pairs without paths sort behind every partition (partition field = n_parts)
-        keys[at] = (KeyT)px_key(pr.cnt ? part : n_parts, ks, kb, E, lb, sbits, zbits);
-        vals[at] = (uint32_t)at;
+            for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vs[k2];
+            px[at] = x;
+            // pairs without paths sort behind every partition (partition field = n_parts)
+            keys[at] = (KeyT)px_key(pr.cnt ? sr.part : n_parts, ks, vkey[b], E, lb, sbits, zbits);
+            vals[at] = (uint32_t)at;
+        }
     }
 }
 
@@ -1775,7 +1763,7 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
 {
     typedef PairXE<E> PX;
     int rc;
-    if ((rc = ensure_vkey(c)) || (rc = ensure_pair_ends(c))) return rc;
+    if ((rc = ensure_vkey(c))) return rc;
     const uint32_t len = c->slab_end - c->slab_begin, D = 3 * E, p = c->p;
     const uint64_t ne = c->n_edges;
     const StartRec *srec = c->srec.as<StartRec>();
@@ -1859,16 +1847,10 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
 #define GNNPE_PX_SORT(KT)                                                                                               \
     do {                                                                                                                \
         KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                        \
-        if (ne && c->vkey_sbits < 32)                                                                                   \
-            hipLaunchKernelGGL((k_px_pairs<E, KT, uint32_t>), dim3(grid_for(ne)), dim3(kBlock), 0, c->stream, ne, p, c->slab_begin, \
-                               c->pst.as<uint2>(), c->rank.as<uint32_t>(), srec, pairs, c->eoff.as<uint64_t>(),         \
-                               reinterpret_cast<const uint32_t *>(c->vkey.as<uint64_t>() + c->n + 1), c->vkey_sbits,    \
-                               c->vde.as<double>(), c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in); \
-        else if (ne)                                                                                                    \
-            hipLaunchKernelGGL((k_px_pairs<E, KT, uint64_t>), dim3(grid_for(ne)), dim3(kBlock), 0, c->stream, ne, p, c->slab_begin, \
-                               c->pst.as<uint2>(), c->rank.as<uint32_t>(), srec, pairs, c->eoff.as<uint64_t>(),         \
-                               c->vkey.as<uint64_t>(), 32u, c->vde.as<double>(), c->px_pbase.as<uint64_t>(), ufirst, lb, \
-                               sbits, zbits, px, k_in, v_in);                                                          \
+        if (len)                                                                                                        \
+            hipLaunchKernelGGL((k_px_pairs<E, KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
+                               pairs, c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(), c->vde.as<double>(), \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
         if (n_hub_pairs)                                                                                                \
             hipLaunchKernelGGL((k_px_hub_units<E, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,     \
                                (uint32_t)n_hub_pairs, p, c->slab_begin, c->px_hubs.as<uint2>(), srec, pairs, c->eoff.as<uint64_t>(), \
