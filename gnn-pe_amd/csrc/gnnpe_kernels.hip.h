@@ -183,25 +183,33 @@ __global__ __launch_bounds__(256) void k_vde_hubs(uint32_t n_hub, const uint32_t
         double acc = 0.0;
         // (two loops, one per address space of the table: a pointer that may be either makes every lookup a flat load)
         auto sum_row = [&](auto tab) {
-            // the next four labels are in flight while this group's table values are added
+            // the next kPf labels are in flight while this group's table values are added.  (Round 4, first version: four in
+            // flight -- the longest row of config 5, 4 517 entries, then walks 1 130 dependent load round trips on its own,
+            // which was the whole kernel's 0.50 ms; sixteen: 0.19 ms, thirty-two: 0.17 -- profiles/r04_deep_kernel_stats.csv.)
+            constexpr uint32_t kPf = 16;
             const uint32_t *lp = nbr_label + st;
-            uint32_t j = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-            if (d >= 4) l0 = lp[0], l1 = lp[1], l2 = lp[2], l3 = lp[3];
-            for (; j + 8 <= d; j += 4) {
-                const uint32_t n0 = lp[j + 4], n1 = lp[j + 5], n2 = lp[j + 6], n3 = lp[j + 7];
-                const double a0 = tab[l0 * E + k], a1 = tab[l1 * E + k], a2 = tab[l2 * E + k], a3 = tab[l3 * E + k];
-                acc += a0;
-                acc += a1;
-                acc += a2;
-                acc += a3;
-                l0 = n0, l1 = n1, l2 = n2, l3 = n3;
+            uint32_t j = 0, lc[kPf], ln[kPf];
+#pragma unroll
+            for (uint32_t i = 0; i < kPf; i++) lc[i] = 0;
+            if (d >= kPf) {
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) lc[i] = lp[i];
             }
-            if (j + 4 <= d) {
-                acc += tab[l0 * E + k];
-                acc += tab[l1 * E + k];
-                acc += tab[l2 * E + k];
-                acc += tab[l3 * E + k];
-                j += 4;
+            for (; j + 2 * kPf <= d; j += kPf) {
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) ln[i] = lp[j + kPf + i];
+                double a[kPf];
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) a[i] = tab[lc[i] * E + k];
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) acc += a[i];  // ascending entry order: the reference's sum, bit for bit
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) lc[i] = ln[i];
+            }
+            if (j + kPf <= d) {
+#pragma unroll
+                for (uint32_t i = 0; i < kPf; i++) acc += tab[lc[i] * E + k];
+                j += kPf;
             }
             for (; j < d; j++) acc += tab[lp[j] * E + k];
             return tab[labels[v] * E + k];
