@@ -265,7 +265,7 @@ def test_aux_index_of_a_large_partition_by_properties(oracle, source):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["compact", "wide"])
-@pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1), ("biglabels", 2, 2)])
+@pytest.mark.parametrize("kind,e,p", [("gnm", 2, 1), ("gnm", 2, 3), ("gnm", 1, 2), ("gnm", 4, 2), ("powerlaw", 2, 2), ("test", 2, 1), ("gnm", 8, 1), ("biglabels", 2, 2), ("powerlaw", 8, 1), ("powerlaw", 4, 2), ("powerlaw", 1, 1)])
 def test_leaf_kernel_aux_rows_equal_the_generic_pass(oracle, test_graph, monkeypatch, kind, e, p, form):
     """gnnpe_build_index_partition_aux_device: the auxiliary index the pair-major LEAF KERNEL computes while it assembles
     the leaves (+ the upper levels) must equal, bit for bit, the generic pass over the finished image with the partition's
