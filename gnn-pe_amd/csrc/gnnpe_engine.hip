@@ -574,8 +574,11 @@ static int run_vde(gnnpe_ctx *c)
                       (uint32_t)mx, c->n_labels);
         c->labels_checked = true;
     }
-    GNNPE_HIP_TRY(hipMemsetAsync(c->nx.p, 0, bytes, c->stream));
-    GNNPE_HIP_TRY(hipMemsetAsync(c->vde.p, 0, bytes, c->stream));
+    // (with the whole graph loaded every vertex' row is summed below -- k_vde or k_vde_hubs -- and nothing needs clearing)
+    if (!(c->rows_identity && c->n_rows == n)) {
+        GNNPE_HIP_TRY(hipMemsetAsync(c->nx.p, 0, bytes, c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(c->vde.p, 0, bytes, c->stream));
+    }
     hipLaunchKernelGGL(k_x_from_labels, dim3(grid_for((uint64_t)n * e)), dim3(kBlock), 0, c->stream, n, e,
                        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->x.as<double>());
     const uint32_t nr = c->n_rows;
