@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Launch rule: one process per GPU.  Under a launcher (WORLD_SIZE set) this file is one rank.  Started plainly with
+--gpus N > 1 it starts N rank processes itself (`launch_ranks`: children of `python -m torch.distributed.run`, before this
+process touches HIP), relays rank 0's JSON line and leaves with their exit code; N = 1 runs in this process.
+
 One STEP = one full pass of the hot path over the synthetic 1M-vertex / 10M-edge labelled graph
 (BASELINE.json configs[2]; l=2, e=2): vde [N>1: + all-gather of the vde rows] -> count (rank-sorted row blocks,
 pair records, scan) -> fill (path ids + fp64 path embeddings written to HBM).  Inputs resident in HBM before the
@@ -329,6 +333,23 @@ def e2e_leg(g, sn, p, index, label, allow_large=False):
         return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: one child process per GPU through torch.distributed.run
+    (rendezvous on 127.0.0.1, a free port), the children's stdout / stderr inherited so rank 0's JSON line is this
+    command's JSON line.  The parent never initialises HIP (no torch.cuda call, no engine); it only waits.  Returns the
+    launcher's exit code (non-zero when any rank failed)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     global T_START
     T_START = time.perf_counter()
@@ -365,6 +386,11 @@ def main():
                     help="N>1 slab planning: equal path counts instead of the fitted step-cost model (dist.STEP_COST_WEIGHTS)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N rank processes ourselves (children, never an exec) BEFORE anything
+        # in this process touches HIP, relay their output, leave with their exit code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -372,8 +398,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
@@ -614,10 +638,13 @@ def main():
                     traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms,
                     emit_shapes=None if shapes is None else dict(
-                        starts_ms=round(shapes["starts_ms"], 3), tiles_ms=round(shapes["tiles_ms"], 3), kept=shapes["kept"],
-                        note="gnnpe_emit_calibrate_device: both emit kernels timed into the output buffer (host clock around stream "
-                             "synchronisations, best of two after a first touch), the faster kept for it: k_fill_ranked = one wave per "
-                             "start vertex, resident grid; k_fill_tiles = one wave per 64-row output tile, launch order"),
+                        starts_ms=round(shapes["starts_ms"], 3), starts_low_ms=round(shapes["starts_low_ms"], 3),
+                        tiles_ms=round(shapes["tiles_ms"], 3), kept=shapes["kept"],
+                        note="gnnpe_emit_calibrate_device: three emit launches timed into the output buffer (host clock around stream "
+                             "synchronisations, best of two after a first touch), the fastest kept for it: starts = k_fill_ranked, one "
+                             "wave per start vertex taken in order from ticket counters, resident grid of five workgroups per CU; "
+                             "starts_low = the same at three workgroups per CU; tiles = k_fill_tiles, one wave per 64-row output tile, "
+                             "launch order"),
                     output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],
                                      probe=pool_rep["probe"],
                                      frac_median_candidate=(peak_bytes / (med_ms / 1e3) / HBM_PEAK_GBS) if med_ms else None,

@@ -109,11 +109,12 @@ SIGNATURES = {
     "gnnpe_fill_kernel_name": (C.c_char_p, []),
     "gnnpe_set_fill_variant": (C.c_int, [_vp, C.c_int]),
     "gnnpe_set_emit_shape": (C.c_int, [_vp, C.c_int]),
+    "gnnpe_index_file_bytes": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_int]),
     "gnnpe_emit_kernel_name": (C.c_char_p, [_vp]),
-    "gnnpe_emit_calibrate_device": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "gnnpe_emit_calibrate_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
-ABI_VERSION = 4  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
+ABI_VERSION = 5  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
 _lib = None
 
 
@@ -326,11 +327,13 @@ class OutputPool:
     while one of them is alive (Engine.close() does not ask -- drop the views before closing the engine).  Create the pool
     AFTER eng.count_paths() so that the probe is the emit kernel itself."""
 
-    def __init__(self, eng, rows_cap, L, D, candidates=1):
+    NO_CALIBRATION = 0x80000000  # GNNPE_POOL_NO_CALIBRATION
+
+    def __init__(self, eng, rows_cap, L, D, candidates=1, calibrate=True):
         self.eng, self.lib = eng, eng.lib
         self.rows_cap, self.L, self.D = int(max(rows_cap, 1)), int(L), int(D)
         h = C.c_void_p()
-        eng._ck(self.lib.gnnpe_output_pool_create(eng.ctx, self.rows_cap, self.L, self.D, int(candidates), C.byref(h)))
+        eng._ck(self.lib.gnnpe_output_pool_create(eng.ctx, self.rows_cap, self.L, self.D, int(candidates) | (0 if calibrate else self.NO_CALIBRATION), C.byref(h)))
         self.h = h
         self._views = []  # weak references to the arrays handed to torch
         eng._pools.append(self)
@@ -574,17 +577,32 @@ class Engine:
         self._ck(self.lib.gnnpe_set_fill_variant(self.ctx, int(v)))
 
     def set_emit_shape(self, shape):
-        """0 = by graph, 1 = one wave per start vertex (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles)."""
+        """0 = whatever gnnpe_emit_calibrate_device measured faster into the buffer (start-vertex waves where nothing was measured),
+        1 = one wave per start vertex (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles), 3 = persistent waves taking
+        tiles from ticket counters (k_fill_tickets; e <= 2, else the tile kernel), 4 = shape 1 held to three workgroups per CU.
+        Graphs with hub rows always take the start-vertex kernel."""
         self._ck(self.lib.gnnpe_set_emit_shape(self.ctx, int(shape)))
+
+    EMIT_SHAPES = (1, 2, 3, 4)
+    EMIT_SHAPE_NAMES = {1: "starts", 2: "tiles", 3: "tickets", 4: "starts_low"}
+    EMIT_SHAPE_KERNELS = {1: "k_fill_ranked", 2: "k_fill_tiles", 3: "k_fill_tickets", 4: "k_fill_ranked"}
+
+    def has_emit_shape(self, shape):
+        return int(shape) in self.EMIT_SHAPES
 
     def emit_kernel_name(self):
         return self.lib.gnnpe_emit_kernel_name(self.ctx).decode()
 
-    def emit_calibrate_device(self, dev_vids=None, dev_pde=None):
-        """Times both emit shapes into these buffers and keeps the faster for them: dict(starts_ms, tiles_ms, kept)."""
-        a, b, k = C.c_float(), C.c_float(), C.c_int()
-        self._ck(self.lib.gnnpe_emit_calibrate_device(self.ctx, _dev(dev_vids), _dev(dev_pde), C.byref(a), C.byref(b), C.byref(k)))
-        return dict(starts_ms=a.value, tiles_ms=b.value, kept={1: "starts", 2: "tiles"}[k.value])
+    def emit_calibrate_device(self, dev_vids=None, dev_pde=None, rows_cap=None):
+        """Times the emit shapes 1 (start-vertex waves), 4 (the same at three workgroups per CU) and 2 (output tiles) into these
+        buffers and keeps the fastest for them: dict(starts_ms, starts_low_ms, tiles_ms, kept, kept_shape).  rows_cap = the
+        buffers' capacity in rows (default: the tensors' first dimension)."""
+        if rows_cap is None:
+            t = dev_pde if dev_pde is not None else dev_vids
+            rows_cap = int(t.shape[0]) if hasattr(t, "shape") else (1 << 62)
+        ms, k = (C.c_float * 5)(), C.c_int()
+        self._ck(self.lib.gnnpe_emit_calibrate_device(self.ctx, int(rows_cap), _dev(dev_vids), _dev(dev_pde), ms, C.byref(k)))
+        return dict(starts_ms=ms[1], starts_low_ms=ms[4], tiles_ms=ms[2], kept=self.EMIT_SHAPE_NAMES[k.value], kept_shape=k.value)
 
     # halo exchange helpers (SURVEY 8(e))
     def halo_need(self, slab_bounds, dev_ids, cap):

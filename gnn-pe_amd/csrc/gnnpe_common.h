@@ -165,13 +165,17 @@ struct gnnpe_ctx {
     // output-tile-driven emit (gnnpe_fill_tiles.hip.h): {start, middle} of every pair (structure, valid with poffs) and the
     // tile table of one count (first pair of every 64-row output tile), built by the first fill that wants it
     gnnpe::DevBuf pst, tfirst;
+    gnnpe::DevBuf tk_ctl, tk_jobs;  // emit shape 3: ticket heads + job counter; strip jobs {tile, first pair}
     bool pst_valid = false;
     uint32_t tile_rows = 0;  // rows per tile the table was built for
     uint64_t tile_gen = 0, tile_cap = 0;  // count the table belongs to; tiles it covers (+ 1 sentinel entry)
     // emit shape measured per output buffer (gnnpe_emit_calibrate_device): {buffer, faster shape}; consulted when emit_shape is 0
     std::vector<std::pair<const void *, int>> emit_prefs;
     const char *last_emit_kernel = "";
-    int emit_shape = 0;  // 0 = by graph (tiles unless the graph has hub rows), 1 = start-vertex waves, 2 = output tiles
+    int last_emit_per_cu = 0;  // workgroups per CU the last k_fill_ranked launch was held to (0: no cap)
+    // 0 = as gnnpe_emit_calibrate_device measured for the fill's buffer (start-vertex waves where nothing was measured), 1 = start-vertex
+    // waves, 2 = output tiles, 3 = ticket waves, 4 = start-vertex waves at three workgroups per CU (include/gnnpe_hip.h)
+    int emit_shape = 0;
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
@@ -206,3 +210,6 @@ struct gnnpe_ctx {
     // pinned host words for small read-backs
     uint64_t *h_pinned = nullptr;
 };
+
+// drops the emit shape measured for any buffer that starts in [lo, lo + bytes) (gnnpe_engine.hip; called where buffers are freed)
+void gnnpe_forget_emit_pref(gnnpe_ctx *c, const void *lo, size_t bytes);

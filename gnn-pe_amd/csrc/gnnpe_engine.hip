@@ -6,6 +6,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <random>
 #include <vector>
 
@@ -16,6 +18,7 @@
 #include "gnnpe_fill_pairwave.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
 #include "gnnpe_fill_tiles.hip.h"
+#include "gnnpe_fill_tickets.hip.h"
 #include "gnnpe_fill_deep.hip.h"
 
 namespace gnnpe {
@@ -87,19 +90,80 @@ int resolve_total(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
-// blocks of a kernel that fit one CU (occupancy query, once per instantiation)
-template <class K> static int blocks_per_cu(K kernel)
+// blocks of a kernel that fit one CU with `dyn_lds` bytes of dynamic LDS (occupancy query, cached per kernel ADDRESS and
+// size: every instantiation of a kernel template has the same function-pointer type)
+static int blocks_per_cu_at(const void *kernel, size_t dyn_lds)
 {
-    static int cached = 0;
-    if (!cached) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 4;
-        cached = nb;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({kernel, dyn_lds});
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, dyn_lds) != hipSuccess || nb < 1) nb = 4;
+    cache[{kernel, dyn_lds}] = nb;
+    return nb;
+}
+template <class K> static int blocks_per_cu(K kernel) { return blocks_per_cu_at(reinterpret_cast<const void *>(kernel), 0); }
+
+// Holding a kernel to `want` workgroups per CU: the dynamic LDS (bytes nobody touches) that does it, from the kernel's own
+// static LDS and the device's LDS per CU, checked with the occupancy query.  {0, natural occupancy} when the kernel does not
+// reach `want` anyway.
+struct OccPlan {
+    size_t pad;
+    int per_cu;
+};
+template <class K> static OccPlan occupancy_plan(K kernel_fn, int want, int device)
+{
+    const void *kernel = reinterpret_cast<const void *>(kernel_fn);
+    const int natural = blocks_per_cu_at(kernel, 0);
+    if (want <= 0 || natural <= want) return {0, natural};
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, OccPlan> cache;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find({kernel, want});
+        if (it != cache.end()) return it->second;
     }
-    return cached;
+    hipFuncAttributes fa;
+    int lds_cu = 0;
+    OccPlan plan = {0, natural};
+    if (hipFuncGetAttributes(&fa, kernel) == hipSuccess &&
+        hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && lds_cu > 0) {
+        // a block size half way between "fits want + 1 times" and "fits want times", less the kernel's own -- NOT the largest
+        // that fits `want` times: at 54 112 B per workgroup the occupancy query still answers three per CU and the chip runs
+        // two (4.5 ms instead of 3.3: profiles/r05_emit_ab.txt section 5) -- then checked against the occupancy query
+        long pad = ((long)lds_cu / want + (long)lds_cu / (want + 1)) / 2 - (long)fa.sharedSizeBytes;
+        pad = std::max<long>(0, std::min<long>(pad, 64 * 1024 - (long)fa.sharedSizeBytes - 256));
+        pad &= ~255L;
+        int got = blocks_per_cu_at(kernel, (size_t)pad);
+        while (got > want && pad + 512 < 64 * 1024 - (long)fa.sharedSizeBytes) {
+            pad += 512;
+            got = blocks_per_cu_at(kernel, (size_t)pad);
+        }
+        while (got < want && pad >= 512) {
+            pad -= 512;
+            got = blocks_per_cu_at(kernel, (size_t)pad);
+        }
+        plan = {(size_t)pad, got};
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    cache[{kernel, want}] = plan;
+    return plan;
 }
 
 }  // namespace gnnpe
+
+// a buffer's measured emit shape is forgotten when the buffer goes away (another allocation may get its address)
+void gnnpe_forget_emit_pref(gnnpe_ctx *c, const void *lo, size_t bytes)
+{
+    const char *a = static_cast<const char *>(lo);
+    for (size_t k = 0; k < c->emit_prefs.size(); k++) {
+        const char *q = static_cast<const char *>(c->emit_prefs[k].first);
+        if (q >= a && q < a + std::max<size_t>(bytes, 1)) c->emit_prefs.erase(c->emit_prefs.begin() + (long)k--);
+    }
+}
+static void forget_emit_pref(gnnpe_ctx *c, const void *key) { gnnpe_forget_emit_pref(c, key, 1); }
 
 using namespace gnnpe;
 
@@ -228,7 +292,10 @@ int gnnpe_dev_free(gnnpe_ctx *c, void *dev_ptr)
 {
     GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
-    if (dev_ptr) GNNPE_HIP_TRY(hipFree(dev_ptr));
+    if (dev_ptr) {
+        gnnpe_forget_emit_pref(c, dev_ptr, 1);
+        GNNPE_HIP_TRY(hipFree(dev_ptr));
+    }
     return GNNPE_OK;
 }
 
@@ -818,6 +885,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
 #undef GNNPE_RRM
         // diagnostic launches beside the real one (GNNPE_ROWS_PROBE, scripts/count_ab.py): pieces of the kernel on their own,
         // into scratch copies of its outputs; whole graph on one device, e = 2, packed ids only
+#ifdef GNNPE_DIAG
         if (const char *ev = getenv("GNNPE_ROWS_PROBE")) {
             const int mode = atoi(ev);
             if (mode >= 1 && mode <= 3 && c->rows_identity && e == 2 && packed && c->slab_begin == 0 && c->slab_end == c->n) {
@@ -834,6 +902,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
                 GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
             }
         }
+#endif
         GNNPE_HIP_TRY(hipGetLastError());
     }
     if (c->n_hub) {
@@ -1237,19 +1306,39 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         // write one moving window of the output
         const StartRec *sr = c->srec.as<StartRec>();
         const bool packed = packed_ids(c);
-        // Occupancy cap: dynamic LDS the kernel never touches, sized so that FIVE workgroups fit a CU at e <= 2 (14 688 B static
-        // + 13 000 B = 27 688 B).  With the start's loads batched (round 4) a wave keeps more bytes in flight, and fewer
-        // resident waves write faster -- same process, same buffers (scripts/emit_ab_libs.py): 8 / 7 / 6 / 5 / 4 workgroups
-        // per CU 3.37 / 3.05 / 2.95 / 2.93 / 3.00 ms in a fast allocation (the registers alone would admit 8); 128 staged rows
-        // per wave at 6 / 5 / 4 workgroups: 3.13 / 3.18 / 3.70 ms against 2.98 with 64.
-        size_t lds_pad = e <= 2 ? 13000 : 0;
-        if (const char *ev = getenv("GNNPE_FILL_LDS_PAD")) lds_pad = (size_t)atoi(ev);
+        // Occupancy cap of the start-vertex kernel at e <= 2 (dynamic LDS the kernel never touches; occupancy_plan): with a
+        // start's loads batched a wave keeps many bytes in flight, and FEWER resident waves write faster.  Same process, same
+        // buffers: in an allocation of the fast class 8 / 7 / 6 / 5 / 4 / 3 workgroups per CU 3.37 / 3.05 / 2.95 / 2.93 / 3.00 /
+        // 3.27 ms (round 4, scripts/emit_ab_libs.py; profiles/r05_emit_ab.txt), in one of the slow class 5 / 4 / 3 / 2:
+        // 3.65 / 3.59 / 3.51 / 4.40 ms.  So: five (shape 1), or three (shape 4) where gnnpe_emit_calibrate_device measured that
+        // faster into the buffer.
+        int want_per_cu = e <= 2 ? 5 : 0;
+        // Start vertices from ticket counters, in order (the kernel's comment): 16 heads; GNNPE_RANKED_TICKETS=0 restores the
+        // static assignment w, w + waves, ... for A/B runs.  Same process, same buffers, fast / slow class, five workgroups
+        // per CU: 2.77 / 3.46 ms against 2.88 / 3.68; three per CU into the slow class 3.32 against 3.51.
+        uint32_t *rk_heads = nullptr;
+        uint32_t rk_nh = 16;
+        if (const char *ev = getenv("GNNPE_RANKED_TICKETS")) rk_nh = (uint32_t)std::max(0, std::min(64, atoi(ev)));
 #define GNNPE_LK(KERN)                                                                                                  \
     do {                                                                                                                \
         auto kern = KERN;                                                                                               \
-        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)(lds_pad ? std::min<int>(blocks_per_cu(kern), (int)(160 * 1024 / (14688 + lds_pad))) : blocks_per_cu(kern)) * c->num_cus; \
+        OccPlan plan = occupancy_plan(kern, want_per_cu, c->device);                                                    \
+        if (const char *ev = getenv("GNNPE_FILL_LDS_PAD")) { /* A/B aid: this much dynamic LDS, whatever it admits */    \
+            plan.pad = (size_t)std::max(0, std::min(48 * 1024, atoi(ev)));                                              \
+            plan.per_cu = blocks_per_cu_at(reinterpret_cast<const void *>(kern), plan.pad);                             \
+        }                                                                                                               \
+        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)plan.per_cu * c->num_cus;                        \
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, fit))), block(kBlock);                           \
-        hipLaunchKernelGGL(kern, grid, block, lds_pad, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len); \
+        const uint32_t nh_l = std::min<uint32_t>(rk_nh, grid.x * 4u); /* every head needs a wave that serves it */      \
+        if (getenv("GNNPE_EMIT_DEBUG"))                                                                                 \
+            fprintf(stderr, "[emit] k_fill_ranked: %d workgroups per CU wanted, %d planned, %zu B of dynamic LDS, grid %u, %u ticket heads\n", \
+                    want_per_cu, plan.per_cu, plan.pad, grid.x, nh_l);                                                  \
+        if (nh_l) {                                                                                                     \
+            if ((rc = c->tk_ctl.reserve(kTicketCtlWords * 4 + 64))) return rc;                                          \
+            GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kTicketHeadWords * 4, c->stream));              \
+            rk_heads = c->tk_ctl.as<uint32_t>();                                                                        \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, block, plan.pad, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len, rk_heads, nh_l); \
     } while (0)
 #define GNNPE_L(EE)                                                                                                     \
     do {                                                                                                                \
@@ -1269,9 +1358,73 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             for (const auto &pr : c->emit_prefs)
                 if (pr.first == key) shape = pr.second;
         }
-        if (const char *ev = getenv("GNNPE_EMIT")) shape = !strcmp(ev, "tiles") ? 2 : !strcmp(ev, "starts") ? 1 : shape;
-        const bool tiles = c->n_hub == 0 && shape == 2 && c->n_edges != 0;
-        if (tiles && (P.out_ids || d_pde)) {
+        if (const char *ev = getenv("GNNPE_EMIT"))
+            shape = !strcmp(ev, "tickets") ? 3 : !strcmp(ev, "tiles") ? 2 : !strcmp(ev, "starts") ? 1 : !strcmp(ev, "starts_low") ? 4 : shape;
+        if (shape == 4 && e <= 2) want_per_cu = 3;
+        // the ticket kernel exists for e <= 2 and addresses the record blocks and the vde table with 32-bit offsets; anything
+        // else that asks for it gets the one-shot tile kernel
+        const bool tickets = c->n_hub == 0 && shape == 3 && c->n_edges != 0 && end > begin && e <= 2 &&
+                             c->rrecs.bytes < (1ull << 32) && (uint64_t)c->n * e * 8 < (1ull << 32);
+        const bool tiles = c->n_hub == 0 && (shape == 2 || (shape == 3 && !tickets)) && c->n_edges != 0;
+        if (tickets && (P.out_ids || d_pde)) {
+            // persistent waves, tiles in ticket order, three tiles in flight per wave (gnnpe_fill_tickets.hip.h); the tiles its
+            // pipeline does not take go through a job list to k_fill_tile_jobs in a second launch
+            const uint32_t ts = 64u;
+            if ((rc = ensure_tile_table(c, end, ts))) return rc;
+            const uint64_t t_lo = begin / ts, t_hi = (end + ts - 1) / ts;
+            GNNPE_REQUIRE(t_hi < (1ull << 32), GNNPE_ERR_ARG, "emit shape 3: more than 2^32 output tiles");
+            const uint64_t total_arg = c->total_known ? c->total_paths : ~0ull;
+            uint32_t tpt = 4;
+            if (const char *ev = getenv("GNNPE_TICKET_TILES")) tpt = (uint32_t)std::max(1, std::min(64, atoi(ev)));
+            uint32_t nh = kTicketHeads;
+            if (const char *ev = getenv("GNNPE_TICKET_HEADS")) nh = (uint32_t)std::max(4, std::min<int>(kTicketHeads, atoi(ev) & ~3));
+            const uint64_t job_cap = (t_hi - t_lo) + c->n_edges / kJobStrip + 8;
+            if ((rc = c->tk_ctl.reserve(kTicketCtlWords * 4 + 64)) || (rc = c->tk_jobs.reserve(job_cap * sizeof(uint2)))) return rc;
+            GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, kTicketCtlWords * 4 + 64, c->stream));
+            uint32_t *ctl = c->tk_ctl.as<uint32_t>();
+            int occ_env = 0;
+            if (const char *ev = getenv("GNNPE_TICKET_OCC")) occ_env = atoi(ev);
+            uint32_t tk_exp = 0;
+#ifdef GNNPE_DIAG
+            if (const char *ev = getenv("GNNPE_TICKET_EXP")) tk_exp = (uint32_t)atoi(ev);  // diagnostic builds only: 1 no stores, 2 no record loads
+#endif
+#define GNNPE_LQ(EE, PK, SP, OCC)                                                                                          \
+    do {                                                                                                                   \
+        auto kern = k_fill_tickets<EE, PK, SP, 4, OCC>;                                                                    \
+        int per_cu = blocks_per_cu(kern);                                                                                  \
+        if (occ_env > 0) per_cu = std::min(per_cu, occ_env);                                                               \
+        const uint64_t want = (t_hi - t_lo + 3) / 4;                                                                       \
+        const dim3 grid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)per_cu * c->num_cus))), block(kBlock); \
+        const uint32_t nh_l = std::min<uint32_t>(nh, grid.x * 4u); /* every head needs a workgroup that serves it */       \
+        hipLaunchKernelGGL(kern, grid, block, 0, c->stream, P, c->tfirst.as<uint64_t>(), c->rpairs.as<RankedPair>(),       \
+                           c->pst.as<uint2>(), c->rrecs.as<char>(), (uint32_t)c->rrecs.bytes, (uint32_t)((uint64_t)c->n * e * 8), \
+                           t_lo, t_hi, total_arg, tpt, nh_l, tk_exp, ctl, c->tk_jobs.as<uint2>());                         \
+        auto jkern = k_fill_tile_jobs<EE, PK, (int)kJobStrip, 4>;                                                          \
+        const dim3 jgrid((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)blocks_per_cu(jkern) * c->num_cus))); \
+        hipLaunchKernelGGL(jkern, jgrid, block, 0, c->stream, P, c->tfirst.as<uint64_t>(), c->rpairs.as<RankedPair>(),     \
+                           c->pst.as<uint2>(), c->rrecs.as<char>(), total_arg, ctl + kTicketHeads * kTicketHeadWords,      \
+                           c->tk_jobs.as<uint2>());                                                                        \
+    } while (0)
+#define GNNPE_LQS(EE, SP, OCC)                                                    \
+    do {                                                                          \
+        if (packed) GNNPE_LQ(EE, true, SP, OCC); else GNNPE_LQ(EE, false, SP, OCC); \
+    } while (0)
+            if (e == 1) GNNPE_LQS(1, 32, 5);
+            else GNNPE_LQS(2, 32, 5);
+#undef GNNPE_LQS
+#undef GNNPE_LQ
+#ifdef GNNPE_DIAG
+            if (tk_exp & 16u) {
+                unsigned long long h[8];
+                GNNPE_HIP_TRY(hipMemcpyAsync(h, ctl + kTicketCtlWords, 64, hipMemcpyDeviceToHost, c->stream));
+                GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+                const double tiles_w = (double)(t_hi - t_lo) / 16.0;  // tiles of the stamped waves (one wave in 16), about
+                fprintf(stderr, "[ticket stamps] %llu waves stamped; cycles per tile: wait %.0f  park %.0f  strip+records %.0f  pairs %.0f  ticket %.0f  stores %.0f\n",
+                        h[7], h[0] / tiles_w, h[1] / tiles_w, h[2] / tiles_w, h[3] / tiles_w, 0.0, h[4] / tiles_w);
+            }
+#endif
+            c->last_emit_kernel = "k_fill_tickets";
+        } else if (tiles && (P.out_ids || d_pde)) {
             // rows per tile in units of 64 (GNNPE_TILE_SHAPE=<units> for A/B runs)
             int kt = 1;
             if (const char *ev = getenv("GNNPE_TILE_SHAPE")) kt = atoi(ev) == 2 ? 2 : 1;
@@ -1283,8 +1436,10 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             // GNNPE_TILE_EXP (diagnostic instantiation, e = 2 with packed ids only): bit 0 no stores, bit 1 no record loads,
             // bit 4 in-kernel stamps (cycles per phase of one wave in 64, printed to stderr)
             uint32_t xf = 0;
+#ifdef GNNPE_DIAG  // diagnostic builds only (make DIAG=1): the knock-outs produce wrong rows by design
             if (const char *ev = getenv("GNNPE_TILE_EXP")) xf = (uint32_t)atoi(ev);
             if (!(e == 2 && packed)) xf = 0;
+#endif
             const dim3 grid((unsigned)((t_hi - t_lo + 3) / 4)), block(kBlock);
             unsigned long long *d_stamps = nullptr;
             if (xf & 16u) {
@@ -1298,9 +1453,12 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     do {                                                                              \
         if (packed) GNNPE_LTK(EE, true, KT, SP, false); else GNNPE_LTK(EE, false, KT, SP, false); \
     } while (0)
+#ifdef GNNPE_DIAG
             if (xf) {
                 if (kt == 2) GNNPE_LTK(2, true, 2, 64, true); else GNNPE_LTK(2, true, 1, 64, true);
-            } else if (e == 1) {
+            } else
+#endif
+            if (e == 1) {
                 if (kt == 2) GNNPE_LTS(1, 2, 64); else GNNPE_LTS(1, 1, 64);
             } else if (e == 2) {
                 if (kt == 2) GNNPE_LTS(2, 2, 64); else GNNPE_LTS(2, 1, 64);
@@ -1325,6 +1483,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         } else if (P.out_ids || d_pde) {
             GNNPE_BY_E(e, GNNPE_L)
             c->last_emit_kernel = "k_fill_ranked";
+            c->last_emit_per_cu = want_per_cu;
         }
 #undef GNNPE_L
 #undef GNNPE_LK
@@ -1413,14 +1572,15 @@ int gnnpe_rows_checksum_device(gnnpe_ctx *c, uint64_t n_rows, uint32_t L, const 
 
 int gnnpe_set_emit_shape(gnnpe_ctx *c, int shape)
 {
-    GNNPE_REQUIRE(c && shape >= 0 && shape <= 2, GNNPE_ERR_ARG, "emit shape must be 0 (by graph), 1 (start waves) or 2 (output tiles)");
+    GNNPE_REQUIRE(c && shape >= 0 && shape <= 4, GNNPE_ERR_ARG,
+                  "emit shape must be 0 (as calibrated), 1 (start waves), 2 (output tiles), 3 (ticket waves) or 4 (start waves, three workgroups per CU)");
     c->emit_shape = shape;
     return GNNPE_OK;
 }
 
 const char *gnnpe_emit_kernel_name(gnnpe_ctx *c) { return c ? c->last_emit_kernel : ""; }
 
-int gnnpe_emit_calibrate_device(gnnpe_ctx *c, void *dev_vids, void *dev_pde, float *ms_starts, float *ms_tiles, int *shape_kept)
+int gnnpe_emit_calibrate_device(gnnpe_ctx *c, uint64_t rows_cap, void *dev_vids, void *dev_pde, float *ms_by_shape, int *shape_kept)
 {
     GNNPE_REQUIRE(c && (dev_vids || dev_pde), GNNPE_ERR_ARG, "gnnpe_emit_calibrate_device: no output buffer");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
@@ -1428,16 +1588,21 @@ int gnnpe_emit_calibrate_device(gnnpe_ctx *c, void *dev_vids, void *dev_pde, flo
     if (rc) return rc;
     GNNPE_REQUIRE(c->counted && c->counted_variant == kVarRanked && c->l == 2, GNNPE_ERR_ARG,
                   "gnnpe_emit_calibrate_device: needs an l=2 count of the rank-sorted enumeration on this context");
+    GNNPE_REQUIRE(c->total_paths <= rows_cap, GNNPE_ERR_ARG, "gnnpe_emit_calibrate_device: the buffers hold %llu rows, the count is %llu paths",
+                  (unsigned long long)rows_cap, (unsigned long long)c->total_paths);
     const void *key = dev_pde ? dev_pde : dev_vids;
-    for (size_t k = 0; k < c->emit_prefs.size(); k++)
-        if (c->emit_prefs[k].first == key) c->emit_prefs.erase(c->emit_prefs.begin() + (long)k--);
-    float ms[3] = {0.f, 0.f, 0.f};
+    forget_emit_pref(c, key);
+    float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     int kept = 1;
     // only one shape exists for graphs with hub rows or without paths; below 2^24 paths a launch is too short to tell
     if (c->n_hub == 0 && c->total_paths >= (1ull << 24)) {
         const int saved = c->emit_shape;
+        const uint32_t e = c->have_table ? c->e : 2;
         GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int shape = 1; shape <= 2 && rc == GNNPE_OK; shape++) {
+        const int shapes[3] = {1, 4, 2};  // start-vertex waves at five and at three workgroups per CU, output tiles
+        for (int k = 0; k < 3 && rc == GNNPE_OK; k++) {
+            const int shape = shapes[k];
+            if (shape == 4 && e > 2) continue;  // (no occupancy cap at these widths: the same launch as shape 1)
             c->emit_shape = shape;
             float best = 1e30f;
             for (int rep = 0; rep < 3 && rc == GNNPE_OK; rep++) {  // the first launch touches the pages and builds the tile table
@@ -1454,12 +1619,12 @@ int gnnpe_emit_calibrate_device(gnnpe_ctx *c, void *dev_vids, void *dev_pde, flo
         }
         c->emit_shape = saved;
         if (rc) return rc;
-        kept = ms[2] < ms[1] ? 2 : 1;
+        for (int k = 0; k < 3; k++)
+            if (ms[shapes[k]] > 0.f && ms[shapes[k]] < ms[kept]) kept = shapes[k];
     }
     if (c->emit_prefs.size() >= 16) c->emit_prefs.erase(c->emit_prefs.begin());
     c->emit_prefs.emplace_back(key, kept);
-    if (ms_starts) *ms_starts = ms[1];
-    if (ms_tiles) *ms_tiles = ms[2];
+    for (int k = 0; ms_by_shape && k < 5; k++) ms_by_shape[k] = ms[k];
     if (shape_kept) *shape_kept = kept;
     return GNNPE_OK;
 }

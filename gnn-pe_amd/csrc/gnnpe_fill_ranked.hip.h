@@ -408,7 +408,8 @@ struct __attribute__((packed, aligned(4))) IdRow {
 template <int E, bool PACKED, int kBatch>
 __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
                                                      const RankedPair *__restrict__ pairs,
-                                                     const char *__restrict__ recs, uint32_t slab_len)
+                                                     const char *__restrict__ recs, uint32_t slab_len,
+                                                     uint32_t *__restrict__ heads, uint32_t nh)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int D = 3 * E;
@@ -498,11 +499,31 @@ __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParam
 
     // a wave's start vertices: w, w + nw, ... (wave-uniform, so the start record arrives through the scalar cache); the NEXT
     // start's record is requested one start ahead
+    // heads != nullptr: start vertices IN ORDER from ticket counters instead (ticket k of head h = start k * nh + h; one returning
+    // increment per start vertex, requested one start ahead): waves that get ahead cannot run away from the others, so the rows
+    // the chip writes at one moment stay one window of the output whatever the waves' speeds
     uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const uint32_t head = heads ? w % nh : 0u;
+    auto draw = [&]() -> uint32_t {
+        uint32_t tk = 0;
+        if (lane == 0) tk = __builtin_amdgcn_atomic_inc32(heads + head * 32u, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
+        return tk;
+    };
+    uint32_t tk = 0;
+    if (heads) {
+        tk = draw();
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * nh + head;
+        tk = draw();
+    }
     if (w >= slab_len) return;
     StartRec sr = srec[w];
-    for (; w < slab_len; w += nw) {
-        const StartRec sr_next = srec[min(w + nw, slab_len - 1u)];
+    while (w < slab_len) {
+        uint32_t w_next = w + nw;
+        if (heads) {
+            w_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk) * nh + head;
+            tk = draw();
+        }
+        const StartRec sr_next = srec[min(w_next, slab_len - 1u)];
         RankedPair pr;
         uint32_t bk;
         if (sr.end != sr.base && sr.base < P.end && sr.end > P.begin) {
@@ -654,6 +675,7 @@ __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParam
             }
         }
         sr = sr_next;
+        w = w_next;
     }
 }
 

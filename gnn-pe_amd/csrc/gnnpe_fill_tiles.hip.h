@@ -64,12 +64,16 @@ __global__ void k_tile_first(uint64_t n_pairs, const uint64_t *__restrict__ eoff
 //   burst  records parked at their rows, rows -> global memory: consecutive lanes on consecutive 16-byte pieces of the pde
 //          rows, 12-byte id rows
 // DIAG: the diagnostic instantiation (in-kernel stamps, knock-outs); the product launches DIAG = false.
+// The body is a device function of the tile index and a range of the tile's pairs [k_lo, k_hi): the one-wave-per-tile kernel
+// passes the whole tile; the job kernel behind k_fill_tickets (gnnpe_fill_tickets.hip.h) passes one strip of a tile whose
+// pairs do not fit that kernel's pipeline -- strips are independent of each other, the tile row of a strip's first record
+// being eoff[its first pair] - the tile's first slot.
 template <int E, bool PACKED, int KT, int SP, int WPB, bool DIAG>
-__global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_tiles(FillParams P, const uint64_t *__restrict__ tfirst,
-                                                         const RankedPair *__restrict__ pairs, const uint2 *__restrict__ pst,
-                                                         const char *__restrict__ recs, uint64_t tile_lo, uint64_t tile_hi,
-                                                         uint64_t total_arg, uint32_t exp_flags,
-                                                         unsigned long long *__restrict__ stamps)
+__device__ __forceinline__ void fill_tile_strips(const FillParams &P, const uint64_t *__restrict__ tfirst,
+                                                 const RankedPair *__restrict__ pairs, const uint2 *__restrict__ pst,
+                                                 const char *__restrict__ recs, const uint64_t t, const uint64_t total,
+                                                 const uint32_t k_lo, const uint32_t k_hi, uint32_t exp_flags,
+                                                 unsigned long long *__restrict__ stamps)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int D = 3 * E;
@@ -101,11 +105,6 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
         }
     };
     stamp(-1, false);
-    // the tile index is wave-uniform, and the compiler must know it: the table entries then come through the scalar cache, past
-    // the vector memory pipeline in which this CU's loads and stores queue (stamps: 2 500 cycles for the table hop through it)
-    const uint64_t t = tile_lo + (uint64_t)blockIdx.x * WPB + (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
-    if (t >= tile_hi) return;
-    const uint64_t total = total_arg != ~0ull ? total_arg : P.eoff[P.n_edges];
     const uint64_t slot0 = t * TS;
     if (slot0 >= total) return;  // capped launches cover the buffer's capacity, not the count
     const bool want_pde = P.out_pde != nullptr;
@@ -119,7 +118,8 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
     const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tf0);
     const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tf1);
     int32_t carry = -(int32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tf0 >> 32));  // tile row of the strip's first record
-    const uint32_t np = e1 - e0 + 1;
+    const uint32_t np = min(e1 - e0 + 1, k_hi);
+    if (k_lo) carry = (int32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(P.eoff[(uint64_t)e0 + k_lo] - slot0));
     stamp(0, false);
 
     // rows [r_lo, r_hi) of the tile -> output slots slot0 + row, clipped to [P.begin, P.end)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    for (uint32_t k0 = 0; k0 < np && carry < TS; k0 += SP) {
+    for (uint32_t k0 = k_lo; k0 < np && carry < TS; k0 += SP) {
         // strip: SP pairs, one lane each
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4 pw = {0u, 0u, 0u, 0u};
@@ -336,6 +336,39 @@ __global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_
         if (k0 + SP < np && carry < TS) {  // another strip: clear the marks of this one
             if (lane < (unsigned)(NMARK / 4)) reinterpret_cast<uint32_t *>(smark)[lane] = 0u;
         }
+    }
+}
+
+template <int E, bool PACKED, int KT, int SP, int WPB, bool DIAG>
+__global__ __launch_bounds__(64 * WPB, (KT == 1 && E <= 2) ? 8 : 1) void k_fill_tiles(FillParams P, const uint64_t *__restrict__ tfirst,
+                                                         const RankedPair *__restrict__ pairs, const uint2 *__restrict__ pst,
+                                                         const char *__restrict__ recs, uint64_t tile_lo, uint64_t tile_hi,
+                                                         uint64_t total_arg, uint32_t exp_flags,
+                                                         unsigned long long *__restrict__ stamps)
+{
+    // the tile index is wave-uniform, and the compiler must know it: the table entries then come through the scalar cache, past
+    // the vector memory pipeline in which this CU's loads and stores queue (stamps: 2 500 cycles for the table hop through it)
+    const uint64_t t = tile_lo + (uint64_t)blockIdx.x * WPB + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
+    if (t >= tile_hi) return;
+    const uint64_t total = total_arg != ~0ull ? total_arg : P.eoff[P.n_edges];
+    fill_tile_strips<E, PACKED, KT, SP, WPB, DIAG>(P, tfirst, pairs, pst, recs, t, total, 0u, ~0u, exp_flags, stamps);
+}
+
+// Strip jobs {tile, first pair of the strip within the tile}.  A resident grid walks the list (its length is known on the
+// device only).  Written by k_fill_tickets for the tiles its pipeline does not take.
+template <int E, bool PACKED, int SP, int WPB>
+__global__ __launch_bounds__(64 * WPB, (E <= 2) ? 8 : 1) void k_fill_tile_jobs(FillParams P, const uint64_t *__restrict__ tfirst,
+                                                         const RankedPair *__restrict__ pairs, const uint2 *__restrict__ pst,
+                                                         const char *__restrict__ recs, uint64_t total_arg,
+                                                         const uint32_t *__restrict__ job_count, const uint2 *__restrict__ jobs)
+{
+    const uint32_t n_jobs = *job_count;
+    const uint64_t total = total_arg != ~0ull ? total_arg : P.eoff[P.n_edges];
+    const uint32_t nw = gridDim.x * WPB;
+    for (uint32_t j = blockIdx.x * WPB + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id()); j < n_jobs; j += nw) {
+        const uint2 jb = jobs[j];
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb.x), k_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)jb.y);
+        fill_tile_strips<E, PACKED, 1, SP, WPB, false>(P, tfirst, pairs, pst, recs, (uint64_t)t, total, k_lo, k_lo + SP, 0u, nullptr);
     }
 }
 

@@ -1343,6 +1343,22 @@ static uint64_t plan_levels(uint64_t cnt, uint32_t F, std::vector<uint64_t> &lev
     return n_nodes;
 }
 
+// entries per node of the two builders: the pair-major build fills to capacity - 1 (index_fanout), the tuple-array build to
+// capacity - 2; one lane assembles one entry, so small entries fill a node to 64 at most
+static uint32_t builder_fanout(uint32_t D, int builder)
+{
+    const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);  // rtnode.cpp:27-28
+    if (builder == 0) return index_fanout(D);
+    return cap >= 3 ? std::min(cap - 2, 64u) : 1u;
+}
+
+extern "C" uint64_t gnnpe_index_file_bytes(uint64_t points, uint32_t D, int builder)
+{
+    if (D == 0 || D > 254) return 0;
+    std::vector<uint64_t> level_n;
+    return (plan_levels(points, std::max(1u, builder_fanout(D, builder)), level_n) + 1) * (uint64_t)kBlockLen;
+}
+
 static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
 {
     GNNPE_REQUIRE(c && dev_image && nbytes, GNNPE_ERR_ARG, "null argument");
@@ -1354,7 +1370,7 @@ static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, 
     GNNPE_REQUIRE(cap >= 3, GNNPE_ERR_UNSUPPORTED, "entry size for dim %u gives node capacity %u", D, cap);
     // the reference splits a node on reaching capacity-1 (rtnode.cpp:528,576): keep <= capacity-2; one lane
     // assembles one entry, so very small entries (dim <= 3) fill a node to 64 instead
-    const uint32_t F = std::min(cap - 2, 64u);
+    const uint32_t F = builder_fanout(D, 1);
     int rc;
 
     std::vector<uint64_t> level_n;

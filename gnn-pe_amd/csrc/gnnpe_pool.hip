@@ -94,7 +94,10 @@ int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void *
 void pool_free(gnnpe_pool *p)
 {
     if (!p) return;
-    if (p->base) (void)hipFree(p->base);
+    if (p->base) {
+        gnnpe_forget_emit_pref(p->ctx, p->base, p->bytes);  // the next allocation at this address is another buffer
+        (void)hipFree(p->base);
+    }
     delete p;
 }
 
@@ -107,6 +110,8 @@ extern "C" {
 int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32_t D, uint32_t candidates, gnnpe_pool **out)
 {
     GNNPE_REQUIRE(c && out && L >= 1 && L <= 16 && D <= 512, GNNPE_ERR_ARG, "gnnpe_output_pool_create: bad argument");
+    const bool calibrate = !(candidates & GNNPE_POOL_NO_CALIBRATION);
+    candidates &= ~GNNPE_POOL_NO_CALIBRATION;
     GNNPE_REQUIRE(candidates >= 1 && candidates <= 64, GNNPE_ERR_ARG, "gnnpe_output_pool_create: 1..64 candidate allocations");
     *out = nullptr;
     GNNPE_HIP_TRY(hipSetDevice(c->device));
@@ -193,9 +198,10 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     p->probed_with_kernel = with_kernel && K > 1;
     c->pools.push_back(p);
     *out = p;
-    // which emit shape is faster into the buffer that was kept (both are timed: six launches)
-    if (with_kernel && bytes >= min_probe && c->l == 2 &&
-        (rc = gnnpe_emit_calibrate_device(c, p->base + p->ids_off, D ? p->base + p->pde_off : nullptr, nullptr, nullptr, nullptr)) != GNNPE_OK)
+    // which emit shape is faster into the buffer that was kept (three shapes timed, nine launches: worth it for a buffer that is
+    // filled more than a few times; callers that fill it once per chunk pass GNNPE_POOL_NO_CALIBRATION)
+    if (calibrate && with_kernel && bytes >= min_probe && c->l == 2 &&
+        (rc = gnnpe_emit_calibrate_device(c, p->rows_cap, p->base + p->ids_off, D ? p->base + p->pde_off : nullptr, nullptr, nullptr)) != GNNPE_OK)
         (void)hipGetLastError();  // a failed calibration leaves the default shape; the pool is usable
     return GNNPE_OK;
 }

@@ -139,33 +139,23 @@ inline void warn_if_index_too_large_for_reference(const std::string &path)
                         "(blk_file.h:33) -- use a larger -p\n", g_tool, path.c_str(), st.st_size / 1073741824.0);
 }
 
-// Size of the index.dat a partition of `points` paths becomes (bulk-loaded tree: nodes filled to capacity - 1, one 4 KiB
-// block per node + the header block; rtnode.cpp:27-28, blk_file.cpp:38-52), so that the 2 GiB limit above is checked BEFORE
-// anything is written.
-inline uint64_t index_file_bytes(uint64_t points, uint32_t D)
-{
-    const uint64_t cap = (4096 - 5) / (16ull * D + 4), fill = cap > 1 ? cap - 1 : 1;
-    uint64_t level = std::max<uint64_t>(1, (points + fill - 1) / fill), blocks = level;
-    while (level > 1 || blocks == 1) {  // the root must be an inner node (custom.h:375): at least two levels
-        level = (level + fill - 1) / fill;
-        blocks += level;
-        if (level == 1) break;
-    }
-    return (blocks + 1) * 4096;
-}
+// Size of the index.dat a partition of `points` paths becomes, so that the 2 GiB limit above is checked BEFORE anything is
+// written: the library's own figure for the builder that will write the file (gnnpe_index_file_bytes: 0 = the pair-major build
+// of the single-GPU path, 1 = the tuple-array build of --gpus N; their nodes hold different numbers of entries).
+inline uint64_t index_file_bytes(uint64_t points, uint32_t D, int builder) { return gnnpe_index_file_bytes(points, D, builder); }
 // --index: the message for a partition whose index.dat would reach 2 GiB (empty when every file stays below), naming the
 // smallest -p that keeps partitions of equal size below it.  The caller refuses unless --allow-large.
-inline std::string index_size_problem(const std::vector<uint64_t> &part_count, uint64_t P, uint32_t D)
+inline std::string index_size_problem(const std::vector<uint64_t> &part_count, uint64_t P, uint32_t D, int builder)
 {
     uint64_t worst = 0;
     uint32_t worst_pid = 0;
     for (uint32_t i = 0; i < part_count.size(); i++) {
-        const uint64_t b = index_file_bytes(part_count[i], D);
+        const uint64_t b = index_file_bytes(part_count[i], D, builder);
         if (b > worst) worst = b, worst_pid = i;
     }
     if (worst < (1ull << 31)) return "";
     uint32_t p_min = (uint32_t)part_count.size();
-    while (index_file_bytes((P + p_min - 1) / p_min, D) >= (1ull << 31)) p_min++;
+    while (index_file_bytes((P + p_min - 1) / p_min, D, builder) >= (1ull << 31)) p_min++;
     return "partition " + std::to_string(worst_pid) + " holds " + std::to_string(part_count[worst_pid]) + " paths: its index.dat would be " +
            std::to_string(worst >> 20) + " MiB, and the reference's online binary cannot seek in index files of 2 GiB or more "
            "(blk_file.h:33); partitions of equal size stay below that from -p " + std::to_string(p_min);

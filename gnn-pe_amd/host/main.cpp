@@ -361,7 +361,9 @@ int main(int argc, char **argv)
     std::vector<uint64_t> part_count(o.partition_num, 0);  // main.cpp:102: header of partition_paths.txt
     for (uint32_t i = 0; i < g.n; i++) part_count[membership[sorted_nodes[i]]] += per_start[i];
     if (o.write_index) {  // before anything is written
-        const std::string big = index_size_problem(part_count, P, (o.path_length + 1) * o.vde_dim);
+        const std::string big = index_size_problem(part_count, P, (o.path_length + 1) * o.vde_dim,
+                                                   // the pair-major build exists for l = 2 at the widths with a specialised enumeration; else the tuple-array build
+                                                   (o.path_length == 2 && (o.vde_dim <= 4 || o.vde_dim == 8)) ? 0 : 1);
         if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
         if (!big.empty()) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
     }
@@ -402,7 +404,7 @@ int main(int argc, char **argv)
         // the emitted rows live in the library's output pool: one allocation (no candidate draw since round 4); when one
         // chunk holds every path the pool times both emit shapes into it and later fills take the faster one
         gnnpe_pool *pool = nullptr;
-        check(gnnpe_output_pool_create(ctx, chunk, L, 0, 1, &pool), "output pool");
+        check(gnnpe_output_pool_create(ctx, chunk, L, 0, 1u | GNNPE_POOL_NO_CALIBRATION, &pool), "output pool");
         check(gnnpe_output_pool_acquire(pool, &d_ids, nullptr, nullptr), "output pool");
         check(gnnpe_dev_alloc(ctx, chunk * 4, &d_part), "alloc part");
         check(gnnpe_dev_alloc(ctx, chunk * 8, &d_sel), "alloc sel");

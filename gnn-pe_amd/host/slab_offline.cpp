@@ -618,7 +618,7 @@ void rank_main(int r, Shared &S)
         void *p = nullptr;
         PoolIds(gnnpe_ctx *c, uint64_t rows, uint32_t L_)
         {
-            check(gnnpe_output_pool_create(c, rows, L_, 0, 1, &pool), "output pool");
+            check(gnnpe_output_pool_create(c, rows, L_, 0, 1u | GNNPE_POOL_NO_CALIBRATION, &pool), "output pool");
             check(gnnpe_output_pool_acquire(pool, &p, nullptr, nullptr), "output pool");
         }
         ~PoolIds() { gnnpe_output_pool_destroy(pool); }
@@ -650,7 +650,7 @@ void rank_main(int r, Shared &S)
         for (int q = 0; q < r; q++) part_off[pid] += by[q];
     }
     if (o.write_index) {  // every rank sees the same totals: all of them stop here, before any file exists
-        const std::string big = index_size_problem(part_tot, P, L * e);
+        const std::string big = index_size_problem(part_tot, P, L * e, 1);
         if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
         if (!big.empty() && r == 0) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
     }

@@ -132,9 +132,8 @@ def main(argv=None):
 
     # ---- render this rank's share, chunk by chunk ----
     chunk = max(1, min(args.chunk, max(total, 1)))
-    # the emitted rows go through the library's output pool (one allocation; when the chunk is the whole output the pool
-    # times both emit shapes into it and the fills take the faster one: gnnpe_output_pool_create)
-    pool = binding.OutputPool(eng, chunk, L, 0, candidates=1)
+    # the emitted rows go through the library's output pool (one allocation, filled once per chunk: no shape calibration)
+    pool = binding.OutputPool(eng, chunk, L, 0, candidates=1, calibrate=False)
     ids = pool.ids_tensor(device)
     part = torch.empty(chunk, dtype=torch.int32, device=device)
     sel = torch.empty(chunk, dtype=torch.int64, device=device)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNPE_ABI_VERSION 4
+#define GNNPE_ABI_VERSION 5
 
 #define GNNPE_OK 0
 #define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
@@ -197,7 +197,11 @@ int gnnpe_fill_paths_capped_device(gnnpe_ctx *ctx, uint64_t cap_rows, void *dev_
  * doubles, D = 0 for none), times the consumer in each -- the emit kernel itself when the context holds an l = L-1
  * count of at most rows_cap paths (call gnnpe_count_paths first), a streaming write otherwise -- keeps the fastest and
  * frees the others before it returns (transient memory: candidates x the output size, bounded by the free memory).
- * candidates = 1 takes what comes, unprobed.  The buffers stay valid until gnnpe_output_pool_destroy. */
+ * candidates = 1 takes what comes, unprobed.  The buffers stay valid until gnnpe_output_pool_destroy.
+ * With an l = 2 count on the context the pool also runs gnnpe_emit_calibrate_device on the buffer it keeps (nine launches
+ * of the emit kernels): pass candidates | GNNPE_POOL_NO_CALIBRATION where the buffer is filled once or twice (a CLI that
+ * fills it once per chunk), so that the launches that choose a shape do not outnumber the ones that use it. */
+#define GNNPE_POOL_NO_CALIBRATION 0x80000000u
 typedef struct gnnpe_pool gnnpe_pool;
 int gnnpe_output_pool_create(gnnpe_ctx *ctx, uint64_t rows_cap, uint32_t L, uint32_t D, uint32_t candidates, gnnpe_pool **pool);
 int gnnpe_output_pool_acquire(gnnpe_pool *pool, void **dev_ids, void **dev_pde, uint64_t *rows_cap);
@@ -369,22 +373,33 @@ const char *gnnpe_fill_kernel_name(void);
  *   1 one wave per (start, middle) pair, direct stores, run-time embedding width: the generic form used for widths
  *     without a specialised instantiation (e not in {1,2,3,4,8}); selectable as the A/B baseline */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
-/* Shape of the emit launch of variant 4 (the reference's dfs + gen_pde, custom.h:66-92, 546-572); outputs are identical:
- *   0    whichever gnnpe_emit_calibrate_device measured faster into the fill's output buffer; shape 1 for a buffer nobody
+/* Shape of the emit launch of variant 4 (the reference's dfs + gen_pde, custom.h:66-92, 546-572); outputs are identical.
+ * Times: BASELINE config 3 into an allocation of the fast / of the slow class, profiles/r05_emit_ab.txt.
+ *   0    whichever gnnpe_emit_calibrate_device measured fastest into the fill's output buffer; shape 1 for a buffer nobody
  *        calibrated (default)
- *   1    one wave per start vertex, resident grid (k_fill_ranked): 3.1 / 3.6 ms at BASELINE config 3 into a fast / slow
- *        allocation (profiles/r04_emit_ab.txt)
- *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.25 /
- *        3.4 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
- * The environment variable GNNPE_EMIT=tiles|starts overrides the context's setting (same-process A/B runs). */
+ *   1    one wave per start vertex, resident grid, five workgroups per CU, start vertices taken in order from ticket
+ *        counters (k_fill_ranked): 2.77 / 3.46 ms
+ *   4    the same kernel held to three workgroups per CU: 3.24 / 3.32 ms (at widths e > 2 there is no occupancy cap: = shape 1)
+ *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.22 /
+ *        3.33 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
+ *   3    persistent waves that take output tiles in order from ticket counters, three tiles in flight per wave
+ *        (k_fill_tickets, e <= 2; other widths: shape 2): 3.9 / 4.1 ms -- measured and never chosen, kept for the A/B
+ * The environment variable GNNPE_EMIT=starts|starts_low|tiles|tickets overrides the context's setting (same-process A/B runs). */
 int gnnpe_set_emit_shape(gnnpe_ctx *ctx, int shape);
-/* Times both emit shapes into the caller's output buffers (rows [0, total) of the context's current l=2 count, three launches
- * each: the buffers are overwritten with the paths) and remembers the faster one FOR THESE BUFFERS: with emit shape 0
- * later fills into them take it.  The rate a kernel reaches depends on the allocation it writes to and on its shape
- * (DESIGN.md section 4): start-vertex waves are faster into some allocations, output tiles into others.  ms_starts /
- * ms_tiles / shape_kept may be null; both times are 0 when only one shape applies (hub rows, fewer than 2^24 paths).
- * gnnpe_output_pool_create calibrates the buffer it keeps. */
-int gnnpe_emit_calibrate_device(gnnpe_ctx *ctx, void *dev_vids, void *dev_pde, float *ms_starts, float *ms_tiles, int *shape_kept);
+/* Times the emit shapes 1, 4 and 2 into the caller's output buffers (rows [0, total) of the context's current l=2 count, which
+ * must fit rows_cap, the buffers' capacity in rows; three launches each: the buffers are overwritten with the paths) and
+ * remembers the fastest FOR THESE BUFFERS: with emit shape 0 later fills into them take it.  The rate a kernel reaches depends
+ * on the allocation it writes to and on its shape.  ms_by_shape (5 floats, indexed by shape; may be null)
+ * receives the times, 0 for a shape that was not run -- all 0 when only one shape applies (hub rows, fewer than 2^24 paths).
+ * The entry is dropped when the buffer is freed through gnnpe_dev_free / gnnpe_output_pool_destroy.
+ * gnnpe_output_pool_create calibrates the buffer it keeps unless told not to. */
+int gnnpe_emit_calibrate_device(gnnpe_ctx *ctx, uint64_t rows_cap, void *dev_vids, void *dev_pde, float *ms_by_shape, int *shape_kept);
+/* Bytes of the index.dat a partition of `points` paths of dimension D becomes (header block + one 4 KiB block per node of the
+ * bulk-loaded tree; rtnode.cpp:27-28, blk_file.cpp:38-52), by the builder that writes it: 0 = the pair-major build behind
+ * gnnpe_build_index / gnnpe_build_index_partition_device (nodes of min(capacity - 1, 64) entries), 1 = the tuple-array build
+ * gnnpe_build_index_device (min(capacity - 2, 64): what the multi-GPU path uses).  No GPU, no context: callers check the
+ * reference's 2 GiB limit (blk_file.h:32-33) BEFORE anything is built or written.  0 for a dimension no node holds. */
+uint64_t gnnpe_index_file_bytes(uint64_t points, uint32_t D, int builder);
 /* Name of the emit kernel the context's last fill launched ("" before the first fill): the rocprofv3 row to match. */
 const char *gnnpe_emit_kernel_name(gnnpe_ctx *ctx);
 

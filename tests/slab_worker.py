@@ -230,10 +230,33 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
                 P, oids, opde = args.oracle_rows
                 ok = int(sb.global_total) == P
                 CH = 1 << 24
-                for a in range(0, emit, CH):
-                    b = min(emit, a + CH)
-                    ok = ok and np.array_equal(ids[a:b].cpu().numpy().view(np.uint32), oids[base + a:base + b])
-                    ok = ok and np.array_equal(pde[a:b].cpu().numpy().view(np.uint64), opde[base + a:base + b].view(np.uint64))
+
+                def rows_equal():
+                    good = True
+                    for a in range(0, emit, CH):
+                        b = min(emit, a + CH)
+                        good = good and np.array_equal(ids[a:b].cpu().numpy().view(np.uint32), oids[base + a:base + b])
+                        good = good and np.array_equal(pde[a:b].cpu().numpy().view(np.uint64), opde[base + a:base + b].view(np.uint64))
+                    return good
+                ok = ok and rows_equal()
+                # every emit shape a caller can get, through the enqueue-only step (count without a read-back, capped fill), then
+                # shape 0 after the library's calibration of THESE buffers
+                kernels = {}
+                for shape in (1, 4, 2, 3, 0):
+                    eng.set_emit_shape(shape)
+                    kept = shape
+                    if shape == 0:
+                        kept = eng.emit_calibrate_device(ids, pde, rows_cap=max(emit, 1))["kept_shape"]
+                    ids.zero_()
+                    pde.zero_()
+                    torch.cuda.current_stream(dev).synchronize()
+                    eng.count_paths_enqueue(args.l)
+                    eng.fill_paths_capped_device(max(emit, 1), ids, pde)
+                    eng.sync()
+                    kernels[str(shape)] = eng.emit_kernel_name()
+                    ok = ok and eng.count_total() == total and kernels[str(shape)] == eng.EMIT_SHAPE_KERNELS[kept] and rows_equal()
+                eng.set_emit_shape(0)
+                res["emit_kernels"] = kernels
                 res["oracle_exact"] = bool(ok)
             res["middle_sum"] = int(ids[:emit, 1].to(torch.int64).sum())
         else:

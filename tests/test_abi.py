@@ -52,3 +52,24 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(binding.GnnpeError, match="no HIP device|no CPU fallback"):
         binding.Engine(0)
+
+
+def test_index_file_bytes_uses_each_builders_own_fan_out():
+    """the pre-write 2 GiB guard must size index.dat with the fan-out of the builder that writes it.  Node capacity
+    (4096 - 5) / (16 D + 4) (rtnode.cpp:27-28); the pair-major build fills min(capacity - 1, 64) entries per node, the tuple-array
+    build (the multi-GPU path) min(capacity - 2, 64); one block per node + the header block (blk_file.cpp:38-52)."""
+    lib = binding.load()
+
+    def blocks(points, fan):
+        level = [max(1, -(-points // fan))] if points else [1]
+        while points and (len(level) == 1 or level[-1] > 1):
+            level.append(-(-level[-1] // fan))
+        return sum(level) + 1
+    for D, fan0, fan1 in ((3, 64, 64), (6, 39, 38), (12, 19, 18), (24, 9, 8), (32, 6, 5)):  # e = 1, 2, 4, 8 at l = 2; l = 3 at e = 8
+        for points in (0, 1, fan0, fan0 + 1, 6400, 415_545, 19_993_708, 33_600_000):
+            assert lib.gnnpe_index_file_bytes(points, D, 0) == blocks(points, fan0) * 4096, (D, points)
+            assert lib.gnnpe_index_file_bytes(points, D, 1) == blocks(points, fan1) * 4096, (D, points)
+    # e = 1: 64 entries per node, not capacity - 1 = 77 -- 3.36e7 paths are past 2 GiB although 77 per node would fit
+    assert lib.gnnpe_index_file_bytes(33_600_000, 3, 0) >= 1 << 31 > blocks(33_600_000, 77) * 4096
+    # D = 6 on the multi-GPU path: 38 per node is 2.6 % more blocks than 39
+    assert lib.gnnpe_index_file_bytes(19_993_708, 6, 1) > lib.gnnpe_index_file_bytes(19_993_708, 6, 0) > 1 << 31

@@ -151,12 +151,15 @@ def test_config2_100k_1m_equals_the_oracle_and_the_start_shape(binding, oracle):
     ids = torch.empty((total, 3), dtype=torch.int32, device=dev)
     pde = torch.empty((total, 6), dtype=torch.float64, device=dev)
     cal = eng.emit_calibrate_device(ids, pde)
-    assert cal["starts_ms"] > 0 and cal["tiles_ms"] > 0 and cal["kept"] in ("starts", "tiles")
-    assert (cal["kept"] == "tiles") == (cal["tiles_ms"] < cal["starts_ms"])
+    times = {"starts": cal["starts_ms"], "starts_low": cal["starts_low_ms"], "tiles": cal["tiles_ms"]}
+    assert all(t > 0 for t in times.values()) and cal["kept"] in times
+    assert times[cal["kept"]] == min(times.values())
+    with pytest.raises(binding.GnnpeError):  # the buffers' capacity is checked: a count that does not fit is refused
+        eng.emit_calibrate_device(ids, pde, rows_cap=total - 1)
     ids.zero_()
     eng.fill_paths_device(0, total, ids, pde, None)
     eng.sync()
-    assert eng.emit_kernel_name() == {"starts": "k_fill_ranked", "tiles": "k_fill_tiles"}[cal["kept"]]
+    assert eng.emit_kernel_name() == eng.EMIT_SHAPE_KERNELS[cal["kept_shape"]]
     assert np.array_equal(ids.cpu().numpy().view(np.uint32), ref) and np.array_equal(pde.cpu().numpy(), ovde[ref].reshape(len(ref), 6))
     other = torch.empty((total, 3), dtype=torch.int32, device=dev)
     eng.fill_paths_device(0, total, other, None, None)

@@ -354,3 +354,30 @@ def test_index_size_guard_and_every_partition_through_the_reference(tmp_path):
     assert out.returncode == 0, out.stderr[-300:]
     assert "This R-Tree contains" not in out.stdout  # it inserted nothing: every partition's tree came from our files
     assert int(re.search(r"Answer Number: (\d+)", out.stdout).group(1)) == ref["answer_number"] == 2
+
+
+@pytest.mark.parametrize("mode", ["e1_single_gpu", "e2_two_slabs"])
+def test_index_size_estimate_equals_the_files_written(tmp_path, mode):
+    """what the 2 GiB guard compares with the limit is gnnpe_index_file_bytes(paths of the partition, D, builder); it must
+    be the size of the file the run then writes -- at e = 1 (nodes of 64 entries, not capacity - 1 = 77) and on the multi-GPU
+    path (`--gpus 2`: the tuple-array build, capacity - 2 entries per node)."""
+    from gnnpe_amd import binding
+    lib = binding.load()
+    g = synth.gnm_graph(4000, 40000, n_labels=6, seed=31)
+    sn = synth.degree_order(g["offsets"])
+    p = 3
+    mem = synth.block_membership(g["n"], p)
+    gp = str(tmp_path / "g.graph")
+    synth.write_graph_file(gp, g)
+    d = str(tmp_path / "d")
+    os.makedirs(d)
+    synth.make_dataset_dir(d, p)
+    synth.write_membership(os.path.join(d, "gnn-pe", "membership.txt"), sn, mem)
+    e, extra, builder = (1, [], 0) if mode == "e1_single_gpu" else (2, ["--gpus", "2", "--same-device"], 1)
+    r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-m", "offline", "-p", str(p), "-e", str(e), "--index"] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(p):
+        cnt = int(open(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "partition_paths.txt")).readline())
+        size = os.path.getsize(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "index.dat"))
+        assert cnt > 10000 and size == lib.gnnpe_index_file_bytes(cnt, 3 * e, builder), (i, cnt, size)
+        assert size != lib.gnnpe_index_file_bytes(cnt, 3 * e, 1 - builder) or e == 1  # (e = 1: both builders fill 64)

@@ -6,6 +6,7 @@ import gzip
 import hashlib
 import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -291,6 +292,47 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
         eng.sync()
         assert np.array_equal(ids[:b - a].cpu().numpy().view(np.uint32), oids[a:b]), a
         assert np.array_equal(pde[:b - a].cpu().numpy().view(np.uint64), opde[a:b].view(np.uint64)), a
+    del ids, pde
+
+    # The bench's own call pattern -- count_paths_enqueue, then fill_paths_capped_device into ONE full-size 12 GB buffer -- with
+    # every emit kernel a caller can get: the start-vertex shape at five and at three workgroups per CU (k_fill_ranked, start
+    # vertices from ticket counters), the output-tile shape (k_fill_tiles: the kernel BENCH_r04 timed), the ticket-wave shape
+    # (k_fill_tickets + k_fill_tile_jobs), and shape 0 after the library's calibration (whichever it measured fastest into THIS
+    # buffer).  The oracle's rows live on the device for the comparison (12 GB more).
+    t0 = time.perf_counter()
+    o_ids = torch.from_numpy(oids.view(np.int32)).to(dev)
+    o_pde = torch.from_numpy(opde.view(np.int64)).to(dev)
+    ids = torch.empty((total, 3), dtype=torch.int32, device=dev)
+    pde = torch.empty((total, 6), dtype=torch.float64, device=dev)
+    CMP = 1 << 24  # rows per comparison: contiguous slices below 2^31 bytes
+
+    def same_as_oracle():
+        for a in range(0, total, CMP):
+            b = min(total, a + CMP)
+            if not torch.equal(ids[a:b], o_ids[a:b]) or not torch.equal(pde[a:b].view(torch.int64), o_pde[a:b]):
+                return False
+        return True
+
+    shapes = [sh for sh in (1, 4, 2, 3) if eng.has_emit_shape(sh)]
+    seen = {}
+    for shape in shapes + [0]:
+        eng.set_emit_shape(shape)
+        if shape == 0:
+            cal = eng.emit_calibrate_device(ids, pde)
+            assert cal["kept"] in ("starts", "starts_low", "tiles"), cal
+        ids.zero_()
+        pde.zero_()
+        torch.cuda.synchronize()  # (torch's stream is not the engine's: the clearing must have finished before the fill is queued)
+        eng.vde(want=False)
+        eng.count_paths_enqueue(2)
+        eng.fill_paths_capped_device(total, ids, pde)
+        eng.sync()
+        assert eng.count_total() == P
+        name = eng.emit_kernel_name()
+        assert name == eng.EMIT_SHAPE_KERNELS[shape if shape else cal["kept_shape"]], (shape, name)
+        assert same_as_oracle(), (shape, name)
+        seen[shape] = name
+    print(f"config 3, full-size buffer, shapes {seen}: bit-exact vs the oracle; {time.perf_counter() - t0:.1f} s for this half")
     eng.close()
 
 

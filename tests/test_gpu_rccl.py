@@ -103,3 +103,24 @@ def test_bench_multi_gpu_path_over_a_one_rank_rccl_group(tmp_path):
     assert d["n_gpus"] == 1 and d["config"]["collectives"] == "rccl" and d["config"]["paths"] == synth.expected_paths_l2(g["offsets"])
     assert d["value"] > 1e9 and d["halo"]["owned_entries"] == 2 * g["m"] and d["halo"]["halo_rows"] == 0
     assert "vde_and_allgather_ms" in d["phases_ms"]["per_step"]
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts N = 1): bench.py starts the two rank
+    processes itself before touching HIP, relays rank 0's JSON line and leaves with the children's exit code.  On this
+    single-GPU box both ranks share device 0 (GNNPE_BENCH_SAME_DEVICE=1: collectives staged over gloo, RCCL refuses two
+    ranks on one device); on a multi-GPU node the same command runs over RCCL.  Replaces the split of main.cpp:87-96."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--vertices", "100000", "--edges", "1000000",
+                        "--steps", "3", "--warmup", "1", "--no-index", "--no-cpu-baseline", "--no-config5"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    g = synth.gnm_graph(100_000, 1_000_000)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "slab2"
+    assert d["config"]["paths"] == synth.expected_paths_l2(g["offsets"])
+    assert d["sanity"].startswith("path count and middle-vertex checksum match")
+    assert d["halo"]["halo_rows"] > 0 and d["value"] > 1e6  # (collectives staged through host memory here: no rate to speak of)

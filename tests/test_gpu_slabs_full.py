@@ -76,8 +76,11 @@ def _check_l2_slabs(tmp_path, g, world, same_device=True, weights="1,0,0", oracl
     _run(world, ["--graph", gp, "--out", out, "-l", "2", "-e", "2", "--weights", weights] + (["--oracle", "1"] if oracle_exact else []),
          same_device)
     res = _results(out, world)
-    if oracle_exact:  # every id and every double of every rank against the oracle's all-core pass (rows [base, base + total))
-        assert all(r["oracle_exact"] for r in res), [r["rank"] for r in res if not r["oracle_exact"]]
+    if oracle_exact:  # every id and every double of every rank against the oracle's all-core pass (rows [base, base + total)),
+        # from the default fill and from every emit shape (start-vertex waves at both occupancies, output tiles, ticket waves, the
+        # calibrated choice) through the enqueue-only step
+        assert all(r["oracle_exact"] for r in res), [(r["rank"], r.get("emit_kernels")) for r in res if not r["oracle_exact"]]
+        assert all(r["emit_kernels"]["2"] == "k_fill_tiles" and r["emit_kernels"]["3"] == "k_fill_tickets" for r in res)
     want = synth.expected_paths_l2(g["offsets"])
     assert sum(r["total"] for r in res) == want == res[0]["global_total"]
     base = 0
