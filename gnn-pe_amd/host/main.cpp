@@ -322,6 +322,71 @@ int main(int argc, char **argv)
         if (o.sidecars) die("--sidecars is a single-GPU option");
         return slab::run_offline_slabs(o, g, sorted_nodes, membership, table, t_start, t_loaded);
     }
+    // --index: the partitions' index.dat files are the work of a SECOND context on the same device, on a thread of its own, beside
+    // the text files: the two share nothing but the host arrays, the 22 GB of index blocks cross PCIe while the text is rendered
+    // and written, and the files of both kinds go to the file system side by side (one file takes ~10 GB/s on these boxes whatever
+    // the number of writers, scripts/fs_write_probe.cpp; sixteen files take 30-40).  The thread builds its context and its count,
+    // then waits for the main thread's size check before it writes anything.
+    struct IndexJob {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        int go = 0;  // 0: wait, 1: write the files, -1: give up
+        double seconds = 0.0;
+        std::string error;
+    };
+    static IndexJob *index_job = nullptr;
+    std::vector<std::string> ips, aps;
+    for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+        ips.push_back(partitions_path + "partition-" + std::to_string(pid) + "/index.dat");
+        aps.push_back(partitions_path + "partition-" + std::to_string(pid) + "/aux_index.bin");
+    }
+    if (o.write_index) {
+        index_job = new IndexJob();
+        index_job->th = std::thread([&, job = index_job] {
+            const auto i0 = Clock::now();
+            auto fail = [&](const char *what) { job->error = std::string(what) + ": " + gnnpe_last_error(); };
+            gnnpe_ctx *ctx = gnnpe_create(0);
+            if (!ctx) return fail("gnnpe_create (index)");
+            uint64_t P2 = 0;
+            if (gnnpe_load_csr(ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()) != 0 ||
+                gnnpe_set_order(ctx, sorted_nodes.data(), membership.data(), o.partition_num) != 0 ||
+                gnnpe_set_label_table(ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()) != 0 ||
+                gnnpe_vde(ctx, nullptr, nullptr, nullptr) != 0 || gnnpe_count_paths(ctx, o.path_length, nullptr, &P2) != 0) {
+                fail("index context");
+                gnnpe_destroy(ctx);
+                return;
+            }
+            {
+                std::unique_lock<std::mutex> lk(job->mu);
+                job->cv.wait(lk, [&] { return job->go != 0; });
+                if (job->go < 0) {
+                    gnnpe_destroy(ctx);
+                    return;
+                }
+            }
+            std::vector<const char *> ipp, app;
+            for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+                ipp.push_back(ips[pid].c_str());
+                app.push_back(aps[pid].c_str());
+            }
+            // every partition's image first, then the files side by side; with --sidecars also the trees' auxiliary index
+            // (custom.h:268-364), which the online side otherwise rebuilds on every start
+            if (gnnpe_build_index_files(ctx, o.partition_num, ipp.data(), o.sidecars ? app.data() : nullptr) != 0) fail("build_index_files");
+            gnnpe_destroy(ctx);
+            job->seconds = secs(i0, Clock::now());
+        });
+        atexit([] {  // an error exit on the main thread: the index thread is told to give up and joined first
+            if (index_job && index_job->th.joinable()) {
+                {
+                    std::unique_lock<std::mutex> lk(index_job->mu);
+                    if (index_job->go == 0) index_job->go = -1;
+                }
+                index_job->cv.notify_all();
+                index_job->th.join();
+            }
+        });
+    }
     std::vector<Device> devs(1);
     devs[0].ctx = early_ctx ? early_ctx : gnnpe_create(0);  // (again on this thread if the early one failed: for its message)
     if (!devs[0].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
@@ -366,6 +431,11 @@ int main(int argc, char **argv)
                                                    (o.path_length == 2 && (o.vde_dim <= 4 || o.vde_dim == 8)) ? 0 : 1);
         if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
         if (!big.empty()) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
+        {
+            std::unique_lock<std::mutex> lk(index_job->mu);
+            index_job->go = 1;  // the size check has passed: the index thread may write
+        }
+        index_job->cv.notify_all();
     }
     for (int d = 0; d < o.gpus; d++) {
         if (o.gpus > 1) {
@@ -461,41 +531,26 @@ int main(int argc, char **argv)
         fwrite(hvde.data(), 8, hvde.size(), f);
         fclose(f);
     }
-    double t_index = 0.0;
+    double t_index = 0.0, t_index_wait = 0.0;
     if (o.write_index) {  // optional accelerator: the reference online run reuses an existing index.dat (custom.h:222-235)
         const auto i0 = Clock::now();
-        gnnpe_ctx *ctx = devs[0].ctx;
-        if (o.gpus > 1) {
-            uint64_t t = 0;
-            check(gnnpe_set_slab(ctx, 0, g.n), "set_slab(all)");
-            check(gnnpe_count_paths(ctx, o.path_length, nullptr, &t), "count_paths(all)");
-        }
-        // every partition's image first, then the files side by side; with --sidecars also the trees' auxiliary index
-        // (custom.h:268-364), which the online side otherwise rebuilds on every start
-        std::vector<std::string> ips, aps;
-        std::vector<const char *> ipp, app;
-        for (uint32_t pid = 0; pid < o.partition_num; pid++) {
-            ips.push_back(partitions_path + "partition-" + std::to_string(pid) + "/index.dat");
-            aps.push_back(partitions_path + "partition-" + std::to_string(pid) + "/aux_index.bin");
-        }
-        for (uint32_t pid = 0; pid < o.partition_num; pid++) {
-            ipp.push_back(ips[pid].c_str());
-            app.push_back(aps[pid].c_str());
-        }
-        check(gnnpe_build_index_files(ctx, o.partition_num, ipp.data(), o.sidecars ? app.data() : nullptr), "build_index_files");
+        index_job->th.join();
+        t_index_wait = secs(i0, Clock::now());
+        if (!index_job->error.empty()) die(index_job->error);
         for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
-        t_index = secs(i0, Clock::now());
+        t_index = index_job->seconds;
     }
     for (auto &d : devs) gnnpe_destroy(d.ctx);
 
     if (o.timing) {
         fprintf(stderr,
                 "{\"paths\": %llu, \"gpus\": %d, \"load_s\": %.3f, \"setup_s\": %.3f, \"vde_count_s\": %.3f, "
-                "\"emit_render_copy_s\": %.3f, \"write_total_s\": %.3f, \"end_to_end_s\": %.3f, "
-                "\"all_paths_bytes\": %llu, \"partition_bytes\": %llu, \"index_build_s\": %.3f}\n",
+                "\"emit_render_copy_s\": %.3f, \"write_total_s\": %.3f, \"text_gb_per_s\": %.2f, \"end_to_end_s\": %.3f, "
+                "\"all_paths_bytes\": %llu, \"partition_bytes\": %llu, \"index_build_s\": %.3f, \"index_wait_after_text_s\": %.3f}\n",
                 (unsigned long long)P, o.gpus, secs(t_start, t_loaded), secs(t_loaded, t_setup), secs(t_setup, t_counted),
-                t_gpu, secs(t_counted, t_written), secs(t_start, Clock::now()), (unsigned long long)bytes_all,
-                (unsigned long long)bytes_part, t_index);
+                t_gpu, secs(t_counted, t_written), (bytes_all + bytes_part) / 1e9 / std::max(1e-9, secs(t_counted, t_written)),
+                secs(t_start, Clock::now()), (unsigned long long)bytes_all,
+                (unsigned long long)bytes_part, t_index, t_index_wait);
     }
     return 0;
 }

@@ -16,7 +16,7 @@ synth.write_graph_file(gp, g)
 synth.make_dataset_dir(root, p)
 synth.write_membership(os.path.join(root, "gnn-pe", "membership.txt"), sn, synth.block_membership(n, p))
 t_gen = time.time() - t0
-cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnn-pe_amd", "gnnpe_main")
+cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gnn-pe_amd", os.environ.get("GNNPE_CLI", "gnnpe_main"))
 t0 = time.time()
 r = subprocess.run([cli, "-f", root + "/", "-d", gp, "-m", "offline", "-p", str(p), "--timing"] + extra, capture_output=True, text=True)
 wall = time.time() - t0
