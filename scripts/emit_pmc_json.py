@@ -6,10 +6,11 @@ src, dst = sys.argv[1], sys.argv[2]
 per = {}
 for ln in open(src):
     f = ln.split()
-    if len(f) >= 4 and f[1] in ("k_fill_ranked", "k_fill_tiles") and f[2] == "mean":
+    if len(f) >= 4 and f[1] in ("k_fill_ranked", "k_fill_tiles", "k_fill_tickets", "k_fill_tile_jobs") and f[2] == "mean":
         per.setdefault(f[1], {})[f[0]] = float(f[3])
-out = {"command": "scripts/emit_pmc.sh = rocprofv3 --pmc <set> -- python3 scripts/emit_ab.py --bufs 1 --quick (one pass per counter set; BASELINE "
-                  "config 3, 2.0e8 paths, both emit kernels into the same buffers in one process)",
+out = {"command": "scripts/emit_pmc3.sh (round 5; round 4: emit_pmc.sh) = rocprofv3 --pmc <set> -- python3 scripts/emit_ab3.py --quick (one pass per counter "
+                  "set; BASELINE config 3, 2.0e8 paths, the emit kernels into the same buffers in one process; k_fill_ranked with its start "
+                  "vertices from ticket counters, five workgroups per CU)",
        "algorithmic_bytes": 200031576 * 92}
 for k, c in per.items():
     rd = c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
