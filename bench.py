@@ -485,7 +485,7 @@ def main():
     cap_rows = pool.rows_cap
     ids_view = pool.ids_tensor(device)
     # both emit shapes timed into the kept buffer (the pool has done this already; again here for the numbers)
-    shapes = eng.emit_calibrate_device(out_ids, out_pde) if (args.fill_variant == 4 and total > 0) else None
+    shapes = eng.emit_calibrate_device(out_ids, out_pde, rows_cap=cap_rows) if (args.fill_variant == 4 and total > 0) else None
 
     fill_ms = []
     enqueue_only = args.fill_variant == 4 and e in (1, 2, 3, 4, 8)
@@ -566,7 +566,7 @@ def main():
         p_ids = torch.empty((max(total, 1), L), dtype=torch.int32, device=device)
         p_pde = None if args.ids_only else torch.empty((max(total, 1), e * L), dtype=torch.float64, device=device)
         p_ev = []
-        eng.emit_calibrate_device(p_ids, p_pde)
+        eng.emit_calibrate_device(p_ids, p_pde, rows_cap=max(total, 1))
         one_step(False, p_ids, p_pde)
         barrier()
         tp = time.perf_counter()

@@ -166,3 +166,38 @@ def test_config2_100k_1m_equals_the_oracle_and_the_start_shape(binding, oracle):
     eng.sync()
     assert eng.emit_kernel_name() == "k_fill_ranked" and torch.equal(other, ids)
     eng.close()
+
+
+@pytest.mark.parametrize("heads", ["0", "1", "5", "64"])
+def test_start_vertices_from_ticket_counters_or_static(binding, oracle, monkeypatch, heads):
+    """k_fill_ranked takes its start vertices in order from ticket counters (16 by default; GNNPE_RANKED_TICKETS = their number,
+    0 = the static assignment w, w + waves, ... kept for A/B runs): every setting emits the reference's rows, on a graph with
+    hub rows (degree > 64: streamed in id order by the same kernel), at both occupancies, whole and in chunks."""
+    from gnnpe_amd import synth
+    monkeypatch.setenv("GNNPE_RANKED_TICKETS", heads)
+    g = synth.powerlaw_graph(3000, 30000, exponent=2.1, max_degree=300, n_labels=5, seed=11)
+    assert int(np.diff(g["offsets"].astype(np.int64)).max()) > 64
+    sn = synth.degree_order(g["offsets"])
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    for shape in (1, 4):
+        eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2, shape)
+        x, nx, vde = eng.vde()
+        total = eng.count_paths(2)
+        assert total == len(ref) > 100000
+        ids, pde, _ = eng.fill_paths()
+        assert eng.emit_kernel_name() == "k_fill_ranked"
+        assert np.array_equal(ids, ref) and np.array_equal(pde, vde[ref].reshape(len(ref), 6))
+        for b_, e_ in [(0, 1), (63, 65), (1000, 50000), (total - 3, total)]:
+            ci, cp, _ = eng.fill_paths(b_, e_)
+            assert np.array_equal(ci, ref[b_:e_]) and np.array_equal(cp, vde[ref[b_:e_]].reshape(e_ - b_, 6)), (shape, b_, e_)
+        eng.close()
+    # a graph smaller than the grid: fewer waves than heads
+    g = synth.gnm_graph(40, 120, n_labels=3, seed=2)
+    sn = synth.degree_order(g["offsets"])
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 3)
+    eng = _engine(binding, g, sn, np.zeros(40, np.uint32), 1, 2, 1)
+    eng.vde(want=False)
+    assert eng.count_paths(2) == len(ref)
+    ids, _, _ = eng.fill_paths(pde=False)
+    assert np.array_equal(ids, ref)
+    eng.close()
