@@ -157,6 +157,8 @@ struct gnnpe_ctx {
     bool counted = false;
     uint32_t l = 0;
     uint64_t n_edges = 0;  // directed (start, middle) pairs of the slab
+    bool eoff_valid = false;  // the per-pair offsets of the current count exist (rank-sorted enumeration: built on demand, gnnpe_ensure_eoff)
+    gnnpe::DevBuf scan_status;  // k_start_scan: one status word per tile of 256 start vertices, then its ticket counter
     uint64_t total_paths = 0;
     bool total_known = false;  // false after gnnpe_count_paths_enqueue until gnnpe::resolve_total fetches eoff[n_edges]
     gnnpe::DevBuf poffs, erow, pnbr, ecnt, eoff, cub_tmp, scratch, mark, small;
@@ -213,3 +215,5 @@ struct gnnpe_ctx {
 
 // drops the emit shape measured for any buffer that starts in [lo, lo + bytes) (gnnpe_engine.hip; called where buffers are freed)
 void gnnpe_forget_emit_pref(gnnpe_ctx *c, const void *lo, size_t bytes);
+// per-pair output offsets of the current count, built on demand (gnnpe_engine.hip; internal, not part of the ABI header)
+extern "C" int gnnpe_ensure_eoff(gnnpe_ctx *c);

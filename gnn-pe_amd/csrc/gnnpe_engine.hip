@@ -959,6 +959,25 @@ static int ensure_slab_struct(gnnpe_ctx *c)
     return GNNPE_OK;
 }
 
+// eoff[pair] = output slot of the pair's first path, for the consumers that need it per PAIR (the tile table, the index build's
+// pair records, per-start counts, the l = 2 strip jobs): the rank-sorted count leaves only the start records and the total
+// (k_start_scan); the scan over the 2.0e7 pair counts runs here, once per count, when somebody asks.
+int gnnpe_ensure_eoff(gnnpe_ctx *c)
+{
+    if (c->eoff_valid) return GNNPE_OK;
+    GNNPE_REQUIRE(c->counted && c->counted_variant == kVarRanked, GNNPE_ERR_ARG, "per-pair offsets: no count of the rank-sorted enumeration");
+    const uint64_t ne = c->n_edges;
+    int rc;
+    hipcub::TransformInputIterator<uint64_t, CntOfPair, const RankedPair *> it(c->rpairs.as<RankedPair>(), CntOfPair());
+    size_t tb = 0;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+    if ((rc = c->cub_tmp.reserve(tb))) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+    c->eoff_valid = true;
+    return GNNPE_OK;
+}
+
 // what the output-tile-driven emit needs beside the count: the pairs' end points (once per graph / order / slab) and the
 // tile table of this count for the tiles of rows [0, rows_hi)
 static int ensure_tile_table(gnnpe_ctx *c, uint64_t rows_hi, uint32_t ts)
@@ -976,6 +995,7 @@ static int ensure_tile_table(gnnpe_ctx *c, uint64_t rows_hi, uint32_t ts)
         c->pst_valid = true;
     }
     const uint64_t need = (rows_hi + ts - 1) / ts + 1;  // tiles + the sentinel entry
+    if ((rc = gnnpe_ensure_eoff(c))) return rc;  // (also for the strip jobs of emit shape 3, which read eoff themselves)
     if (c->tile_gen == c->count_gen && c->tile_cap >= need && c->tile_rows == ts) return GNNPE_OK;
     if ((rc = c->tfirst.reserve((need + 1) * 8))) return rc;
     if (ne)
@@ -1099,14 +1119,11 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
         GNNPE_HIP_TRY(hipGetLastError());
     }
 
-    // 3. exclusive scan: eoff[pair] = output slot of the pair's first path; eoff[ne] = total
+    // 3. exclusive scan: eoff[pair] = output slot of the pair's first path; eoff[ne] = total.  The rank-sorted enumeration's
+    // default emit needs the STARTS' offsets only: k_start_scan below; eoff itself is built on demand (ensure_eoff)
+    c->eoff_valid = true;
     if (var == kVarRanked) {
-        hipcub::TransformInputIterator<uint64_t, CntOfPair, const RankedPair *> it(c->rpairs.as<RankedPair>(), CntOfPair());
-        size_t tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
-        if ((rc = c->cub_tmp.reserve(tb))) return rc;
-        tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->eoff.as<uint64_t>(), (int64_t)(ne + 1), c->stream));
+        c->eoff_valid = false;
     } else if (var == kVarDeep) {
         // unit counts -> unit offsets (in place), then the pair offsets the per-start counts read
         uint64_t *uoff = c->uoff.as<uint64_t>();
@@ -1122,11 +1139,21 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
     }
 
     // 4. per-start records that shorten the emit kernel's dependent-load chain; enqueued before the one read-back
-    if (var == kVarRanked && len) {
-        if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec)))) return rc;
-        hipLaunchKernelGGL(k_start_recs, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, sb,
-                           c->sorted.as<uint32_t>(), c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),
-                           c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->srec.as<StartRec>());
+    if (var == kVarRanked) {
+        const uint32_t n_tiles = (len + kStartTile - 1) / kStartTile;
+        if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))) || (rc = c->scan_status.reserve((size_t)n_tiles * 8 + 64))) return rc;
+        // status words, then the ticket counter (a line of its own behind them)
+        GNNPE_HIP_TRY(hipMemsetAsync(c->scan_status.p, 0, (size_t)n_tiles * 8 + 64, c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(c->eoff.as<uint64_t>() + ne, 0, 8, c->stream));  // (no start vertices: no paths)
+        if (len) {
+            unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)blocks_per_cu(k_start_scan) * c->num_cus));
+            if (const char *ev = getenv("GNNPE_START_SCAN_GRID")) grid = (unsigned)std::max(1, std::min<int>((int)n_tiles, atoi(ev)));
+            if (getenv("GNNPE_EMIT_DEBUG")) fprintf(stderr, "[count] k_start_scan: %u tiles, grid %u (%d per CU)\n", n_tiles, grid, blocks_per_cu(k_start_scan));
+            hipLaunchKernelGGL(k_start_scan, dim3(grid), dim3(kStartTile), 0, c->stream, len, sb, c->sorted.as<uint32_t>(),
+                               c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(), c->rpairs.as<RankedPair>(),
+                               c->scan_status.as<unsigned long long>(), reinterpret_cast<uint32_t *>(c->scan_status.as<char>() + (size_t)n_tiles * 8 + 32),
+                               c->srec.as<StartRec>(), c->eoff.as<uint64_t>() + ne);
+        }
         GNNPE_HIP_TRY(hipGetLastError());
     }
     c->l = l;
@@ -1145,6 +1172,7 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
     if (c->have_vde && (var == kVarPairWave || var == kVarDeep) && (rc = ensure_nbr_vde(c))) return rc;
     if (host_total) *host_total = w;
     if (host_per_start && len) {
+        if ((rc = gnnpe_ensure_eoff(c))) return rc;
         if ((rc = c->scratch.reserve((size_t)len * 8))) return rc;
         hipLaunchKernelGGL(k_per_start_counts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len,
                            c->poffs.as<uint32_t>(), c->eoff.as<uint64_t>(), c->scratch.as<uint64_t>());

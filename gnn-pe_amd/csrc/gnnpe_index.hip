@@ -1779,7 +1779,7 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
 {
     typedef PairXE<E> PX;
     int rc;
-    if ((rc = ensure_vkey(c))) return rc;
+    if ((rc = ensure_vkey(c)) || (rc = gnnpe_ensure_eoff(c))) return rc;  // (the pair records hold a path index: per-pair offsets)
     const uint32_t len = c->slab_end - c->slab_begin, D = 3 * E, p = c->p;
     const uint64_t ne = c->n_edges;
     const StartRec *srec = c->srec.as<StartRec>();

@@ -458,6 +458,110 @@ __global__ void k_start_recs(uint32_t len, uint32_t slab_begin, const uint32_t *
     }
 }
 
+// The start vertices' output offsets WITHOUT the scan over the pairs (round 5): the emit kernel of the start-vertex shape needs one
+// number per START vertex -- its first output slot -- not one per pair.  One pass: a workgroup takes a tile of 256 start vertices
+// (tiles in order from a ticket counter), sums every start's pair counts (16 lanes per start over its consecutive pair records),
+// scans the 256 sums, learns the tile's prefix by decoupled look-back over the tiles before it (status word = value << 2 | state:
+// 1 = the tile's own sum, 2 = its inclusive prefix; one 64-bit atomic word, so value and state arrive together) and writes the
+// start records.  It replaces the two scan launches over 2.0e7 pairs (read 320 MB, write 160 MB) and k_start_recs (0.18 ms together at
+// BASELINE config 3) by one launch that reads the pair counts once; the per-pair offsets (eoff) are built only for who needs them
+// (tile table, index build, per-start counts: ensure_eoff in gnnpe_engine.hip).  total_out = eoff[n_edges], where the total lives.
+constexpr int kStartTile = 256;
+__global__ __launch_bounds__(kStartTile) void k_start_scan(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
+                                                           const uint32_t *__restrict__ member, const uint32_t *__restrict__ adj_start,
+                                                           const uint32_t *__restrict__ poffs, const RankedPair *__restrict__ pairs,
+                                                           unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
+                                                           StartRec *__restrict__ recs, uint64_t *__restrict__ total_out)
+{
+    typedef hipcub::BlockScan<uint64_t, kStartTile> Scan;
+    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ uint64_t s_cnt[kStartTile];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_tile;
+    const uint32_t n_tiles = (len + kStartTile - 1) / kStartTile, tid = threadIdx.x, sub = tid & 15u, grp = tid >> 4;
+    for (;;) {
+        if (tid == 0) s_tile = __builtin_amdgcn_atomic_inc32(ticket, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        // 1. the starts' own counts: 16 lanes per start vertex, sixteen start vertices per lane group -- all their row bounds first,
+        // then all their pair counts (two per lane and start: 32 pairs cover a start of BASELINE's graphs), so that a tile is two
+        // round trips, not thirty-two; longer rows finish in a loop
+        constexpr int NPASS = kStartTile / 16;
+        uint32_t e0[NPASS], e1[NPASS], sum[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const uint32_t i = min(tile * kStartTile + pass * 16 + grp, len - 1u);  // (past the last start: its bounds again, dropped below)
+            e0[pass] = poffs[i];
+            e1[pass] = poffs[i + 1];
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            const bool in = tile * kStartTile + pass * 16 + grp < len;
+            const uint32_t k0 = e0[pass] + sub, k1 = k0 + 16;
+            const uint32_t c0 = pairs[min(k0, e1[pass] ? e1[pass] - 1u : 0u)].cnt, c1 = pairs[min(k1, e1[pass] ? e1[pass] - 1u : 0u)].cnt;
+            sum[pass] = (in && k0 < e1[pass] ? c0 & ~kHubFlag : 0u) + (in && k1 < e1[pass] ? c1 & ~kHubFlag : 0u);
+            if (!in) e1[pass] = 0;
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; pass++) {
+            for (uint32_t k = e0[pass] + sub + 32; k < e1[pass]; k += 16) sum[pass] += pairs[k].cnt & ~kHubFlag;
+            uint32_t v = sum[pass];  // a start vertex emits fewer than 2^32 paths (degree x degree)
+            v += __shfl_xor(v, 8, 16);
+            v += __shfl_xor(v, 4, 16);
+            v += __shfl_xor(v, 2, 16);
+            v += __shfl_xor(v, 1, 16);
+            if (sub == 0) s_cnt[pass * 16 + grp] = v;
+        }
+        __syncthreads();
+        // 2. inside the tile
+        const uint64_t mine = s_cnt[tid];
+        uint64_t excl = 0, aggregate = 0;
+        Scan(s_scan).ExclusiveSum(mine, excl, aggregate);
+        // 3. the tile's prefix: look back over the tiles before it (taken in ticket order, so every one of them is running), 64 of
+        // them per step -- one lane each; a single thread walking back one tile per round trip made the pass 0.15 ms
+        if (tid < 64) {
+            if (tid == 0)
+                __hip_atomic_store(&status[tile], (unsigned long long)((aggregate << 2) | (tile ? 1ull : 2ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t prefix = 0;
+            int64_t top = (int64_t)tile - 1;  // nearest predecessor of the window
+            while (top >= 0) {
+                const int64_t idx = top - (int64_t)tid;
+                // (in front of tile 0: an inclusive prefix of zero)
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;
+                const uint64_t inc = __ballot((w & 3ull) == 2ull), none = __ballot((w & 3ull) == 0ull);
+                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+                const uint64_t need = first_inc >= 63u ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);  // lanes up to the first inclusive prefix
+                if (none & need) {  // one of them has not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t v = tid <= first_inc ? (uint64_t)(w >> 2) : 0ull;
+                for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+                prefix += v;
+                if (first_inc < 64u) break;
+                top -= 64;
+            }
+            if (tid == 0) {
+                if (tile) __hip_atomic_store(&status[tile], (unsigned long long)(((prefix + aggregate) << 2) | 2ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = prefix;
+                if (tile == n_tiles - 1) *total_out = prefix + aggregate;
+            }
+        }
+        __syncthreads();
+        // 4. the start records
+        const uint32_t i = tile * kStartTile + tid;
+        if (i < len) {
+            const uint32_t e0 = poffs[i], e1 = poffs[i + 1];
+            const uint32_t s = sorted[slab_begin + i];
+            const uint64_t base = s_prefix + excl;
+            StartRec r = {base, base + mine, e0, e1 - e0, s, member[s], adj_start[s], 0u, 0u, 0u};
+            recs[i] = r;
+        }
+        __syncthreads();  // s_tile, s_cnt and s_prefix are rewritten by the next tile
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // halo helpers
 // ------------------------------------------------------------------------------------------------
