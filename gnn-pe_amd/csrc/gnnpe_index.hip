@@ -606,17 +606,36 @@ __global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__res
         double vs[E];
 #pragma unroll
         for (int k = 0; k < E; k++) vs[k] = vde[(uint64_t)sr.s * E + k];
-        for (uint32_t k = sub; k < sr.ds; k += 16) {
-            const uint32_t q = sr.e0 + k;
+        uint64_t before = 0;  // paths of this start vertex' pairs in front of the strip of 16 (eoff == nullptr: the offsets are not built)
+        for (uint32_t k0 = 0; k0 < sr.ds; k0 += 16) {
+            const uint32_t k = k0 + sub;
+            const bool valid = k < sr.ds;
+            const uint32_t q = sr.e0 + (valid ? k : sr.ds - 1u);
             const RankedPair pr = pairs[q];
-            if (pr.cnt & kHubFlag) continue;  // k_px_hub_units
+            // the pair's first path inside its start vertex: eoff[q] - sr.base, or -- graphs without hub rows, whose index build then
+            // never needs the per-pair offsets -- a scan over the strip's 16 lanes
+            uint64_t within;
+            if (eoff) {
+                within = eoff[q] - sr.base;
+            } else {
+                const uint32_t cnt = valid ? (pr.cnt & ~kHubFlag) : 0u;
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o, 16);
+                    if ((int)sub >= o) incl += t;
+                }
+                within = before + (incl - cnt);
+                before += __shfl(incl, 15, 16);
+            }
+            if (!valid || (pr.cnt & kHubFlag)) continue;  // hub pairs: k_px_hub_units
             const uint64_t at = ufirst ? ufirst[q] : (uint64_t)q;
             const uint32_t b = nbrs[sr.a_s + k];
             PairXE<E> x;
             x.block = pr.block;
             x.cnt = pr.cnt;
             x.G = pr.G;
-            x.son0 = pbase[g] + (eoff[q] - sr.base);
+            x.son0 = pbase[g] + within;
             x.ds = sr.ds;
             x.ls = (uint32_t)(ks >> 32);
 #pragma unroll
@@ -1779,7 +1798,11 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
 {
     typedef PairXE<E> PX;
     int rc;
-    if ((rc = ensure_vkey(c)) || (rc = gnnpe_ensure_eoff(c))) return rc;  // (the pair records hold a path index: per-pair offsets)
+    if ((rc = ensure_vkey(c))) return rc;
+    // the pair records hold a path index.  Hub pairs take it from the per-pair offsets; a graph without hub rows computes it inside
+    // k_px_pairs (a scan over a start vertex' pairs), so its index build leaves eoff unbuilt
+    if (c->n_hub && (rc = gnnpe_ensure_eoff(c))) return rc;
+    const uint64_t *eoff_or_null = c->n_hub ? c->eoff.as<uint64_t>() : nullptr;
     const uint32_t len = c->slab_end - c->slab_begin, D = 3 * E, p = c->p;
     const uint64_t ne = c->n_edges;
     const StartRec *srec = c->srec.as<StartRec>();
@@ -1865,7 +1888,7 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
         KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                        \
         if (len)                                                                                                        \
             hipLaunchKernelGGL((k_px_pairs<E, KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
-                               pairs, c->eoff.as<uint64_t>(), c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(), c->vde.as<double>(), \
+                               pairs, eoff_or_null, c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(), c->vde.as<double>(),     \
                                c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
         if (n_hub_pairs)                                                                                                \
             hipLaunchKernelGGL((k_px_hub_units<E, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,     \
