@@ -1370,8 +1370,14 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
     } while (0)
 #define GNNPE_L(EE)                                                                                                     \
     do {                                                                                                                \
-        if (packed) GNNPE_LK((k_fill_ranked<EE, true, kFillRows>));                                                     \
-        else GNNPE_LK((k_fill_ranked<EE, false, kFillRows>));                                                           \
+        if (packed && EE <= 2 && getenv("GNNPE_FILL_ROWS")) { /* A/B aid: rows staged per wave between flushes */            \
+            const int rr = atoi(getenv("GNNPE_FILL_ROWS"));                                                             \
+            if (rr == 256) GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 256>));                                        \
+            else if (rr == 64) GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 64>));                                     \
+            else GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 128>));                                                  \
+        }                                                                                                               \
+        else if (packed) GNNPE_LK((k_fill_ranked<EE, true, fill_rows(EE)>));                                            \
+        else GNNPE_LK((k_fill_ranked<EE, false, fill_rows(EE)>));                                                       \
     } while (0)
         // pde_label is gathered from the emitted ids; without an id output of the caller's they go to scratch
         if (d_pdl && !d_vids) {

@@ -396,10 +396,14 @@ __global__ __launch_bounds__(256) void k_hub_pairs(uint32_t n_hub, const uint32_
 // Measured (config 3, profiles/r02*): the launch moves what the fabric can move for this read/write mix (20.4 GB at
 // 5.0 TB/s before the aligned blocks); waves per SIMD beyond 5 change nothing, spilling to reach 8 costs 6-25 %.
 // ------------------------------------------------------------------------------------------------------------------
-// rows staged per wave between flushes.  Same-process A/B at config 3 (scripts/fill_ab.py: same records, same output
-// buffers): 64 rows 3.440 ms, 128 rows 3.466, 192 rows 3.462; forcing 8 waves per SIMD (64 VGPRs, spills) 3.598; plain
-// instead of non-temporal pde stores 3.748; grids of 2x / 4x / 16x the resident workgroups 3.458 / 3.451 / 3.440.
+// rows staged per wave between flushes.  Round 2, static start vertices, same-process A/B at config 3 (scripts/fill_ab.py): 64 rows
+// 3.440 ms, 128 rows 3.466, 192 rows 3.462; round 4 (five workgroups per CU): 128 rows 3.18 against 2.98.  Round 5, start vertices in
+// order from ticket counters (profiles/r05_emit_ab.txt section 6, six allocations, same buffers): 128 rows are as fast or faster in EVERY
+// allocation -- fast class 2.73 ms against 2.77 (0.843 of the spec), in between the same, slow class 3.29 against 3.44 / 3.38 against
+// 3.49 -- 192 / 256 rows gain further in one kind of slow allocation (3.24 / 3.22) and lose in the others (256: 2.82 in the fast
+// class).  So 128 at the widths whose rows are small (e <= 2: 21 bytes of LDS per row); the wide embeddings keep 64.
 constexpr int kFillRows = 64;
+__host__ __device__ constexpr int fill_rows(int e) { return e <= 2 ? 128 : kFillRows; }
 
 struct __attribute__((packed, aligned(4))) IdRow {
     uint32_t s, b, c;

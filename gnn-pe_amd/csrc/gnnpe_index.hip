@@ -2057,9 +2057,12 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     // the label tables (16-bit ranks and the doubles by rank: 10 bytes per entry) ride in LDS when they fit beside the windows
     // without costing a wave of occupancy (eight workgroups of 15 904 + 4 480 bytes fill a CU's 160 KB)
     const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 448) ? c->n_labels * e : 0u;
+    // GNNPE_LEAF_LDS_PAD (A/B aid): this much more dynamic LDS nobody touches = fewer resident workgroups per CU
+    uint32_t leaf_pad = 0;
+    if (const char *ev = getenv("GNNPE_LEAF_LDS_PAD")) leaf_pad = (uint32_t)std::max(0, std::min(40000, atoi(ev)));
 #define GNNPE_PXL(EE, PK, AX) GNNPE_PXN(EE, PK, AX, 1)
 #define GNNPE_PXN(EE, PK, AX, NN)                                                                                       \
-    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX, NN>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10, c->stream, cnt, nl, r0, r1, \
+    hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX, NN>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10 + leaf_pad, c->stream, cnt, nl, r0, r1, \
                        c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
                        c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds,        \
                        c->px_raux_dbits, image, mbr_a, adeg, ambr)
