@@ -378,10 +378,11 @@ int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
  *   0    whichever gnnpe_emit_calibrate_device measured fastest into the fill's output buffer; shape 1 for a buffer nobody
  *        calibrated (default)
  *   1    one wave per start vertex, resident grid, five workgroups per CU, start vertices taken in order from ticket
- *        counters (k_fill_ranked): 2.77 / 3.46 ms
- *   4    the same kernel held to three workgroups per CU: 3.24 / 3.32 ms (at widths e > 2 there is no occupancy cap: = shape 1)
- *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.22 /
- *        3.33 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
+ *        counters, 128 rows staged per flush (k_fill_ranked): 2.73-2.83 / 3.3-3.4 ms
+ *   4    the same kernel held to three workgroups per CU: 3.05-3.25 / 3.13-3.6 ms -- the faster one in one kind of slow
+ *        allocation (at widths e > 2 there is no occupancy cap: = shape 1)
+ *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.2-3.3 /
+ *        3.3-3.55 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
  *   3    persistent waves that take output tiles in order from ticket counters, three tiles in flight per wave
  *        (k_fill_tickets, e <= 2; other widths: shape 2): 3.9 / 4.1 ms -- measured and never chosen, kept for the A/B
  * The environment variable GNNPE_EMIT=starts|starts_low|tiles|tickets overrides the context's setting (same-process A/B runs). */
