@@ -487,31 +487,39 @@ __global__ __launch_bounds__(kStartTile) void k_start_scan(uint32_t len, uint32_
         // 1. the starts' own counts: 16 lanes per start vertex, sixteen start vertices per lane group -- all their row bounds first,
         // then all their pair counts (two per lane and start: 32 pairs cover a start of BASELINE's graphs), so that a tile is two
         // round trips, not thirty-two; longer rows finish in a loop
-        constexpr int NPASS = kStartTile / 16;
-        uint32_t e0[NPASS], e1[NPASS], sum[NPASS];
+        // (in two halves of eight start vertices per lane group: 48 registers of row bounds and sums held the kernel to five
+        // workgroups per CU)
+        constexpr int NPASS = kStartTile / 16, HALF = NPASS / 2;
 #pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            const uint32_t i = min(tile * kStartTile + pass * 16 + grp, len - 1u);  // (past the last start: its bounds again, dropped below)
-            e0[pass] = poffs[i];
-            e1[pass] = poffs[i + 1];
-        }
+        for (int h = 0; h < 2; h++) {
+            uint32_t e0[HALF], e1[HALF], sum[HALF];
 #pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            const bool in = tile * kStartTile + pass * 16 + grp < len;
-            const uint32_t k0 = e0[pass] + sub, k1 = k0 + 16;
-            const uint32_t c0 = pairs[min(k0, e1[pass] ? e1[pass] - 1u : 0u)].cnt, c1 = pairs[min(k1, e1[pass] ? e1[pass] - 1u : 0u)].cnt;
-            sum[pass] = (in && k0 < e1[pass] ? c0 & ~kHubFlag : 0u) + (in && k1 < e1[pass] ? c1 & ~kHubFlag : 0u);
-            if (!in) e1[pass] = 0;
-        }
+            for (int pp = 0; pp < HALF; pp++) {
+                const int pass = h * HALF + pp;
+                const uint32_t i = min(tile * kStartTile + pass * 16 + grp, len - 1u);  // (past the last start: its bounds again, dropped below)
+                e0[pp] = poffs[i];
+                e1[pp] = poffs[i + 1];
+            }
 #pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            for (uint32_t k = e0[pass] + sub + 32; k < e1[pass]; k += 16) sum[pass] += pairs[k].cnt & ~kHubFlag;
-            uint32_t v = sum[pass];  // a start vertex emits fewer than 2^32 paths (degree x degree)
-            v += __shfl_xor(v, 8, 16);
-            v += __shfl_xor(v, 4, 16);
-            v += __shfl_xor(v, 2, 16);
-            v += __shfl_xor(v, 1, 16);
-            if (sub == 0) s_cnt[pass * 16 + grp] = v;
+            for (int pp = 0; pp < HALF; pp++) {
+                const int pass = h * HALF + pp;
+                const bool in = tile * kStartTile + pass * 16 + grp < len;
+                const uint32_t k0 = e0[pp] + sub, k1 = k0 + 16, last = e1[pp] ? e1[pp] - 1u : 0u;
+                const uint32_t c0 = pairs[min(k0, last)].cnt, c1 = pairs[min(k1, last)].cnt;
+                sum[pp] = (in && k0 < e1[pp] ? c0 & ~kHubFlag : 0u) + (in && k1 < e1[pp] ? c1 & ~kHubFlag : 0u);
+                if (!in) e1[pp] = 0;
+            }
+#pragma unroll
+            for (int pp = 0; pp < HALF; pp++) {
+                const int pass = h * HALF + pp;
+                for (uint32_t k = e0[pp] + sub + 32; k < e1[pp]; k += 16) sum[pp] += pairs[k].cnt & ~kHubFlag;
+                uint32_t v = sum[pp];  // a start vertex emits fewer than 2^32 paths (degree x degree)
+                v += __shfl_xor(v, 8, 16);
+                v += __shfl_xor(v, 4, 16);
+                v += __shfl_xor(v, 2, 16);
+                v += __shfl_xor(v, 1, 16);
+                if (sub == 0) s_cnt[pass * 16 + grp] = v;
+            }
         }
         __syncthreads();
         // 2. inside the tile
