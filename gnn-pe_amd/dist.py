@@ -58,8 +58,10 @@ def _start_weights(offsets, sorted_nodes, nbrs):
 # (scripts/emulate_rank.py, N = 8): a first fit gave step_ms ~ 0.11 + 0.0191 P + 0.0738 O + 0.0247 H with P = paths (M),
 # O = adjacency entries of the slab's own rows (M: vde, pair records, per-pair work of the emit kernel), H = entries held
 # and rank-sorted per step (M: own + truncated halo rows), i.e. weights 1 : 3.9 : 1.3; trying the neighbourhood on the
-# box, 1 : 6 : 1.3 gave the flattest ranks (0.99 - 1.06 ms against 0.96 - 1.09).
-STEP_COST_WEIGHTS = (1.0, 6.0, 1.3)
+# box, 1 : 6 : 1.3 gave the flattest ranks (0.99 - 1.06 ms against 0.96 - 1.09).  Round 5 (the emit kernel is 10-15 % faster per path,
+# the start records come from one pass): 1 : 6 : 1.3 now gives 0.80 - 0.957 ms, 1 : 3 : 0.7 the flattest ranks, 0.878 - 0.936
+# (profiles/r05_emulate_rank8.txt).
+STEP_COST_WEIGHTS = (1.0, 3.0, 0.7)
 
 
 def plan_slabs(offsets, sorted_nodes, n_ranks, nbrs=None, weights=(1.0, 0.0, 0.0), entry_cost=None):
