@@ -494,19 +494,21 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
 // b's row block {c, id-position, vde[c]}, vde[b] is the block's header, and the path's index inside the partition is
 // the pair's first index + popcount(G below the id-position).  So the unit that is SORTED is the pair, not the path
 // (20 M instead of 200 M keys at config 3), with key = [partition | label(s) | label(b) | z-order of vde[s], vde[b]]
-// (per-vertex quantised parts, ensure_vkey), ties in path order; leaves take 38 consecutive points of the sorted pairs.
+// (per-vertex quantised parts, ensure_vkey), ties in path order; leaves take F consecutive points of the sorted pairs
+// (index_fanout: 39 at e = 2).
 // Which leaves a query opens: labels of s and b exact, their embeddings in one quantisation cell, c free --
 // scripts/index_key_study.py counts 55 leaves per query against 34 for the per-path label-major key and 10 087 in
 // path order (64 labels), at the same number of level-1 nodes.
-// E doubles of vde[s] ride in the record: the leaf kernel then fetches nothing per pair but the record itself and b's row
-// block (round 2 gathered vde[s] from the table: 4-5 random 128-byte line fills per leaf for 16 useful bytes each).
-// ds / ls: degree and label of s, for the leaf's auxiliary index (custom.h:276-311); b's and c's come from raux (below).
-template <int E> struct __attribute__((aligned(16))) PairXE {
+// The record says nothing about s itself (until round 5 it carried vde[s], degree and label of s: 48 bytes at e = 2, 96 at
+// e = 8): b's row block is in DESCENDING rank order, so the cnt neighbours ranked after s are its first cnt records and the
+// record at position cnt is s' own -- {s | id-position, vde[s]}, in the aux copy of the block with s' {degree, label} word --
+// inside the lines the leaf reads anyway.  A hub row keeps id order: its units carry the position of s (spos).
+struct __attribute__((aligned(16))) PairX {
     uint32_t block, cnt;  // row block of b (kRowAlign units); paths of the unit (| kUnitHub)
     uint64_t G, son0;     // son0: index inside the partition of the unit's first path (hub unit: first row entry << 32)
-    uint32_t ds, ls;
-    double vs[E];
+    uint32_t spos, pad;   // hub unit: position of s' record in b's id-ordered row
 };
+static_assert(sizeof(PairX) == 32, "two 16-byte pieces");
 
 // leaf fill: entries per node.  The reference's node capacity is (4096 - 5) / (16 D + 4) (rtnode.cpp:27-28) and its own
 // insert path splits a node that reaches capacity - 1 (rtnode.cpp:528), so capacity - 1 is the fullest node it ever
@@ -555,7 +557,7 @@ __global__ void k_px_pbase_single(uint32_t len, const StartRec *__restrict__ sre
 
 // Sorted items are UNITS: a pair whose middle row has at most 64 entries is one unit (its records are addressed through
 // G), a hub pair is cut into units of 64 consecutive entries of the id-ordered hub row, each with the 64-bit mask of the
-// entries ranked after s (the r-th path of the unit is the r-th set bit).  PairXE.cnt bit 31 marks a hub unit, whose
+// entries ranked after s (the r-th path of the unit is the r-th set bit).  PairX.cnt bit 31 marks a hub unit, whose
 // first record index rides in the high half of son0.
 constexpr uint32_t kUnitHub = 0x80000000u;
 
@@ -581,37 +583,50 @@ __global__ void k_px_unit_counts(uint32_t len, const StartRec *__restrict__ srec
     }
 }
 
-__device__ __forceinline__ uint64_t px_key(uint64_t part, uint64_t ks, uint64_t kb, uint32_t e, uint32_t lb, uint32_t sbits, uint32_t zbits)
+// Sort key of a unit: [partition | label(s) | label(b) | per level of the quantisation: E bits of s, E bits of b].  The vertex
+// words hold a vertex' spread bits D apart (a path key interleaves three vertices, k_path_keys); a pair has two, and the
+// third vertex' always-zero slots are squeezed out here -- the order is the same, the key is zb * E bits shorter (config 3:
+// 25 -> 21 bits = three radix passes instead of four).
+// WordT: the wide table's {label << 32 | spread bits} or the narrow copy's {label << sbits | spread bits} (k_vkey_narrow).
+template <typename WordT> __device__ __forceinline__ uint32_t vword_label(WordT w, uint32_t sbits, uint32_t lb)
 {
-    const uint64_t lmask = (1ull << lb) - 1ull, smask = (1ull << sbits) - 1ull;
-    const uint64_t lab = (((part << lb) | ((ks >> 32) & lmask)) << lb) | ((kb >> 32) & lmask);
-    const uint64_t z = ((ks & smask) << (2 * e)) | ((kb & smask) << e);
-    return (lab << zbits) | z;
+    const uint32_t l = sizeof(WordT) == 8 ? (uint32_t)((uint64_t)w >> 32) : (uint32_t)((uint64_t)w >> sbits);
+    return l & ((1u << lb) - 1u);
+}
+template <typename WordT>
+__device__ __forceinline__ uint64_t px_key(uint64_t part, WordT ws, WordT wb, uint32_t e, uint32_t lb, uint32_t sbits, uint32_t zb)
+{
+    const uint64_t smask = (1ull << sbits) - 1ull, emask = (1ull << e) - 1ull;
+    const uint64_t lab = (((part << lb) | vword_label(ws, sbits, lb)) << lb) | vword_label(wb, sbits, lb);
+    const uint64_t zs = (uint64_t)ws & smask, zv = (uint64_t)wb & smask;
+    uint64_t z = 0;
+    for (uint32_t l = 0; l < zb; l++)
+        z |= ((((zs >> (l * 3u * e)) & emask) << e) | ((zv >> (l * 3u * e)) & emask)) << (l * 2u * e);
+    return (lab << (zb * 2u * e)) | z;
 }
 
 // one record + one sort key per ordinary pair, at the pair's unit slot; 16 lanes per start vertex
-template <int E, typename KeyT>
+template <int E, typename KeyT, typename WordT>
 __global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__restrict__ srec, const RankedPair *__restrict__ pairs,
-                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const uint64_t *__restrict__ vkey,
-                           const double *__restrict__ vde, const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst,
-                           uint32_t lb, uint32_t sbits, uint32_t zbits, PairXE<E> *__restrict__ px, KeyT *__restrict__ keys,
-                           uint32_t *__restrict__ vals)
+                           const uint64_t *__restrict__ eoff, const uint32_t *__restrict__ nbrs, const WordT *__restrict__ vkey,
+                           const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst, uint32_t lb, uint32_t sbits,
+                           uint32_t zb, PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const unsigned sub = threadIdx.x & 15u;
     uint64_t g = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
     const uint64_t ng = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (; g < len; g += ng) {
         const StartRec sr = srec[g];
-        const uint64_t ks = vkey[sr.s];
-        double vs[E];
-#pragma unroll
-        for (int k = 0; k < E; k++) vs[k] = vde[(uint64_t)sr.s * E + k];
+        const WordT ks = vkey[sr.s];
+        const uint64_t pb = pbase[g];
         uint64_t before = 0;  // paths of this start vertex' pairs in front of the strip of 16 (eoff == nullptr: the offsets are not built)
         for (uint32_t k0 = 0; k0 < sr.ds; k0 += 16) {
             const uint32_t k = k0 + sub;
             const bool valid = k < sr.ds;
             const uint32_t q = sr.e0 + (valid ? k : sr.ds - 1u);
             const RankedPair pr = pairs[q];
+            const uint32_t b = nbrs[sr.a_s + (valid ? k : sr.ds - 1u)];
+            const WordT kb = vkey[b];
             // the pair's first path inside its start vertex: eoff[q] - sr.base, or -- graphs without hub rows, whose index build then
             // never needs the per-pair offsets -- a scan over the strip's 16 lanes
             uint64_t within;
@@ -630,19 +645,16 @@ __global__ void k_px_pairs(uint32_t len, uint32_t n_parts, const StartRec *__res
             }
             if (!valid || (pr.cnt & kHubFlag)) continue;  // hub pairs: k_px_hub_units
             const uint64_t at = ufirst ? ufirst[q] : (uint64_t)q;
-            const uint32_t b = nbrs[sr.a_s + k];
-            PairXE<E> x;
-            x.block = pr.block;
-            x.cnt = pr.cnt;
-            x.G = pr.G;
-            x.son0 = pbase[g] + within;
-            x.ds = sr.ds;
-            x.ls = (uint32_t)(ks >> 32);
-#pragma unroll
-            for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vs[k2];
-            px[at] = x;
+            // {block, cnt, G | son0, spos, pad}: two 16-byte stores, consecutive lanes 32 bytes apart
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const uint64_t son0 = pb + within;
+            const u32x4 p0 = {pr.block, pr.cnt, (uint32_t)pr.G, (uint32_t)(pr.G >> 32)};
+            const u32x4 p1 = {(uint32_t)son0, (uint32_t)(son0 >> 32), 0u, 0u};
+            u32x4 *dst = reinterpret_cast<u32x4 *>(px + at);
+            dst[0] = p0;
+            dst[1] = p1;
             // pairs without paths sort behind every partition (partition field = n_parts)
-            keys[at] = (KeyT)px_key(pr.cnt ? sr.part : n_parts, ks, vkey[b], E, lb, sbits, zbits);
+            keys[at] = (KeyT)px_key<WordT>(pr.cnt ? sr.part : n_parts, ks, kb, E, lb, sbits, zb);
             vals[at] = (uint32_t)at;
         }
     }
@@ -654,10 +666,9 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
                                                       const uint2 *__restrict__ hub_list, const StartRec *__restrict__ srec,
                                                       const RankedPair *__restrict__ pairs, const uint64_t *__restrict__ eoff,
                                                       const uint32_t *__restrict__ nbrs, const char *__restrict__ recs,
-                                                      const uint64_t *__restrict__ vkey, const double *__restrict__ vde,
-                                                      const uint64_t *__restrict__ pbase, const uint64_t *__restrict__ ufirst,
-                                                      uint32_t lb, uint32_t sbits, uint32_t zbits, PairXE<E> *__restrict__ px,
-                                                      KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                      const uint64_t *__restrict__ vkey, const uint64_t *__restrict__ pbase,
+                                                      const uint64_t *__restrict__ ufirst, uint32_t lb, uint32_t sbits, uint32_t zb,
+                                                      PairX *__restrict__ px, KeyT *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const unsigned lane = threadIdx.x & 63u;
     uint64_t w = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
@@ -669,25 +680,31 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
         const uint32_t d = (uint32_t)pr.G, thr = slab_begin + g, b = nbrs[sr.a_s + (q - sr.e0)];
         const RecWide<E> *row = reinterpret_cast<const RecWide<E> *>(recs + (uint64_t)pr.block * kRowAlign + 8 * E);
         const uint64_t ks = vkey[sr.s];
-        const uint64_t key_ok = px_key(sr.part, ks, vkey[b], E, lb, sbits, zbits);
-        const uint64_t key_no = px_key(n_parts, ks, vkey[b], E, lb, sbits, zbits);
+        const uint64_t key_ok = px_key<uint64_t>(sr.part, ks, vkey[b], E, lb, sbits, zb);
+        const uint64_t key_no = px_key<uint64_t>(n_parts, ks, vkey[b], E, lb, sbits, zb);
         uint64_t son = pbase[g] + (eoff[q] - sr.base);
         const uint64_t at0 = ufirst[q];
+        // s' own entry of the row: the one whose rank is s' (ranks are a permutation) -- a pass of its own over the row's ranks
+        // in front of the units, which all carry it (hub pairs are few)
+        uint32_t spos = 0;
+        for (uint32_t j0 = 0; j0 < d; j0 += 64u) {
+            const uint32_t j = j0 + lane;
+            const uint64_t me = __ballot(j < d && row[j].aux == thr);
+            if (me) spos = j0 + (uint32_t)__ffsll((long long)me) - 1u;
+        }
         for (uint32_t u = 0; u * 64u < d; u++) {
             const uint32_t j = u * 64u + lane;
             const bool keep = j < d && row[j].aux > thr;
             const uint64_t mask = __ballot(keep);
             const uint32_t cnt = (uint32_t)__popcll(mask);
             if (lane == 0) {
-                PairXE<E> x;
+                PairX x;
                 x.block = pr.block;
                 x.cnt = cnt | kUnitHub;
                 x.G = mask;
                 x.son0 = son | ((uint64_t)(u * 64u) << 32);
-                x.ds = sr.ds;
-                x.ls = (uint32_t)(ks >> 32);
-#pragma unroll
-                for (int k2 = 0; k2 < E; k2++) x.vs[k2] = vde[(uint64_t)sr.s * E + k2];
+                x.spos = spos;
+                x.pad = 0u;
                 px[at0 + u] = x;
                 keys[at0 + u] = (KeyT)(cnt ? key_ok : key_no);
                 vals[at0 + u] = (uint32_t)(at0 + u);
@@ -696,34 +713,115 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
         }
     }
 }
-// cnt32[i] = paths of sorted unit i (cnt32[ne] = 0): the prefix scan then reads 4 bytes per unit instead of striding over
-// the 48-byte records (0.26 -> 0.1 ms at config 3)
-template <int E>
-__global__ void k_px_permute(uint64_t ne, const uint32_t *__restrict__ order, const PairXE<E> *__restrict__ px, PairXE<E> *__restrict__ out,
-                             uint32_t *__restrict__ cnt32)
+// The units in sorted order AND the points in front of each (pref[i]; pref[ne] = all points) in one pass: a workgroup takes a
+// tile of kPermTile sorted units (tiles in order from a ticket counter), gathers their records -- one 16-byte piece per thread
+// and step, consecutive lanes storing consecutive pieces (a record per thread stored its pieces a record apart: 0.70 ms for
+// 2.0e7 48-byte records at config 3) -- scans the tile's counts and learns the tile's prefix by decoupled look-back (status word =
+// value << 2 | state, as in k_start_scan).  Until round 5 the counts went to an array of their own and a rocPRIM scan followed
+// (0.13 ms + 160 MB at config 3).
+constexpr int kPermBlock = 256, kPermTile = 1024;
+__global__ __launch_bounds__(kPermBlock) void k_px_permute_scan(uint64_t ne, const uint32_t *__restrict__ order, const PairX *__restrict__ px,
+                                                                PairX *__restrict__ out, uint64_t *__restrict__ pref,
+                                                                unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket)
 {
-    // one 16-byte piece per thread: consecutive lanes store consecutive pieces (a record per thread stored its three pieces
-    // 48 bytes apart: 0.70 ms for 2.0e7 records at config 3)
-    constexpr uint64_t PC = sizeof(PairXE<E>) / 16;
-    static_assert(sizeof(PairXE<E>) % 16 == 0, "pair records are whole 16-byte pieces");
+    constexpr int PC = (int)(sizeof(PairX) / 16), kSteps = kPermTile * PC / kPermBlock, kPer = kPermTile / kPermBlock;
+    static_assert(PC == 2 && kPermBlock % PC == 0, "a thread keeps to one piece of its records");
+    typedef hipcub::BlockScan<uint64_t, kPermBlock> Scan;
+    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ uint32_t s_cnt[kPermTile];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_tile;
     const uint4 *src = reinterpret_cast<const uint4 *>(px);
     uint4 *dst = reinterpret_cast<uint4 *>(out);
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < ne * PC; t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 v = src[(uint64_t)order[t / PC] * PC + t % PC];
-        dst[t] = v;
-        if (t % PC == 0) cnt32[t / PC] = v.y & 0x7FFFFFFFu;  // {block, cnt, G}: the record's first piece
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_tiles = (ne + kPermTile - 1) / kPermTile;
+    for (;;) {
+        if (tid == 0) s_tile = __builtin_amdgcn_atomic_inc32(ticket, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
+        __syncthreads();
+        const uint64_t tile = s_tile;
+        if (tile >= n_tiles) break;
+        const uint64_t r0 = tile * kPermTile;
+        // 1. the tile's records: every step's source index first, then every step's piece, then the stores
+        uint32_t o[kSteps];
+        uint4 v[kSteps];
+#pragma unroll
+        for (int i = 0; i < kSteps; i++) o[i] = order[min(r0 + (uint64_t)(i * kPermBlock + tid) / PC, ne - 1)];
+#pragma unroll
+        for (int i = 0; i < kSteps; i++) v[i] = src[(uint64_t)o[i] * PC + (tid % PC)];
+#pragma unroll
+        for (int i = 0; i < kSteps; i++) {
+            const uint32_t piece = i * kPermBlock + tid;
+            const bool in = r0 + piece / PC < ne;
+            if (in) dst[r0 * PC + piece] = v[i];
+            if (tid % PC == 0) s_cnt[piece / PC] = in ? (v[i].y & 0x7FFFFFFFu) : 0u;  // {block, cnt, G}: the record's first piece
+        }
+        __syncthreads();
+        // 2. inside the tile: kPer consecutive units per thread
+        uint32_t c[kPer];
+        uint64_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            c[j] = s_cnt[tid * kPer + j];
+            mine += c[j];
+        }
+        uint64_t excl = 0, aggregate = 0;
+        Scan(s_scan).ExclusiveSum(mine, excl, aggregate);
+        // 3. the tile's prefix: look back over the tiles before it (taken in ticket order, so every one of them is running)
+        if (tid < 64) {
+            if (tid == 0)
+                __hip_atomic_store(&status[tile], (unsigned long long)((aggregate << 2) | (tile ? 1ull : 2ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t prefix = 0;
+            int64_t top = (int64_t)tile - 1;
+            while (top >= 0) {
+                const int64_t idx = top - (int64_t)tid;
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;
+                const uint64_t inc = __ballot((w & 3ull) == 2ull), none = __ballot((w & 3ull) == 0ull);
+                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+                const uint64_t need = first_inc >= 63u ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);
+                if (none & need) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t x = tid <= first_inc ? (uint64_t)(w >> 2) : 0ull;
+                for (int sh = 32; sh; sh >>= 1) x += __shfl_xor(x, sh, 64);
+                prefix += x;
+                if (first_inc < 64u) break;
+                top -= 64;
+            }
+            if (tid == 0) {
+                if (tile) __hip_atomic_store(&status[tile], (unsigned long long)(((prefix + aggregate) << 2) | 2ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = prefix;
+                if (tile == n_tiles - 1) pref[ne] = prefix + aggregate;
+            }
+        }
+        __syncthreads();
+        // 4. the points in front of every unit of the tile
+        uint64_t run = s_prefix + excl;
+        const uint64_t rt = r0 + (uint64_t)tid * kPer;
+        if (rt + kPer <= ne) {  // (16-byte stores: pref is 8-byte aligned times an even index)
+            static_assert(kPer == 4, "two 16-byte stores per thread");
+            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 a = {run, run + c[0]}, b = {run + c[0] + c[1], run + c[0] + c[1] + c[2]};
+            reinterpret_cast<u64x2 *>(pref + rt)[0] = a;
+            reinterpret_cast<u64x2 *>(pref + rt)[1] = b;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPer; j++) {
+                if (rt + j < ne) pref[rt + j] = run;
+                run += c[j];
+            }
+        }
+        __syncthreads();  // s_tile, s_cnt and s_prefix are rewritten by the next tile
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt32[ne] = 0u;
 }
-template <int E> struct CntOfPairX {
-    __host__ __device__ uint64_t operator()(const PairXE<E> &p) const { return (uint64_t)(p.cnt & 0x7FFFFFFFu); }
-};
 struct U32ToU64 {
     __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
 };
-// first sorted pair of every partition (bounds[n_parts] = first pair without paths)
+// first sorted pair of every partition (bounds[n_parts] = first pair without paths) and the points in front of it
+// (bounds[n_parts + 1 + pt]): launched behind the prefix scan, one copy to the host for both
 template <typename KeyT>
-__global__ void k_px_bounds(uint64_t ne, uint32_t n_parts, const KeyT *__restrict__ sorted_keys, uint32_t shift, uint64_t *__restrict__ bounds)
+__global__ void k_px_bounds(uint64_t ne, uint32_t n_parts, const KeyT *__restrict__ sorted_keys, uint32_t shift,
+                            const uint64_t *__restrict__ pref, uint64_t *__restrict__ bounds)
 {
     const uint32_t pt = blockIdx.x * blockDim.x + threadIdx.x;
     if (pt > n_parts) return;
@@ -733,6 +831,7 @@ __global__ void k_px_bounds(uint64_t ne, uint32_t n_parts, const KeyT *__restric
         if (((uint64_t)sorted_keys[mid] >> shift) < pt) lo = mid + 1; else hi = mid;
     }
     bounds[pt] = lo;
+    bounds[n_parts + 1 + pt] = pref[lo];
 }
 // first[j] = sorted pair that holds the first point of leaf j (the largest k with pref[k] <= point index).  Pair-driven: a
 // pair with points [a, z) of the partition names the leaves whose first point j * F falls inside -- none or one for most
@@ -816,9 +915,9 @@ __global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint3
 // first[j] + t (its record and its first point) IN REGISTERS -- the entry lanes fetch their pair's fields from that lane
 // through the crossbar (ds_bpermute), so the wave's LDS is the leaf window alone and eight waves per SIMD still fit at
 // F = 39 -- then entry t: pair by binary search over the pairs' first entries, record r of the pair's row block, vde[s]
-// from the pair record, vde[b] from the block header.
+// from s' own record in b's row block (position cnt of the rank-ordered block: PairX), vde[b] from the block header.
 // Auxiliary index of the leaf (Partition::build_auxiliary_index, custom.h:276-311), when `adeg` is given: the entry's
-// three vertices' {degree, label} come from the pair record (s) and from the raux strip beside b's row block (b, c),
+// three vertices' {degree, label} come from the aux copy of b's row block (header: b; records: s and c),
 // the label features from the label table, the L + 2D reductions run side by side on DPP -- what round 2 computed in a
 // second pass that re-read the whole image and gathered every path's tuple (7.6 ms at config 3).
 // Stores: a leaf's used prefix only (kStoreU4 16-byte pieces); the image's tails are zeroed once per buffer (k_scrub_tails).
@@ -826,13 +925,13 @@ template <int E, bool PACKED, int AUX, int NL>  // AUX: 0 = image only; 1 = aux 
 __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t n_pts, uint64_t n_leaves, uint64_t r0, uint64_t r1,
                                                                         const uint64_t *__restrict__ pref,
                                                                         const uint32_t *__restrict__ first,
-                                                                        const PairXE<E> *__restrict__ px, const char *__restrict__ recs_plain,
+                                                                        const PairX *__restrict__ px, const char *__restrict__ recs_plain,
                                                                         const char *__restrict__ recs_aux,
                                                                         const uint16_t *__restrict__ xrank,
                                                                         const double *__restrict__ xsorted, uint32_t n_labels,
                                                                         uint32_t xrank_lds, uint32_t dbits, char *__restrict__ image,
                                                                         double *__restrict__ node_mbr, uint32_t *__restrict__ adeg,
-                                                                        double *__restrict__ ambr)
+                                                                        double *__restrict__ ambr, uint32_t xcd_chunk)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int D = 3 * E;
@@ -880,11 +979,19 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // index_aux_ab.py): image 5.27-5.29 ms against 5.17-5.18 with one leaf per wave, with the auxiliary rows 6.57 against
     // 6.39.  So the kernel does not wait for latency at eight waves per SIMD: it moves the lines it touches (29.6 GB by the
     // counters) at 5.7 TB/s, above what a plain 71 % write / 29 % read stream reaches on these boxes (4.9-5.2 TB/s).
-    const uint64_t jw = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kLeafWaves + wv)) * NL;
+    // xcd_chunk (A/B aid, GNNPE_LEAF_XCD_CHUNK; scripts/leaf_xcd_ab.py): workgroups go to the eight XCDs in turn; inside every run
+    // of 8 * xcd_chunk workgroups the one on XCD x takes the x-th run of xcd_chunk consecutive leaf groups, so that neighbours in
+    // the sorted pairs and in `first` meet in one L2.  Within +-2 % for every chunk (profiles/r05_leaf_xcd_ab.txt): off.
+    uint32_t bid = blockIdx.x;
+    if (xcd_chunk) {
+        const uint32_t span = 8u * xcd_chunk, base = bid / span * span;
+        if (base + span <= gridDim.x) bid = base + ((bid - base) & 7u) * xcd_chunk + ((bid - base) >> 3);
+    }
+    const uint64_t jw = (uint64_t)__builtin_amdgcn_readfirstlane((int)(bid * kLeafWaves + wv)) * NL;
     bool have_leaf[NL];
     uint64_t g0[NL], rel_cur[NL];
     uint32_t ne[NL];
-    PairXE<E> x_cur[NL];
+    PairX x_cur[NL];
     // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
     uint32_t fj[NL + 1];
 #pragma unroll
@@ -893,7 +1000,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // `pref - pbase` in front of leaf 1's loads: a lane without a pair of its own asks for the leaf's first pair again, the
     // very address lane 0 asks for)
     bool have_pair[NL];
-    constexpr int kPxW = (int)(sizeof(PairXE<E>) / 4);
+    constexpr int kPxW = (int)(sizeof(PairX) / 4) - 1;  // (the last dword is padding)
     uint32_t xw[NL][kPxW];
 #pragma unroll
     for (int q = 0; q < NL; q++) {
@@ -922,15 +1029,12 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
         for (int z = 0; z < kPxW; z++)
             if (!have_pair[q]) xw[q][z] = 0u;
-        // PairXE<E>: {block, cnt, G, son0, ds, ls, vs[E]} (dwords 0, 1, 2-3, 4-5, 6, 7, 8 ...)
+        // PairX: {block, cnt, G, son0, spos} (dwords 0, 1, 2-3, 4-5, 6)
         x_cur[q].block = xw[q][0];
         x_cur[q].cnt = xw[q][1];
         x_cur[q].G = ((uint64_t)xw[q][3] << 32) | xw[q][2];
         x_cur[q].son0 = ((uint64_t)xw[q][5] << 32) | xw[q][4];
-        x_cur[q].ds = xw[q][6];
-        x_cur[q].ls = xw[q][7];
-#pragma unroll
-        for (int k = 0; k < E; k++) x_cur[q].vs[k] = __longlong_as_double((long long)(((uint64_t)xw[q][9 + 2 * k] << 32) | xw[q][8 + 2 * k]));
+        x_cur[q].spos = xw[q][6];
     }
     // the label tables go into LDS BEHIND the pairs' loads (round 4): filled and fenced by a workgroup barrier at the kernel's
     // start they were a round trip of their own in front of everything; here their wait is the wait for the pairs
@@ -946,20 +1050,21 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     constexpr int kHdrW = 2 * E + (int)(kHX / 4);
     constexpr int RWd = (int)(sizeof(Rec) / 4), RWw = (int)(sizeof(RecWide<E>) / 4);
     constexpr int kRecW = RWw + (int)(kXW / 4);  // dwords of the longest record (a hub unit's) with its word
-    uint32_t e_pp[NL], fh[NL], e_ds[NL], e_ls[NL], rr_[NL];
+    uint32_t e_pp[NL], fh[NL], rr_[NL];
     uint64_t e_G[NL], sw[NL];
-    double vs[NL][E];
-    uint32_t hv[NL][kHdrW], wq[NL][kRecW];
+    uint32_t hv[NL][kHdrW], wq[NL][kRecW], ws[NL][kRecW];  // block header, the entry's own record (c), s' record
 #pragma unroll
     for (int q = 0; q < NL; q++) {
         // this lane's pair as the entry lanes will ask for it
         uint32_t pp = 0xFFu;
-        uint32_t p_first = 0;
+        uint32_t p_first = 0, p_sat = 0;
         uint64_t p_son = 0;
         if (rel_cur[q] < g0[q] + ne[q] && lane < kStrip) {
             pp = (uint32_t)(rel_cur[q] >= g0[q] ? rel_cur[q] - g0[q] : 0u);  // first entry of the pair inside this leaf
             // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
             p_first = (x_cur[q].cnt & kUnitHub) ? ((uint32_t)(x_cur[q].son0 >> 32) | kUnitHub) : 0u;
+            // s' own record: behind the cnt records ranked after it; in a hub row (id order) where the unit says
+            p_sat = (x_cur[q].cnt & kUnitHub) ? x_cur[q].spos : x_cur[q].cnt;
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
             p_son = ((x_cur[q].son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur[q] >= g0[q] ? 0u : (uint32_t)(g0[q] - rel_cur[q]));
         }
@@ -985,13 +1090,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         fh[q] = (uint32_t)__shfl((int)p_first, (int)a);
         e_G[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x_cur[q].G >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)x_cur[q].G, (int)a);
         sw[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(p_son >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)p_son, (int)a);
-#pragma unroll
-        for (int k = 0; k < E; k++) vs[q][k] = __shfl(x_cur[q].vs[k], (int)a);
-        e_ds[q] = e_ls[q] = 0;
-        if constexpr (AUX != 0) {
-            e_ds[q] = (uint32_t)__shfl((int)x_cur[q].ds, (int)a);
-            e_ls[q] = (uint32_t)__shfl((int)x_cur[q].ls, (int)a);
-        }
+        const uint32_t s_at = (uint32_t)__shfl((int)p_sat, (int)a);
         // (a wave's missing leaf: the first record of the buffer's first block)
         const uint32_t r = have_leaf[q] ? le - e_pp[q] + (uint32_t)(sw[q] & 0xFFu) : 0u;  // point inside the unit
         rr_[q] = r;
@@ -1021,13 +1120,21 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         // per further partition).  Dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower.
         const uint32_t stride = (hub ? (uint32_t)RWw : (uint32_t)RWd) + kXW / 4;
         const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)rec_at * stride;
+        const uint32_t *rs = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)(have_leaf[q] ? s_at : 0u) * stride;
 #pragma unroll
         for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[q][z] = __builtin_nontemporal_load(rq + z);
+        // (s' record: the pair's entries all ask for the same words, in a line the pair's records touch anyway or the next one)
+#pragma unroll
+        for (int z = 0; z < RWd + (int)(kXW / 4); z++) ws[q][z] = rs[z];
         if constexpr (RWw > RWd) {  // (packed ids: a hub unit's record is one dword longer; a wave-uniform branch)
             static_assert(RWw - RWd <= 1, "one dword more");
-            uint32_t extra = 0u;
-            if (__ballot(hub)) extra = rq[hub ? kRecW - 1 : 0];
+            uint32_t extra = 0u, extra_s = 0u;
+            if (__ballot(hub)) {
+                extra = rq[hub ? kRecW - 1 : 0];
+                extra_s = rs[hub ? kRecW - 1 : 0];
+            }
             wq[q][kRecW - 1] = extra;
+            ws[q][kRecW - 1] = extra_s;
         }
     }
     // every load of the wave is in flight: ONE wait, in front of the first leaf's assembly
@@ -1037,6 +1144,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         for (int z = 0; z < kHdrW; z++) asm volatile("" : "+v"(hv[q][z]));
 #pragma unroll
         for (int z = 0; z < kRecW; z++) asm volatile("" : "+v"(wq[q][z]));
+#pragma unroll
+        for (int z = 0; z < kRecW; z++) asm volatile("" : "+v"(ws[q][z]));
     }
 #pragma unroll
     for (int q = 0; q < NL; q++) {
@@ -1058,10 +1167,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         for (int k = 0; k < kRk; k++) rk[k] = 0u;
         if (act) {
             const bool hub = (fh[q] & kUnitHub) != 0u;
-            double vc[E];
+            double vc[E], vs[E];
             uint32_t son;
-            uint64_t wc = 0;  // {degree, label} of the entry's third vertex (AUX)
-            uint32_t first_dw = wq[q][0];
+            uint64_t wc = 0, wsv = 0;  // {degree, label} of the entry's third and first vertex (AUX)
+            uint32_t first_dw = wq[q][0], first_s = ws[q][0];
             // (records decoded dword by dword, by selects -- an index that depends on the lane would put the array into scratch:
             // wide {id, aux, vde}, packed {id | id-position << 26, vde} -- gnnpe_records.h)
             constexpr int kV = PACKED ? 1 : 2;  // first dword of an ordinary record's vde (a hub unit's: 2)
@@ -1070,24 +1179,35 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 const uint32_t lo32 = hub ? wq[q][2 + 2 * k] : wq[q][kV + 2 * k];
                 const uint32_t hi32 = hub ? wq[q][2 + 2 * k + 1] : wq[q][kV + 2 * k + 1];
                 vc[k] = __longlong_as_double((long long)(((uint64_t)hi32 << 32) | lo32));
+                const uint32_t slo = hub ? ws[q][2 + 2 * k] : ws[q][kV + 2 * k];
+                const uint32_t shi = hub ? ws[q][2 + 2 * k + 1] : ws[q][kV + 2 * k + 1];
+                vs[k] = __longlong_as_double((long long)(((uint64_t)shi << 32) | slo));
             }
             if constexpr (AUX == 1) {
                 const uint32_t w0 = hub ? wq[q][RWw] : wq[q][RWd], w1 = hub ? wq[q][RWw + 1] : wq[q][RWd + 1];
                 wc = ((uint64_t)w1 << 32) | w0;
+                const uint32_t s0 = hub ? ws[q][RWw] : ws[q][RWd], s1 = hub ? ws[q][RWw + 1] : ws[q][RWd + 1];
+                wsv = ((uint64_t)s1 << 32) | s0;
             }
             uint32_t ip;
             if constexpr (PACKED) ip = first_dw >> kPackedIdBits; else ip = wq[q][1];
-            if (PACKED && !hub) first_dw &= (1u << kPackedIdBits) - 1u;
+            if (PACKED && !hub) {
+                first_dw &= (1u << kPackedIdBits) - 1u;
+                first_s &= (1u << kPackedIdBits) - 1u;
+            }
             son = hub ? (uint32_t)(sw[q] >> 8) + rr_[q]
                       : (uint32_t)((sw[q] >> 8) + (uint64_t)__popcll(e_G[q] & ((1ull << (ip & 63u)) - 1ull)));
-            if constexpr (AUX == 2) wc = (uint64_t)(first_dw & ((1u << (dbits & 31u)) - 1u)) | ((uint64_t)(first_dw >> (dbits & 31u)) << 32);
+            if constexpr (AUX == 2) {
+                wc = (uint64_t)(first_dw & ((1u << (dbits & 31u)) - 1u)) | ((uint64_t)(first_dw >> (dbits & 31u)) << 32);
+                wsv = (uint64_t)(first_s & ((1u << (dbits & 31u)) - 1u)) | ((uint64_t)(first_s >> (dbits & 31u)) << 32);
+            }
             double vb[E];
 #pragma unroll
             for (int k = 0; k < E; k++) vb[k] = __longlong_as_double((long long)(((uint64_t)hv[q][2 * k + 1] << 32) | hv[q][2 * k]));
             uint32_t *ent = w + 2 + lane * kEnt;
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double val = k < E ? vs[q][k] : (k < 2 * E ? vb[k - E] : vc[k - 2 * E]);
+                const double val = k < E ? vs[k] : (k < 2 * E ? vb[k - E] : vc[k - 2 * E]);
                 const uint64_t bits64 = (uint64_t)__double_as_longlong(val);
                 const uint32_t x = (uint32_t)bits64, y = (uint32_t)(bits64 >> 32);
                 ent[4 * k] = x;      // bounces[2k]   (custom.h:246)
@@ -1098,10 +1218,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             ent[4 * D] = son;  // the path's index inside the partition (custom.h:243)
             if constexpr (AUX != 0) {
                 const uint64_t wb = ((uint64_t)hv[q][2 * E + 1] << 32) | hv[q][2 * E];
-                dg[0] = e_ds[q];
+                dg[0] = (uint32_t)wsv;
                 dg[1] = (uint32_t)wb;
                 dg[2] = (uint32_t)wc;
-                const uint32_t lab[3] = {e_ls[q], (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
+                const uint32_t lab[3] = {(uint32_t)(wsv >> 32), (uint32_t)(wb >> 32), (uint32_t)(wc >> 32)};
                 uint16_t h[2 * D + 1];
                 h[2 * D] = 0;
 #pragma unroll
@@ -1796,7 +1916,7 @@ static uint32_t bits_for(uint64_t max_value)
 // their records in that order, the prefix of their path counts and every partition's range
 template <int E> static int build_pair_order(gnnpe_ctx *c)
 {
-    typedef PairXE<E> PX;
+    typedef PairX PX;
     int rc;
     if ((rc = ensure_vkey(c))) return rc;
     // the pair records hold a path index.  Hub pairs take it from the per-pair offsets; a graph without hub rows computes it inside
@@ -1845,7 +1965,8 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
     // unit keys {u64 x nu x 2}, unit values {u32 x nu x 2}, device bounds {u64 x (p + 1)}
     const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
                  o_pos = o_cnt + ((size_t)len + 2) * 8, o_keys = o_pos + ((size_t)len + 2) * 8, o_vals = o_keys + (nu + 1) * 16,
-                 o_bnd = o_vals + (nu + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
+                 o_bnd = o_vals + (nu + 1) * 8, o_stat = o_bnd + ((size_t)p + 2) * 16,
+                 o_end = o_stat + (nu / kPermTile + 4) * 8;  // (look-back words of k_px_permute_scan, then its ticket)
     if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((nu + 1) * sizeof(PX))) ||
         (rc = c->px_sorted.reserve((nu + 1) * sizeof(PX))) || (rc = c->px_pref.reserve((nu + 2) * 8)) ||
         (rc = c->px_pbase.reserve(((size_t)len + 1) * 8)))
@@ -1878,57 +1999,64 @@ template <int E> static int build_pair_order(gnnpe_ctx *c)
         hipLaunchKernelGGL(k_px_pbase, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, part_out, idx_out, pos, c->px_pbase.as<uint64_t>());
     }
     // 2. unit records + keys, sorted, permuted, scanned
-    const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * D, sbits = c->vkey_zb ? (c->vkey_zb - 1) * D + E : 0;
-    const uint32_t shift = 2 * lb + zbits, kbits = bits_for(p) + shift;
+    const uint32_t lb = c->vkey_lb, zb = c->vkey_zb, sbits = zb ? (zb - 1) * D + E : 0;
+    const uint32_t shift = 2 * lb + zb * 2 * E, kbits = bits_for(p) + shift;  // (px_key: the pair key has no slots for a third vertex)
+    const bool narrow = c->vkey_sbits != 32;  // the vertex words as 32-bit {label << sbits | spread bits}: half the table to gather from
     GNNPE_REQUIRE(kbits <= 64, GNNPE_ERR_UNSUPPORTED, "pair key needs %u bits", kbits);
     PX *px = c->px_recs.as<PX>(), *pxs = c->px_sorted.as<PX>();
     GNNPE_HIP_TRY(hipMemsetAsync(pxs + nu, 0, sizeof(PX), c->stream));  // sentinel of the scan
 #define GNNPE_PX_SORT(KT)                                                                                               \
     do {                                                                                                                \
         KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                        \
-        if (len)                                                                                                        \
-            hipLaunchKernelGGL((k_px_pairs<E, KT>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, srec, \
-                               pairs, eoff_or_null, c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(), c->vde.as<double>(),     \
-                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
+        if (len && narrow)                                                                                              \
+            hipLaunchKernelGGL((k_px_pairs<E, KT, uint32_t>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, \
+                               srec, pairs, eoff_or_null, c->nbrs.as<uint32_t>(),                                         \
+                               reinterpret_cast<const uint32_t *>(c->vkey.as<uint64_t>() + c->n + 1),                     \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zb, px, k_in, v_in);                      \
+        else if (len)                                                                                                   \
+            hipLaunchKernelGGL((k_px_pairs<E, KT, uint64_t>), dim3(grid_for((uint64_t)len * 16)), dim3(kBlock), 0, c->stream, len, p, \
+                               srec, pairs, eoff_or_null, c->nbrs.as<uint32_t>(), c->vkey.as<uint64_t>(),                  \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zb, px, k_in, v_in);                      \
         if (n_hub_pairs)                                                                                                \
             hipLaunchKernelGGL((k_px_hub_units<E, KT>), dim3(grid_for(n_hub_pairs * 64)), dim3(kBlock), 0, c->stream,     \
                                (uint32_t)n_hub_pairs, p, c->slab_begin, c->px_hubs.as<uint2>(), srec, pairs, c->eoff.as<uint64_t>(), \
-                               c->nbrs.as<uint32_t>(), c->rrecs.as<char>(), c->vkey.as<uint64_t>(), c->vde.as<double>(),  \
-                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zbits, px, k_in, v_in);                   \
+                               c->nbrs.as<uint32_t>(), c->rrecs.as<char>(), c->vkey.as<uint64_t>(),                        \
+                               c->px_pbase.as<uint64_t>(), ufirst, lb, sbits, zb, px, k_in, v_in);                      \
         tb = 0;                                                                                                         \
         GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
         if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                   \
         tb = c->cub_tmp.bytes;                                                                                          \
         GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
-        hipLaunchKernelGGL((k_px_bounds<KT>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, nu, p, k_out, shift, d_bounds); \
     } while (0)
     if (nu) {
         if (kbits <= 32) GNNPE_PX_SORT(uint32_t); else GNNPE_PX_SORT(uint64_t);
-        // (the sort's input values are dead by now: their array takes the sorted units' counts)
-        hipLaunchKernelGGL((k_px_permute<E>), dim3(grid_for(nu * (sizeof(PairXE<E>) / 16))), dim3(kBlock), 0, c->stream, nu, v_out, px, pxs, v_in);
+        unsigned long long *stat = reinterpret_cast<unsigned long long *>(tmp + o_stat);
+        const uint64_t n_tiles = (nu + kPermTile - 1) / kPermTile;
+        GNNPE_HIP_TRY(hipMemsetAsync(stat, 0, (n_tiles + 1) * 8, c->stream));
+        hipLaunchKernelGGL(k_px_permute_scan, dim3((unsigned)std::min<uint64_t>(n_tiles, 256 * 8)), dim3(kPermBlock), 0, c->stream, nu,
+                           v_out, px, pxs, c->px_pref.as<uint64_t>(), stat, reinterpret_cast<uint32_t *>(stat + n_tiles));
     } else {
-        GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, ((size_t)p + 1) * 8, c->stream));
-        GNNPE_HIP_TRY(hipMemsetAsync(v_in, 0, 4, c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(c->px_pref.p, 0, 8, c->stream));
     }
 #undef GNNPE_PX_SORT
-    {
-        hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t *> it(v_in, U32ToU64());
-        tb = 0;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
-        if ((rc = c->cub_tmp.reserve(tb))) return rc;
-        tb = c->cub_tmp.bytes;
-        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, it, c->px_pref.as<uint64_t>(), (int64_t)(nu + 1), c->stream));
-    }
     c->px_raux_valid = false;  // the {degree, label} strips are built by the first build that asks for the auxiliary index
+    // 3. partition ranges and their first points, to the host: one copy, one wait (until round 5 the bounds, a wait, then a copy per
+    // partition and another wait: 0.17 ms of the build at p = 1)
+    {
+        const void *k_sorted = tmp + o_keys + (nu + 1) * (kbits <= 32 ? 4 : 8);  // k_out of the sort above
+        if (kbits <= 32)
+            hipLaunchKernelGGL((k_px_bounds<uint32_t>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, nu, p, (const uint32_t *)k_sorted,
+                               shift, c->px_pref.as<uint64_t>(), d_bounds);
+        else
+            hipLaunchKernelGGL((k_px_bounds<uint64_t>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, nu, p, (const uint64_t *)k_sorted,
+                               shift, c->px_pref.as<uint64_t>(), d_bounds);
+    }
     GNNPE_HIP_TRY(hipGetLastError());
-    // 3. partition ranges and their first points, to the host
-    c->px_bounds.assign((size_t)p + 1, 0);
-    c->px_points.assign((size_t)p + 1, 0);
-    GNNPE_HIP_TRY(hipMemcpyAsync(c->px_bounds.data(), d_bounds, ((size_t)p + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> both(2 * ((size_t)p + 1));
+    GNNPE_HIP_TRY(hipMemcpyAsync(both.data(), d_bounds, both.size() * 8, hipMemcpyDeviceToHost, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    for (uint32_t k = 0; k <= p; k++)
-        GNNPE_HIP_TRY(hipMemcpyAsync(&c->px_points[k], c->px_pref.as<uint64_t>() + c->px_bounds[k], 8, hipMemcpyDeviceToHost, c->stream));
-    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->px_bounds.assign(both.begin(), both.begin() + p + 1);
+    c->px_points.assign(both.begin() + p + 1, both.end());
     c->px_valid = true;
     c->px_gen = c->count_gen;
     return GNNPE_OK;
@@ -2060,12 +2188,14 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     // GNNPE_LEAF_LDS_PAD (A/B aid): this much more dynamic LDS nobody touches = fewer resident workgroups per CU
     uint32_t leaf_pad = 0;
     if (const char *ev = getenv("GNNPE_LEAF_LDS_PAD")) leaf_pad = (uint32_t)std::max(0, std::min(40000, atoi(ev)));
+    uint32_t xcd_chunk = 0;
+    if (const char *ev = getenv("GNNPE_LEAF_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(0, atoi(ev));
 #define GNNPE_PXL(EE, PK, AX) GNNPE_PXN(EE, PK, AX, 1)
 #define GNNPE_PXN(EE, PK, AX, NN)                                                                                       \
     hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX, NN>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10 + leaf_pad, c->stream, cnt, nl, r0, r1, \
-                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairXE<EE>>(), c->rrecs.as<char>(), \
+                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<PairX>(), c->rrecs.as<char>(), \
                        c->px_raux.as<char>(), c->xrank.as<uint16_t>(), c->xsorted.as<double>(), c->n_labels, xrank_lds,        \
-                       c->px_raux_dbits, image, mbr_a, adeg, ambr)
+                       c->px_raux_dbits, image, mbr_a, adeg, ambr, xcd_chunk)
 #define GNNPE_PXE(EE)                                                           \
     do {                                                                        \
         if (with_aux && c->px_raux_compact) {                                   \
