@@ -1102,10 +1102,44 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
             hipLaunchKernelGGL(k_deep_row_batches, dim3(grid_for((uint64_t)c->n + 1)), dim3(kBlock), 0, c->stream, c->n, c->adj_deg.as<uint32_t>(),
                                c->rb_cnt.as<uint32_t>());
             if ((rc = scan_u32(c, c->rb_cnt.as<uint32_t>(), c->rb_first.as<uint32_t>(), (uint64_t)c->n + 1))) return rc;
-            hipLaunchKernelGGL(k_deep3_count_rows, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
-                               c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
-                               c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                               c->rb_first.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), nu, d_missing);
+            // the entry-major count (k_deep3_count_hist) unless GNNPE_DEEP_COUNT=merge asks for the pointer walk (tests run both)
+            const char *cmode = getenv("GNNPE_DEEP_COUNT");
+            if (cmode && !strcmp(cmode, "merge")) {
+                hipLaunchKernelGGL(k_deep3_count_rows, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
+                                   c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
+                                   c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                                   c->rb_first.as<uint32_t>(), ufirst, c->uoff.as<uint64_t>(), nu, d_missing);
+            } else {
+                uint32_t *lowcnt = c->rb_cnt.as<uint32_t>();  // (the row-batch counts are dead behind their scan)
+                hipLaunchKernelGGL(k_deep_lowcnt, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n,
+                                   c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                                   c->adj_deg.as<uint32_t>(), c->rank.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), lowcnt);
+                // the row-batches of the long rows: counted, then listed
+                uint32_t *d_nhb = c->small.as<uint32_t>() + 20;
+                uint64_t n_hub_batches = 0;
+                for (int pass = 0; pass < 2; pass++) {
+                    GNNPE_HIP_TRY(hipMemsetAsync(d_nhb, 0, 4, c->stream));
+                    hipLaunchKernelGGL(k_deep_hub_batches, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->adj_deg.as<uint32_t>(), d_nhb,
+                                       pass ? c->deep_hub_batches.as<uint2>() : (uint2 *)nullptr);
+                    if (pass == 0) {
+                        if ((rc = read_back_u64(c, d_nhb, 4, &n_hub_batches))) return rc;
+                        n_hub_batches &= 0xFFFFFFFFull;
+                        if (!n_hub_batches) break;
+                        if ((rc = c->deep_hub_batches.reserve((n_hub_batches + 1) * 8))) return rc;
+                    }
+                }
+                hipLaunchKernelGGL(k_deep3_count_hist, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
+                                   c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
+                                   c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                                   c->rb_first.as<uint32_t>(), lowcnt, ufirst, c->uoff.as<uint64_t>(), nu, d_missing);
+                if (n_hub_batches)
+                    hipLaunchKernelGGL(k_deep3_count_hist_coop, dim3((unsigned)std::min<uint64_t>(n_hub_batches, (uint64_t)c->num_cus * 4)),
+                                       dim3(64 * kCoopWaves), 0, c->stream, P, len,
+                                       c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
+                                       c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
+                                       c->deep_hub_batches.as<uint2>(), (uint32_t)n_hub_batches, lowcnt, ufirst, c->uoff.as<uint64_t>(), nu,
+                                       d_missing);
+            }
             uint64_t miss = 0;
             if ((rc = read_back_u64(c, d_missing, 4, &miss))) return rc;
             GNNPE_REQUIRE((uint32_t)miss == 0xFFFFFFFFu, GNNPE_ERR_ARG,

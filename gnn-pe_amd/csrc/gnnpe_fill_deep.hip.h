@@ -207,6 +207,285 @@ __global__ __launch_bounds__(256) void k_deep3_count_rows(FillParams P, uint32_t
     if (blockIdx.x == 0 && threadIdx.x == 0) uoff[n_units] = 0;
 }
 
+// ---- the count, entry-major (round 5) -----------------------------------------------------------------------------------
+// k_deep3_count_rows above walks, per lane, a pointer through row c's sorted ranks: one DEPENDENT global load per threshold and
+// lane, 2.3e9 wave iterations of a round trip each at config 5 -- the 0.63 s are latency.  The same numbers without a dependent
+// load: for a row-batch (b, 64 third vertices) and b's start vertices s_0 < s_1 < ... (ascending rank, thresholds T),
+//   count(s_t, b, batch) = sum over the batch's c != s_t of ( deg c - [rank b > T_t] - |{d in N(c): rank d <= T_t}| )
+// and the last term summed over the batch is P(t) = |{(c, d): rank d <= T_t}|: a HISTOGRAM of the batch's rows over the
+// thresholds.  So the wave keeps T and the histogram in LDS and STREAMS the batch's rows (64 consecutive sorted ranks per step,
+// coalesced, every load independent of every other), finds each entry's bin by a binary search in LDS, and -- the entries of a
+// step being ascending, equal bins are runs -- adds each run's length with one LDS atomic per run (no two lanes of an
+// instruction on one address).  A prefix over the bins gives P(t); the start vertex' own term, when s_t is one of the batch's
+// third vertices, is deg s - [rank b > T_t] - lowcnt[s] with lowcnt[v] = |{d in N(v): rank d < rank v}| (k_deep_lowcnt, once
+// per count).  Thresholds beyond kHistChunk (hub rows b) take further passes over the batch's rows.
+// Two launches.  Rows b of up to kHistChunk neighbours: one WAVE per row-batch, T and the bins in the wave's own 4.25 KB of
+// LDS.  Longer rows (k_deep_hub_batches lists their batches): one WORKGROUP of eight waves per row-batch with up to kCoopChunk
+// thresholds in 37 KB shared by the waves, which take the batch's rows in pieces of 256 entries in turn -- chunking the
+// thresholds instead means streaming the batch's rows once per chunk, and at config 5 the long rows b are where the long rows
+// c are: 3.96e9 steps with chunks of 512 (2.71e9 with 1 024) against 1.72e9 without.
+constexpr int kHistChunk = 512, kCoopWaves = 8, kCoopChunk = 4608;
+__global__ void k_deep_lowcnt(uint32_t n, const uint8_t *__restrict__ present, const uint32_t *__restrict__ adj_start,
+                              const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rank,
+                              const uint32_t *__restrict__ sorted_ranks, uint32_t *__restrict__ lowcnt)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        if (present && !present[v]) {  // (a row that is not on this device starts no path here)
+            lowcnt[v] = 0u;
+            continue;
+        }
+        const uint32_t *row = sorted_ranks + adj_start[v];
+        const uint32_t r = rank[v];
+        uint32_t a = 0, z = adj_deg[v];
+        while (a < z) {
+            const uint32_t mid = (a + z) >> 1;
+            if (row[mid] < r) a = mid + 1; else z = mid;
+        }
+        lowcnt[v] = a;
+    }
+}
+// the row-batches {row, batch} of the rows longer than kHistChunk, in no particular order; counter[0] = their number
+__global__ void k_deep_hub_batches(uint32_t n, const uint32_t *__restrict__ adj_deg, uint32_t *__restrict__ counter, uint2 *__restrict__ list)
+{
+    for (uint64_t v = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; v < n; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = adj_deg[v];
+        if (d <= (uint32_t)kHistChunk) continue;
+        const uint32_t nb = (d + 63u) / 64u, at = atomicAdd(counter, nb);
+        if (list)
+            for (uint32_t j = 0; j < nb; j++) list[at + j] = make_uint2((uint32_t)v, j);
+    }
+}
+
+// NS steps side by side: 64 consecutive sorted ranks of a row each -> bins.  bin(x) = thresholds below x (x == T_t is the start
+// vertex itself: rank d <= T_t, bin t); bin ntc = ranked after every threshold of the pass: never counted.  The search is a
+// chain of log2(ntc) dependent LDS reads; a wave that walked one chain at a time spent its life waiting for the LDS (the whole
+// count 774 ms, slower than the pointer walk's 648; four chains 595)
+template <int NS>
+__device__ __forceinline__ void deep_hist_steps(const uint32_t *T, uint32_t *H, uint32_t ntc, uint32_t top, unsigned lane, const uint32_t *x)
+{
+    uint32_t g[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) g[u] = 0;
+    for (uint32_t bit = top; bit; bit >>= 1) {
+        uint32_t tv[NS];
+#pragma unroll
+        for (int u = 0; u < NS; u++) tv[u] = T[min(g[u] + bit, ntc) - 1u];
+#pragma unroll
+        for (int u = 0; u < NS; u++)
+            if (g[u] + bit <= ntc && tv[u] < x[u]) g[u] += bit;
+    }
+    uint32_t g_next[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) g_next[u] = (uint32_t)__shfl_down((int)g[u], 1);
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+        // the entries of a step ascend, so equal bins are runs: the last lane of a run adds its length (idle lanes: bin ntc)
+        const bool end = g[u] < ntc && (lane == 63u || g_next[u] != g[u]);
+        const uint64_t ends = __ballot(end);
+        if (end) {
+            const uint64_t before = ends & ((1ull << lane) - 1ull);
+            const uint32_t first = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+            atomicAdd(&H[g[u]], lane - first + 1u);
+        }
+    }
+}
+// entries [off, off + 256) of a row: up to four steps
+__device__ __forceinline__ void deep_hist_piece(const uint32_t *T, uint32_t *H, uint32_t ntc, uint32_t top, unsigned lane,
+                                                const uint32_t *__restrict__ row, uint32_t off, uint32_t rd)
+{
+    if (off + 256u <= rd) {
+        const uint32_t x[4] = {row[off + lane], row[off + 64u + lane], row[off + 128u + lane], row[off + 192u + lane]};
+        deep_hist_steps<4>(T, H, ntc, top, lane, x);
+    } else if (off + 64u < rd) {  // two to four steps: the same four chains, idle entries ranked after everything
+        uint32_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = off + 64u * u + lane < rd ? row[off + 64u * u + lane] : 0xFFFFFFFFu;
+        deep_hist_steps<4>(T, H, ntc, top, lane, x);
+    } else if (off < rd) {
+        const uint32_t x[1] = {off + lane < rd ? row[off + lane] : 0xFFFFFFFFu};
+        deep_hist_steps<1>(T, H, ntc, top, lane, x);
+    }
+}
+// what a batch's waves share: the row, its start vertices' range of sorted ranks, the third vertices in the lanes
+struct DeepBatch {
+    uint32_t b, j, bst, bd, t_lo, t_hi, rank_b, cd, cst, deg_sum, n_third;
+    uint64_t have;
+};
+__device__ __forceinline__ DeepBatch deep_batch(const FillParams &P, uint32_t b, uint32_t j, uint32_t sb, uint32_t se,
+                                                const uint8_t *__restrict__ present, const uint32_t *__restrict__ rank,
+                                                const uint32_t *__restrict__ sorted_ranks, uint32_t *__restrict__ missing_row, unsigned lane)
+{
+    DeepBatch B;
+    B.b = b;
+    B.j = j;
+    B.bst = P.adj_start[b];
+    B.bd = P.adj_deg[b];
+    const uint32_t *sr_b = sorted_ranks + B.bst;
+    {  // b's neighbours that start paths here = its sorted ranks inside [sb, se)
+        uint32_t a = 0, z = B.bd;
+        while (a < z) {
+            const uint32_t mid = (a + z) >> 1;
+            if (sr_b[mid] < sb) a = mid + 1; else z = mid;
+        }
+        B.t_lo = a;
+        z = B.bd;
+        while (a < z) {
+            const uint32_t mid = (a + z) >> 1;
+            if (sr_b[mid] < se) a = mid + 1; else z = mid;
+        }
+        B.t_hi = a;
+    }
+    B.rank_b = rank[b];
+    B.cd = B.cst = 0;
+    const uint32_t k = j * 64u + lane;
+    if (B.t_lo != B.t_hi && k < B.bd) {
+        const uint32_t c = P.nbrs[B.bst + k];
+        if (present && !present[c]) {
+            atomicMin(missing_row, c);  // 2-hop row not on this device
+        } else {
+            B.cd = P.adj_deg[c];
+            B.cst = P.adj_start[c];
+        }
+    }
+    B.have = __ballot(B.cd != 0u);
+    B.deg_sum = wave_sum_u32(B.cd);
+    B.n_third = (uint32_t)__popcll(B.have);
+    return B;
+}
+// threshold a0 + tt of the batch with incl = P(t): its unit's count
+__device__ __forceinline__ void deep_hist_unit(const FillParams &P, const DeepBatch &B, uint32_t a0, uint32_t tt, uint32_t r_t, uint32_t incl,
+                                               uint32_t sb, const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos,
+                                               const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ lowcnt,
+                                               const uint64_t *__restrict__ ufirst, uint64_t *__restrict__ uoff, uint64_t n_units)
+{
+    const uint32_t q = rank_arg[B.bst + a0 + tt];  // entry of row b that holds this neighbour
+    const uint32_t s = P.nbrs[q];
+    const uint32_t rp = revpos[q];  // position of b inside N(s): s starts paths here, so its row is an owned one
+    const uint64_t u = rp != 0xFFFFFFFFu ? ufirst[poffs[r_t - sb] + rp] + B.j : ~0ull;  // the pair (s, b), this batch
+    const uint32_t b_kept = B.rank_b > r_t ? 1u : 0u;  // b is a neighbour of every c and must not close the path
+    uint32_t cnt = B.deg_sum - B.n_third * b_kept - incl;
+    const uint32_t ks = q - B.bst;  // s among b's neighbours: one of this batch's third vertices?
+    if (ks / 64u == B.j && ((B.have >> (ks & 63u)) & 1ull)) cnt -= P.adj_deg[s] - b_kept - lowcnt[s];  // c == s
+    if (u < n_units) uoff[u] = cnt;  // counts; scanned in place by the caller
+}
+
+__global__ __launch_bounds__(256) void k_deep3_count_hist(FillParams P, uint32_t n, uint32_t slab_len, const uint8_t *__restrict__ present,
+                                                          const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sorted_ranks,
+                                                          const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos,
+                                                          const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ rb_first,
+                                                          const uint32_t *__restrict__ lowcnt, const uint64_t *__restrict__ ufirst,
+                                                          uint64_t *__restrict__ uoff, uint64_t n_units, uint32_t *__restrict__ missing_row)
+{
+    __shared__ uint32_t s_T[4][kHistChunk];
+    __shared__ uint32_t s_H[4][kHistChunk + 64];  // (the prefix stage reads whole steps of 64 bins)
+    const unsigned lane = lane_id();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *const T = s_T[wv], *const H = s_H[wv];
+    const uint32_t n_rb = rb_first[n];
+    uint64_t rb = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t sb = P.slab_begin, se = P.slab_begin + slab_len;
+    for (; rb < n_rb; rb += nw) {
+        uint32_t lo = 0, hi = n;  // the row of this batch: largest b with rb_first[b] <= rb (rows without entries share a value)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (rb_first[mid] <= rb) lo = mid; else hi = mid;
+        }
+        if (P.adj_deg[lo] > (uint32_t)kHistChunk) continue;  // k_deep3_count_hist_coop
+        const DeepBatch B = deep_batch(P, lo, (uint32_t)rb - rb_first[lo], sb, se, present, rank, sorted_ranks, missing_row, lane);
+        if (B.t_lo == B.t_hi) continue;  // (a row two hops out: a third vertex only)
+        const uint32_t ntc = B.t_hi - B.t_lo, a0 = B.t_lo;
+        for (uint32_t i = lane; i < ntc; i += 64) T[i] = sorted_ranks[B.bst + a0 + i];
+        for (uint32_t i = lane; i < ((ntc + 64u) & ~63u); i += 64) H[i] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t top = 1u << (31 - __builtin_clz(ntc));  // largest power of two <= ntc
+        for (uint64_t m = B.have; m; m &= m - 1) {
+            const int ci = __builtin_ctzll(m);
+            const uint32_t rd = rl32(B.cd, ci);
+            const uint32_t *row = sorted_ranks + rl32(B.cst, ci);
+            for (uint32_t off = 0; off < rd; off += 256u) deep_hist_piece(T, H, ntc, top, lane, row, off, rd);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // bins -> P(t), 64 thresholds at a time; every threshold's unit gets its count
+        uint32_t carry = 0;
+        for (uint32_t t0 = 0; t0 < ntc; t0 += 64) {
+            const uint32_t tt = t0 + lane;
+            const uint32_t incl = wave_scan_add(H[tt]) + carry;
+            carry = rl32(incl, 63);
+            if (tt < ntc) deep_hist_unit(P, B, a0, tt, T[tt], incl, sb, rank_arg, revpos, poffs, lowcnt, ufirst, uoff, n_units);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) uoff[n_units] = 0;
+}
+
+__global__ __launch_bounds__(64 * kCoopWaves) void k_deep3_count_hist_coop(FillParams P, uint32_t slab_len, const uint8_t *__restrict__ present,
+                                                                           const uint32_t *__restrict__ rank,
+                                                                           const uint32_t *__restrict__ sorted_ranks,
+                                                                           const uint32_t *__restrict__ rank_arg,
+                                                                           const uint32_t *__restrict__ revpos, const uint32_t *__restrict__ poffs,
+                                                                           const uint2 *__restrict__ batches, uint32_t n_batches,
+                                                                           const uint32_t *__restrict__ lowcnt, const uint64_t *__restrict__ ufirst,
+                                                                           uint64_t *__restrict__ uoff, uint64_t n_units,
+                                                                           uint32_t *__restrict__ missing_row)
+{
+    constexpr int NT = 64 * kCoopWaves, kPer = (kCoopChunk + NT - 1) / NT;
+    typedef hipcub::BlockScan<uint32_t, NT> Scan;
+    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ uint32_t T[kCoopChunk];
+    __shared__ uint32_t H[kPer * NT];  // (bins, then their inclusive prefix in place)
+    const unsigned lane = lane_id(), tid = threadIdx.x;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t sb = P.slab_begin, se = P.slab_begin + slab_len;
+    for (uint32_t it = blockIdx.x; it < n_batches; it += gridDim.x) {
+        const uint2 bj = batches[it];
+        const DeepBatch B = deep_batch(P, bj.x, bj.y, sb, se, present, rank, sorted_ranks, missing_row, lane);  // (every wave the same)
+        for (uint32_t a0 = B.t_lo; a0 < B.t_hi; a0 += (uint32_t)kCoopChunk) {
+            const uint32_t ntc = min((uint32_t)kCoopChunk, B.t_hi - a0);
+            for (uint32_t i = tid; i < ntc; i += NT) T[i] = sorted_ranks[B.bst + a0 + i];
+            for (uint32_t i = tid; i < (uint32_t)(kPer * NT); i += NT) H[i] = 0u;
+            __syncthreads();
+            const uint32_t top = 1u << (31 - __builtin_clz(ntc));
+            // the batch's rows in pieces of 256 entries, dealt to the waves in turn
+            uint32_t piece0 = 0;  // pieces of the rows before this one
+            for (uint64_t m = B.have; m; m &= m - 1) {
+                const int ci = __builtin_ctzll(m);
+                const uint32_t rd = rl32(B.cd, ci);
+                const uint32_t *row = sorted_ranks + rl32(B.cst, ci);
+                const uint32_t np = (rd + 255u) / 256u;
+                for (uint32_t pc = (wv + (uint32_t)kCoopWaves - piece0 % (uint32_t)kCoopWaves) % (uint32_t)kCoopWaves; pc < np; pc += (uint32_t)kCoopWaves)
+                    deep_hist_piece(T, H, ntc, top, lane, row, pc * 256u, rd);
+                piece0 += np;
+            }
+            __syncthreads();
+            // bins -> inclusive prefix, in place: kPer consecutive bins per thread
+            uint32_t h[kPer], mine = 0;
+#pragma unroll
+            for (int z = 0; z < kPer; z++) {
+                h[z] = H[tid * kPer + z];
+                mine += h[z];
+            }
+            uint32_t excl = 0;
+            Scan(s_scan).ExclusiveSum(mine, excl);
+#pragma unroll
+            for (int z = 0; z < kPer; z++) {
+                excl += h[z];
+                H[tid * kPer + z] = excl;
+            }
+            __syncthreads();
+            for (uint32_t tt = tid; tt < ntc; tt += NT)
+                deep_hist_unit(P, B, a0, tt, T[tt], H[tt], sb, rank_arg, revpos, poffs, lowcnt, ufirst, uoff, n_units);
+            __syncthreads();  // T and H are rewritten by the next pass
+        }
+    }
+}
+
 // The kept rows of one 64-candidate step -- (c, d, entry) compacted in LDS by the caller -- written as one contiguous piece of
 // every output: rows [r_lo, r_lo + rows) of the step to output rows o0 ....  pde: a row is 4e doubles = 2e pieces of 16 bytes.
 // For e = 2, 4, 8 the pieces of a row (or of half a row) divide the wave, so a lane keeps ONE column for the whole step: the

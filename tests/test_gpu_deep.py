@@ -112,6 +112,54 @@ def test_l3_hub_rows_beyond_one_wave(binding, oracle):
     eng.close()
 
 
+def _star_with_chords(hub_degree, chords, seed):
+    """vertex 0 joined to 1..hub_degree, plus random edges among the leaves: a middle vertex with more start vertices than the
+    count kernel's LDS holds thresholds (kHistChunk = 512 per wave, kCoopChunk = 4 608 per workgroup), and a start vertex that is one of its own batch's third vertices"""
+    rng = np.random.default_rng(seed)
+    n = hub_degree + 1
+    edges = {(0, v) for v in range(1, n)}
+    while len(edges) < hub_degree + chords:
+        a, b = rng.integers(1, n, 2)
+        if a != b:
+            edges.add((min(a, b), max(a, b)))
+    ea = np.array(sorted(edges), dtype=np.int64)
+    src = np.concatenate([ea[:, 0], ea[:, 1]])
+    dst = np.concatenate([ea[:, 1], ea[:, 0]])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    offsets = np.zeros(n + 1, np.uint32)
+    np.add.at(offsets, src + 1, 1)
+    offsets = np.cumsum(offsets, dtype=np.uint64).astype(np.uint32)
+    return dict(n=n, offsets=offsets, nbrs=dst.astype(np.uint32), labels=rng.integers(0, 4, n).astype(np.uint32))
+
+
+@pytest.mark.parametrize("count", ["hist", "merge"])
+def test_l3_both_count_kernels_against_the_checker(binding, oracle, monkeypatch, count):
+    """k_deep3_count_hist / _coop (rows streamed into an LDS histogram over the thresholds; the default) and k_deep3_count_rows
+    (one pointer per lane walked through row c) give every start vertex the checker's count and every path its slot: a
+    power-law graph, a flat one, an arbitrary processing order, middle vertices with more neighbours than a wave's LDS holds
+    thresholds (512: the workgroup form takes them) and than a workgroup's does (4 608: two passes)."""
+    monkeypatch.setenv("GNNPE_DEEP_COUNT", count)
+    cases = [(synth.powerlaw_graph(1500, 9000, exponent=2.0, max_degree=400, n_labels=4, seed=3), "degree"),
+             (synth.gnm_graph(700, 4200, n_labels=5, seed=8), "random"),
+             (_star_with_chords(2300, 2500, seed=2), "degree"),
+             (_star_with_chords(1030, 900, seed=6), "random"),
+             (_star_with_chords(5000, 1500, seed=4), "degree")]
+    for g, how in cases:
+        sn = synth.degree_order(g["offsets"]) if how == "degree" else np.random.default_rng(1).permutation(g["n"]).astype(np.uint32)
+        eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2)
+        eng.vde(want=False)
+        total, per_start = eng.count_paths(3, per_start=True)
+        assert np.array_equal(per_start, oracle.count_per_start(g["offsets"], g["nbrs"], sn, 4))
+        want = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+        assert total == len(want)
+        chunk = 1 << 19
+        for b in range(0, total, chunk):
+            ids, _, _ = eng.fill_paths(b, min(total, b + chunk), pde=False)
+            assert np.array_equal(ids, want[b:b + chunk]), b
+        eng.close()
+
+
 @pytest.mark.parametrize("mode", ["slices", "units"])
 @pytest.mark.parametrize("e", [2, 3, 4, 8])
 def test_l3_both_emit_paths_agree_with_the_checker(binding, oracle, monkeypatch, mode, e):
