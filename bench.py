@@ -242,7 +242,7 @@ def config5_leg(torch, stream, local_rank, labels, seed):
     """BASELINE config 5 on ONE GPU (the 8-GPU split of it is in tests/test_gpu_slabs_full.py): power-law 4M / 64M, l = 3
     (4-vertex paths: the reference's rule with the depth fixed, SURVEY D4 -- parity unpinned, the count is checked in the
     tests against the closed form sum_E (du-1)(dv-1) - 3T), e = 8.  The 4.2e13 paths fit nowhere, so the leg times the count
-    (vde + per-row rank sort + k_deep3_count_rows + scans) and the emission (k_deep3_slices: slice counts, kept rows per slice, emit) on sampled ranges of 2^24 and 2^26 paths."""
+    (vde + per-row rank sort + k_deep3_count_hist / _coop + scans) and the emission (k_deep3_slices: slice counts, kept rows per slice, emit) on sampled ranges of 2^24 and 2^26 paths."""
     L, e = 4, 8
     t0 = time.perf_counter()
     g = synth.powerlaw_graph(4_000_000, 64_000_000, exponent=2.1, max_degree=3000, n_labels=labels, seed=seed)

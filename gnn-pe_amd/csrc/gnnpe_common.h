@@ -182,7 +182,7 @@ struct gnnpe_ctx {
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
     gnnpe::DevBuf rank_arg, rb_cnt, rb_first;  // ... the entry each sorted rank came from; row-batches (64 third vertices) per row
-    gnnpe::DevBuf deep_hub_batches;            // ... {row, batch} of the rows the workgroup form of the l=3 count takes
+    gnnpe::DevBuf deep_hub_batches, deep_ubase;  // ... {row, batch} of the rows the workgroup form of the l=3 count takes; first unit of (s, b) by b's sorted position
     gnnpe::DevBuf ufirst, upair, uoff;  // l=3 work units: first unit of a pair, pair of a unit, output slot of a unit
     gnnpe::DevBuf dsl_first, dsl_kept;  // l=3 emission: first slice of every unit of the requested range, kept rows per slice (and their scan)
     uint64_t n_units = 0;

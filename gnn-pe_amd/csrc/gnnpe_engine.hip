@@ -1128,16 +1128,21 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
                         if ((rc = c->deep_hub_batches.reserve((n_hub_batches + 1) * 8))) return rc;
                     }
                 }
+                if ((rc = c->deep_ubase.reserve((c->nbr_used + 1) * 8))) return rc;
+                hipLaunchKernelGGL(k_deep_unit_bases, dim3(grid_for((uint64_t)c->n * 16)), dim3(kBlock), 0, c->stream, c->n, sb, se,
+                                   c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                                   c->adj_deg.as<uint32_t>(), c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(),
+                                   c->poffs.as<uint32_t>(), ufirst, c->deep_ubase.as<uint64_t>());
                 hipLaunchKernelGGL(k_deep3_count_hist, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
                                    c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
-                                   c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                                   c->rb_first.as<uint32_t>(), lowcnt, ufirst, c->uoff.as<uint64_t>(), nu, d_missing);
+                                   c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->deep_ubase.as<uint64_t>(),
+                                   c->rb_first.as<uint32_t>(), lowcnt, c->uoff.as<uint64_t>(), nu, d_missing);
                 if (n_hub_batches)
                     hipLaunchKernelGGL(k_deep3_count_hist_coop, dim3((unsigned)std::min<uint64_t>(n_hub_batches, (uint64_t)c->num_cus * 4)),
                                        dim3(64 * kCoopWaves), 0, c->stream, P, len,
                                        c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
-                                       c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
-                                       c->deep_hub_batches.as<uint2>(), (uint32_t)n_hub_batches, lowcnt, ufirst, c->uoff.as<uint64_t>(), nu,
+                                       c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->deep_ubase.as<uint64_t>(),
+                                       c->deep_hub_batches.as<uint2>(), (uint32_t)n_hub_batches, lowcnt, c->uoff.as<uint64_t>(), nu,
                                        d_missing);
             }
             uint64_t miss = 0;

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_deep3_count_rows(FillParams P, uint32_t
 // thresholds in 37 KB shared by the waves, which take the batch's rows in pieces of 256 entries in turn -- chunking the
 // thresholds instead means streaming the batch's rows once per chunk, and at config 5 the long rows b are where the long rows
 // c are: 3.96e9 steps with chunks of 512 (2.71e9 with 1 024) against 1.72e9 without.
-constexpr int kHistChunk = 512, kCoopWaves = 8, kCoopChunk = 4608;
+constexpr int kHistChunk = 511, kCoopWaves = 8, kCoopChunk = 4095;  // (tables of 512 / 4 096 words: a power of two ABOVE the thresholds)
 __global__ void k_deep_lowcnt(uint32_t n, const uint8_t *__restrict__ present, const uint32_t *__restrict__ adj_start,
                               const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ rank,
                               const uint32_t *__restrict__ sorted_ranks, uint32_t *__restrict__ lowcnt)
@@ -256,54 +256,98 @@ __global__ void k_deep_hub_batches(uint32_t n, const uint32_t *__restrict__ adj_
     }
 }
 
-// NS steps side by side: 64 consecutive sorted ranks of a row each -> bins.  bin(x) = thresholds below x (x == T_t is the start
-// vertex itself: rank d <= T_t, bin t); bin ntc = ranked after every threshold of the pass: never counted.  The search is a
-// chain of log2(ntc) dependent LDS reads; a wave that walked one chain at a time spent its life waiting for the LDS (the whole
-// count 774 ms, slower than the pointer walk's 648; four chains 595)
-template <int NS>
-__device__ __forceinline__ void deep_hist_steps(const uint32_t *T, uint32_t *H, uint32_t ntc, uint32_t top, unsigned lane, const uint32_t *x)
+// ubase[position of s in row b's sorted ranks] = first unit of the pair (s, b) (all ones: s starts no path here).  A row-batch
+// writes one count per start vertex of its row, and every batch of the row needs the same five dependent gathers to find where
+// (entry of b -> s -> position of b in N(s) -> first pair of s -> first unit of the pair): 1.72e9 units x 5 at config 5.  Once
+// per count instead: 16 lanes per row.
+__global__ void k_deep_unit_bases(uint32_t n, uint32_t sb, uint32_t se, const uint8_t *__restrict__ present, const uint32_t *__restrict__ adj_start,
+                                  const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ sorted_ranks,
+                                  const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos, const uint32_t *__restrict__ poffs,
+                                  const uint64_t *__restrict__ ufirst, uint64_t *__restrict__ ubase)
 {
-    uint32_t g[NS];
+    const unsigned sub = threadIdx.x & 15u;
+    uint64_t v = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 4;
+    const uint64_t nv = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (; v < n; v += nv) {
+        if (present && !present[v]) continue;
+        const uint32_t st = adj_start[v], d = adj_deg[v];
+        for (uint32_t t = sub; t < d; t += 16) {
+            const uint32_t r = sorted_ranks[st + t];
+            uint64_t u = ~0ull;
+            if (r >= sb && r < se) {
+                const uint32_t rp = revpos[rank_arg[st + t]];  // position of v inside N(s): s starts paths here, so its row is an owned one
+                if (rp != 0xFFFFFFFFu) u = ufirst[poffs[r - sb] + rp];
+            }
+            ubase[st + t] = u;
+        }
+    }
+}
+
+// NS steps side by side: 64 consecutive sorted ranks of a row each -> bins.  bin(x) = thresholds below x (x == T_t is the start
+// vertex itself: rank d <= T_t, bin t); bin ntc = ranked after every threshold of the pass: counted nowhere.  The search is a
+// chain of dependent LDS reads; a wave that walked one chain at a time spent its life waiting for the LDS (the whole count
+// 774 ms, slower than the pointer walk's 648; four chains 595).  And the kernel is bound by VALU issue (a wave64 instruction is
+// four cycles; ~100 of them per step made 420 cycles per step and SIMD): so the table is padded with all-ones to a power of
+// two above ntc (1 << L words), which leaves an iteration of the search three instructions -- read at a constant offset,
+// compare, add -- and the runs of equal bins (the entries of a step ascend) are credited by their boundaries alone: the
+// lane where the bin changes adds its position + 1 to its own bin and takes it off the next lane's (bin ntc collects what is
+// left and is never read).
+template <int NS, int L>
+__device__ __forceinline__ void deep_hist_steps(const uint32_t *T, uint32_t *H, unsigned lane, const uint32_t *x)
+{
+    uint32_t g4[NS];  // bin as a byte offset
 #pragma unroll
-    for (int u = 0; u < NS; u++) g[u] = 0;
-    for (uint32_t bit = top; bit; bit >>= 1) {
+    for (int u = 0; u < NS; u++) g4[u] = 0;
+#pragma unroll
+    for (int k = L - 1; k >= 0; k--) {
         uint32_t tv[NS];
 #pragma unroll
-        for (int u = 0; u < NS; u++) tv[u] = T[min(g[u] + bit, ntc) - 1u];
+        for (int u = 0; u < NS; u++) tv[u] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T) + g4[u] + ((1u << k) - 1u) * 4u);
 #pragma unroll
-        for (int u = 0; u < NS; u++)
-            if (g[u] + bit <= ntc && tv[u] < x[u]) g[u] += bit;
+        for (int u = 0; u < NS; u++) g4[u] += tv[u] < x[u] ? (4u << k) : 0u;
     }
-    uint32_t g_next[NS];
-#pragma unroll
-    for (int u = 0; u < NS; u++) g_next[u] = (uint32_t)__shfl_down((int)g[u], 1);
 #pragma unroll
     for (int u = 0; u < NS; u++) {
-        // the entries of a step ascend, so equal bins are runs: the last lane of a run adds its length (idle lanes: bin ntc)
-        const bool end = g[u] < ntc && (lane == 63u || g_next[u] != g[u]);
-        const uint64_t ends = __ballot(end);
-        if (end) {
-            const uint64_t before = ends & ((1ull << lane) - 1ull);
-            const uint32_t first = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
-            atomicAdd(&H[g[u]], lane - first + 1u);
+        // lane + 1's bin (wave_shl:1; lane 63 reads the all-ones `old`: a boundary)
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)g4[u], 0x130, 0xF, 0xF, false);
+        if (nx != g4[u]) {
+            atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(H) + g4[u]), lane + 1u);
+            if (lane != 63u) atomicSub(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(H) + nx), lane + 1u);
         }
     }
 }
 // entries [off, off + 256) of a row: up to four steps
-__device__ __forceinline__ void deep_hist_piece(const uint32_t *T, uint32_t *H, uint32_t ntc, uint32_t top, unsigned lane,
-                                                const uint32_t *__restrict__ row, uint32_t off, uint32_t rd)
+template <int L>
+__device__ __forceinline__ void deep_hist_piece(const uint32_t *T, uint32_t *H, unsigned lane, const uint32_t *__restrict__ row, uint32_t off,
+                                                uint32_t rd)
 {
     if (off + 256u <= rd) {
         const uint32_t x[4] = {row[off + lane], row[off + 64u + lane], row[off + 128u + lane], row[off + 192u + lane]};
-        deep_hist_steps<4>(T, H, ntc, top, lane, x);
+        deep_hist_steps<4, L>(T, H, lane, x);
     } else if (off + 64u < rd) {  // two to four steps: the same four chains, idle entries ranked after everything
         uint32_t x[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) x[u] = off + 64u * u + lane < rd ? row[off + 64u * u + lane] : 0xFFFFFFFFu;
-        deep_hist_steps<4>(T, H, ntc, top, lane, x);
+        deep_hist_steps<4, L>(T, H, lane, x);
     } else if (off < rd) {
         const uint32_t x[1] = {off + lane < rd ? row[off + lane] : 0xFFFFFFFFu};
-        deep_hist_steps<1>(T, H, ntc, top, lane, x);
+        deep_hist_steps<1, L>(T, H, lane, x);
+    }
+}
+// the batch's rows (the share of wave `wv` of `n_waves`: pieces of 256 entries dealt in turn) into the bins
+template <int L, uint32_t n_waves>
+__device__ __forceinline__ void deep_hist_rows(const uint32_t *T, uint32_t *H, unsigned lane, const uint32_t *__restrict__ sorted_ranks,
+                                               uint64_t have, uint32_t cd, uint32_t cst, uint32_t wv)
+{
+    static_assert((n_waves & (n_waves - 1u)) == 0u, "the deal is a mask, not a division");
+    uint32_t piece0 = 0;  // pieces of the rows before this one
+    for (uint64_t m = have; m; m &= m - 1) {
+        const int ci = __builtin_ctzll(m);
+        const uint32_t rd = rl32(cd, ci);
+        const uint32_t *row = sorted_ranks + rl32(cst, ci);
+        const uint32_t np = (rd + 255u) / 256u;
+        for (uint32_t pc = (wv + n_waves - piece0 % n_waves) % n_waves; pc < np; pc += n_waves) deep_hist_piece<L>(T, H, lane, row, pc * 256u, rd);
+        piece0 += np;
     }
 }
 // what a batch's waves share: the row, its start vertices' range of sorted ranks, the third vertices in the lanes
@@ -354,30 +398,28 @@ __device__ __forceinline__ DeepBatch deep_batch(const FillParams &P, uint32_t b,
 }
 // threshold a0 + tt of the batch with incl = P(t): its unit's count
 __device__ __forceinline__ void deep_hist_unit(const FillParams &P, const DeepBatch &B, uint32_t a0, uint32_t tt, uint32_t r_t, uint32_t incl,
-                                               uint32_t sb, const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos,
-                                               const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ lowcnt,
-                                               const uint64_t *__restrict__ ufirst, uint64_t *__restrict__ uoff, uint64_t n_units)
+                                               const uint32_t *__restrict__ rank_arg, const uint64_t *__restrict__ ubase,
+                                               const uint32_t *__restrict__ lowcnt, uint64_t *__restrict__ uoff, uint64_t n_units)
 {
-    const uint32_t q = rank_arg[B.bst + a0 + tt];  // entry of row b that holds this neighbour
-    const uint32_t s = P.nbrs[q];
-    const uint32_t rp = revpos[q];  // position of b inside N(s): s starts paths here, so its row is an owned one
-    const uint64_t u = rp != 0xFFFFFFFFu ? ufirst[poffs[r_t - sb] + rp] + B.j : ~0ull;  // the pair (s, b), this batch
+    const uint64_t u0 = ubase[B.bst + a0 + tt];      // the pair (s, b)'s first unit
+    const uint32_t ks = rank_arg[B.bst + a0 + tt] - B.bst;  // s among b's neighbours: one of this batch's third vertices?
     const uint32_t b_kept = B.rank_b > r_t ? 1u : 0u;  // b is a neighbour of every c and must not close the path
     uint32_t cnt = B.deg_sum - B.n_third * b_kept - incl;
-    const uint32_t ks = q - B.bst;  // s among b's neighbours: one of this batch's third vertices?
-    if (ks / 64u == B.j && ((B.have >> (ks & 63u)) & 1ull)) cnt -= P.adj_deg[s] - b_kept - lowcnt[s];  // c == s
-    if (u < n_units) uoff[u] = cnt;  // counts; scanned in place by the caller
+    if (ks / 64u == B.j && ((B.have >> (ks & 63u)) & 1ull)) {  // c == s
+        const uint32_t s = P.nbrs[B.bst + ks];
+        cnt -= P.adj_deg[s] - b_kept - lowcnt[s];
+    }
+    if (u0 != ~0ull && u0 + B.j < n_units) uoff[u0 + B.j] = cnt;  // counts; scanned in place by the caller
 }
 
 __global__ __launch_bounds__(256) void k_deep3_count_hist(FillParams P, uint32_t n, uint32_t slab_len, const uint8_t *__restrict__ present,
                                                           const uint32_t *__restrict__ rank, const uint32_t *__restrict__ sorted_ranks,
-                                                          const uint32_t *__restrict__ rank_arg, const uint32_t *__restrict__ revpos,
-                                                          const uint32_t *__restrict__ poffs, const uint32_t *__restrict__ rb_first,
-                                                          const uint32_t *__restrict__ lowcnt, const uint64_t *__restrict__ ufirst,
+                                                          const uint32_t *__restrict__ rank_arg, const uint64_t *__restrict__ ubase,
+                                                          const uint32_t *__restrict__ rb_first, const uint32_t *__restrict__ lowcnt,
                                                           uint64_t *__restrict__ uoff, uint64_t n_units, uint32_t *__restrict__ missing_row)
 {
-    __shared__ uint32_t s_T[4][kHistChunk];
-    __shared__ uint32_t s_H[4][kHistChunk + 64];  // (the prefix stage reads whole steps of 64 bins)
+    __shared__ uint32_t s_T[4][kHistChunk + 1];
+    __shared__ uint32_t s_H[4][kHistChunk + 1 + 64];  // (the prefix stage reads whole steps of 64 bins)
     const unsigned lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *const T = s_T[wv], *const H = s_H[wv];
@@ -395,17 +437,18 @@ __global__ __launch_bounds__(256) void k_deep3_count_hist(FillParams P, uint32_t
         const DeepBatch B = deep_batch(P, lo, (uint32_t)rb - rb_first[lo], sb, se, present, rank, sorted_ranks, missing_row, lane);
         if (B.t_lo == B.t_hi) continue;  // (a row two hops out: a third vertex only)
         const uint32_t ntc = B.t_hi - B.t_lo, a0 = B.t_lo;
-        for (uint32_t i = lane; i < ntc; i += 64) T[i] = sorted_ranks[B.bst + a0 + i];
+        // table: the thresholds, then all-ones up to the power of two the search walks (3, 5, 7 or 9 levels)
+        const uint32_t levels = max(3u, (32u - (uint32_t)__builtin_clz(ntc)) | 1u), padded = 1u << levels;
+        for (uint32_t i = lane; i < padded; i += 64) T[i] = i < ntc ? sorted_ranks[B.bst + a0 + i] : 0xFFFFFFFFu;
         for (uint32_t i = lane; i < ((ntc + 64u) & ~63u); i += 64) H[i] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t top = 1u << (31 - __builtin_clz(ntc));  // largest power of two <= ntc
-        for (uint64_t m = B.have; m; m &= m - 1) {
-            const int ci = __builtin_ctzll(m);
-            const uint32_t rd = rl32(B.cd, ci);
-            const uint32_t *row = sorted_ranks + rl32(B.cst, ci);
-            for (uint32_t off = 0; off < rd; off += 256u) deep_hist_piece(T, H, ntc, top, lane, row, off, rd);
+        switch (levels) {
+        case 3: deep_hist_rows<3, 1u>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, 0u); break;
+        case 5: deep_hist_rows<5, 1u>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, 0u); break;
+        case 7: deep_hist_rows<7, 1u>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, 0u); break;
+        default: deep_hist_rows<9, 1u>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, 0u); break;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -416,7 +459,7 @@ __global__ __launch_bounds__(256) void k_deep3_count_hist(FillParams P, uint32_t
             const uint32_t tt = t0 + lane;
             const uint32_t incl = wave_scan_add(H[tt]) + carry;
             carry = rl32(incl, 63);
-            if (tt < ntc) deep_hist_unit(P, B, a0, tt, T[tt], incl, sb, rank_arg, revpos, poffs, lowcnt, ufirst, uoff, n_units);
+            if (tt < ntc) deep_hist_unit(P, B, a0, tt, T[tt], incl, rank_arg, ubase, lowcnt, uoff, n_units);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -429,17 +472,18 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_deep3_count_hist_coop(FillP
                                                                            const uint32_t *__restrict__ rank,
                                                                            const uint32_t *__restrict__ sorted_ranks,
                                                                            const uint32_t *__restrict__ rank_arg,
-                                                                           const uint32_t *__restrict__ revpos, const uint32_t *__restrict__ poffs,
+                                                                           const uint64_t *__restrict__ ubase,
                                                                            const uint2 *__restrict__ batches, uint32_t n_batches,
-                                                                           const uint32_t *__restrict__ lowcnt, const uint64_t *__restrict__ ufirst,
+                                                                           const uint32_t *__restrict__ lowcnt,
                                                                            uint64_t *__restrict__ uoff, uint64_t n_units,
                                                                            uint32_t *__restrict__ missing_row)
 {
     constexpr int NT = 64 * kCoopWaves, kPer = (kCoopChunk + NT - 1) / NT;
     typedef hipcub::BlockScan<uint32_t, NT> Scan;
     __shared__ typename Scan::TempStorage s_scan;
-    __shared__ uint32_t T[kCoopChunk];
+    __shared__ uint32_t T[kCoopChunk + 1];
     __shared__ uint32_t H[kPer * NT];  // (bins, then their inclusive prefix in place)
+    static_assert(kPer * NT > kCoopChunk, "bin ntc has a word");
     const unsigned lane = lane_id(), tid = threadIdx.x;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t sb = P.slab_begin, se = P.slab_begin + slab_len;
@@ -448,20 +492,15 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_deep3_count_hist_coop(FillP
         const DeepBatch B = deep_batch(P, bj.x, bj.y, sb, se, present, rank, sorted_ranks, missing_row, lane);  // (every wave the same)
         for (uint32_t a0 = B.t_lo; a0 < B.t_hi; a0 += (uint32_t)kCoopChunk) {
             const uint32_t ntc = min((uint32_t)kCoopChunk, B.t_hi - a0);
-            for (uint32_t i = tid; i < ntc; i += NT) T[i] = sorted_ranks[B.bst + a0 + i];
+            const uint32_t lv = 32u - (uint32_t)__builtin_clz(ntc), levels = lv <= 6u ? 6u : lv <= 9u ? 9u : 12u, padded = 1u << levels;
+            for (uint32_t i = tid; i < padded; i += NT) T[i] = i < ntc ? sorted_ranks[B.bst + a0 + i] : 0xFFFFFFFFu;
             for (uint32_t i = tid; i < (uint32_t)(kPer * NT); i += NT) H[i] = 0u;
             __syncthreads();
-            const uint32_t top = 1u << (31 - __builtin_clz(ntc));
             // the batch's rows in pieces of 256 entries, dealt to the waves in turn
-            uint32_t piece0 = 0;  // pieces of the rows before this one
-            for (uint64_t m = B.have; m; m &= m - 1) {
-                const int ci = __builtin_ctzll(m);
-                const uint32_t rd = rl32(B.cd, ci);
-                const uint32_t *row = sorted_ranks + rl32(B.cst, ci);
-                const uint32_t np = (rd + 255u) / 256u;
-                for (uint32_t pc = (wv + (uint32_t)kCoopWaves - piece0 % (uint32_t)kCoopWaves) % (uint32_t)kCoopWaves; pc < np; pc += (uint32_t)kCoopWaves)
-                    deep_hist_piece(T, H, ntc, top, lane, row, pc * 256u, rd);
-                piece0 += np;
+            switch (levels) {
+            case 6: deep_hist_rows<6, (uint32_t)kCoopWaves>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, wv); break;
+            case 9: deep_hist_rows<9, (uint32_t)kCoopWaves>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, wv); break;
+            default: deep_hist_rows<12, (uint32_t)kCoopWaves>(T, H, lane, sorted_ranks, B.have, B.cd, B.cst, wv); break;
             }
             __syncthreads();
             // bins -> inclusive prefix, in place: kPer consecutive bins per thread
@@ -480,7 +519,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void k_deep3_count_hist_coop(FillP
             }
             __syncthreads();
             for (uint32_t tt = tid; tt < ntc; tt += NT)
-                deep_hist_unit(P, B, a0, tt, T[tt], H[tt], sb, rank_arg, revpos, poffs, lowcnt, ufirst, uoff, n_units);
+                deep_hist_unit(P, B, a0, tt, T[tt], H[tt], rank_arg, ubase, lowcnt, uoff, n_units);
             __syncthreads();  // T and H are rewritten by the next pass
         }
     }
