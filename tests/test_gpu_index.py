@@ -171,6 +171,32 @@ def test_pair_major_partition_images(oracle, e, p):
     eng.close()
 
 
+def test_leaf_kernel_switches_change_no_byte(monkeypatch):
+    """The A/B switches of the leaf kernel (none changes a result): workgroups handed to the XCDs in runs of
+    leaf groups, fewer resident workgroups by an LDS pad -- the image and the auxiliary arrays of a power-law graph (hub units
+    included) are the default build's, byte for byte, and a second default build is the first."""
+    from gnnpe_amd import binding
+    g = synth.powerlaw_graph(3000, 24000, exponent=2.0, max_degree=300, n_labels=6, seed=12)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2)
+    eng.vde(want=False)
+    eng.count_paths(2)
+
+    def build():
+        r = eng.build_index_partition_aux_device(0, fetch=True)
+        return eng.copy_to_host(r[0], r[1]).tobytes(), [np.asarray(a).tobytes() for a in r[3:6]]
+
+    base = build()
+    assert build() == base
+    for k, v in (("GNNPE_LEAF_XCD_CHUNK", "3"), ("GNNPE_LEAF_XCD_CHUNK", "64"), ("GNNPE_LEAF_LDS_PAD", "20000")):
+        monkeypatch.setenv(k, v)
+        assert build() == base, (k, v)
+        monkeypatch.delenv(k)
+    eng.count_paths(2)  # a new count: the pair order is sorted again -- to the same order
+    assert build() == base
+    eng.close()
+
+
 def test_pair_major_with_hub_rows(oracle, test_graph):
     """Test/data_graph.graph has a row of degree 168: its pairs are cut into units of 64 row entries with a kept mask, and
     sorted with the ordinary pairs.  Same contract: every path once, son = its index, lo = hi = its pde row."""
