@@ -9,7 +9,7 @@ import pytest
 from conftest import GOLDEN, ROOT
 from gnnpe_amd import synth
 
-CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+CLI = os.environ.get("GNNPE_CLI", os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main"))  # (GNNPE_CLI: a sanitizer build of the host side)
 
 
 @pytest.fixture(scope="module", autouse=True)
