@@ -1052,19 +1052,54 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     constexpr int kRecW = RWw + (int)(kXW / 4);  // dwords of the longest record (a hub unit's) with its word
     uint32_t e_pp[NL], fh[NL], rr_[NL];
     uint64_t e_G[NL], sw[NL];
-    uint32_t hv[NL][kHdrW], wq[NL][kRecW], ws[NL][kRecW];  // block header, the entry's own record (c), s' record
+    uint32_t hv[NL][kHdrW], wq[NL][kRecW];  // block header, the entry's own record (c)
+    // s' own record is fetched by the lane that HOLDS the pair (a handful of lanes per leaf), as soon as the pair record is there --
+    // its vde words and, with AUX, its {degree, label} word -- and handed to the pair's entries through the crossbar behind the
+    // wait.  (Every entry lane fetching it itself, 4-5 more dword loads per lane: +0.32 ms on the 5.3 ms kernel.)
+    constexpr int kSW = 2 * E + (AUX == 1 ? 2 : AUX == 2 ? 1 : 0);
+    uint32_t hs[NL][kSW], e_a[NL];
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+        const bool hubh = (x_cur[q].cnt & kUnitHub) != 0u;
+        const uint32_t sath = hubh ? x_cur[q].spos : x_cur[q].cnt;  // behind the cnt records ranked after s; a hub row: where the unit says
+        const uint32_t strideh = (hubh ? (uint32_t)(sizeof(RecWide<E>) / 4) : (uint32_t)(sizeof(Rec) / 4)) + kXW / 4;
+        const uint32_t *rsh = reinterpret_cast<const uint32_t *>(recs + (uint64_t)x_cur[q].block * kUnitBytes + 8 * E + kHX) + (uint64_t)sath * strideh;
+        const uint32_t voff = hubh ? 2u : (PACKED ? 1u : 2u);  // first dword of the record's vde
+        {
+            // (one load per four words: the record is dword-aligned, the hardware takes the unaligned 16 bytes)
+            typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+            typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
+            int z = 0;
+#pragma unroll
+            for (; z + 4 <= 2 * E; z += 4) {
+                const u32x4a v4 = *reinterpret_cast<const u32x4a *>(rsh + voff + z);
+                hs[q][z] = v4.x;
+                hs[q][z + 1] = v4.y;
+                hs[q][z + 2] = v4.z;
+                hs[q][z + 3] = v4.w;
+            }
+            if (z + 2 <= 2 * E) {
+                const u32x2a v2 = *reinterpret_cast<const u32x2a *>(rsh + voff + z);
+                hs[q][z] = v2.x;
+                hs[q][z + 1] = v2.y;
+            }
+        }
+        if constexpr (AUX == 1) {
+            hs[q][2 * E] = rsh[strideh - 2];
+            hs[q][2 * E + 1] = rsh[strideh - 1];
+        }
+        if constexpr (AUX == 2) hs[q][2 * E] = rsh[0];
+    }
 #pragma unroll
     for (int q = 0; q < NL; q++) {
         // this lane's pair as the entry lanes will ask for it
         uint32_t pp = 0xFFu;
-        uint32_t p_first = 0, p_sat = 0;
+        uint32_t p_first = 0;
         uint64_t p_son = 0;
         if (rel_cur[q] < g0[q] + ne[q] && lane < kStrip) {
             pp = (uint32_t)(rel_cur[q] >= g0[q] ? rel_cur[q] - g0[q] : 0u);  // first entry of the pair inside this leaf
             // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
             p_first = (x_cur[q].cnt & kUnitHub) ? ((uint32_t)(x_cur[q].son0 >> 32) | kUnitHub) : 0u;
-            // s' own record: behind the cnt records ranked after it; in a hub row (id order) where the unit says
-            p_sat = (x_cur[q].cnt & kUnitHub) ? x_cur[q].spos : x_cur[q].cnt;
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
             p_son = ((x_cur[q].son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur[q] >= g0[q] ? 0u : (uint32_t)(g0[q] - rel_cur[q]));
         }
@@ -1090,7 +1125,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         fh[q] = (uint32_t)__shfl((int)p_first, (int)a);
         e_G[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x_cur[q].G >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)x_cur[q].G, (int)a);
         sw[q] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(p_son >> 32), (int)a) << 32) | (uint32_t)__shfl((int)(uint32_t)p_son, (int)a);
-        const uint32_t s_at = (uint32_t)__shfl((int)p_sat, (int)a);
+        e_a[q] = a;
         // (a wave's missing leaf: the first record of the buffer's first block)
         const uint32_t r = have_leaf[q] ? le - e_pp[q] + (uint32_t)(sw[q] & 0xFFu) : 0u;  // point inside the unit
         rr_[q] = r;
@@ -1120,21 +1155,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         // per further partition).  Dword loads: a 16-byte + a 4-byte load of the dword-aligned record were 5 % slower.
         const uint32_t stride = (hub ? (uint32_t)RWw : (uint32_t)RWd) + kXW / 4;
         const uint32_t *rq = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)rec_at * stride;
-        const uint32_t *rs = reinterpret_cast<const uint32_t *>(blk + 8 * E + kHX) + (uint64_t)(have_leaf[q] ? s_at : 0u) * stride;
 #pragma unroll
         for (int z = 0; z < RWd + (int)(kXW / 4); z++) wq[q][z] = __builtin_nontemporal_load(rq + z);
-        // (s' record: the pair's entries all ask for the same words, in a line the pair's records touch anyway or the next one)
-#pragma unroll
-        for (int z = 0; z < RWd + (int)(kXW / 4); z++) ws[q][z] = rs[z];
         if constexpr (RWw > RWd) {  // (packed ids: a hub unit's record is one dword longer; a wave-uniform branch)
             static_assert(RWw - RWd <= 1, "one dword more");
-            uint32_t extra = 0u, extra_s = 0u;
-            if (__ballot(hub)) {
-                extra = rq[hub ? kRecW - 1 : 0];
-                extra_s = rs[hub ? kRecW - 1 : 0];
-            }
+            uint32_t extra = 0u;
+            if (__ballot(hub)) extra = rq[hub ? kRecW - 1 : 0];
             wq[q][kRecW - 1] = extra;
-            ws[q][kRecW - 1] = extra_s;
         }
     }
     // every load of the wave is in flight: ONE wait, in front of the first leaf's assembly
@@ -1145,8 +1172,14 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
 #pragma unroll
         for (int z = 0; z < kRecW; z++) asm volatile("" : "+v"(wq[q][z]));
 #pragma unroll
-        for (int z = 0; z < kRecW; z++) asm volatile("" : "+v"(ws[q][z]));
+        for (int z = 0; z < kSW; z++) asm volatile("" : "+v"(hs[q][z]));
     }
+    // s' words from the lane that holds the entry's pair (wave-wide shuffles: idle lanes read lane 0's)
+    uint32_t es[NL][kSW];
+#pragma unroll
+    for (int q = 0; q < NL; q++)
+#pragma unroll
+        for (int z = 0; z < kSW; z++) es[q][z] = (uint32_t)__shfl((int)hs[q][z], (int)e_a[q]);
 #pragma unroll
     for (int q = 0; q < NL; q++) {
         if (!have_leaf[q]) continue;  // (wave-uniform)
@@ -1170,7 +1203,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
             double vc[E], vs[E];
             uint32_t son;
             uint64_t wc = 0, wsv = 0;  // {degree, label} of the entry's third and first vertex (AUX)
-            uint32_t first_dw = wq[q][0], first_s = ws[q][0];
+            uint32_t first_dw = wq[q][0], first_s = AUX == 2 ? es[q][kSW - 1] : 0u;
             // (records decoded dword by dword, by selects -- an index that depends on the lane would put the array into scratch:
             // wide {id, aux, vde}, packed {id | id-position << 26, vde} -- gnnpe_records.h)
             constexpr int kV = PACKED ? 1 : 2;  // first dword of an ordinary record's vde (a hub unit's: 2)
@@ -1179,15 +1212,12 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
                 const uint32_t lo32 = hub ? wq[q][2 + 2 * k] : wq[q][kV + 2 * k];
                 const uint32_t hi32 = hub ? wq[q][2 + 2 * k + 1] : wq[q][kV + 2 * k + 1];
                 vc[k] = __longlong_as_double((long long)(((uint64_t)hi32 << 32) | lo32));
-                const uint32_t slo = hub ? ws[q][2 + 2 * k] : ws[q][kV + 2 * k];
-                const uint32_t shi = hub ? ws[q][2 + 2 * k + 1] : ws[q][kV + 2 * k + 1];
-                vs[k] = __longlong_as_double((long long)(((uint64_t)shi << 32) | slo));
+                vs[k] = __longlong_as_double((long long)(((uint64_t)es[q][2 * k + 1] << 32) | es[q][2 * k]));
             }
             if constexpr (AUX == 1) {
                 const uint32_t w0 = hub ? wq[q][RWw] : wq[q][RWd], w1 = hub ? wq[q][RWw + 1] : wq[q][RWd + 1];
                 wc = ((uint64_t)w1 << 32) | w0;
-                const uint32_t s0 = hub ? ws[q][RWw] : ws[q][RWd], s1 = hub ? ws[q][RWw + 1] : ws[q][RWd + 1];
-                wsv = ((uint64_t)s1 << 32) | s0;
+                wsv = ((uint64_t)es[q][2 * E + 1] << 32) | es[q][2 * E];
             }
             uint32_t ip;
             if constexpr (PACKED) ip = first_dw >> kPackedIdBits; else ip = wq[q][1];
