@@ -506,7 +506,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_paths(uint64_t 
 struct __attribute__((aligned(16))) PairX {
     uint32_t block, cnt;  // row block of b (kRowAlign units); paths of the unit (| kUnitHub)
     uint64_t G, son0;     // son0: index inside the partition of the unit's first path (hub unit: first row entry << 32)
-    uint32_t spos, pad;   // hub unit: position of s' record in b's id-ordered row
+    uint32_t spos, plo;   // hub unit: position of s' record in b's id-ordered row; sorted records: low 32 bits of the points in front
+                          // of the unit (k_px_permute_scan) -- a partition holds fewer than 2^31, so the leaves need no more
 };
 static_assert(sizeof(PairX) == 32, "two 16-byte pieces");
 
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_px_hub_units(uint32_t n_hub_pairs, uint
                 x.G = mask;
                 x.son0 = son | ((uint64_t)(u * 64u) << 32);
                 x.spos = spos;
-                x.pad = 0u;
+                x.plo = 0u;
                 px[at0 + u] = x;
                 keys[at0 + u] = (KeyT)(cnt ? key_ok : key_no);
                 vals[at0 + u] = (uint32_t)(at0 + u);
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(kPermBlock) void k_px_permute_scan(uint64_t ne, con
         const uint64_t tile = s_tile;
         if (tile >= n_tiles) break;
         const uint64_t r0 = tile * kPermTile;
-        // 1. the tile's records: every step's source index first, then every step's piece, then the stores
+        // 1. the tile's records: every step's source index first, then every step's piece; the counts into LDS
         uint32_t o[kSteps];
         uint4 v[kSteps];
 #pragma unroll
@@ -751,9 +752,7 @@ __global__ __launch_bounds__(kPermBlock) void k_px_permute_scan(uint64_t ne, con
 #pragma unroll
         for (int i = 0; i < kSteps; i++) {
             const uint32_t piece = i * kPermBlock + tid;
-            const bool in = r0 + piece / PC < ne;
-            if (in) dst[r0 * PC + piece] = v[i];
-            if (tid % PC == 0) s_cnt[piece / PC] = in ? (v[i].y & 0x7FFFFFFFu) : 0u;  // {block, cnt, G}: the record's first piece
+            if (tid % PC == 0) s_cnt[piece / PC] = r0 + piece / PC < ne ? (v[i].y & 0x7FFFFFFFu) : 0u;  // {block, cnt, G}: the first piece
         }
         __syncthreads();
         // 2. inside the tile: kPer consecutive units per thread
@@ -795,21 +794,32 @@ __global__ __launch_bounds__(kPermBlock) void k_px_permute_scan(uint64_t ne, con
             }
         }
         __syncthreads();
-        // 4. the points in front of every unit of the tile
+        // 4. the points in front of every unit of the tile: all 64 bits to `pref`, the low 32 back into LDS for the records
         uint64_t run = s_prefix + excl;
         const uint64_t rt = r0 + (uint64_t)tid * kPer;
-        if (rt + kPer <= ne) {  // (16-byte stores: pref is 8-byte aligned times an even index)
+        {
             static_assert(kPer == 4, "two 16-byte stores per thread");
-            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-            const u64x2 a = {run, run + c[0]}, b = {run + c[0] + c[1], run + c[0] + c[1] + c[2]};
-            reinterpret_cast<u64x2 *>(pref + rt)[0] = a;
-            reinterpret_cast<u64x2 *>(pref + rt)[1] = b;
-        } else {
+            const uint64_t p4[4] = {run, run + c[0], run + c[0] + c[1], run + c[0] + c[1] + c[2]};
 #pragma unroll
-            for (int j = 0; j < kPer; j++) {
-                if (rt + j < ne) pref[rt + j] = run;
-                run += c[j];
+            for (int j = 0; j < kPer; j++) s_cnt[tid * kPer + j] = (uint32_t)p4[j];
+            if (rt + kPer <= ne) {  // (16-byte stores: pref is 8-byte aligned times an even index)
+                typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 a = {p4[0], p4[1]}, b = {p4[2], p4[3]};
+                reinterpret_cast<u64x2 *>(pref + rt)[0] = a;
+                reinterpret_cast<u64x2 *>(pref + rt)[1] = b;
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPer; j++)
+                    if (rt + j < ne) pref[rt + j] = p4[j];
             }
+        }
+        __syncthreads();
+        // 5. the records, the second piece with the low word of its unit's prefix (PairX::plo)
+#pragma unroll
+        for (int i = 0; i < kSteps; i++) {
+            const uint32_t piece = i * kPermBlock + tid;
+            if (tid % PC == 1) v[i].w = s_cnt[piece / PC];  // {son0, spos, plo}
+            if (r0 + piece / PC < ne) dst[r0 * PC + piece] = v[i];
         }
         __syncthreads();  // s_tile, s_cnt and s_prefix are rewritten by the next tile
     }
@@ -989,8 +999,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     }
     const uint64_t jw = (uint64_t)__builtin_amdgcn_readfirstlane((int)(bid * kLeafWaves + wv)) * NL;
     bool have_leaf[NL];
-    uint64_t g0[NL], rel_cur[NL];
-    uint32_t ne[NL];
+    uint64_t g0[NL];
+    uint32_t ne[NL], rel_cur[NL];  // (rel_cur: points of the partition in front of this lane's pair; all ones: no pair)
     PairX x_cur[NL];
     // the pairs of leaf j are first[j] .. first[j + 1] (the last one may continue in the next leaf): only those lanes load
     uint32_t fj[NL + 1];
@@ -1000,7 +1010,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
     // `pref - pbase` in front of leaf 1's loads: a lane without a pair of its own asks for the leaf's first pair again, the
     // very address lane 0 asks for)
     bool have_pair[NL];
-    constexpr int kPxW = (int)(sizeof(PairX) / 4) - 1;  // (the last dword is padding)
+    constexpr int kPxW = (int)(sizeof(PairX) / 4);
     uint32_t xw[NL][kPxW];
 #pragma unroll
     for (int q = 0; q < NL; q++) {
@@ -1012,24 +1022,23 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         const uint64_t kk = (uint64_t)fj[q] + lane;
         have_pair[q] = have_leaf[q] && kk < r1 && kk <= f_end;
         const uint64_t kc = have_pair[q] ? kk : (have_leaf[q] ? (uint64_t)fj[q] : r0);
-        rel_cur[q] = pref[kc];
         const uint32_t *src = reinterpret_cast<const uint32_t *>(px + kc);
 #pragma unroll
         for (int z = 0; z < kPxW; z++) xw[q][z] = src[z];
     }
 #pragma unroll
     for (int q = 0; q < NL; q++) {
-        asm volatile("" : "+v"(rel_cur[q]));
 #pragma unroll
         for (int z = 0; z < kPxW; z++) asm volatile("" : "+v"(xw[q][z]));
     }
 #pragma unroll
     for (int q = 0; q < NL; q++) {
-        rel_cur[q] = have_pair[q] ? rel_cur[q] - pbase : ~0ull;
+        // (the record's low word of the points in front of it, minus the partition's: exact below 2^32 points a partition)
+        rel_cur[q] = have_pair[q] ? xw[q][7] - (uint32_t)pbase : 0xFFFFFFFFu;
 #pragma unroll
         for (int z = 0; z < kPxW; z++)
             if (!have_pair[q]) xw[q][z] = 0u;
-        // PairX: {block, cnt, G, son0, spos} (dwords 0, 1, 2-3, 4-5, 6)
+        // PairX: {block, cnt, G, son0, spos, plo} (dwords 0, 1, 2-3, 4-5, 6, 7)
         x_cur[q].block = xw[q][0];
         x_cur[q].cnt = xw[q][1];
         x_cur[q].G = ((uint64_t)xw[q][3] << 32) | xw[q][2];
@@ -1096,12 +1105,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_pack_leaves_pairs(uint64_t 
         uint32_t pp = 0xFFu;
         uint32_t p_first = 0;
         uint64_t p_son = 0;
-        if (rel_cur[q] < g0[q] + ne[q] && lane < kStrip) {
-            pp = (uint32_t)(rel_cur[q] >= g0[q] ? rel_cur[q] - g0[q] : 0u);  // first entry of the pair inside this leaf
+        const uint32_t g032 = (uint32_t)g0[q];
+        if (rel_cur[q] < g032 + ne[q] && lane < kStrip) {
+            pp = rel_cur[q] >= g032 ? rel_cur[q] - g032 : 0u;  // first entry of the pair inside this leaf
             // hub unit: its first record inside the id-ordered hub row, flagged in bit 31
             p_first = (x_cur[q].cnt & kUnitHub) ? ((uint32_t)(x_cur[q].son0 >> 32) | kUnitHub) : 0u;
             // low byte: points of the unit before this leaf's first point (the unit may have begun in the previous leaf)
-            p_son = ((x_cur[q].son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur[q] >= g0[q] ? 0u : (uint32_t)(g0[q] - rel_cur[q]));
+            p_son = ((x_cur[q].son0 & 0xFFFFFFFFull) << 8) | (uint64_t)(rel_cur[q] >= g032 ? 0u : g032 - rel_cur[q]);
         }
         if (lane < kStrip) s_pp[wv][q][lane] = (uint8_t)pp;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
