@@ -44,6 +44,9 @@ SIGNATURES = {
     "gnnpe_host_label_table": (C.c_int, [C.c_uint32, C.c_uint32, _f64p]),
     "gnnpe_host_load_graph": (C.c_int, [C.c_char_p, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p),
                                         _u32p]),
+    "gnnpe_host_load_multigraph": (C.c_int, [C.c_char_p, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p),
+                                             _u32p, C.POINTER(_u32p), C.POINTER(_u32p)]),
+    "gnnpe_set_multigraph_rows": (C.c_int, [_vp, C.c_uint32, _u64p, _u32p]),
     "gnnpe_host_read_membership": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _u32p, _u32p]),
     "gnnpe_host_free": (None, [_vp]),
     "gnnpe_halo_need": (C.c_int, [_vp, C.c_uint32, _u32p, _vp, C.c_uint64, _u64p]),
@@ -114,7 +117,7 @@ SIGNATURES = {
     "gnnpe_emit_calibrate_device": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
-ABI_VERSION = 5  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
+ABI_VERSION = 6  # GNNPE_ABI_VERSION of include/gnnpe_hip.h
 _lib = None
 
 
@@ -182,13 +185,35 @@ def host_label_table(n_labels, e):
     return out
 
 
-def host_load_graph(path):
-    """R0 through the library's own loader (host/graph_loader.cpp).  Returns a dict like synth graphs."""
+def simple_rows(offsets, nbrs):
+    """The rows the reference's DFS + hash set amount to (custom.h:68-77): every ascending list without its repeats.
+    offsets [n + 1], nbrs: a CSR as graph.cpp:211-233 leaves a file with duplicate `e` lines.  Returns (offsets, nbrs) uint32."""
+    offsets, nbrs = _np(offsets, np.uint32), _np(nbrs, np.uint32)
+    n = len(offsets) - 1
+    row = np.repeat(np.arange(n, dtype=np.uint32), np.diff(offsets.astype(np.int64)))
+    keep = np.ones(len(nbrs), bool)
+    if len(nbrs):
+        keep[1:] = (nbrs[1:] != nbrs[:-1]) | (row[1:] != row[:-1])
+    so = np.zeros(n + 1, np.uint32)
+    so[1:] = np.cumsum(np.bincount(row[keep], minlength=n))
+    return so, np.ascontiguousarray(nbrs[keep])
+
+
+def host_load_graph(path, strict=True):
+    """R0 through the library's own loader (host/graph_loader.cpp).  Returns a dict like synth graphs.  strict=False: a file with
+    duplicate `e` lines is loaded as the reference loads it (offsets / nbrs keep the repeats) and the dict also holds
+    simple_offsets / simple_nbrs, the rows the enumeration runs on (None for a simple graph).  Self-loops are refused either way
+    (the reference's loader leaves a slot uninitialised for them: graph.cpp:211-218)."""
     lib = load()
     n, m = C.c_uint32(), C.c_uint32()
     po, pn, pl = _u32p(), _u32p(), _u32p()
     meta = (C.c_uint32 * 3)()
-    rc = lib.gnnpe_host_load_graph(path.encode(), C.byref(n), C.byref(m), C.byref(po), C.byref(pn), C.byref(pl), meta)
+    if not strict:
+        pso, psn = _u32p(), _u32p()
+        rc = lib.gnnpe_host_load_multigraph(path.encode(), C.byref(n), C.byref(m), C.byref(po), C.byref(pn), C.byref(pl), meta,
+                                            C.byref(pso), C.byref(psn))
+    else:
+        rc = lib.gnnpe_host_load_graph(path.encode(), C.byref(n), C.byref(m), C.byref(po), C.byref(pn), C.byref(pl), meta)
     if rc == -1:
         raise FileNotFoundError(lib.gnnpe_last_error().decode())
     if rc:
@@ -196,10 +221,19 @@ def host_load_graph(path):
     offs = np.ctypeslib.as_array(po, shape=(n.value + 1,)).copy()
     nbrs = np.ctypeslib.as_array(pn, shape=(max(2 * m.value, 1),)).copy()[: 2 * m.value]
     labels = np.ctypeslib.as_array(pl, shape=(max(n.value, 1),)).copy()[: n.value]
+    extra = {}
+    if not strict:
+        if pso:
+            so = np.ctypeslib.as_array(pso, shape=(n.value + 1,)).copy()
+            extra = dict(simple_offsets=so, simple_nbrs=np.ctypeslib.as_array(psn, shape=(max(int(so[-1]), 1),)).copy()[: int(so[-1])])
+            lib.gnnpe_host_free(pso)
+            lib.gnnpe_host_free(psn)
+        else:
+            extra = dict(simple_offsets=None, simple_nbrs=None)
     for p in (po, pn, pl):
         lib.gnnpe_host_free(p)
     return dict(n=n.value, m=m.value, offsets=offs, nbrs=nbrs, labels=labels, labels_count=meta[0], max_degree=meta[1],
-                max_label_frequency=meta[2])
+                max_label_frequency=meta[2], **extra)
 
 
 def host_query_plan(path, e):
@@ -432,6 +466,18 @@ class Engine:
         self._ck(self.lib.gnnpe_load_csr(self.ctx, n, _ptr(offsets, _u32p), _ptr(nbrs, _u32p), _ptr(labels, _u32p)))
         self.n = n
         self.slab = (0, n)
+
+    def load_multigraph(self, offsets, nbrs, labels):
+        """R0 for a CSR with repeated entries, as the reference's loader leaves a file with duplicate `e` lines: the simple rows
+        for the enumeration (custom.h:68-77), the stored rows for gen_vde and the degree columns (include/gnnpe_hip.h)."""
+        so, sn = simple_rows(offsets, nbrs)
+        self.load_csr(so, sn, labels)
+        if len(sn) != len(nbrs):
+            self.set_multigraph_rows(_np(offsets, np.uint32).astype(np.uint64), nbrs)
+
+    def set_multigraph_rows(self, row_offsets, row_nbrs):
+        row_offsets, row_nbrs = _np(row_offsets, np.uint64), _np(row_nbrs, np.uint32)
+        self._ck(self.lib.gnnpe_set_multigraph_rows(self.ctx, len(row_offsets) - 1, _ptr(row_offsets, _u64p), _ptr(row_nbrs, _u32p)))
 
     def load_rows(self, n, labels, rows, row_offsets, row_nbrs, nbr_capacity=0):
         labels, rows = _np(labels, np.uint32), _np(rows, np.uint32)

@@ -108,6 +108,10 @@ struct gnnpe_ctx {
     uint64_t nbr_used = 0, nbr_owned = 0, nbr_cap = 0;
     gnnpe::DevBuf adj_start, adj_deg, present, owned, nbrs, nbr_rank, labels, rows, held, revpos, srec;
     gnnpe::DevBuf nbr_label;  // label of every OWNED adjacency entry (what gen_vde sums over): built with the rows
+    // non-simple input (gnnpe_set_multigraph_rows): the owned rows with their repeated entries -- offsets by row
+    // position and the entries' labels -- for gen_vde; everything else runs on the simple rows above
+    bool multigraph = false;
+    gnnpe::DevBuf mg_off, mg_label;
     // rows longer than 64 entries ("hub" rows of the l=2 enumeration): ids and adjacency ranges; graph-only, rebuilt
     // whenever rows are loaded / appended / dropped
     gnnpe::DevBuf hub_rows, hub_beg, hub_end;

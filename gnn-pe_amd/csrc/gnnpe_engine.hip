@@ -324,6 +324,7 @@ static int alloc_vertex_arrays(gnnpe_ctx *c, uint32_t n)
 static void invalidate_derived(gnnpe_ctx *c)
 {
     c->halo_min_rank = 0;  // called by the loaders only: a freshly loaded graph has no halo rows
+    c->multigraph = false;
     c->have_vde = false;
     c->have_deg_all = false;
     c->aux_vdl_valid = false;
@@ -507,6 +508,60 @@ int gnnpe_load_rows(gnnpe_ctx *c, uint32_t n, const uint32_t *labels, uint32_t n
     return GNNPE_OK;
 }
 
+int gnnpe_set_multigraph_rows(gnnpe_ctx *c, uint32_t n_rows, const uint64_t *row_offsets, const uint32_t *row_nbrs)
+{
+    GNNPE_REQUIRE(c && c->have_graph && row_offsets, GNNPE_ERR_ARG, "gnnpe_set_multigraph_rows: load the simple rows first");
+    GNNPE_REQUIRE(n_rows == c->n_rows, GNNPE_ERR_ARG, "gnnpe_set_multigraph_rows: %u rows given, %u loaded", n_rows, c->n_rows);
+    GNNPE_REQUIRE(c->n_held == c->n_rows, GNNPE_ERR_ARG, "gnnpe_set_multigraph_rows: call it before halo rows are appended");
+    GNNPE_HIP_TRY(hipSetDevice(c->device));
+    for (uint32_t k = 0; k < n_rows; k++)
+        GNNPE_REQUIRE(row_offsets[k] <= row_offsets[k + 1], GNNPE_ERR_ARG, "gnnpe_set_multigraph_rows: offsets not monotone at row %u", k);
+    const uint64_t used = row_offsets[n_rows] - row_offsets[0];
+    GNNPE_REQUIRE(used == 0 || row_nbrs, GNNPE_ERR_ARG, "gnnpe_set_multigraph_rows: null neighbour buffer");
+    GNNPE_REQUIRE(used < (1ull << 32), GNNPE_ERR_RANGE, "gnnpe_set_multigraph_rows: %llu entries exceed 32-bit addressing",
+                  (unsigned long long)used);
+    int rc;
+    if ((rc = c->mg_off.reserve(((size_t)n_rows + 1) * 8)) || (rc = c->mg_label.reserve((used + 1) * 4)) ||
+        (rc = c->scratch.reserve((used + 1) * 4)) || (rc = c->small.reserve(1024)))
+        return rc;
+    std::vector<uint64_t> off0(row_offsets, row_offsets + n_rows + 1);
+    for (auto &o : off0) o -= row_offsets[0];
+    uint32_t *d_nbr = c->scratch.as<uint32_t>(), *d_bad = c->small.as<uint32_t>() + 8;
+    GNNPE_HIP_TRY(hipMemcpyAsync(c->mg_off.p, off0.data(), off0.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if (used) GNNPE_HIP_TRY(hipMemcpyAsync(d_nbr, row_nbrs + row_offsets[0], used * 4, hipMemcpyHostToDevice, c->stream));
+    GNNPE_HIP_TRY(hipMemsetAsync(d_bad, 0xFF, 4, c->stream));
+    const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
+    if (n_rows)
+        hipLaunchKernelGGL(k_check_multi_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, c->stream, c->n, n_rows, rows,
+                           c->mg_off.as<uint64_t>(), d_nbr, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(),
+                           c->nbrs.as<uint32_t>(), d_bad);
+    GNNPE_HIP_TRY(hipGetLastError());
+    uint64_t bad = 0;
+    if ((rc = read_back_u64(c, d_bad, 4, &bad))) return rc;  // (synchronises: off0 may go)
+    GNNPE_REQUIRE((uint32_t)bad == 0xFFFFFFFFu, GNNPE_ERR_ARG,
+                  "gnnpe_set_multigraph_rows: row %u is not an ascending list of ids < n (the vertex itself excluded) whose distinct "
+                  "entries are the loaded row (graph.cpp:211-233 / custom.h:68-77)", (uint32_t)bad);
+    if (used)
+        hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(used)), dim3(kBlock), 0, c->stream, used, d_nbr, c->labels.as<uint32_t>(),
+                           c->mg_label.as<uint32_t>());
+    if (c->rows_identity && n_rows == c->n) {
+        // `degree` is the stored row's length (graph.h:154-156): what the auxiliary index and the online filter compare
+        if ((rc = c->deg_all.reserve(((size_t)c->n + 1) * 4))) return rc;
+        if (c->n)
+            hipLaunchKernelGGL(k_row_lengths_u64, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->n, c->mg_off.as<uint64_t>(),
+                               c->deg_all.as<uint32_t>());
+        c->have_deg_all = true;
+        c->aux_vdl_valid = false;
+    }
+    GNNPE_HIP_TRY(hipGetLastError());
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->multigraph = true;
+    c->have_vde = false;
+    c->nbr_vde_valid = false;
+    c->have_pge = false;
+    return GNNPE_OK;
+}
+
 int gnnpe_set_order(gnnpe_ctx *c, const uint32_t *sorted_nodes, const uint32_t *membership, uint32_t p)
 {
     GNNPE_REQUIRE(c && sorted_nodes && membership, GNNPE_ERR_ARG, "gnnpe_set_order: null argument");
@@ -649,7 +704,12 @@ static int run_vde(gnnpe_ctx *c)
     hipLaunchKernelGGL(k_x_from_labels, dim3(grid_for((uint64_t)n * e)), dim3(kBlock), 0, c->stream, n, e,
                        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->x.as<double>());
     const uint32_t nr = c->n_rows;
-    if (nr) {
+    if (nr && c->multigraph) {
+        hipLaunchKernelGGL(k_vde_multi, dim3(grid_for((uint64_t)nr * e)), dim3(kBlock), 0, c->stream, nr, e,
+                           c->rows_identity ? (const uint32_t *)nullptr : c->rows.as<uint32_t>(), c->mg_off.as<uint64_t>(),
+                           c->mg_label.as<uint32_t>(), c->labels.as<uint32_t>(), c->xtab.as<double>(), c->nx.as<double>(),
+                           c->vde.as<double>());
+    } else if (nr) {
         const uint32_t *rows = c->rows_identity ? nullptr : c->rows.as<uint32_t>();
         dim3 grid((nr + 255) / 256), block(256);
         const size_t tab_lds = (uint64_t)c->n_labels * e <= (uint64_t)kVdeTabMax ? (size_t)c->n_labels * e * 8 : 0;

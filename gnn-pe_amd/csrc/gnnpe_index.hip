@@ -1528,14 +1528,18 @@ static uint32_t builder_fanout(uint32_t D, int builder)
 {
     const uint32_t cap = (kBlockLen - 5) / (16 * D + 4);  // rtnode.cpp:27-28
     if (builder == 0) return index_fanout(D);
-    return cap >= 3 ? std::min(cap - 2, 64u) : 1u;
+    return cap >= 3 ? std::max(2u, std::min(cap - 2, 64u)) : 0u;  // (capacity 3: two entries, as the pair-major build; a fan-out of one never reaches a root)
 }
 
 extern "C" uint64_t gnnpe_index_file_bytes(uint64_t points, uint32_t D, int builder)
 {
-    if (D == 0 || D > 254) return 0;
+    // a node must hold three entries (build_image and the pair-major build REQUIRE the same): from D = 85 on none does, and
+    // a fan-out below two would never reach a single root
+    if (D == 0 || (kBlockLen - 5) / (16ull * D + 4) < 3) return 0;
+    const uint32_t F = builder_fanout(D, builder);
+    if (F < 2) return 0;
     std::vector<uint64_t> level_n;
-    return (plan_levels(points, std::max(1u, builder_fanout(D, builder)), level_n) + 1) * (uint64_t)kBlockLen;
+    return (plan_levels(points, F, level_n) + 1) * (uint64_t)kBlockLen;
 }
 
 static int build_image(gnnpe_ctx *c, uint64_t cnt, LeafSrc S, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])

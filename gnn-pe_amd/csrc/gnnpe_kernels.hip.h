@@ -58,6 +58,58 @@ __global__ void k_gather_u32(uint64_t cnt, const uint32_t *__restrict__ idx, con
         out[q] = table[idx[q]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// non-simple graphs (gnnpe_set_multigraph_rows): the rows as graph.cpp:211-233 leaves them -- repeats kept -- beside the
+// simple rows the enumeration runs on.
+// ------------------------------------------------------------------------------------------------
+// row k of the multigraph form, stripped of its repeats, must be the loaded row of the same vertex; *bad = smallest row position
+// where it is not (or where the list is not ascending / holds an id >= n or the vertex itself)
+__global__ void k_check_multi_rows(uint32_t n, uint32_t n_rows, const uint32_t *__restrict__ rows, const uint64_t *__restrict__ moff,
+                                   const uint32_t *__restrict__ mnbr, const uint32_t *__restrict__ adj_start,
+                                   const uint32_t *__restrict__ adj_deg, const uint32_t *__restrict__ nbrs, uint32_t *__restrict__ bad)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_rows; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = rows ? rows[k] : (uint32_t)k;
+        const uint32_t st = adj_start[v], d = adj_deg[v];
+        uint32_t j = 0, prev = 0;
+        bool ok = true, have_prev = false;
+        for (uint64_t i = moff[k]; i < moff[k + 1] && ok; i++) {
+            const uint32_t u = mnbr[i];
+            if (u >= n || u == v || (have_prev && u < prev)) ok = false;
+            else if (!(have_prev && u == prev)) {
+                if (j < d && nbrs[st + j] == u) j++;
+                else ok = false;
+            }
+            prev = u;
+            have_prev = true;
+        }
+        if (!ok || j != d) atomicMin(bad, (uint32_t)k);
+    }
+}
+
+// gen_vde over the multigraph rows (custom.h:527-540): one thread per (row, dimension), the row's entries in their stored
+// (ascending) order from 0.0 -- the reference's operation order; a repeated entry is summed as often as it is stored
+__global__ void k_vde_multi(uint32_t n_rows, uint32_t e, const uint32_t *__restrict__ rows, const uint64_t *__restrict__ moff,
+                            const uint32_t *__restrict__ mlabel, const uint32_t *__restrict__ labels, const double *__restrict__ xtab,
+                            double *__restrict__ nx, double *__restrict__ vde)
+{
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < (uint64_t)n_rows * e; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = t / e;
+        const uint32_t d = (uint32_t)(t % e);
+        const uint32_t v = rows ? rows[k] : (uint32_t)k;
+        double s = 0.0;
+        for (uint64_t i = moff[k]; i < moff[k + 1]; i++) s += xtab[(uint64_t)mlabel[i] * e + d];
+        nx[(uint64_t)v * e + d] = s;
+        vde[(uint64_t)v * e + d] = xtab[(uint64_t)labels[v] * e + d] + s;
+    }
+}
+
+__global__ void k_row_lengths_u64(uint32_t n_rows, const uint64_t *__restrict__ off, uint32_t *__restrict__ len)
+{
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < n_rows; k += (uint64_t)gridDim.x * blockDim.x)
+        len[k] = (uint32_t)(off[k + 1] - off[k]);
+}
+
 // slab row degrees: pdeg[i] = deg(sorted[slab_begin + i]); pdeg[len] = 0 (scan sentinel)
 __global__ void k_slab_degrees(uint32_t len, uint32_t slab_begin, const uint32_t *__restrict__ sorted,
                                const uint32_t *__restrict__ deg, uint32_t *__restrict__ pdeg)

@@ -150,6 +150,7 @@ extern "C" {
 int gnnpe_pge_groups(gnnpe_ctx *c, double *host_path_group, double *host_path_label_group)
 {
     GNNPE_REQUIRE(c && c->have_vde, GNNPE_ERR_ARG, "gnnpe_pge_groups: call gnnpe_vde first");
+    GNNPE_REQUIRE(!c->multigraph, GNNPE_ERR_UNSUPPORTED, "gnnpe_pge_groups: simple graphs only (gnnpe_set_multigraph_rows was called)");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     const uint32_t n = c->n, e = c->e;
     const size_t bytes = (size_t)n * 4 * e * 8;

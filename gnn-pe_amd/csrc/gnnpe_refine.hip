@@ -122,6 +122,7 @@ int gnnpe_refine(gnnpe_ctx *c, const char *query_graph_path, const uint32_t *can
 {
     GNNPE_REQUIRE(c && query_graph_path && candidate_bitmap && answers, GNNPE_ERR_ARG, "gnnpe_refine: null argument");
     GNNPE_REQUIRE(c->have_graph && c->rows_identity, GNNPE_ERR_UNSUPPORTED, "gnnpe_refine: the whole graph must be on the device (gnnpe_load_csr)");
+    GNNPE_REQUIRE(!c->multigraph, GNNPE_ERR_UNSUPPORTED, "gnnpe_refine: simple graphs only (gnnpe_set_multigraph_rows was called)");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     *answers = 0;
     gnnpe_host::StaticGraph q;

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/gnnpe_hip.h"
+#include "graph_loader.h"
 
 using Clock = std::chrono::steady_clock;
 
@@ -30,6 +31,7 @@ struct Options {
     int gpus = 1;
     uint64_t chunk_paths = 8ull << 20;  // 8M paths per pass: small enough to pipeline render, copy-back and file writes
     bool allow_large = false, timing = false, sidecars = false, write_index = false;
+    bool strict = false;  // refuse a graph file with a duplicate `e` line (the reference loads it as it is: graph.cpp:211-218)
     bool same_device = false;  // testing aid: all --gpus contexts on device 0 (halo by device copies: RCCL needs distinct GPUs)
     std::string transport = "rccl";  // --gpus N > 1: "rccl" (ncclSend/ncclRecv over xGMI) or "copy" (device-to-device copies)
     // --transport given explicitly: take the slab path (host/slab_offline.cpp) even with --gpus 1 -- a 1-rank communicator
@@ -96,6 +98,7 @@ inline Options parse_args(int argc, char **argv, const char *tool = "gnnpe_main"
         if (a == "--sidecars") { o.sidecars = true; continue; }
         if (a == "--index") { o.write_index = true; continue; }
         if (a == "--same-device") { o.same_device = true; continue; }
+        if (a == "--strict") { o.strict = true; continue; }
         if (a.rfind("--", 0) == 0) {
             std::string name = a.substr(2);
             size_t eq = name.find('=');
@@ -149,6 +152,9 @@ inline std::string index_size_problem(const std::vector<uint64_t> &part_count, u
 {
     uint64_t worst = 0;
     uint32_t worst_pid = 0;
+    if (index_file_bytes(1, D, builder) == 0)  // no node holds three entries of this width (rtnode.cpp:27-28): nothing to size
+        die("--index: an entry of " + std::to_string(D) + " dimensions (" + std::to_string(16ull * D + 4) +
+            " bytes) gives a node capacity below 3 in a 4096-byte block; use a smaller -e");
     for (uint32_t i = 0; i < part_count.size(); i++) {
         const uint64_t b = index_file_bytes(part_count[i], D, builder);
         if (b > worst) worst = b, worst_pid = i;
@@ -159,6 +165,16 @@ inline std::string index_size_problem(const std::vector<uint64_t> &part_count, u
     return "partition " + std::to_string(worst_pid) + " holds " + std::to_string(part_count[worst_pid]) + " paths: its index.dat would be " +
            std::to_string(worst >> 20) + " MiB, and the reference's online binary cannot seek in index files of 2 GiB or more "
            "(blk_file.h:33); partitions of equal size stay below that from -p " + std::to_string(p_min);
+}
+
+// R0 onto a context: the rows the enumeration runs on and, for a file that is not a simple graph, the rows as the reference's
+// loader holds them (graph_loader.h) for gen_vde and the degree columns
+inline int load_graph_into(gnnpe_ctx *ctx, const gnnpe_host::StaticGraph &g)
+{
+    int rc = gnnpe_load_csr(ctx, g.n, g.enum_offsets().data(), g.enum_neighbors().data(), g.labels.data());
+    if (rc != 0 || g.simple) return rc;
+    std::vector<uint64_t> off(g.offsets.begin(), g.offsets.end());
+    return gnnpe_set_multigraph_rows(ctx, g.n, off.data(), g.neighbors.data());
 }
 
 inline bool is_dir(const std::string &p)

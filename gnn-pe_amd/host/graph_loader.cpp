@@ -84,7 +84,7 @@ bool read_file(const std::string &path, FileView *v)
 
 }  // namespace
 
-int StaticGraph::load(const std::string &path, std::string *err)
+int StaticGraph::load(const std::string &path, std::string *err, bool strict)
 {
     FileView buf;
     if (!read_file(path, &buf)) {
@@ -175,6 +175,11 @@ int StaticGraph::load(const std::string &path, std::string *err)
                     errs[t] = "edge " + std::to_string(a) + " " + std::to_string(b) + " does not fit the declared degrees";
                     return;
                 }
+                if (a == b) {  // see graph_loader.h: the reference's own result for such a line is undefined
+                    errs[t] = "self-loop at vertex " + std::to_string(a) + ": the reference's loader writes both ends of `e v v` into one "
+                              "slot and leaves the next one uninitialised (graph.cpp:211-218), so its own result for such a file is undefined";
+                    return;
+                }
                 out.push_back(a);
                 out.push_back(b);
             } else if (type == 'v') {
@@ -238,28 +243,52 @@ int StaticGraph::load(const std::string &path, std::string *err)
     labels_count = std::max<uint32_t>((uint32_t)freq.size(), n ? max_label + 1 : 0);  // graph.cpp:223
     max_label_frequency = 0;
     for (auto &kv : freq) max_label_frequency = std::max(max_label_frequency, kv.second);
-    // graph.cpp:231-233: every list ascending; the closed-form enumeration needs a simple graph
+    // graph.cpp:231-233: every list ascending; repeats and self-loops are found on the way (see graph_loader.h)
     std::atomic<uint32_t> next_block{0};
-    std::atomic<uint32_t> bad_vertex{0xFFFFFFFFu};
+    std::atomic<uint32_t> dup_vertex{0xFFFFFFFFu}, loop_vertex{0xFFFFFFFFu};
+    auto note = [](std::atomic<uint32_t> &slot, uint32_t v) {
+        uint32_t cur = slot.load();
+        while (v < cur && !slot.compare_exchange_weak(cur, v)) {}
+    };
     auto sort_rows = [&](unsigned) {
         for (;;) {
             const uint32_t v0 = next_block.fetch_add(4096, std::memory_order_relaxed);
             if (v0 >= nn) return;
             for (uint32_t v = v0; v < std::min(nn, v0 + 4096); v++) {
                 std::sort(neighbors.begin() + offsets[v], neighbors.begin() + offsets[v + 1]);
-                for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++)
-                    if (neighbors[j] == v || (j > offsets[v] && neighbors[j] == neighbors[j - 1])) {
-                        uint32_t cur = bad_vertex.load();
-                        while (v < cur && !bad_vertex.compare_exchange_weak(cur, v)) {}
-                        break;
-                    }
+                bool dup = false, loop = false;
+                for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++) {
+                    loop |= neighbors[j] == v;
+                    dup |= j > offsets[v] && neighbors[j] == neighbors[j - 1];
+                }
+                if (loop) note(loop_vertex, v);
+                if (dup) note(dup_vertex, v);
             }
         }
     };
     run(sort_rows);
-    if (bad_vertex.load() != 0xFFFFFFFFu) {
-        if (err) *err = "self-loop or duplicate edge at vertex " + std::to_string(bad_vertex.load()) + " (simple graphs only)";
+    simple_offsets.clear();
+    simple_neighbors.clear();
+    if (loop_vertex.load() != 0xFFFFFFFFu) {
+        if (err)
+            *err = "self-loop at vertex " + std::to_string(loop_vertex.load()) + ": the reference's loader writes both ends of `e v v` into one "
+                   "slot and leaves the next one uninitialised (graph.cpp:211-218), so its own result for such a file is undefined";
         return -2;
+    }
+    simple = dup_vertex.load() == 0xFFFFFFFFu;
+    if (!simple && strict) {
+        if (err) *err = "duplicate edge at vertex " + std::to_string(dup_vertex.load()) + " (--strict: simple graphs only)";
+        return -2;
+    }
+    if (!simple) {
+        // the rows the reference's enumeration amounts to: every list without its repeats
+        simple_offsets.assign((size_t)n + 1, 0);
+        simple_neighbors.reserve(neighbors.size());
+        for (uint32_t v = 0; v < nn; v++) {
+            for (uint32_t j = offsets[v]; j < offsets[v + 1]; j++)
+                if (j == offsets[v] || neighbors[j] != neighbors[j - 1]) simple_neighbors.push_back(neighbors[j]);
+            simple_offsets[v + 1] = (uint32_t)simple_neighbors.size();
+        }
     }
     return 0;
 }

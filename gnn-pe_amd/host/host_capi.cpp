@@ -24,8 +24,28 @@ void set_error(const char *fmt, ...);
 
 extern "C" {
 
+static int load_graph_file(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs, uint32_t **labels,
+                           uint32_t meta[3], uint32_t **simple_offsets, uint32_t **simple_nbrs);
+
 int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs, uint32_t **labels,
                           uint32_t meta[3])
+{
+    return load_graph_file(path, n, m, offsets, nbrs, labels, meta, nullptr, nullptr);
+}
+
+int gnnpe_host_load_multigraph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs, uint32_t **labels,
+                               uint32_t meta[3], uint32_t **simple_offsets, uint32_t **simple_nbrs)
+{
+    if (!simple_offsets || !simple_nbrs) {
+        gnnpe::set_error("gnnpe_host_load_multigraph: null argument");
+        return GNNPE_ERR_ARG;
+    }
+    return load_graph_file(path, n, m, offsets, nbrs, labels, meta, simple_offsets, simple_nbrs);
+}
+
+// simple_offsets == nullptr: strict (a non-simple file is malformed)
+static int load_graph_file(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs, uint32_t **labels,
+                           uint32_t meta[3], uint32_t **simple_offsets, uint32_t **simple_nbrs)
 {
     if (!path || !n || !m || !offsets || !nbrs || !labels) {
         gnnpe::set_error("gnnpe_host_load_graph: null argument");
@@ -33,7 +53,7 @@ int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t *
     }
     gnnpe_host::StaticGraph g;
     std::string err;
-    const int rc = g.load(path, &err);
+    const int rc = g.load(path, &err, simple_offsets == nullptr);
     if (rc != 0) {
         gnnpe::set_error("%s", err.c_str());
         return rc;
@@ -48,6 +68,10 @@ int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t *
     *offsets = dup(g.offsets);
     *nbrs = dup(g.neighbors);
     *labels = dup(g.labels);
+    if (simple_offsets) {
+        *simple_offsets = g.simple ? nullptr : dup(g.simple_offsets);
+        *simple_nbrs = g.simple ? nullptr : dup(g.simple_neighbors);
+    }
     if (meta) {
         meta[0] = g.labels_count;
         meta[1] = g.max_degree;
@@ -81,7 +105,7 @@ int gnnpe_host_query_plan(const char *query_graph_path, uint32_t e, uint32_t *n_
     }
     gnnpe_host::StaticGraph q;
     std::string err;
-    int rc = q.load(query_graph_path, &err);
+    int rc = q.load(query_graph_path, &err, true);
     if (rc != 0) {
         gnnpe::set_error("%s", err.c_str());
         return rc;
@@ -115,7 +139,7 @@ int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs,
     }
     gnnpe_host::StaticGraph q, g;
     std::string err;
-    int rc = q.load(query_graph_path, &err);
+    int rc = q.load(query_graph_path, &err, true);
     if (rc != 0) {
         gnnpe::set_error("%s", err.c_str());
         return rc;

@@ -164,7 +164,7 @@ int run_filter(const Options &o)
     if (o.path_length != 2) die("-m filter: only -l 2 (the reference's online side only works for it)");
     StaticGraph g;
     std::string err;
-    int rc = g.load(o.data_graph, &err);
+    int rc = g.load(o.data_graph, &err, o.strict);
     if (rc == -1) {
         printf("%s\n", err.c_str());
         exit(-1);
@@ -190,7 +190,7 @@ int run_filter(const Options &o)
     const uint32_t n_labels = std::max<uint32_t>(g.labels_count, 1);
     std::vector<double> table((size_t)n_labels * o.vde_dim);
     check(gnnpe_host_label_table(n_labels, o.vde_dim, table.data()), "label table");
-    check(gnnpe_load_csr(ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
+    check(load_graph_into(ctx, g), "load_csr");
     check(gnnpe_set_order(ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
     check(gnnpe_set_label_table(ctx, n_labels, o.vde_dim, table.data()), "set_label_table");
     check(gnnpe_vde(ctx, nullptr, nullptr, nullptr), "vde");
@@ -267,6 +267,9 @@ int main(int argc, char **argv)
     if (o.partition_num == 0) die("-p must be >= 1");
     if (o.mode == "online" || o.mode == "filter") return run_filter(o);
     if (o.mode != "offline") return 0;  // the reference does nothing for other modes
+    if (o.write_index && gnnpe_index_file_bytes(1, L * o.vde_dim, 0) == 0)  // before the graph is read or a GPU is touched
+        die("--index: an entry of " + std::to_string(L * o.vde_dim) + " dimensions (" + std::to_string(16ull * L * o.vde_dim + 4) +
+            " bytes) gives a node capacity below 3 in a 4096-byte block (rtnode.cpp:27-28); use a smaller -e");
 
     // HIP start-up (0.1-0.2 s: runtime initialisation, context, code objects) runs beside the graph load.  An error
     // exit in between (die() -> exit()) must not tear the process down under that thread: it is joined first.
@@ -286,7 +289,7 @@ int main(int argc, char **argv)
 
     StaticGraph g;
     std::string err;
-    int rc = g.load(o.data_graph, &err);
+    int rc = g.load(o.data_graph, &err, o.strict);
     if (rc == -1) {  // graph.cpp:166-169
         printf("%s\n", err.c_str());
         exit(-1);
@@ -346,10 +349,16 @@ int main(int argc, char **argv)
         index_job->th = std::thread([&, job = index_job] {
             const auto i0 = Clock::now();
             auto fail = [&](const char *what) { job->error = std::string(what) + ": " + gnnpe_last_error(); };
+            // test hook (tests/test_gpu_cli.py): GNNPE_FAULT_RANK=index:create fails this thread as an out-of-memory would
+            const char *fault = getenv("GNNPE_FAULT_RANK");
+            if (fault && !strcmp(fault, "index:create")) {
+                job->error = "gnnpe_create (index): injected fault";
+                return;
+            }
             gnnpe_ctx *ctx = gnnpe_create(0);
             if (!ctx) return fail("gnnpe_create (index)");
             uint64_t P2 = 0;
-            if (gnnpe_load_csr(ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()) != 0 ||
+            if (load_graph_into(ctx, g) != 0 ||
                 gnnpe_set_order(ctx, sorted_nodes.data(), membership.data(), o.partition_num) != 0 ||
                 gnnpe_set_label_table(ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()) != 0 ||
                 gnnpe_vde(ctx, nullptr, nullptr, nullptr) != 0 || gnnpe_count_paths(ctx, o.path_length, nullptr, &P2) != 0) {
@@ -390,7 +399,7 @@ int main(int argc, char **argv)
     std::vector<Device> devs(1);
     devs[0].ctx = early_ctx ? early_ctx : gnnpe_create(0);  // (again on this thread if the early one failed: for its message)
     if (!devs[0].ctx) die(std::string("gnnpe_create: ") + gnnpe_last_error());
-    check(gnnpe_load_csr(devs[0].ctx, g.n, g.offsets.data(), g.neighbors.data(), g.labels.data()), "load_csr");
+    check(load_graph_into(devs[0].ctx, g), "load_csr");
     check(gnnpe_set_order(devs[0].ctx, sorted_nodes.data(), membership.data(), o.partition_num), "set_order");
     check(gnnpe_set_label_table(devs[0].ctx, std::max<uint32_t>(g.labels_count, 1), o.vde_dim, table.data()), "set_label_table");
     const auto t_setup = Clock::now();
@@ -536,9 +545,23 @@ int main(int argc, char **argv)
         const auto i0 = Clock::now();
         index_job->th.join();
         t_index_wait = secs(i0, Clock::now());
-        if (!index_job->error.empty()) die(index_job->error);
-        for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
         t_index = index_job->seconds;
+        if (!index_job->error.empty()) {
+            // the second context is an overlap, not a requirement: two copies of the graph and its count state plus
+            // the main thread's chunk buffers may not fit where one did.  The text is written and its buffers are freed: build
+            // the files on the main context, one after the other, as round 4 did.
+            fprintf(stderr, "%s: note: index context failed (%s); building index.dat on the main context instead\n", o.tool,
+                    index_job->error.c_str());
+            std::vector<const char *> ipp, app;
+            for (uint32_t pid = 0; pid < o.partition_num; pid++) {
+                ipp.push_back(ips[pid].c_str());
+                app.push_back(aps[pid].c_str());
+            }
+            check(gnnpe_build_index_files(devs[0].ctx, o.partition_num, ipp.data(), o.sidecars ? app.data() : nullptr),
+                  "build_index_files (main context)");
+            t_index = secs(i0, Clock::now());
+        }
+        for (auto &ip : ips) warn_if_index_too_large_for_reference(ip);
     }
     for (auto &d : devs) gnnpe_destroy(d.ctx);
 

@@ -28,7 +28,7 @@ int main(int argc, char **argv)
 
     gnnpe_host::StaticGraph g;
     std::string err;
-    int rc = g.load(o.data_graph, &err);
+    int rc = g.load(o.data_graph, &err, true);  // GNN-PGE: simple graphs only
     if (rc == -1) {  // graph.cpp:166-169
         printf("%s\n", err.c_str());
         exit(-1);

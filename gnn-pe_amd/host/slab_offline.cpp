@@ -115,7 +115,13 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     void load()
     {
-        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // GNNPE_RCCL_LIB=<path>: another library with RCCL's entry points -- tests/fake_rccl (a stand-in over device copies between
+        // the rank threads) walks the N >= 2 schedule on a single-GPU box, where RCCL itself refuses the same device twice
+        if (const char *other = getenv("GNNPE_RCCL_LIB")) {
+            lib = dlopen(other, RTLD_NOW | RTLD_LOCAL);
+            if (!lib) die(std::string("cannot load GNNPE_RCCL_LIB=") + other + ": " + dlerror());
+        }
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) die(std::string("cannot load librccl: ") + dlerror());
 #define GNNPE_SYM(field, name)                                          \
@@ -446,17 +452,18 @@ uint64_t id_lines_bytes(uint64_t first, uint64_t cnt)
 std::vector<uint32_t> plan_slabs(const StaticGraph &g, const std::vector<uint32_t> &sorted_nodes, int R)
 {
     const uint32_t n = g.n;
+    const std::vector<uint32_t> &go = g.enum_offsets(), &gn = g.enum_neighbors();  // the rows the enumeration runs on
     std::vector<double> w(n);
     double dsum = 0.0;
-    for (uint32_t v = 0; v < n; v++) dsum += g.offsets[v + 1] - g.offsets[v];
+    for (uint32_t v = 0; v < n; v++) dsum += go[v + 1] - go[v];
     double later = dsum;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t s = sorted_nodes[i];
-        later -= g.offsets[s + 1] - g.offsets[s];
+        later -= go[s + 1] - go[s];
         double two_hop = 0.0;
-        for (uint32_t q = g.offsets[s]; q < g.offsets[s + 1]; q++) {
-            const uint32_t b = g.neighbors[q];
-            two_hop += (double)(g.offsets[b + 1] - g.offsets[b]) - 1.0;
+        for (uint32_t q = go[s]; q < go[s + 1]; q++) {
+            const uint32_t b = gn[q];
+            two_hop += (double)(go[b + 1] - go[b]) - 1.0;
         }
         w[i] = two_hop * (dsum > 0 ? later / dsum : 0.0) + 1e-3;
     }
@@ -499,7 +506,8 @@ void rank_main(int r, Shared &S)
     const uint32_t n = g.n, L = o.path_length + 1, e = o.vde_dim, p = o.partition_num;
     const std::vector<uint32_t> &sn = *S.sorted_nodes, &mem = *S.membership;
     const uint32_t lo = S.bounds[r], hi = S.bounds[r + 1], n_own = hi - lo;
-    const uint64_t m2 = g.offsets[n];
+    const std::vector<uint32_t> &go = g.enum_offsets(), &gn = g.enum_neighbors();  // the rows the enumeration runs on (graph_loader.h)
+    const uint64_t m2 = go[n];
     const auto t0 = Clock::now();
 
     gnnpe_ctx *ctx = gnnpe_create(o.same_device ? 0 : r);
@@ -515,13 +523,21 @@ void rank_main(int r, Shared &S)
     // ---- this rank's rows only ----
     std::vector<uint32_t> rows(sn.begin() + lo, sn.begin() + hi);
     std::vector<uint64_t> roff(n_own + 1, 0);
-    for (uint32_t k = 0; k < n_own; k++) roff[k + 1] = roff[k] + (g.offsets[rows[k] + 1] - g.offsets[rows[k]]);
+    for (uint32_t k = 0; k < n_own; k++) roff[k + 1] = roff[k] + (go[rows[k] + 1] - go[rows[k]]);
     std::vector<uint32_t> rnbr(roff[n_own]);
     for (uint32_t k = 0; k < n_own; k++)
-        std::copy(g.neighbors.begin() + g.offsets[rows[k]], g.neighbors.begin() + g.offsets[rows[k] + 1], rnbr.begin() + roff[k]);
+        std::copy(gn.begin() + go[rows[k]], gn.begin() + go[rows[k] + 1], rnbr.begin() + roff[k]);
     const uint64_t own_entries = roff[n_own];
     S.owned_entries[r] = own_entries;
     check(gnnpe_load_rows(ctx, n, g.labels.data(), n_own, rows.data(), roff.data(), rnbr.data(), m2), "load_rows");
+    if (!g.simple) {  // the same rows as the reference's loader holds them: what gen_vde sums over (include/gnnpe_hip.h)
+        std::vector<uint64_t> moff(n_own + 1, 0);
+        for (uint32_t k = 0; k < n_own; k++) moff[k + 1] = moff[k] + (g.offsets[rows[k] + 1] - g.offsets[rows[k]]);
+        std::vector<uint32_t> mnbr(moff[n_own]);
+        for (uint32_t k = 0; k < n_own; k++)
+            std::copy(g.neighbors.begin() + g.offsets[rows[k]], g.neighbors.begin() + g.offsets[rows[k] + 1], mnbr.begin() + moff[k]);
+        check(gnnpe_set_multigraph_rows(ctx, n_own, moff.data(), mnbr.data()), "set_multigraph_rows");
+    }
     check(gnnpe_set_order(ctx, sn.data(), mem.data(), p), "set_order");
     check(gnnpe_set_slab(ctx, lo, hi), "set_slab");
     check(gnnpe_set_label_table(ctx, std::max<uint32_t>(g.labels_count, 1), e, S.table->data()), "set_label_table");
@@ -774,7 +790,10 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
                       Clock::time_point t_loaded)
 {
     const int R = o.gpus;
-    const bool use_rccl = !o.same_device && o.transport != "copy";
+    // --same-device puts every context on device 0, which RCCL refuses inside one communicator: device copies then -- unless the
+    // caller names a library that can (GNNPE_RCCL_LIB, see Rccl::load) and asks for the rccl transport explicitly
+    const bool standin = getenv("GNNPE_RCCL_LIB") != nullptr && o.transport_explicit;
+    const bool use_rccl = o.transport != "copy" && (!o.same_device || standin);
     try {
     const auto t_tp = Clock::now();
     Transport tp(R, use_rccl);  // loads librccl when the transport is rccl: seconds (its code objects), once per process
@@ -844,7 +863,7 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
                 "\"partition_bytes\": %llu, \"csr_entries\": %llu, \"ranks\": [%s]}\n",
                 (unsigned long long)S.P, R, use_rccl ? "rccl" : "copy", secs(t_start, t_loaded), rccl_load_s, mx(S.t_init), mx(S.t_halo), mx(S.t_count), mx(S.t_emit),
                 mx(S.t_sizing), mx(S.t_index), secs(t_start, Clock::now()), (unsigned long long)S.bytes_all, (unsigned long long)S.bytes_part,
-                (unsigned long long)g.offsets[g.n], per.c_str());
+                (unsigned long long)g.enum_offsets()[g.n], per.c_str());
     }
     } catch (const std::exception &ex) {
         fprintf(stderr, "%s: %s\n", o.tool, ex.what());

@@ -56,6 +56,33 @@ def gnm_graph(n, m, n_labels=64, seed=SEED):
     return dict(n=n, m=m, offsets=offs, nbrs=nbrs, labels=labels, eu=eu, ev=ev)
 
 
+def multigraph(n, m, n_dup=0, n_loops=0, n_labels=8, seed=SEED):
+    """A NON-simple input: G(n, m) plus `n_dup` repeated `e` lines (one edge many times, some with the endpoints swapped) and
+    `n_loops` self-loop lines (for refusal tests: the reference's loader has no defined result for them), the lines shuffled.  The
+    dict is what the reference's loader makes of the duplicate lines (graph.cpp:211-233: every line adds an entry to both endpoints'
+    lists; lists sorted): m = number of `e` lines, offsets / nbrs with the repeats, eu / ev in file order.  `write_graph_file`
+    writes it (a self-loop line counts two in its vertex' degree field)."""
+    g = gnm_graph(n, m, n_labels=n_labels, seed=seed)
+    rng = np.random.default_rng(seed + 7)
+    eu, ev = g["eu"].astype(np.int64), g["ev"].astype(np.int64)
+    if n_dup and m:
+        pick = rng.integers(0, m, size=n_dup)
+        pick[: n_dup // 3] = pick[0]  # one edge many times
+        du, dv = eu[pick], ev[pick]
+        swap = rng.random(n_dup) < 0.5
+        eu = np.concatenate([eu, np.where(swap, dv, du)])
+        ev = np.concatenate([ev, np.where(swap, du, dv)])
+    if n_loops:
+        lv = rng.integers(0, n, size=n_loops)
+        lv[: n_loops // 4] = lv[0]  # one vertex with several loops
+        eu = np.concatenate([eu, lv])
+        ev = np.concatenate([ev, lv])
+    perm = rng.permutation(len(eu))
+    eu, ev = eu[perm], ev[perm]
+    offs, nbrs = _csr_from_edges(n, eu, ev)
+    return dict(n=n, m=len(eu), offsets=offs, nbrs=nbrs, labels=g["labels"], eu=eu.astype(np.uint32), ev=ev.astype(np.uint32))
+
+
 def powerlaw_graph(n, m, exponent=2.1, max_degree=2000, n_labels=64, seed=SEED):
     """Chung-Lu style power-law graph with a degree cap (config 5 stress input).
 

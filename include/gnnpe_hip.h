@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNNPE_ABI_VERSION 5
+#define GNNPE_ABI_VERSION 6
 
 #define GNNPE_OK 0
 #define GNNPE_ERR_ARG (-1)     /* bad argument / call order */
@@ -81,6 +81,19 @@ int gnnpe_load_rows(gnnpe_ctx *ctx, uint32_t n, const uint32_t *host_labels, uin
                     const uint32_t *host_rows, const uint64_t *host_row_offsets, const uint32_t *host_row_nbrs,
                     uint64_t nbr_capacity);
 
+/* Non-simple input: duplicate `e` lines.  Static_Graph::loadGraphFromFile stores what it reads (graph.cpp:211-218: no
+ * de-duplication), so `degree` (graph.h:154-156) and the neighbour sum of gen_vde (custom.h:527-534) count the repeats, while
+ * the hash set drops a path met again (custom.h:68-77).  The engine's enumeration takes simple rows, so such a graph is loaded
+ * in two steps: gnnpe_load_csr / gnnpe_load_rows with every row WITHOUT its repeats (what the DFS + hash set amount to;
+ * gnnpe_host_load_multigraph returns both forms), then this call with the same rows as the reference holds them (ascending,
+ * repeats kept; row k of the loaded rows occupies row_nbrs[row_offsets[k] .. row_offsets[k+1])).  The library checks on the
+ * device that the two forms belong together.  Afterwards gnnpe_vde sums over the rows given here, and with the whole graph
+ * loaded the degree columns of the auxiliary index and the online filter are these rows' lengths (a slab-only context passes
+ * them through gnnpe_set_degrees).  Reset by the next gnnpe_load_csr / gnnpe_load_rows.  GNN-PGE's groups and the refinement
+ * refuse a context in this state.  Self entries are refused here as everywhere: for `e u u` the reference's loader writes one
+ * slot twice and leaves the next one uninitialised (graph.cpp:211-218) -- it has no defined result to match. */
+int gnnpe_set_multigraph_rows(gnnpe_ctx *ctx, uint32_t n_rows, const uint64_t *host_row_offsets, const uint32_t *host_row_nbrs);
+
 /* R1: processing order and partition of every vertex, as main.cpp:77-85 reads them from
  * membership.txt (line i = "<sorted_nodes[i]> <membership[sorted_nodes[i]]>").  p = partition_num. */
 int gnnpe_set_order(gnnpe_ctx *ctx, const uint32_t *host_sorted_nodes, const uint32_t *host_membership,
@@ -107,6 +120,11 @@ int gnnpe_host_label_table(uint32_t n_labels, uint32_t e, double *out);
  * Returns 0, -1 (cannot open: the reference exits with -1) or -2 (malformed; gnnpe_last_error). */
 int gnnpe_host_load_graph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs,
                           uint32_t **labels, uint32_t meta[3]);
+/* The same loader without the refusal of duplicate `e` lines (gnnpe_host_load_graph answers -2 for them; both answer -2 for a
+ * self-loop): offsets / nbrs are the rows as graph.cpp:211-233 leaves them; for a file with repeated lines simple_offsets /
+ * simple_nbrs receive the de-duplicated rows (see gnnpe_set_multigraph_rows), else NULL. */
+int gnnpe_host_load_multigraph(const char *path, uint32_t *n, uint32_t *m, uint32_t **offsets, uint32_t **nbrs,
+                               uint32_t **labels, uint32_t meta[3], uint32_t **simple_offsets, uint32_t **simple_nbrs);
 /* membership.txt (main.cpp:77-85): sorted_nodes[n], membership[n] caller-allocated; p = partition_num. */
 int gnnpe_host_read_membership(const char *path, uint32_t n, uint32_t p, uint32_t *sorted_nodes, uint32_t *membership);
 void gnnpe_host_free(void *ptr);

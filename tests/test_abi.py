@@ -73,3 +73,30 @@ def test_index_file_bytes_uses_each_builders_own_fan_out():
     assert lib.gnnpe_index_file_bytes(33_600_000, 3, 0) >= 1 << 31 > blocks(33_600_000, 77) * 4096
     # D = 6 on the multi-GPU path: 38 per node is 2.6 % more blocks than 39
     assert lib.gnnpe_index_file_bytes(19_993_708, 6, 1) > lib.gnnpe_index_file_bytes(19_993_708, 6, 0) > 1 << 31
+
+
+def test_index_file_bytes_answers_zero_for_a_dimension_no_node_holds():
+    """from D = 85 on a 4096-byte block holds fewer than three entries ((4096 - 5) / (16 D + 4), rtnode.cpp:27-28); the
+    function used to loop for ever there (a fan-out of 1 never reaches a single root).  It needs no GPU and no context."""
+    lib = binding.load()
+    for D in (85, 96, 128, 254, 255, 1000, 0):
+        for builder in (0, 1):
+            assert lib.gnnpe_index_file_bytes(1_000_000, D, builder) == 0, (D, builder)
+    # capacity 3 (D = 64 .. 84): both builders fill two entries per node
+    for builder in (0, 1):
+        assert lib.gnnpe_index_file_bytes(8, 84, builder) == (4 + 2 + 1 + 1) * 4096
+
+
+def test_cli_refuses_index_for_a_width_no_node_holds(tmp_path):
+    """gnnpe_main --index -e 32 (D = 96) dies with a message before touching the GPU or writing anything."""
+    import subprocess
+    from conftest import GOLDEN
+    from gnnpe_amd import synth
+    import numpy as np
+    cli = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
+    tmp = str(tmp_path)
+    synth.make_dataset_dir(tmp, 1)
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    r = subprocess.run([cli, "-f", tmp + "/", "-d", graph, "-m", "offline", "-p", "1", "-e", "32", "--index"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "node capacity below 3" in r.stderr, r.stderr

@@ -363,3 +363,27 @@ def test_injected_rank_fault_ends_every_rank(tmp_path, case):
     # and without the fault the same command succeeds
     r = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1000:]
+
+
+def test_index_context_failure_falls_back_to_the_main_context(tmp_path, oracle):
+    """`--index` builds index.dat through a second context beside the text path; when that context cannot be had
+    (out of memory beside the main context's buffers -- injected here) the run must not die after all text is written: it builds
+    the files on the main context and says so.  Same files either way."""
+    graph = os.path.join(GOLDEN, "test_graph", "data_graph.graph")
+    imgs = {}
+    for mode in ("plain", "fault"):
+        tmp = str(tmp_path / mode)
+        os.makedirs(tmp)
+        _test_graph_dataset(tmp, 2, lambda n: (np.arange(n) % 2).astype(np.uint32))
+        env = dict(os.environ)
+        if mode == "fault":
+            env["GNNPE_FAULT_RANK"] = "index:create"
+        r = subprocess.run([CLI, "-f", tmp + "/", "-d", graph, "-m", "offline", "-p", "2", "--index"], capture_output=True, text=True,
+                           env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("building index.dat on the main context" in r.stderr) == (mode == "fault"), r.stderr
+        imgs[mode] = [open(os.path.join(tmp, "gnn-pe", "partitions", f"partition-{i}", "index.dat"), "rb").read() for i in range(2)]
+    for i in range(2):
+        a, b = oracle.index_validate(imgs["plain"][i]), oracle.index_validate(imgs["fault"][i])
+        assert a["num_data"] == b["num_data"] > 100000 and a["n_blocks"] == b["n_blocks"]
+        assert np.array_equal(np.sort(a["leaf_son"]), np.sort(b["leaf_son"]))
