@@ -59,7 +59,8 @@ void check(int rc, const char *what)
     if (rc != 0) die(std::string(what) + ": " + gnnpe_last_error());
 }
 // Test hook (tests/test_gpu_cli.py): GNNPE_FAULT_RANK=<rank>:<stage> makes that rank fail at the named stage ("init" =
-// between the two barriers of the communicator set-up, "halo" = before the halo exchange, "emit" = before the emission),
+// between the two barriers of the communicator set-up, "halo" = before the halo exchange, "emit" = before the emission,
+// "index" = before the partitions' tuples are gathered for --index),
 // so that the failure path of an N > 1 run -- the peers' release from barriers and RCCL, the exit code -- is exercised.
 void fault_point(int r, const char *stage)
 {
@@ -691,6 +692,7 @@ void rank_main(int r, Shared &S)
         S.part_total = part_tot;
     }
     tp.barrier();
+    fault_point(r, "emit");
 
     // ---- emit + render + pwrite at this rank's offsets, all ranks concurrently ----
     std::vector<DevMem *> keep(p, nullptr);  // --index: this rank's tuples of every partition, in path-id order
@@ -730,6 +732,7 @@ void rank_main(int r, Shared &S)
 
     // ---- index.dat of partition pid: built by rank pid mod R from every rank's tuples (one all-to-all-v each) ----
     if (o.write_index) {
+        fault_point(r, "index");  // (the peers are then inside the first partition's gather or its send / recv group)
         for (uint32_t pid = 0; pid < p; pid++) {
             const int owner = (int)(pid % (uint32_t)R);
             const std::vector<uint64_t> cnts = tp.gather_word(r, my_part_cnt[pid]);
@@ -829,11 +832,11 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
         while (done.returned < R) {
             if (!deadline_set && tp.failed()) {
                 deadline_set = true;
-                deadline = Clock::now() + std::chrono::seconds(20);
+                deadline = Clock::now() + std::chrono::seconds(10);
             }
             if (deadline_set) {
                 if (done.cv.wait_until(lk, deadline) == std::cv_status::timeout && done.returned < R) {
-                    fprintf(stderr, "%s: %s (%d of %d ranks did not return within 20 s of the failure: still inside a collective)\n", o.tool,
+                    fprintf(stderr, "%s: %s (%d of %d ranks did not return within 10 s of the failure: still inside a collective)\n", o.tool,
                             tp.first_error().c_str(), R - done.returned, R);
                     fflush(stderr);
                     _exit(1);

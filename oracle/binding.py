@@ -72,6 +72,10 @@ class Oracle:
             fn.restype = C.c_uint64
             fn.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _u32p, C.c_uint64]
         L.orc_count_per_start.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _u64p]
+        L.orc_count_per_start_l3.restype = C.c_int
+        L.orc_count_per_start_l3.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u64p]
+        L.orc_enumerate_starts.restype = C.c_uint64
+        L.orc_enumerate_starts.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u64p, _u32p]
         L.orc_gen_vde_x.argtypes = [C.c_uint32, C.c_uint32, _f64p]
         L.orc_gen_vde.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _f64p, _f64p, _f64p]
         L.orc_gen_pde.argtypes = [C.c_uint64, C.c_uint32, _u32p, C.c_uint32, _u32p, _u32p, _f64p, _f64p,
@@ -204,6 +208,31 @@ class Oracle:
         c = np.zeros(n, np.uint64)
         self.L.orc_count_per_start(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), L, _p(c, _u64p))
         return c
+
+    def count_per_start_l3(self, offs, nbrs, sorted_nodes):
+        """count_per_start(L = 4) at sizes the DFS cannot walk (sorted-row merges, all cores); counts by processing position."""
+        n = len(offs) - 1
+        offs, nbrs = np.ascontiguousarray(offs, np.uint32), np.ascontiguousarray(nbrs, np.uint32)
+        sn = np.ascontiguousarray(sorted_nodes, np.uint32)
+        c = np.zeros(n, np.uint64)
+        if self.L.orc_count_per_start_l3(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), _p(c, _u64p)) != 0:
+            raise MemoryError("orc_count_per_start_l3")
+        return c
+
+    def enumerate_starts(self, offs, nbrs, sorted_nodes, L, first, counts):
+        """The closed-form DFS for the start vertices at processing positions first .. first + len(counts) - 1, whose row counts
+        are `counts`: rows in emission order (P x L uint32)."""
+        n = len(offs) - 1
+        offs, nbrs = np.ascontiguousarray(offs, np.uint32), np.ascontiguousarray(nbrs, np.uint32)
+        sn = np.ascontiguousarray(sorted_nodes, np.uint32)
+        so = np.zeros(len(counts) + 1, np.uint64)
+        np.cumsum(np.asarray(counts, np.uint64), out=so[1:])
+        out = np.zeros((int(so[-1]), L), np.uint32)
+        got = self.L.orc_enumerate_starts(n, _p(offs, _u32p), _p(nbrs, _u32p), _p(sn, _u32p), L, int(first), len(counts), _p(so, _u64p),
+                                          _p(out, _u32p))
+        if got != int(so[-1]):
+            raise ValueError("a start vertex has a different number of paths than its count")
+        return out
 
     # R3 custom.h:492-511
     def gen_vde_x(self, label, e):

@@ -285,6 +285,136 @@ void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *ne
 }
 
 /* ------------------------------------------------------------------------------------------
+ * 4-vertex paths (l = 3; the rule of custom.h:66-92 with the depth fixed, SURVEY D4: the reference itself cannot run it, so
+ * everything about l = 3 is "parity unpinned") at sizes the plain DFS above cannot walk: config 5 has 4.2e13 paths.
+ *
+ * orc_count_per_start_l3: the DFS's per-start counts without the DFS.  A path (s, b, c, d) is kept iff it is simple and
+ * rank[d] > rank[s] (cf_rec above).  With g_i(c) = |{d in N(c): rank[d] > i}| and i = rank[s]:
+ *     count(s) = sum_{b in N(s)} sum_{c in N(b), c != s} ( g_i(c) - [rank[b] > i] )
+ * (d != s follows from the ranks, d != b is the bracket: b is always a neighbour of c; c != b and d != c hold in a simple graph).
+ * g_i(c) is a search in c's rank-sorted row; one pass per (b, c) serves all of b's start vertices at once (their ranks are b's
+ * own sorted row): a merge of the two sorted rows, or a binary search per start where c's row is much the longer.  OpenMP over b;
+ * ~3e11 sequential steps at config 5.  Pinned against cf_rec on small graphs (tests/test_oracle_deep.py).
+ *
+ * orc_enumerate_starts: cf_rec for the start vertices at processing positions [first, first + count) only, each start's rows
+ * written at its own offset (start_off[k] = rows of the listed starts before it), OpenMP over the starts.
+ * ------------------------------------------------------------------------------------------ */
+static int cmp_u32_asc(const void *a, const void *b)
+{
+    const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* entries of the ascending row [lo, hi) that are > t */
+static inline uint32_t row_gt(const uint32_t *row, uint32_t len, uint32_t t)
+{
+    uint32_t a = 0, b = len; /* first index with row[idx] > t */
+    while (a < b) {
+        const uint32_t m = a + (b - a) / 2;
+        if (row[m] > t) b = m; else a = m + 1;
+    }
+    return len - a;
+}
+
+int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, const uint32_t *sorted_nodes,
+                           uint64_t *counts)
+{
+    const uint64_t m2 = offsets[n];
+    uint32_t *rank = make_rank(n, sorted_nodes);
+    uint32_t *srank = (uint32_t *)malloc((m2 + 1) * sizeof(uint32_t));
+    if (!rank || !srank) {
+        free(rank);
+        free(srank);
+        return -1;
+    }
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (uint32_t v = 0; v < n; v++) {
+        for (uint32_t q = offsets[v]; q < offsets[v + 1]; q++) srank[q] = rank[neighbors[q]];
+        qsort(srank + offsets[v], offsets[v + 1] - offsets[v], sizeof(uint32_t), cmp_u32_asc);
+    }
+    memset(counts, 0, (size_t)n * sizeof(uint64_t));
+    int failed = 0;
+#pragma omp parallel
+    {
+        uint64_t *H = NULL;
+        uint32_t hcap = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t k = offsets[b + 1] - offsets[b];
+            if (k < 2 || failed) continue;
+            if (k > hcap) {
+                free(H);
+                hcap = k * 2;
+                H = (uint64_t *)malloc((size_t)hcap * 2 * sizeof(uint64_t));
+                if (!H) {
+                    failed = 1;
+                    hcap = 0;
+                    continue;
+                }
+            }
+            uint64_t *own = H + hcap; /* own[j] = g of the start vertex itself at its own threshold */
+            const uint32_t *T = srank + offsets[b]; /* thresholds: the ranks of b's neighbours, ascending */
+            for (uint32_t j = 0; j < k; j++) H[j] = 0;
+            for (uint32_t q = offsets[b]; q < offsets[b + 1]; q++) {
+                const uint32_t c = neighbors[q], dc = offsets[c + 1] - offsets[c];
+                const uint32_t *R = srank + offsets[c];
+                /* position of c among b's start vertices */
+                uint32_t a = 0, z = k;
+                const uint32_t rc = rank[c];
+                while (a < z) {
+                    const uint32_t m = a + (z - a) / 2;
+                    if (T[m] < rc) a = m + 1; else z = m;
+                }
+                const uint32_t jc = a;
+                if ((uint64_t)k * 8 < dc) { /* few thresholds, long row: search each */
+                    for (uint32_t j = 0; j < k; j++) {
+                        const uint32_t g = row_gt(R, dc, T[j]);
+                        H[j] += g;
+                        if (j == jc) own[j] = g;
+                    }
+                } else { /* merge: both ascend */
+                    uint32_t ptr = 0;
+                    for (uint32_t j = 0; j < k; j++) {
+                        while (ptr < dc && R[ptr] <= T[j]) ptr++;
+                        H[j] += dc - ptr;
+                        if (j == jc) own[j] = dc - ptr;
+                    }
+                }
+            }
+            const uint32_t rb = rank[b];
+            for (uint32_t j = 0; j < k; j++) {
+                const uint64_t later = rb > T[j] ? (uint64_t)(k - 1) : 0u;
+                const uint64_t add = H[j] - own[j] - later;
+#pragma omp atomic
+                counts[T[j]] += add;
+            }
+        }
+        free(H);
+    }
+    free(rank);
+    free(srank);
+    return failed ? -1 : 0;
+}
+
+uint64_t orc_enumerate_starts(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, const uint32_t *sorted_nodes,
+                              uint32_t L, uint32_t first, uint32_t count, const uint64_t *start_off, uint32_t *paths)
+{
+    uint32_t *rank = make_rank(n, sorted_nodes);
+    uint64_t total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (uint32_t k = 0; k < count; k++) {
+        const uint64_t room = start_off[k + 1] - start_off[k];
+        cf_state st = {L, offsets, neighbors, rank, paths ? paths + start_off[k] * L : NULL, 0, room};
+        uint32_t path[16];
+        path[0] = sorted_nodes[first + k];
+        cf_rec(&st, path[0], 1, path);
+        total += st.P == room ? st.P : ((uint64_t)1 << 62); /* a start whose rows are not the count it was given */
+    }
+    free(rank);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------
  * R3  gen_vde_x   custom.h:492-511
  *   std::mt19937(seed = label) (:495); e draws of uniform_real_distribution<double>(0,1) (:496-502);
  *   std::accumulate from 0.0 (:504); divide (:505-508).

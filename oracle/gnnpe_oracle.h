@@ -52,6 +52,15 @@ uint64_t orc_enumerate_closed(uint32_t n, const uint32_t *offsets, const uint32_
 void orc_count_per_start(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors,
                          const uint32_t *sorted_nodes, uint32_t L, uint64_t *counts);
 
+/* l = 3 at config-5 size (parity unpinned): the per-start counts of orc_count_per_start(L = 4) without walking the
+ * paths (sorted-row merges, OpenMP), and the closed-form DFS for the start vertices at positions [first, first + count) only,
+ * start k's rows at paths + start_off[k] * L (start_off: count + 1 entries; returns the rows written, or >= 2^62 if a start's
+ * rows are not the number it was given room for).  0 / -1 (out of memory). */
+int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, const uint32_t *sorted_nodes,
+                           uint64_t *counts);
+uint64_t orc_enumerate_starts(uint32_t n, const uint32_t *offsets, const uint32_t *neighbors, const uint32_t *sorted_nodes,
+                              uint32_t L, uint32_t first, uint32_t count, const uint64_t *start_off, uint32_t *paths);
+
 /* ---- online filter, leaf test of Partition::query (custom.h:404-431) over every data path ---- */
 void orc_filter_candidates(uint64_t P, uint32_t L, const uint32_t *paths, uint32_t n, const uint32_t *offsets,
                            const uint32_t *labels, const double *vde, uint32_t e, uint32_t n_qp,

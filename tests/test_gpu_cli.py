@@ -343,7 +343,7 @@ def test_rank_thread_error_is_a_clean_exit(tmp_path):
 def test_injected_rank_fault_ends_every_rank(tmp_path, case):
     """the failure path of `--gpus N` with a fault injected into ONE rank (GNNPE_FAULT_RANK=<rank>:<stage>) while its
     peers sit in barriers / exchanges: the process ends with exit code 1 and that rank's message, well inside the join
-    deadline (a peer stuck in a collective for good is ended by the main thread after 20 s)."""
+    deadline (a peer stuck in a collective for good is ended by the main thread after 10 s)."""
     gpus, transport, fault = case
     g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
     sn = synth.degree_order(g["offsets"])
