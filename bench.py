@@ -664,7 +664,19 @@ def main():
                     step_frac=(global_total * bpp / (ms_per_step / 1e3) / 1e9) / (HBM_PEAK_GBS * world),
                     step_frac_note="the same algorithmic bytes over the whole step (vde + count + scan + fill), per GPU")
 
+    # which kind of allocation the output buffer is: by what the default shape (start-vertex waves, five
+    # workgroups per CU) reaches into it, as a fraction of 8 TB/s -- thresholds from profiles/r05_emit_ab.txt section 7: fast >= 0.80
+    # (2.73-2.83 ms at config 3), between 0.74-0.80 (2.92-3.03), slow below; a slow buffer that takes three workgroups per CU faster
+    # than five is `slow3`, the other kind `slow5`.  Top level so that BENCH records of different boxes compare like with like.
+    emit_class, calibration_ms = None, None
+    if shapes is not None:
+        f5 = peak_bytes / (shapes["starts_ms"] / 1e3) / HBM_PEAK_GBS
+        emit_class = "fast" if f5 >= 0.80 else "between" if f5 >= 0.74 else ("slow3" if shapes["starts_low_ms"] < shapes["starts_ms"] else "slow5")
+        calibration_ms = dict(starts_5_per_cu=round(shapes["starts_ms"], 3), starts_3_per_cu=round(shapes["starts_low_ms"], 3),
+                              tiles=round(shapes["tiles_ms"], 3), kept=shapes["kept"])
+
     out = dict(metric="offline paths-embedded/sec + index-build wallclock, 1M-V/10M-E l=2",
+               emit_class=emit_class, calibration_ms=calibration_ms,
                value_is="paths-embedded/sec of one device-resident pass (vde [+ all-gather] + count + scan + fill)",
                value=value, unit="paths/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_per_step, higher_is_better=True, scaling="strong", vs_baseline=None,

@@ -625,13 +625,14 @@ class Engine:
     def set_emit_shape(self, shape):
         """0 = whatever gnnpe_emit_calibrate_device measured faster into the buffer (start-vertex waves where nothing was measured),
         1 = one wave per start vertex (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles), 3 = persistent waves taking
-        tiles from ticket counters (k_fill_tickets; e <= 2, else the tile kernel), 4 = shape 1 held to three workgroups per CU.
+        tiles from ticket counters (k_fill_tickets: measured, never chosen -- it lives in diagnostic builds, `make DIAG=1`; the
+        shipped library answers with the tile kernel), 4 = shape 1 held to three workgroups per CU.
         Graphs with hub rows always take the start-vertex kernel."""
         self._ck(self.lib.gnnpe_set_emit_shape(self.ctx, int(shape)))
 
-    EMIT_SHAPES = (1, 2, 3, 4)
+    EMIT_SHAPES = (1, 2, 4)
     EMIT_SHAPE_NAMES = {1: "starts", 2: "tiles", 3: "tickets", 4: "starts_low"}
-    EMIT_SHAPE_KERNELS = {1: "k_fill_ranked", 2: "k_fill_tiles", 3: "k_fill_tickets", 4: "k_fill_ranked"}
+    EMIT_SHAPE_KERNELS = {1: "k_fill_ranked", 2: "k_fill_tiles", 3: "k_fill_tiles", 4: "k_fill_ranked"}
 
     def has_emit_shape(self, shape):
         return int(shape) in self.EMIT_SHAPES

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -89,6 +90,33 @@ inline int grid_for(uint64_t items, int per_block = kBlock)
 struct gnnpe_pool;
 struct gnnpe_ctx;
 namespace gnnpe {
+// The environment switches of the shipped library, read ONCE per context (gnnpe_create) and never on a launch path:
+//   GNNPE_EMIT=starts|starts_low|tiles   the emit shape, whatever was set or calibrated (gnnpe_set_emit_shape's 1 / 4 / 2)
+//   GNNPE_DEEP_COUNT=merge               l = 3: the pointer-walk count kernel instead of the histogram one
+//   GNNPE_DEEP_EMIT=slices|units         l = 3: force one of the two emit forms
+//   GNNPE_AUX_WIDE=1                     8-byte {degree, label} words behind the aux records even where they fit the id bits
+//   GNNPE_DEBUG=1                        launch shapes / pool candidates on stderr
+//   GNNPE_TESTING=k=v,...                testing aids: pool_min_probe_bytes (below it the pool takes what comes: 512 MiB),
+//                                        index_keep_bytes (cap on the device copies gnnpe_build_index_files keeps per wave)
+// Everything else that rounds 2-5 switched by environment for A/B runs exists in diagnostic builds only (make DIAG=1:
+// gnnpe::diag_int below): the static start-vertex walk, staged rows, LDS pads, the ticket / strip-job emit kernels, tile heights,
+// rows per wave of the count kernel, the leaf kernel's XCD chunks, candidate draws of the image buffer, knock-outs, stamps.
+struct Switches {
+    int emit = 0;  // 0 none, else the emit shape to force
+    bool deep_merge = false, aux_wide = false, debug = false;
+    int deep_emit = 0;  // 1 slices, 2 units
+    uint64_t pool_min_probe_bytes = 512ull << 20, index_keep_bytes = ~0ull;
+};
+Switches read_switches();  // gnnpe_engine.hip
+#ifdef GNNPE_DIAG
+inline long diag_int(const char *name, long dflt)
+{
+    const char *ev = getenv(name);
+    return ev ? atol(ev) : dflt;
+}
+#else
+constexpr long diag_int(const char *, long dflt) { return dflt; }
+#endif
 void pool_free(gnnpe_pool *p);  // gnnpe_pool.hip: releases a pool's memory (the context is still alive)
 // gnnpe_pool.hip: the fastest of `candidates` allocations of `bytes` under a streaming write
 int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void **out);
@@ -96,6 +124,7 @@ int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void *
 
 struct gnnpe_ctx {
     int device = 0;
+    gnnpe::Switches sw;  // the environment as gnnpe_create found it
     std::vector<gnnpe_pool *> pools;  // output pools created on this context and not yet destroyed: freed with it
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
@@ -176,7 +205,16 @@ struct gnnpe_ctx {
     uint32_t tile_rows = 0;  // rows per tile the table was built for
     uint64_t tile_gen = 0, tile_cap = 0;  // count the table belongs to; tiles it covers (+ 1 sentinel entry)
     // emit shape measured per output buffer (gnnpe_emit_calibrate_device): {buffer, faster shape}; consulted when emit_shape is 0
-    std::vector<std::pair<const void *, int>> emit_prefs;
+    // ... with the count it was measured for (paths, pairs, width) and the three times, so that a second request for the same
+    // buffer and the same count is answered without the nine launches
+    struct EmitPref {
+        const void *key;
+        int shape;
+        uint64_t total, n_edges;
+        uint32_t e;
+        float ms[5];
+    };
+    std::vector<EmitPref> emit_prefs;
     const char *last_emit_kernel = "";
     int last_emit_per_cu = 0;  // workgroups per CU the last k_fill_ranked launch was held to (0: no cap)
     // 0 = as gnnpe_emit_calibrate_device measured for the fill's buffer (start-vertex waves where nothing was measured), 1 = start-vertex

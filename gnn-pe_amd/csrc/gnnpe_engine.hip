@@ -18,7 +18,9 @@
 #include "gnnpe_fill_pairwave.hip.h"
 #include "gnnpe_fill_ranked.hip.h"
 #include "gnnpe_fill_tiles.hip.h"
-#include "gnnpe_fill_tickets.hip.h"
+#ifdef GNNPE_DIAG
+#include "gnnpe_fill_tickets.hip.h"  // emit shape 3: measured, never chosen -- diagnostic builds only
+#endif
 #include "gnnpe_fill_deep.hip.h"
 
 namespace gnnpe {
@@ -154,12 +156,38 @@ template <class K> static OccPlan occupancy_plan(K kernel_fn, int want, int devi
 
 }  // namespace gnnpe
 
+gnnpe::Switches gnnpe::read_switches()
+{
+    Switches w;
+    if (const char *ev = getenv("GNNPE_EMIT"))
+        w.emit = !strcmp(ev, "tickets") ? 3 : !strcmp(ev, "tiles") ? 2 : !strcmp(ev, "starts") ? 1 : !strcmp(ev, "starts_low") ? 4 : 0;
+    if (const char *ev = getenv("GNNPE_DEEP_COUNT")) w.deep_merge = !strcmp(ev, "merge");
+    if (const char *ev = getenv("GNNPE_DEEP_EMIT")) w.deep_emit = !strcmp(ev, "slices") ? 1 : !strcmp(ev, "units") ? 2 : 0;
+    if (const char *ev = getenv("GNNPE_AUX_WIDE")) w.aux_wide = atoi(ev) != 0;
+    if (const char *ev = getenv("GNNPE_DEBUG")) w.debug = atoi(ev) != 0;
+    if (const char *ev = getenv("GNNPE_TESTING")) {  // k=v,k=v
+        const std::string all(ev);
+        size_t at = 0;
+        while (at < all.size()) {
+            const size_t end = std::min(all.find(',', at), all.size()), eq = all.find('=', at);
+            if (eq != std::string::npos && eq < end) {
+                const std::string k = all.substr(at, eq - at);
+                const uint64_t v = strtoull(all.c_str() + eq + 1, nullptr, 10);
+                if (k == "pool_min_probe_bytes") w.pool_min_probe_bytes = v;
+                else if (k == "index_keep_bytes") w.index_keep_bytes = v;
+            }
+            at = end + 1;
+        }
+    }
+    return w;
+}
+
 // a buffer's measured emit shape is forgotten when the buffer goes away (another allocation may get its address)
 void gnnpe_forget_emit_pref(gnnpe_ctx *c, const void *lo, size_t bytes)
 {
     const char *a = static_cast<const char *>(lo);
     for (size_t k = 0; k < c->emit_prefs.size(); k++) {
-        const char *q = static_cast<const char *>(c->emit_prefs[k].first);
+        const char *q = static_cast<const char *>(c->emit_prefs[k].key);
         if (q >= a && q < a + std::max<size_t>(bytes, 1)) c->emit_prefs.erase(c->emit_prefs.begin() + (long)k--);
     }
 }
@@ -192,6 +220,7 @@ gnnpe_ctx *gnnpe_create(int device_id)
     }
     gnnpe_ctx *c = new gnnpe_ctx();
     c->device = device_id;
+    c->sw = read_switches();
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&c->h_pinned, 64 * sizeof(uint64_t))) != hipSuccess) {
         set_error("context setup: %s", hipGetErrorString(e));
@@ -910,10 +939,10 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
         // one row per wave, workgroups in launch order (the kernel's loop is then a single pass): the blocks are written as one
         // dense front; against the resident grid 1.063 -> 1.050 ms for the count phase at config 3 (scripts/count_ab.py)
-        const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 3) / 4, 1u << 30)), block(kBlock);
+        [[maybe_unused]] const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 3) / 4, 1u << 30));
+        const dim3 block(kBlock);
         // rows per wave: 1 (one wave per row) or 4 with the rows' loads batched (GNNPE_ROWS_ILP=1|4 overrides; default below)
-        int rows_ilp = 4;
-        if (const char *ev = getenv("GNNPE_ROWS_ILP")) rows_ilp = atoi(ev);
+        int rows_ilp = (int)diag_int("GNNPE_ROWS_ILP", 4);  // (diagnostic builds: 1 | 2 | 8 for the A/B of DESIGN 3.2)
         if (rows_ilp != 1 && rows_ilp != 2 && rows_ilp != 8) rows_ilp = 4;
         const dim3 gridk((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 4 * rows_ilp - 1) / (4 * rows_ilp), 1u << 30));
 #define GNNPE_RRM(EE, PK, KK)                                                                                       \
@@ -921,6 +950,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
                        c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),              \
                        c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),                   \
                        c->rrecs.as<char>(), c->rpairs.as<RankedPair>())
+#ifdef GNNPE_DIAG
 #define GNNPE_RRK(EE, PK)                                                                                           \
     do {                                                                                                            \
         if (rows_ilp == 8) GNNPE_RRM(EE, PK, 8);                                                                    \
@@ -932,6 +962,9 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
                                c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),           \
                                c->rrecs.as<char>(), c->rpairs.as<RankedPair>());                                    \
     } while (0)
+#else
+#define GNNPE_RRK(EE, PK) GNNPE_RRM(EE, PK, 4)
+#endif
 #define GNNPE_RR(EE)                                                                                               \
     do {                                                                                                           \
         hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
@@ -946,8 +979,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         // diagnostic launches beside the real one (GNNPE_ROWS_PROBE, scripts/count_ab.py): pieces of the kernel on their own,
         // into scratch copies of its outputs; whole graph on one device, e = 2, packed ids only
 #ifdef GNNPE_DIAG
-        if (const char *ev = getenv("GNNPE_ROWS_PROBE")) {
-            const int mode = atoi(ev);
+        if (const int mode = (int)diag_int("GNNPE_ROWS_PROBE", 0)) {
             if (mode >= 1 && mode <= 3 && c->rows_identity && e == 2 && packed && c->slab_begin == 0 && c->slab_end == c->n) {
                 DevBuf probe_recs, probe_pairs;  // freed on return (a diagnostic path may allocate)
                 if ((rc = probe_recs.reserve((c->rblock_units + 1) * kRowAlign)) || (rc = probe_pairs.reserve((ne + 1) * sizeof(RankedPair)))) return rc;
@@ -1163,8 +1195,7 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
                                c->rb_cnt.as<uint32_t>());
             if ((rc = scan_u32(c, c->rb_cnt.as<uint32_t>(), c->rb_first.as<uint32_t>(), (uint64_t)c->n + 1))) return rc;
             // the entry-major count (k_deep3_count_hist) unless GNNPE_DEEP_COUNT=merge asks for the pointer walk (tests run both)
-            const char *cmode = getenv("GNNPE_DEEP_COUNT");
-            if (cmode && !strcmp(cmode, "merge")) {
+            if (c->sw.deep_merge) {
                 hipLaunchKernelGGL(k_deep3_count_rows, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, P, c->n, len,
                                    c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->rank.as<uint32_t>(),
                                    c->rank_sorted.as<uint32_t>(), c->rank_arg.as<uint32_t>(), c->revpos.as<uint32_t>(), c->poffs.as<uint32_t>(),
@@ -1246,8 +1277,8 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
         GNNPE_HIP_TRY(hipMemsetAsync(c->eoff.as<uint64_t>() + ne, 0, 8, c->stream));  // (no start vertices: no paths)
         if (len) {
             unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)blocks_per_cu(k_start_scan) * c->num_cus));
-            if (const char *ev = getenv("GNNPE_START_SCAN_GRID")) grid = (unsigned)std::max(1, std::min<int>((int)n_tiles, atoi(ev)));
-            if (getenv("GNNPE_EMIT_DEBUG")) fprintf(stderr, "[count] k_start_scan: %u tiles, grid %u (%d per CU)\n", n_tiles, grid, blocks_per_cu(k_start_scan));
+            grid = (unsigned)std::max<long>(1, std::min<long>((long)n_tiles, diag_int("GNNPE_START_SCAN_GRID", (long)grid)));
+            if (c->sw.debug) fprintf(stderr, "[count] k_start_scan: %u tiles, grid %u (%d per CU)\n", n_tiles, grid, blocks_per_cu(k_start_scan));
             hipLaunchKernelGGL(k_start_scan, dim3(grid), dim3(kStartTile), 0, c->stream, len, sb, c->sorted.as<uint32_t>(),
                                c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(), c->rpairs.as<RankedPair>(),
                                c->scan_status.as<unsigned long long>(), reinterpret_cast<uint32_t *>(c->scan_status.as<char>() + (size_t)n_tiles * 8 + 32),
@@ -1369,8 +1400,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         const uint64_t u_lo = c->h_pinned[0], u_hi = c->h_pinned[1];
         // slices where hub rows put 10^5 candidates behind one unit; one workgroup per unit (a single kernel) where every
         // unit is a few hundred candidates.  GNNPE_DEEP_EMIT=slices|units overrides (tests run both on the same graphs).
-        const char *mode = getenv("GNNPE_DEEP_EMIT");
-        const bool slices = mode && !strcmp(mode, "slices") ? true : mode && !strcmp(mode, "units") ? false : c->n_hub != 0;
+        const bool slices = c->sw.deep_emit == 1 ? true : c->sw.deep_emit == 2 ? false : c->n_hub != 0;
         if (slices && u_hi > u_lo) {
             // slices (gnnpe_fill_deep.hip.h): units -> slices per unit -> kept rows per slice -> emit, one wave per slice
             GNNPE_REQUIRE(u_hi - u_lo < (1ull << 31), GNNPE_ERR_ARG, "l=3 range covers %llu units; emit in smaller chunks",
@@ -1444,33 +1474,33 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         // static assignment w, w + waves, ... for A/B runs.  Same process, same buffers, fast / slow class, five workgroups
         // per CU: 2.77 / 3.46 ms against 2.88 / 3.68; three per CU into the slow class 3.32 against 3.51.
         uint32_t *rk_heads = nullptr;
-        uint32_t rk_nh = 16;
-        if (const char *ev = getenv("GNNPE_RANKED_TICKETS")) rk_nh = (uint32_t)std::max(0, std::min(64, atoi(ev)));
+        const uint32_t rk_nh = (uint32_t)std::max<long>(0, std::min<long>(64, diag_int("GNNPE_RANKED_TICKETS", 16)));
 #define GNNPE_LK(KERN)                                                                                                  \
     do {                                                                                                                \
         auto kern = KERN;                                                                                               \
         OccPlan plan = occupancy_plan(kern, want_per_cu, c->device);                                                    \
-        if (const char *ev = getenv("GNNPE_FILL_LDS_PAD")) { /* A/B aid: this much dynamic LDS, whatever it admits */    \
-            plan.pad = (size_t)std::max(0, std::min(48 * 1024, atoi(ev)));                                              \
+        if (const long pad_ab = diag_int("GNNPE_FILL_LDS_PAD", -1); pad_ab >= 0) { /* A/B aid: this much dynamic LDS */  \
+            plan.pad = (size_t)std::min<long>(48 * 1024, pad_ab);                                                       \
             plan.per_cu = blocks_per_cu_at(reinterpret_cast<const void *>(kern), plan.pad);                             \
         }                                                                                                               \
         const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)plan.per_cu * c->num_cus;                        \
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, fit))), block(kBlock);                           \
         const uint32_t nh_l = std::min<uint32_t>(rk_nh, grid.x * 4u); /* every head needs a wave that serves it */      \
-        if (getenv("GNNPE_EMIT_DEBUG"))                                                                                 \
+        if (c->sw.debug)                                                                                                \
             fprintf(stderr, "[emit] k_fill_ranked: %d workgroups per CU wanted, %d planned, %zu B of dynamic LDS, grid %u, %u ticket heads\n", \
                     want_per_cu, plan.per_cu, plan.pad, grid.x, nh_l);                                                  \
         if (nh_l) {                                                                                                     \
-            if ((rc = c->tk_ctl.reserve(kTicketCtlWords * 4 + 64))) return rc;                                          \
-            GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kTicketHeadWords * 4, c->stream));              \
+            if ((rc = c->tk_ctl.reserve(kStartHeadsBytes + 64))) return rc;                                             \
+            GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kStartHeadWords * 4, c->stream));               \
             rk_heads = c->tk_ctl.as<uint32_t>();                                                                        \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, block, plan.pad, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len, rk_heads, nh_l); \
     } while (0)
+#ifdef GNNPE_DIAG
 #define GNNPE_L(EE)                                                                                                     \
     do {                                                                                                                \
-        if (packed && EE <= 2 && getenv("GNNPE_FILL_ROWS")) { /* A/B aid: rows staged per wave between flushes */            \
-            const int rr = atoi(getenv("GNNPE_FILL_ROWS"));                                                             \
+        const long rr = diag_int("GNNPE_FILL_ROWS", 0); /* A/B aid: rows staged per wave between flushes */              \
+        if (packed && EE <= 2 && rr) {                                                                                  \
             if (rr == 256) GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 256>));                                        \
             else if (rr == 64) GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 64>));                                     \
             else GNNPE_LK((k_fill_ranked<EE <= 2 ? EE : 2, true, 128>));                                                  \
@@ -1478,6 +1508,13 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         else if (packed) GNNPE_LK((k_fill_ranked<EE, true, fill_rows(EE)>));                                            \
         else GNNPE_LK((k_fill_ranked<EE, false, fill_rows(EE)>));                                                       \
     } while (0)
+#else
+#define GNNPE_L(EE)                                                                                                     \
+    do {                                                                                                                \
+        if (packed) GNNPE_LK((k_fill_ranked<EE, true, fill_rows(EE)>));                                                 \
+        else GNNPE_LK((k_fill_ranked<EE, false, fill_rows(EE)>));                                                       \
+    } while (0)
+#endif
         // pde_label is gathered from the emitted ids; without an id output of the caller's they go to scratch
         if (d_pdl && !d_vids) {
             if ((rc = c->scratch.reserve((end - begin) * 12 + 16))) return rc;
@@ -1489,16 +1526,21 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         if (shape == 0) {  // by what was measured into this buffer, if anything was
             const void *key = d_pde ? d_pde : d_vids;
             for (const auto &pr : c->emit_prefs)
-                if (pr.first == key) shape = pr.second;
+                if (pr.key == key) shape = pr.shape;
         }
-        if (const char *ev = getenv("GNNPE_EMIT"))
-            shape = !strcmp(ev, "tickets") ? 3 : !strcmp(ev, "tiles") ? 2 : !strcmp(ev, "starts") ? 1 : !strcmp(ev, "starts_low") ? 4 : shape;
+        if (c->sw.emit) shape = c->sw.emit;
         if (shape == 4 && e <= 2) want_per_cu = 3;
-        // the ticket kernel exists for e <= 2 and addresses the record blocks and the vde table with 32-bit offsets; anything
-        // else that asks for it gets the one-shot tile kernel
+        // emit shape 3 (persistent ticket waves, gnnpe_fill_tickets.hip.h) lost in every allocation and lives in
+        // diagnostic builds only; the shipped library answers a request for it with the one-shot tile kernel.  It exists for
+        // e <= 2 and addresses the record blocks and the vde table with 32-bit offsets.
+#ifdef GNNPE_DIAG
         const bool tickets = c->n_hub == 0 && shape == 3 && c->n_edges != 0 && end > begin && e <= 2 &&
                              c->rrecs.bytes < (1ull << 32) && (uint64_t)c->n * e * 8 < (1ull << 32);
+#else
+        const bool tickets = false;
+#endif
         const bool tiles = c->n_hub == 0 && (shape == 2 || (shape == 3 && !tickets)) && c->n_edges != 0;
+#ifdef GNNPE_DIAG
         if (tickets && (P.out_ids || d_pde)) {
             // persistent waves, tiles in ticket order, three tiles in flight per wave (gnnpe_fill_tickets.hip.h); the tiles its
             // pipeline does not take go through a job list to k_fill_tile_jobs in a second launch
@@ -1507,20 +1549,14 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             const uint64_t t_lo = begin / ts, t_hi = (end + ts - 1) / ts;
             GNNPE_REQUIRE(t_hi < (1ull << 32), GNNPE_ERR_ARG, "emit shape 3: more than 2^32 output tiles");
             const uint64_t total_arg = c->total_known ? c->total_paths : ~0ull;
-            uint32_t tpt = 4;
-            if (const char *ev = getenv("GNNPE_TICKET_TILES")) tpt = (uint32_t)std::max(1, std::min(64, atoi(ev)));
-            uint32_t nh = kTicketHeads;
-            if (const char *ev = getenv("GNNPE_TICKET_HEADS")) nh = (uint32_t)std::max(4, std::min<int>(kTicketHeads, atoi(ev) & ~3));
+            const uint32_t tpt = (uint32_t)std::max<long>(1, std::min<long>(64, diag_int("GNNPE_TICKET_TILES", 4)));
+            const uint32_t nh = (uint32_t)std::max<long>(4, std::min<long>(kTicketHeads, diag_int("GNNPE_TICKET_HEADS", kTicketHeads) & ~3L));
             const uint64_t job_cap = (t_hi - t_lo) + c->n_edges / kJobStrip + 8;
             if ((rc = c->tk_ctl.reserve(kTicketCtlWords * 4 + 64)) || (rc = c->tk_jobs.reserve(job_cap * sizeof(uint2)))) return rc;
             GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, kTicketCtlWords * 4 + 64, c->stream));
             uint32_t *ctl = c->tk_ctl.as<uint32_t>();
-            int occ_env = 0;
-            if (const char *ev = getenv("GNNPE_TICKET_OCC")) occ_env = atoi(ev);
-            uint32_t tk_exp = 0;
-#ifdef GNNPE_DIAG
-            if (const char *ev = getenv("GNNPE_TICKET_EXP")) tk_exp = (uint32_t)atoi(ev);  // diagnostic builds only: 1 no stores, 2 no record loads
-#endif
+            const int occ_env = (int)diag_int("GNNPE_TICKET_OCC", 0);
+            const uint32_t tk_exp = (uint32_t)diag_int("GNNPE_TICKET_EXP", 0);  // 1 no stores, 2 no record loads, 16 stamps
 #define GNNPE_LQ(EE, PK, SP, OCC)                                                                                          \
     do {                                                                                                                   \
         auto kern = k_fill_tickets<EE, PK, SP, 4, OCC>;                                                                    \
@@ -1546,7 +1582,6 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             else GNNPE_LQS(2, 32, 5);
 #undef GNNPE_LQS
 #undef GNNPE_LQ
-#ifdef GNNPE_DIAG
             if (tk_exp & 16u) {
                 unsigned long long h[8];
                 GNNPE_HIP_TRY(hipMemcpyAsync(h, ctl + kTicketCtlWords, 64, hipMemcpyDeviceToHost, c->stream));
@@ -1555,12 +1590,12 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                 fprintf(stderr, "[ticket stamps] %llu waves stamped; cycles per tile: wait %.0f  park %.0f  strip+records %.0f  pairs %.0f  ticket %.0f  stores %.0f\n",
                         h[7], h[0] / tiles_w, h[1] / tiles_w, h[2] / tiles_w, h[3] / tiles_w, 0.0, h[4] / tiles_w);
             }
-#endif
             c->last_emit_kernel = "k_fill_tickets";
-        } else if (tiles && (P.out_ids || d_pde)) {
+        } else
+#endif
+        if (tiles && (P.out_ids || d_pde)) {
             // rows per tile in units of 64 (GNNPE_TILE_SHAPE=<units> for A/B runs)
-            int kt = 1;
-            if (const char *ev = getenv("GNNPE_TILE_SHAPE")) kt = atoi(ev) == 2 ? 2 : 1;
+            int kt = diag_int("GNNPE_TILE_SHAPE", 1) == 2 ? 2 : 1;
             if (e > 2) kt = 1;
             const uint32_t ts = 64u * (uint32_t)kt;
             if ((rc = ensure_tile_table(c, end, ts))) return rc;
@@ -1568,11 +1603,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             const uint64_t total_arg = c->total_known ? c->total_paths : ~0ull;
             // GNNPE_TILE_EXP (diagnostic instantiation, e = 2 with packed ids only): bit 0 no stores, bit 1 no record loads,
             // bit 4 in-kernel stamps (cycles per phase of one wave in 64, printed to stderr)
-            uint32_t xf = 0;
-#ifdef GNNPE_DIAG  // diagnostic builds only (make DIAG=1): the knock-outs produce wrong rows by design
-            if (const char *ev = getenv("GNNPE_TILE_EXP")) xf = (uint32_t)atoi(ev);
+            uint32_t xf = (uint32_t)diag_int("GNNPE_TILE_EXP", 0);  // diagnostic builds only: the knock-outs produce wrong rows by design
             if (!(e == 2 && packed)) xf = 0;
-#endif
             const dim3 grid((unsigned)((t_hi - t_lo + 3) / 4)), block(kBlock);
             unsigned long long *d_stamps = nullptr;
             if (xf & 16u) {
@@ -1591,10 +1623,15 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                 if (kt == 2) GNNPE_LTK(2, true, 2, 64, true); else GNNPE_LTK(2, true, 1, 64, true);
             } else
 #endif
+#ifdef GNNPE_DIAG
+            if (kt == 2 && e == 1) GNNPE_LTS(1, 2, 64);
+            else if (kt == 2 && e == 2) GNNPE_LTS(2, 2, 64);
+            else
+#endif
             if (e == 1) {
-                if (kt == 2) GNNPE_LTS(1, 2, 64); else GNNPE_LTS(1, 1, 64);
+                GNNPE_LTS(1, 1, 64);
             } else if (e == 2) {
-                if (kt == 2) GNNPE_LTS(2, 2, 64); else GNNPE_LTS(2, 1, 64);
+                GNNPE_LTS(2, 1, 64);
             } else if (e == 3) {
                 GNNPE_LTS(3, 1, 32);
             } else if (e == 4) {
@@ -1724,6 +1761,13 @@ int gnnpe_emit_calibrate_device(gnnpe_ctx *c, uint64_t rows_cap, void *dev_vids,
     GNNPE_REQUIRE(c->total_paths <= rows_cap, GNNPE_ERR_ARG, "gnnpe_emit_calibrate_device: the buffers hold %llu rows, the count is %llu paths",
                   (unsigned long long)rows_cap, (unsigned long long)c->total_paths);
     const void *key = dev_pde ? dev_pde : dev_vids;
+    const uint32_t e_now = c->have_table ? c->e : 2;
+    for (const auto &pr : c->emit_prefs)  // measured before, for this buffer and this count: the same answer without the launches
+        if (pr.key == key && pr.total == c->total_paths && pr.n_edges == c->n_edges && pr.e == e_now) {
+            for (int k = 0; ms_by_shape && k < 5; k++) ms_by_shape[k] = pr.ms[k];
+            if (shape_kept) *shape_kept = pr.shape;
+            return GNNPE_OK;
+        }
     forget_emit_pref(c, key);
     float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     int kept = 1;
@@ -1756,7 +1800,7 @@ int gnnpe_emit_calibrate_device(gnnpe_ctx *c, uint64_t rows_cap, void *dev_vids,
             if (ms[shapes[k]] > 0.f && ms[shapes[k]] < ms[kept]) kept = shapes[k];
     }
     if (c->emit_prefs.size() >= 16) c->emit_prefs.erase(c->emit_prefs.begin());
-    c->emit_prefs.emplace_back(key, kept);
+    c->emit_prefs.push_back(gnnpe_ctx::EmitPref{key, kept, c->total_paths, c->n_edges, e_now, {ms[0], ms[1], ms[2], ms[3], ms[4]}});
     for (int k = 0; ms_by_shape && k < 5; k++) ms_by_shape[k] = ms[k];
     if (shape_kept) *shape_kept = kept;
     return GNNPE_OK;

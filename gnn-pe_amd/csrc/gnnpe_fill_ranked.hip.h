@@ -409,6 +409,10 @@ struct __attribute__((packed, aligned(4))) IdRow {
     uint32_t s, b, c;
 };
 
+// ticket counters of k_fill_ranked's start vertices: up to 64 heads, each on a 128-byte line of its own
+constexpr uint32_t kStartHeadWords = 32;
+constexpr uint32_t kStartHeadsBytes = 64 * kStartHeadWords * 4;
+
 template <int E, bool PACKED, int kBatch>
 __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParams P, const StartRec *__restrict__ srec,
                                                      const RankedPair *__restrict__ pairs,
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256, (E <= 2 ? 5 : 1)) void k_fill_ranked(FillParam
     const uint32_t head = heads ? w % nh : 0u;
     auto draw = [&]() -> uint32_t {
         uint32_t tk = 0;
-        if (lane == 0) tk = __builtin_amdgcn_atomic_inc32(heads + head * 32u, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
+        if (lane == 0) tk = __builtin_amdgcn_atomic_inc32(heads + head * kStartHeadWords, 0xFFFFFFFFu, __ATOMIC_RELAXED, "agent");
         return tk;
     };
     uint32_t tk = 0;

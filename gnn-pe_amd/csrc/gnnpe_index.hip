@@ -1927,8 +1927,7 @@ static bool fast_dim(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 |
 static int reserve_image(gnnpe_ctx *c, uint64_t need)
 {
     if (need <= c->index_image.bytes) return GNNPE_OK;
-    uint32_t cands = 1;
-    if (const char *ev = getenv("GNNPE_IMAGE_CANDIDATES")) cands = (uint32_t)std::max(1, atoi(ev));
+    const uint32_t cands = (uint32_t)std::max<long>(1, diag_int("GNNPE_IMAGE_CANDIDATES", 1));  // (diagnostic builds)
     if (need < (1ull << 30) || cands < 2) return c->index_image.reserve(need);
     c->index_image.release();
     const uint64_t want = need + need / 8 + 256;
@@ -2118,13 +2117,12 @@ template <int E> static int build_raux(gnnpe_ctx *c)
     const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
     const dim3 grid(grid_for((uint64_t)c->n_held * 64)), block(kBlock);
     // the largest degree and label decide the record form: both inside a record's id bits when they fit (once per count: one
-    // 8-byte copy and a stream synchronisation; GNNPE_AUX_WIDE=1 forces the 8-byte words for A/B runs and tests)
+    // 8-byte copy and a stream synchronisation; GNNPE_AUX_WIDE=1, read when the context is created, forces the 8-byte words: tests run both)
     uint32_t vmax[2] = {0u, 0u};
     GNNPE_HIP_TRY(hipMemcpyAsync(vmax, c->aux_vdl.as<uint64_t>() + c->n, 8, hipMemcpyDeviceToHost, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
     const uint32_t dbits = bits_for(vmax[0]), lbits = bits_for(vmax[1]);
-    const char *force_wide = getenv("GNNPE_AUX_WIDE");
-    c->px_raux_compact = dbits + lbits <= kPackedIdBits && dbits >= 1 && !(force_wide && atoi(force_wide));
+    c->px_raux_compact = dbits + lbits <= kPackedIdBits && dbits >= 1 && !c->sw.aux_wide;
     c->px_raux_dbits = dbits;
     if (c->n_held) {
 #define GNNPE_AXB(PK, CP)                                                                                                  \
@@ -2230,10 +2228,8 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     // without costing a wave of occupancy (eight workgroups of 15 904 + 4 480 bytes fill a CU's 160 KB)
     const uint32_t xrank_lds = (with_aux && (uint64_t)c->n_labels * e <= 448) ? c->n_labels * e : 0u;
     // GNNPE_LEAF_LDS_PAD (A/B aid): this much more dynamic LDS nobody touches = fewer resident workgroups per CU
-    uint32_t leaf_pad = 0;
-    if (const char *ev = getenv("GNNPE_LEAF_LDS_PAD")) leaf_pad = (uint32_t)std::max(0, std::min(40000, atoi(ev)));
-    uint32_t xcd_chunk = 0;
-    if (const char *ev = getenv("GNNPE_LEAF_XCD_CHUNK")) xcd_chunk = (uint32_t)std::max(0, atoi(ev));
+    const uint32_t leaf_pad = (uint32_t)std::max<long>(0, std::min<long>(40000, diag_int("GNNPE_LEAF_LDS_PAD", 0)));
+    const uint32_t xcd_chunk = (uint32_t)std::max<long>(0, diag_int("GNNPE_LEAF_XCD_CHUNK", 0));  // (both: diagnostic builds)
 #define GNNPE_PXL(EE, PK, AX) GNNPE_PXN(EE, PK, AX, 1)
 #define GNNPE_PXN(EE, PK, AX, NN)                                                                                       \
     hipLaunchKernelGGL((k_pack_leaves_pairs<EE, PK, AX, NN>), dim3(g), dim3(64 * kLeafWaves), xrank_lds * 10 + leaf_pad, c->stream, cnt, nl, r0, r1, \
@@ -2483,9 +2479,8 @@ int gnnpe_build_index_files(gnnpe_ctx *c, uint32_t n_parts, const char *const *p
         wave.clear();
         return r;
     };
-    // GNNPE_INDEX_KEEP_BYTES (testing aid): an upper bound on the bytes of kept copies, to exercise the waves on a large device
-    uint64_t keep_cap = ~0ull;
-    if (const char *ev = getenv("GNNPE_INDEX_KEEP_BYTES")) keep_cap = strtoull(ev, nullptr, 10);
+    // GNNPE_TESTING=index_keep_bytes=<n> (testing aid): an upper bound on the bytes of kept copies, to exercise the waves on a large device
+    const uint64_t keep_cap = c->sw.index_keep_bytes;
     auto room_for = [&](uint64_t nbytes) {
         size_t free_b = 0, tot_b = 0;
         if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) return false;

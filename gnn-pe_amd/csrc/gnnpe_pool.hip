@@ -76,7 +76,7 @@ int draw_device_buffer(gnnpe_ctx *c, uint64_t bytes, uint32_t candidates, void *
             }
         }
         ms_of.push_back(best);
-        if (getenv("GNNPE_POOL_DEBUG")) fprintf(stderr, "[draw] %llu bytes, candidate %u at %p: %.3f ms\n", (unsigned long long)bytes, k, q, best);
+        if (c->sw.debug) fprintf(stderr, "[draw] %llu bytes, candidate %u at %p: %.3f ms\n", (unsigned long long)bytes, k, q, best);
     }
     if (cand.empty()) {
         set_error("hipMalloc(%llu) failed", (unsigned long long)bytes);
@@ -122,9 +122,8 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     const uint64_t pde_bytes = (rows_cap * D * 8 + MiB2 - 1) / MiB2 * MiB2, ids_bytes = (rows_cap * L * 4 + MiB2 - 1) / MiB2 * MiB2;
     const uint64_t bytes = pde_bytes + ids_bytes;
     // below half a GiB a buffer's class is not measurable (the probe would be launch latency): take what comes.
-    // (GNNPE_POOL_MIN_PROBE_BYTES: testing aid, lowers that bound so that small test graphs exercise the draw)
-    uint64_t min_probe = 512ull << 20;
-    if (const char *ev = getenv("GNNPE_POOL_MIN_PROBE_BYTES")) min_probe = strtoull(ev, nullptr, 10);
+    // (GNNPE_TESTING=pool_min_probe_bytes=<n>: testing aid, lowers that bound so that small test graphs exercise the draw)
+    const uint64_t min_probe = c->sw.pool_min_probe_bytes;
     uint32_t K = 1;
     if (candidates > 1 && bytes >= min_probe) {
         // every candidate is alive until the choice is made: as many as fit beside a quarter of the free memory
@@ -138,7 +137,7 @@ int gnnpe_output_pool_create(gnnpe_ctx *c, uint64_t rows_cap, uint32_t L, uint32
     int rc = resolve_total(c);
     const bool with_kernel = rc == GNNPE_OK && c->counted && c->l + 1 == L && c->total_paths > 0 &&
                              c->total_paths <= rows_cap && (D == 0 || (c->have_vde && D == L * c->e));
-    const bool debug = getenv("GNNPE_POOL_DEBUG") != nullptr;
+    const bool debug = c->sw.debug;
     // timed on the host around stream synchronisations: the probes are milliseconds long, the launch latency inside the
     // bracket is microseconds and the same for every candidate
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));

@@ -71,6 +71,54 @@ def l2_properties(g, sn, dev, ids, pde, vde_ref, lo, hi):
     return out
 
 
+def oracle_l3_check(eng, g, sn, e, n_labels, total):
+    """l = 3 at full size against a checker that is not the engine.  Parity stays unpinned -- no reference
+    runs l = 3 -- but counts and rows come from the oracle's own code: orc_count_per_start_l3 (pinned to its plain DFS
+    on small graphs, tests/test_oracle_deep.py) and orc_enumerate_starts (that DFS, for chosen start vertices)."""
+    import time
+    from oracle import Oracle
+    orc = Oracle()
+    n, L = g["n"], 4
+    out = {}
+    t0 = time.time()
+    want = orc.count_per_start_l3(g["offsets"], g["nbrs"], sn)
+    out["oracle_count_s"] = round(time.time() - t0, 1)
+    got_total, got = eng.count_paths(3, per_start=True)
+    out["per_start_equal"] = bool(np.array_equal(got, want)) and int(got_total) == total == int(want.sum(dtype=np.uint64))
+    out["starts_with_paths"] = int((want > 0).sum())
+    base = np.zeros(n + 1, np.uint64)
+    np.cumsum(want, out=base[1:])
+    # the embeddings the rows must carry: the oracle's gen_vde with e dimensions (custom.h:513-544)
+    x, nx, vde = orc.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)
+    deg = np.diff(g["offsets"].astype(np.int64))
+    rank = np.empty(n, np.int64)
+    rank[sn] = np.arange(n)
+    hub = int(np.argmax(deg))
+    hub_nb = g["nbrs"][g["offsets"][hub]:g["offsets"][hub + 1]].astype(np.int64)
+    pos = rank[hub_nb]
+    k = int(np.argmin(np.abs(want[pos].astype(np.int64) - (1 << 21))))  # a start next to the hub with about 2^21 paths
+    p_hub = int(pos[k])
+    ranges = [("first", 0, min(total, 1 << 21)),
+              ("through the hub", int(base[p_hub]), int(base[p_hub + 1])),
+              ("last", max(0, total - (1 << 16)), total)]
+    out["hub"] = dict(vertex=hub, degree=int(deg[hub]), start_position=p_hub, start_degree=int(deg[sn[p_hub]]))
+    out["ranges"] = []
+    for name, lo, hi in ranges:
+        t0 = time.time()
+        i0 = int(np.searchsorted(base, np.uint64(lo), side="right")) - 1
+        i1 = int(np.searchsorted(base, np.uint64(hi), side="left"))  # starts i0 .. i1 - 1 cover [lo, hi)
+        rows = orc.enumerate_starts(g["offsets"], g["nbrs"], sn, L, i0, want[i0:i1])
+        a = lo - int(base[i0])
+        rows = rows[a:a + (hi - lo)]
+        pde = vde[rows].reshape(len(rows), L * e)  # gen_pde (custom.h:546-572): the vertices' vde rows side by side
+        ids_g, pde_g, _ = eng.fill_paths(lo, hi, ids=True, pde=True, L=L)
+        out["ranges"].append(dict(name=name, begin=lo, end=hi, starts=i1 - i0, seconds=round(time.time() - t0, 1),
+                                  ids_equal=bool(np.array_equal(ids_g, rows)),
+                                  pde_equal=bool(np.array_equal(pde_g.view(np.uint64), pde.view(np.uint64))),
+                                  beyond_32_bits=bool(lo > (1 << 32))))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", required=True, help=".npz with offsets, nbrs, labels")
@@ -86,6 +134,11 @@ def main():
     ap.add_argument("--force-rccl", type=int, default=0,
                     help="world 1 only: a 1-rank process group over RCCL (backend nccl) and the N > 1 step -- halo plan, "
                          "all-to-all-v, vde all-gather, totals all-gather, enqueue-only count + capped fill")
+    ap.add_argument("--oracle-l3", type=int, default=0,
+                    help="world 1, l=3: every start vertex' path count against the oracle's own count (sorted-row merges, all cores), and "
+                         "three global id ranges -- the first rows, the rows of a start vertex next to the highest-degree hub, the last rows "
+                         "(behind the highest-ranked hub starts) -- against rows the oracle's DFS enumerates for the start vertices that "
+                         "cover them: ids and all (l + 1) e doubles bit for bit")
     ap.add_argument("--oracle", type=int, default=0,
                     help="l=2: compare every emitted id and double with the oracle's all-core pass (needs ~15 GB of host memory per 2e8 paths)")
     args = ap.parse_args()
@@ -199,6 +252,9 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
     res = dict(rank=rank, world=world, backend=backend, total=int(total), base=int(base), global_total=int(sb.global_total),
                slab=[int(bounds[rank]), int(bounds[rank + 1])], halo=dict(sb.stats), owned_entries=int(owned_entries))
 
+    if args.oracle_l3 and args.l == 3 and world == 1:
+        res["oracle_l3"] = oracle_l3_check(eng, g, sn, e, args.labels, int(total))
+
     chunk = 1 << 24
     if args.ranges is not None:  # single rank: checksum the requested global ranges
         sums = []
@@ -242,7 +298,7 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
                 # every emit shape a caller can get, through the enqueue-only step (count without a read-back, capped fill), then
                 # shape 0 after the library's calibration of THESE buffers
                 kernels = {}
-                for shape in (1, 4, 2, 3, 0):
+                for shape in (1, 4, 2, 3, 0):  # (3: the ticket waves of diagnostic builds; the shipped library answers with the tile kernel)
                     eng.set_emit_shape(shape)
                     kept = shape
                     if shape == 0:

@@ -171,10 +171,9 @@ def test_pair_major_partition_images(oracle, e, p):
     eng.close()
 
 
-def test_leaf_kernel_switches_change_no_byte(monkeypatch):
-    """The A/B switches of the leaf kernel (none changes a result): workgroups handed to the XCDs in runs of
-    leaf groups, fewer resident workgroups by an LDS pad -- the image and the auxiliary arrays of a power-law graph (hub units
-    included) are the default build's, byte for byte, and a second default build is the first."""
+def test_index_build_is_deterministic_across_builds_and_counts():
+    """The image and the auxiliary arrays of a power-law graph (hub units included): a second build is the first, byte for byte,
+    and so is the build after a new count (the pair order is sorted again -- to the same order)."""
     from gnnpe_amd import binding
     g = synth.powerlaw_graph(3000, 24000, exponent=2.0, max_degree=300, n_labels=6, seed=12)
     sn = synth.degree_order(g["offsets"])
@@ -188,10 +187,7 @@ def test_leaf_kernel_switches_change_no_byte(monkeypatch):
 
     base = build()
     assert build() == base
-    for k, v in (("GNNPE_LEAF_XCD_CHUNK", "3"), ("GNNPE_LEAF_XCD_CHUNK", "64"), ("GNNPE_LEAF_LDS_PAD", "20000")):
-        monkeypatch.setenv(k, v)
-        assert build() == base, (k, v)
-        monkeypatch.delenv(k)
+    # (the leaf kernel's A/B switches -- XCD chunks, LDS pad -- are knobs of diagnostic builds since round 6)
     eng.count_paths(2)  # a new count: the pair order is sorted again -- to the same order
     assert build() == base
     eng.close()
@@ -308,7 +304,7 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
 
 def test_index_files_in_memory_budgeted_waves(tmp_path, monkeypatch):
     """gnnpe_build_index_files keeps device copies of the images only as far as memory allows: with the kept
-    bytes capped (GNNPE_INDEX_KEEP_BYTES, testing aid) the partitions go out in several waves, or one by one straight from
+    bytes capped (GNNPE_TESTING=index_keep_bytes=<n>, testing aid) the partitions go out in several waves, or one by one straight from
     the build buffer, and every file -- index.dat AND aux_index.bin -- equals the unconstrained run's.  Files appear under
     their names only when complete (no .tmp left behind)."""
     from gnnpe_amd import binding
@@ -316,26 +312,28 @@ def test_index_files_in_memory_budgeted_waves(tmp_path, monkeypatch):
     sn = synth.degree_order(g["offsets"])
     p = 5
     mem = (np.arange(g["n"]) % p).astype(np.uint32)
-    eng = _engine(binding, g, sn, mem, p, 2)
-    eng.vde(want=False)
-    eng.count_paths(2)
     outs = {}
     for name, cap in (("all", None), ("two", str(2 * 28 << 20)), ("none", "1")):
         d = tmp_path / name
         d.mkdir()
         if cap is None:
-            monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+            monkeypatch.delenv("GNNPE_TESTING", raising=False)
         else:
-            monkeypatch.setenv("GNNPE_INDEX_KEEP_BYTES", cap)
+            monkeypatch.setenv("GNNPE_TESTING", "index_keep_bytes=" + cap)
+        eng = _engine(binding, g, sn, mem, p, 2)  # (the environment is read when the context is created)
+        eng.vde(want=False)
+        eng.count_paths(2)
         paths = [str(d / f"index{i}.dat") for i in range(p)]
         aux = [str(d / f"aux{i}.bin") for i in range(p)]
         eng.build_index_files(paths, aux)
         assert sorted(os.listdir(d)) == sorted([f"index{i}.dat" for i in range(p)] + [f"aux{i}.bin" for i in range(p)])
         outs[name] = [open(x, "rb").read() for x in paths + aux]
         assert all(len(b) >= 8192 for b in outs[name][:p])
+        if name != "none":
+            eng.close()
     assert outs["two"] == outs["all"] and outs["none"] == outs["all"]
     # a path that cannot be written leaves nothing behind, not a truncated file
-    monkeypatch.delenv("GNNPE_INDEX_KEEP_BYTES", raising=False)
+    monkeypatch.delenv("GNNPE_TESTING", raising=False)
     bad = [str(tmp_path / "missing_dir" / f"index{i}.dat") for i in range(p)]
     with pytest.raises(binding.GnnpeError):
         eng.build_index_files(bad)

@@ -296,9 +296,9 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
 
     # The bench's own call pattern -- count_paths_enqueue, then fill_paths_capped_device into ONE full-size 12 GB buffer -- with
     # every emit kernel a caller can get: the start-vertex shape at five and at three workgroups per CU (k_fill_ranked, start
-    # vertices from ticket counters), the output-tile shape (k_fill_tiles: the kernel BENCH_r04 timed), the ticket-wave shape
-    # (k_fill_tickets + k_fill_tile_jobs), and shape 0 after the library's calibration (whichever it measured fastest into THIS
-    # buffer).  The oracle's rows live on the device for the comparison (12 GB more).
+    # vertices from ticket counters), the output-tile shape (k_fill_tiles: the kernel BENCH_r04 timed; also what the shipped
+    # library answers a request for shape 3 with -- the ticket waves live in diagnostic builds since round 6), and shape 0 after
+    # the library's calibration (whichever it measured fastest into THIS buffer).  The oracle's rows live on the device for the comparison (12 GB more).
     t0 = time.perf_counter()
     o_ids = torch.from_numpy(oids.view(np.int32)).to(dev)
     o_pde = torch.from_numpy(opde.view(np.int64)).to(dev)
@@ -313,7 +313,7 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
                 return False
         return True
 
-    shapes = [sh for sh in (1, 4, 2, 3) if eng.has_emit_shape(sh)]
+    shapes = [1, 4, 2, 3]
     seen = {}
     for shape in shapes + [0]:
         eng.set_emit_shape(shape)

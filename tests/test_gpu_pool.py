@@ -18,7 +18,7 @@ def binding():
 
 @pytest.mark.parametrize("candidates,with_count", [(1, True), (5, True), (3, False)])
 def test_pool_rows_equal_plain_rows(binding, oracle, candidates, with_count, monkeypatch):
-    monkeypatch.setenv("GNNPE_POOL_MIN_PROBE_BYTES", "0")  # the draw is for multi-GiB outputs; let a small graph exercise it
+    monkeypatch.setenv("GNNPE_TESTING", "pool_min_probe_bytes=0")  # the draw is for multi-GiB outputs; let a small graph exercise it
     g = synth.gnm_graph(20000, 160000, n_labels=16, seed=3)
     sn = synth.degree_order(g["offsets"])
     eng = binding.Engine(0)
@@ -79,7 +79,7 @@ def test_pool_rejects_bad_arguments(binding):
 
 def test_pool_probes_with_the_l3_emission_too(binding, oracle, monkeypatch):
     """4-vertex paths: the pool's probe is whichever emit path the context's count selects (here the l = 3 one)"""
-    monkeypatch.setenv("GNNPE_POOL_MIN_PROBE_BYTES", "0")
+    monkeypatch.setenv("GNNPE_TESTING", "pool_min_probe_bytes=0")
     g = synth.gnm_graph(600, 3000, n_labels=5, seed=8)
     sn = synth.degree_order(g["offsets"])
     eng = binding.Engine(0)

@@ -80,7 +80,7 @@ def _check_l2_slabs(tmp_path, g, world, same_device=True, weights="1,0,0", oracl
         # from the default fill and from every emit shape (start-vertex waves at both occupancies, output tiles, ticket waves, the
         # calibrated choice) through the enqueue-only step
         assert all(r["oracle_exact"] for r in res), [(r["rank"], r.get("emit_kernels")) for r in res if not r["oracle_exact"]]
-        assert all(r["emit_kernels"]["2"] == "k_fill_tiles" and r["emit_kernels"]["3"] == "k_fill_tickets" for r in res)
+        assert all(r["emit_kernels"]["2"] == "k_fill_tiles" and r["emit_kernels"]["3"] == "k_fill_tiles" for r in res)
     want = synth.expected_paths_l2(g["offsets"])
     assert sum(r["total"] for r in res) == want == res[0]["global_total"]
     base = 0
@@ -151,6 +151,19 @@ def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
         assert r["base"] == base
         base += r["total"]
         assert r["checksum"] == want, r["rank"]
+    # a checker that is not the engine, at full size.  Every start vertex' count against the oracle's own
+    # count (OpenMP, all cores), and three global id ranges -- the first 2^21 rows, all rows of a start vertex next to the
+    # highest-degree hub (4 517 neighbours: rows THROUGH the hub row, ids beyond 2^32), the last 2^16 rows (the highest-ranked
+    # hub starts) -- against rows the oracle's DFS enumerates for the covering start vertices: ids and all 32 doubles bit for bit.
+    # (Parity stays unpinned: no reference runs l = 3)
+    out_o = str(tmp_path / "wo")
+    _run(1, ["--graph", gp, "--out", out_o, "-l", "3", "-e", "8", "--ranges", "[]", "--oracle-l3", "1"], timeout=2400)
+    o3 = _results(out_o, 1)[0]["oracle_l3"]
+    assert o3["per_start_equal"] and o3["starts_with_paths"] > 3_000_000, o3
+    assert o3["hub"]["degree"] > 4000 and len(o3["ranges"]) == 3
+    for r in o3["ranges"]:
+        assert r["ids_equal"] and r["pde_equal"] and r["end"] > r["begin"], r
+    assert o3["ranges"][1]["beyond_32_bits"] and o3["ranges"][2]["beyond_32_bits"] and o3["ranges"][2]["end"] == total8
 
 
 # ---- RCCL over xGMI: only where the box shows at least two GPUs (the round's box has one) -------------------------

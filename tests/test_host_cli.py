@@ -98,8 +98,25 @@ def test_input_validation_fails_loudly(tmp_path):
         out.append(l)
     out.append(e)
     open(gp, "w").write("\n".join(out) + "\n")
-    r = _run("-f", root, "-d", gp, "-p", "2")
+    r = _run("-f", root, "-d", gp, "-p", "2", "--strict")  # (without --strict the file loads as the reference loads it: round 6)
     assert r.returncode == 1 and "duplicate edge" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = _run("-f", root, "-d", gp, "-p", "2")
+        assert r.returncode == 1 and "no HIP device" in r.stderr  # past the loader: only the GPU is missing here
+    # a self-loop line is refused in every mode (the reference leaves a slot uninitialised for it: graph.cpp:211-218)
+    out2 = []
+    for l in txt:
+        f = l.split()
+        if f[0] == "t":
+            l = f"t {f[1]} {int(f[2]) + 1}"
+        if f[0] == "v" and f[1] == u:
+            l = f"v {f[1]} {f[2]} {int(f[3]) + 2}"
+        out2.append(l)
+    out2.append(f"e {u} {u}")
+    open(gp, "w").write("\n".join(out2) + "\n")
+    r = _run("-f", root, "-d", gp, "-p", "2")
+    assert r.returncode == 1 and "self-loop at vertex " + u in r.stderr
 
 
 def test_cli_flag_forms(tmp_path):
