@@ -669,7 +669,7 @@ def main():
     # (2.73-2.83 ms at config 3), between 0.74-0.80 (2.92-3.03), slow below; a slow buffer that takes three workgroups per CU faster
     # than five is `slow3`, the other kind `slow5`.  Top level so that BENCH records of different boxes compare like with like.
     emit_class, calibration_ms = None, None
-    if shapes is not None:
+    if shapes is not None and shapes["starts_ms"] > 0:  # (nothing is timed below 2^24 paths or on graphs with hub rows)
         f5 = peak_bytes / (shapes["starts_ms"] / 1e3) / HBM_PEAK_GBS
         emit_class = "fast" if f5 >= 0.80 else "between" if f5 >= 0.74 else ("slow3" if shapes["starts_low_ms"] < shapes["starts_ms"] else "slow5")
         calibration_ms = dict(starts_5_per_cu=round(shapes["starts_ms"], 3), starts_3_per_cu=round(shapes["starts_low_ms"], 3),
