@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnnpe_hip.so")
+# (GNNPE_LIB_PATH: the A/B scripts under scripts/ point it at the diagnostic build, `make -C gnn-pe_amd DIAG=1 diag`)
+LIB_PATH = os.environ.get("GNNPE_LIB_PATH") or os.path.join(_HERE, "libgnnpe_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnpe_hip.h")
 
 _u32p = C.POINTER(C.c_uint32)

@@ -221,6 +221,15 @@ struct gnnpe_ctx {
     // waves, 2 = output tiles, 3 = ticket waves, 4 = start-vertex waves at three workgroups per CU (include/gnnpe_hip.h)
     int emit_shape = 0;
     bool ranked_vde_valid = false;  // the ranked records carry the current vde table
+    // round 6, launches folded into their neighbours: k_vde wrote the count kernel's per-vertex records for the slab structure of
+    // generation vinfo_gen (k_pack_vinfo is skipped while that is current); k_start_scan left the emit kernel's ticket heads zero;
+    // the zero sentinel behind the pair records is in place for this many pairs
+    bool vinfo_fused = false, heads_clean = false;
+    uint64_t slab_struct_gen = 0, vinfo_gen = 0, rpairs_sentinel_at = ~0ull;
+    const void *rpairs_sentinel_buf = nullptr;
+    uint32_t *clear_words = nullptr;  // set by the count around build_ranked: words its row kernel zeroes for k_start_scan
+    uint32_t n_clear = 0;
+    bool clear_done = false;
     gnnpe::DevBuf vkey;             // R6: per-vertex sort-key parts {label, spread quantised vde}
     gnnpe::DevBuf rank_sorted, adj_end;  // l=3 count: every row's neighbour ranks in ascending order
     gnnpe::DevBuf rank_arg, rb_cnt, rb_first;  // ... the entry each sorted rank came from; row-batches (64 third vertices) per row

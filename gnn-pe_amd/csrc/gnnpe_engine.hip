@@ -697,6 +697,9 @@ int gnnpe_host_label_table(uint32_t n_labels, uint32_t e, double *out)
     return GNNPE_OK;
 }
 
+enum { kVarPairWave = 1, kVarRanked = 4, kVarDeep = 5 };
+static bool fast_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
+
 // ---- R4 ---------------------------------------------------------------------------------------
 static int run_vde(gnnpe_ctx *c)
 {
@@ -730,10 +733,23 @@ static int run_vde(gnnpe_ctx *c)
         GNNPE_HIP_TRY(hipMemsetAsync(c->nx.p, 0, bytes, c->stream));
         GNNPE_HIP_TRY(hipMemsetAsync(c->vde.p, 0, bytes, c->stream));
     }
-    hipLaunchKernelGGL(k_x_from_labels, dim3(grid_for((uint64_t)n * e)), dim3(kBlock), 0, c->stream, n, e,
-                       c->labels.as<uint32_t>(), c->xtab.as<double>(), c->x.as<double>());
+    // with every vertex a row of this context k_vde writes x itself (and, when the slab's pair offsets are current, the count
+    // kernel's per-vertex gather records: k_pack_vinfo's work) -- two launches less per step at config 3
+    const bool whole = c->rows_identity && c->n_rows == n && !c->multigraph;
+    if (!whole)
+        hipLaunchKernelGGL(k_x_from_labels, dim3(grid_for((uint64_t)n * e)), dim3(kBlock), 0, c->stream, n, e,
+                           c->labels.as<uint32_t>(), c->xtab.as<double>(), c->x.as<double>());
+    double *x_out = whole ? c->x.as<double>() : nullptr;
+    VinfoPack vp = {nullptr, nullptr, nullptr, 0u, 0u};
+    c->vinfo_fused = false;
+    if (whole && c->n_hub == 0 && c->have_order && c->slab_struct_valid && c->fill_variant == kVarRanked && fast_e(e) &&
+        c->vinfo.bytes >= ((size_t)n + 1) * GNNPE_VINFO_STRIDE(e) * 8 && c->poffs.p) {
+        vp = {c->vinfo.as<double>(), c->rank.as<uint32_t>(), c->poffs.as<uint32_t>(), c->slab_begin, c->slab_end};
+        c->vinfo_fused = true;
+        c->vinfo_gen = c->slab_struct_gen;
+    }
     const uint32_t nr = c->n_rows;
-    if (nr && c->multigraph) {
+    if (nr && c->multigraph) {  // (x came from k_x_from_labels above: `whole` is false for a multigraph)
         hipLaunchKernelGGL(k_vde_multi, dim3(grid_for((uint64_t)nr * e)), dim3(kBlock), 0, c->stream, nr, e,
                            c->rows_identity ? (const uint32_t *)nullptr : c->rows.as<uint32_t>(), c->mg_off.as<uint64_t>(),
                            c->mg_label.as<uint32_t>(), c->labels.as<uint32_t>(), c->xtab.as<double>(), c->nx.as<double>(),
@@ -747,7 +763,7 @@ static int run_vde(gnnpe_ctx *c)
         const bool hub_split = c->n_hub != 0 && (e == 1 || e == 2 || e == 4 || e == 8);
 #define GNNPE_VDE_ARGS                                                                                   \
     nr, rows, c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbr_label.as<uint32_t>(),      \
-        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>(), hub_split
+        c->labels.as<uint32_t>(), c->xtab.as<double>(), c->n_labels, e, c->nx.as<double>(), c->vde.as<double>(), hub_split, x_out, vp
         switch (e) {
         case 1: hipLaunchKernelGGL((k_vde<1>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
         case 2: hipLaunchKernelGGL((k_vde<2>), grid, block, tab_lds, c->stream, GNNPE_VDE_ARGS); break;
@@ -861,9 +877,7 @@ int gnnpe_vde_unpack_all(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds,
 //   1 pair-wave  one wave per (s, b) pair, direct stores, run-time embedding width (gnnpe_fill_pairwave.hip.h): the
 //                generic form for widths without a specialised instantiation, and the A/B baseline
 // l = 3 (4-vertex paths, BASELINE config 5) has one implementation: gnnpe_fill_deep.hip.h.
-enum { kVarPairWave = 1, kVarRanked = 4, kVarDeep = 5 };
 
-static bool fast_e(uint32_t e) { return e == 1 || e == 2 || e == 3 || e == 4 || e == 8; }
 
 // nbr_vde[q] = vde[nbrs[q]] for every held adjacency entry (the pair-wave and l=3 kernels stream it)
 static int ensure_nbr_vde(gnnpe_ctx *c)
@@ -930,10 +944,14 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         return rc;
     // pairs whose middle row is not on the device stay empty; with the whole graph loaded every pair is written by
     // the row kernels and only the scan's sentinel entry needs clearing
-    if (c->rows_identity)
-        GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.as<RankedPair>() + ne, 0, sizeof(RankedPair), c->stream));
-    else
+    if (!c->rows_identity) {
         GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.p, 0, (ne + 1) * sizeof(RankedPair), c->stream));
+    } else if (c->rpairs_sentinel_buf != c->rpairs.p || c->rpairs_sentinel_at != ne) {  // (nobody writes slot ne: once per buffer and pair count)
+        GNNPE_HIP_TRY(hipMemsetAsync(c->rpairs.as<RankedPair>() + ne, 0, sizeof(RankedPair), c->stream));
+        c->rpairs_sentinel_buf = c->rpairs.p;
+        c->rpairs_sentinel_at = ne;
+    }
+    if (!c->rows_identity) c->rpairs_sentinel_buf = nullptr;
     if (c->n_held) {
         const uint32_t *held = c->rows_identity ? nullptr : c->held.as<uint32_t>();
         const double *vde = c->have_vde ? c->vde.as<double>() : nullptr;
@@ -942,6 +960,13 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         [[maybe_unused]] const dim3 grid((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 3) / 4, 1u << 30));
         const dim3 block(kBlock);
         // rows per wave: 1 (one wave per row) or 4 with the rows' loads batched (GNNPE_ROWS_ILP=1|4 overrides; default below)
+        // k_vde wrote the per-vertex records when it ran (run_vde) and the slab's pair offsets have not changed since
+        const bool vinfo_current = c->vinfo_fused && c->vinfo_gen == c->slab_struct_gen && c->have_vde;
+        c->vinfo_fused = false;  // (good for one count: the next gnnpe_vde decides again)
+        // k_start_scan's status words + ticket are zeroed by the row kernel (count_paths passes them through the context)
+        uint32_t *clear_words = c->clear_words;
+        const uint32_t n_clear = c->n_clear;
+        c->clear_done = clear_words != nullptr;
         int rows_ilp = (int)diag_int("GNNPE_ROWS_ILP", 4);  // (diagnostic builds: 1 | 2 | 8 for the A/B of DESIGN 3.2)
         if (rows_ilp != 1 && rows_ilp != 2 && rows_ilp != 8) rows_ilp = 4;
         const dim3 gridk((unsigned)std::min<uint64_t>(((uint64_t)c->n_held + 4 * rows_ilp - 1) / (4 * rows_ilp), 1u << 30));
@@ -949,27 +974,31 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
     hipLaunchKernelGGL((k_rows_rank_multi<EE, PK, KK>), gridk, block, 0, c->stream, c->n_held, held,                \
                        c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),              \
                        c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),                   \
-                       c->rrecs.as<char>(), c->rpairs.as<RankedPair>())
+                       c->rrecs.as<char>(), c->rpairs.as<RankedPair>(), clear_words, n_clear,                       \
+                       (uint32_t)diag_int("GNNPE_ROWS_PAIR8", 0))
 #ifdef GNNPE_DIAG
 #define GNNPE_RRK(EE, PK)                                                                                           \
     do {                                                                                                            \
         if (rows_ilp == 8) GNNPE_RRM(EE, PK, 8);                                                                    \
         else if (rows_ilp == 4) GNNPE_RRM(EE, PK, 4);                                                               \
         else if (rows_ilp == 2) GNNPE_RRM(EE, PK, 2);                                                               \
-        else                                                                                                        \
+        else {                                                                                                      \
+            c->clear_done = false;                                                                                  \
             hipLaunchKernelGGL((k_rows_rank<EE, PK>), grid, block, 0, c->stream, c->n_held, held,                   \
                                c->adj_start.as<uint32_t>(), c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(),      \
                                c->vinfo.as<double>(), c->revpos.as<uint32_t>(), c->rblock.as<uint32_t>(),           \
                                c->rrecs.as<char>(), c->rpairs.as<RankedPair>());                                    \
+        }                                                                                                           \
     } while (0)
 #else
 #define GNNPE_RRK(EE, PK) GNNPE_RRM(EE, PK, 4)
 #endif
 #define GNNPE_RR(EE)                                                                                               \
     do {                                                                                                           \
-        hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,                \
-                           c->rank.as<uint32_t>(), c->slab_begin, c->slab_end, c->poffs.as<uint32_t>(),             \
-                           c->vinfo.as<double>());                                                                  \
+        if (!vinfo_current)                                                                                        \
+            hipLaunchKernelGGL((k_pack_vinfo<EE>), dim3(grid_for(c->n)), block, 0, c->stream, c->n, vde,            \
+                               c->rank.as<uint32_t>(), c->slab_begin, c->slab_end, c->poffs.as<uint32_t>(),         \
+                               c->vinfo.as<double>());                                                              \
         if (packed) GNNPE_RRK(EE, true); else GNNPE_RRK(EE, false);                                                 \
     } while (0)
         GNNPE_BY_E(e, GNNPE_RR)
@@ -1047,6 +1076,7 @@ static int ensure_slab_struct(gnnpe_ctx *c)
     if ((rc = read_back_u64(c, c->poffs.as<uint32_t>() + len, 4, &w))) return rc;
     c->n_edges = (uint32_t)w;
     c->slab_struct_valid = true;
+    c->slab_struct_gen++;
     c->pst_valid = false;
     return GNNPE_OK;
 }
@@ -1126,7 +1156,16 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
 
     // 2. per-pair path counts
     if (var == kVarRanked) {
-        if ((rc = build_ranked(c, ne))) return rc;
+        // k_start_scan's status words and ticket counter (step 4) are zeroed by the row kernel in front of it
+        const uint32_t n_tiles_c = (len + kStartTile - 1) / kStartTile;
+        if ((rc = c->scan_status.reserve((size_t)n_tiles_c * 8 + 64))) return rc;
+        c->clear_words = c->scan_status.as<uint32_t>();
+        c->n_clear = n_tiles_c * 2 + 16;
+        c->clear_done = false;
+        rc = build_ranked(c, ne);
+        c->clear_words = nullptr;
+        c->n_clear = 0;
+        if (rc) return rc;
     } else {
         if ((rc = c->ecnt.reserve((ne + 2) * 4)) || (rc = c->nbr_rank.reserve((c->nbr_used + 1) * 4))) return rc;
         // rank of every held neighbour entry: the rank test becomes a contiguous stream
@@ -1272,9 +1311,12 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
     if (var == kVarRanked) {
         const uint32_t n_tiles = (len + kStartTile - 1) / kStartTile;
         if ((rc = c->srec.reserve((size_t)(len + 1) * sizeof(StartRec))) || (rc = c->scan_status.reserve((size_t)n_tiles * 8 + 64))) return rc;
-        // status words, then the ticket counter (a line of its own behind them)
-        GNNPE_HIP_TRY(hipMemsetAsync(c->scan_status.p, 0, (size_t)n_tiles * 8 + 64, c->stream));
-        GNNPE_HIP_TRY(hipMemsetAsync(c->eoff.as<uint64_t>() + ne, 0, 8, c->stream));  // (no start vertices: no paths)
+        // status words, then the ticket counter (a line of its own behind them): zeroed by the row kernel of step 2 where one ran
+        if (!c->clear_done) GNNPE_HIP_TRY(hipMemsetAsync(c->scan_status.p, 0, (size_t)n_tiles * 8 + 64, c->stream));
+        c->clear_done = false;
+        if (!len) GNNPE_HIP_TRY(hipMemsetAsync(c->eoff.as<uint64_t>() + ne, 0, 8, c->stream));  // (no start vertices: no paths; else the last tile writes the total)
+        if ((rc = c->tk_ctl.reserve(kStartHeadsBytes + 64))) return rc;
+        c->heads_clean = false;
         if (len) {
             unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)blocks_per_cu(k_start_scan) * c->num_cus));
             grid = (unsigned)std::max<long>(1, std::min<long>((long)n_tiles, diag_int("GNNPE_START_SCAN_GRID", (long)grid)));
@@ -1282,7 +1324,8 @@ static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, 
             hipLaunchKernelGGL(k_start_scan, dim3(grid), dim3(kStartTile), 0, c->stream, len, sb, c->sorted.as<uint32_t>(),
                                c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(), c->poffs.as<uint32_t>(), c->rpairs.as<RankedPair>(),
                                c->scan_status.as<unsigned long long>(), reinterpret_cast<uint32_t *>(c->scan_status.as<char>() + (size_t)n_tiles * 8 + 32),
-                               c->srec.as<StartRec>(), c->eoff.as<uint64_t>() + ne);
+                               c->srec.as<StartRec>(), c->eoff.as<uint64_t>() + ne, c->tk_ctl.as<uint32_t>(), kStartHeadsBytes / 4u);
+            c->heads_clean = true;  // (the emit kernel's ticket heads: no memset in front of the first fill of this count)
         }
         GNNPE_HIP_TRY(hipGetLastError());
     }
@@ -1491,7 +1534,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                     want_per_cu, plan.per_cu, plan.pad, grid.x, nh_l);                                                  \
         if (nh_l) {                                                                                                     \
             if ((rc = c->tk_ctl.reserve(kStartHeadsBytes + 64))) return rc;                                             \
-            GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kStartHeadWords * 4, c->stream));               \
+            if (!c->heads_clean) GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kStartHeadWords * 4, c->stream)); \
+            c->heads_clean = false;                                                                                     \
             rk_heads = c->tk_ctl.as<uint32_t>();                                                                        \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, block, plan.pad, c->stream, P, sr, c->rpairs.as<RankedPair>(), c->rrecs.as<char>(), len, rk_heads, nh_l); \
@@ -1554,6 +1598,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             const uint64_t job_cap = (t_hi - t_lo) + c->n_edges / kJobStrip + 8;
             if ((rc = c->tk_ctl.reserve(kTicketCtlWords * 4 + 64)) || (rc = c->tk_jobs.reserve(job_cap * sizeof(uint2)))) return rc;
             GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, kTicketCtlWords * 4 + 64, c->stream));
+            c->heads_clean = false;
             uint32_t *ctl = c->tk_ctl.as<uint32_t>();
             const int occ_env = (int)diag_int("GNNPE_TICKET_OCC", 0);
             const uint32_t tk_exp = (uint32_t)diag_int("GNNPE_TICKET_EXP", 0);  // 1 no stores, 2 no record loads, 16 stamps

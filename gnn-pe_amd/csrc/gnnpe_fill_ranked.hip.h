@@ -156,11 +156,14 @@ __global__ __launch_bounds__(256) void k_rows_rank_multi(uint32_t n_held, const 
                                                          const uint32_t *__restrict__ nbrs, const double *__restrict__ vinfo,
                                                          const uint32_t *__restrict__ revpos,
                                                          const uint32_t *__restrict__ rblock, char *__restrict__ recs,
-                                                         RankedPair *__restrict__ pairs)
+                                                         RankedPair *__restrict__ pairs, uint32_t *__restrict__ clear_words,
+                                                         uint32_t n_clear, uint32_t pair8)
 {
     typedef typename RecOf<E, PACKED>::type Rec;
     constexpr int S = GNNPE_VINFO_STRIDE(E);
     const unsigned lane = lane_id();
+    // (k_start_scan's status words and ticket, zeroed here instead of by a memset between the two kernels: a launch less per step)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_clear; i += gridDim.x * blockDim.x) clear_words[i] = 0u;
     const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     uint32_t b[K], st[K], d[K], blk[K];
 #pragma unroll
@@ -226,8 +229,12 @@ __global__ __launch_bounds__(256) void k_rows_rank_multi(uint32_t n_held, const 
             for (int j = 0; j < E; j++) rec.vde[j] = vu[k][j];
             reinterpret_cast<Rec *>(base + 8 * E)[cnt] = rec;
             if (rp[k] != kNoEdge && po != kNoEdge) {
-                RankedPair pr = {blk[k], cnt, G};
-                pairs[po + rp[k]] = pr;
+                if (pair8) {  // diagnostic builds, GNNPE_ROWS_PAIR8=1: what an 8-byte pair record {block, count} would cost the scatter
+                    reinterpret_cast<uint2 *>(pairs)[po + rp[k]] = make_uint2(blk[k], cnt);  // (no G: the emit kernel cannot use these)
+                } else {
+                    RankedPair pr = {blk[k], cnt, G};
+                    pairs[po + rp[k]] = pr;
+                }
             }
         }
     }

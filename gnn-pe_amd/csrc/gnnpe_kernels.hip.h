@@ -126,6 +126,12 @@ __global__ void k_slab_degrees(uint32_t len, uint32_t slab_begin, const uint32_t
 // operation order as the reference loop (:527-534), hence bit-identical fp64 results.
 // The label table (|Sigma| x e doubles) also sits in LDS when it fits.
 // ------------------------------------------------------------------------------------------------
+// what k_vde needs to write the count kernel's per-vertex gather records beside the embeddings (vinfo == nullptr: it does not)
+struct VinfoPack {
+    double *vinfo;
+    const uint32_t *rank, *poffs;
+    uint32_t slab_begin, slab_end;
+};
 constexpr int kVdeStage = 6144;        // neighbour labels staged per pass (24 KiB)
 constexpr int kVdeTabMax = 4096;       // table doubles kept in LDS (32 KiB)
 
@@ -136,7 +142,8 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
                                              const uint32_t *__restrict__ nbr_label,
                                              const uint32_t *__restrict__ labels,
                                              const double *__restrict__ xtab, uint32_t n_labels, uint32_t e_rt,
-                                             double *__restrict__ nx, double *__restrict__ vde, bool hub_split)
+                                             double *__restrict__ nx, double *__restrict__ vde, bool hub_split,
+                                             double *__restrict__ x_out, VinfoPack vp)
 {
     const int e = E ? E : (int)e_rt;
     __shared__ uint32_t s_lab[kVdeStage];
@@ -192,12 +199,31 @@ __global__ __launch_bounds__(256) void k_vde(uint32_t n_rows, const uint32_t *__
         }
     };
     if (tab_in_lds) sum_rows(s_tab); else sum_rows(xtab);
-    if (r < n_rows && !hub) {
+    if (r < n_rows) {
         const uint32_t lv = labels[v];
         auto finish = [&](auto tab) {
             for (int k = 0; k < e; k++) {
-                nx[(uint64_t)v * e + k] = acc[k];
-                vde[(uint64_t)v * e + k] = tab[lv * e + k] + acc[k];
+                const double xv = tab[lv * e + k];
+                // x = the label's feature (custom.h:521): written here when every vertex is a row of this launch, so that the step
+                // needs no k_x_from_labels launch (round 6); hub rows too -- only their sums belong to k_vde_hubs
+                if (x_out) x_out[(uint64_t)v * e + k] = xv;
+                if (!hub) {
+                    nx[(uint64_t)v * e + k] = acc[k];
+                    vde[(uint64_t)v * e + k] = xv + acc[k];
+                }
+            }
+            // the count kernel's gather record {vde[v], rank[v] | first pair slot of v as a start vertex} (k_pack_vinfo), when the
+            // caller knows the slab's pair offsets are current: one launch less per step.  Graphs with hub rows keep the launch.
+            if constexpr (E > 0) {
+                if (vp.vinfo) {
+                    constexpr int S = E + 2;
+#pragma unroll
+                    for (int k = 0; k < E; k++) vp.vinfo[(uint64_t)v * S + k] = tab[lv * E + k] + acc[k];
+                    const uint32_t rk = vp.rank[v];
+                    const uint32_t po = (rk >= vp.slab_begin && rk < vp.slab_end) ? vp.poffs[rk - vp.slab_begin] : 0xFFFFFFFFu;  // kNoEdge
+                    reinterpret_cast<uint64_t *>(vp.vinfo)[(uint64_t)v * S + E] = ((uint64_t)po << 32) | rk;
+                    vp.vinfo[(uint64_t)v * S + E + 1] = 0.0;
+                }
             }
         };
         if (tab_in_lds) finish(s_tab); else finish(xtab);
@@ -523,8 +549,11 @@ __global__ __launch_bounds__(kStartTile) void k_start_scan(uint32_t len, uint32_
                                                            const uint32_t *__restrict__ member, const uint32_t *__restrict__ adj_start,
                                                            const uint32_t *__restrict__ poffs, const RankedPair *__restrict__ pairs,
                                                            unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket,
-                                                           StartRec *__restrict__ recs, uint64_t *__restrict__ total_out)
+                                                           StartRec *__restrict__ recs, uint64_t *__restrict__ total_out,
+                                                           uint32_t *__restrict__ clear_words, uint32_t n_clear)
 {
+    // (the emit kernel's ticket heads, zeroed here instead of by a memset in front of the fill: a launch less per step)
+    for (uint32_t i = blockIdx.x * kStartTile + threadIdx.x; i < n_clear; i += gridDim.x * kStartTile) clear_words[i] = 0u;
     typedef hipcub::BlockScan<uint64_t, kStartTile> Scan;
     __shared__ typename Scan::TempStorage s_scan;
     __shared__ uint64_t s_cnt[kStartTile];
@@ -565,7 +594,7 @@ __global__ __launch_bounds__(kStartTile) void k_start_scan(uint32_t len, uint32_
             for (int pp = 0; pp < HALF; pp++) {
                 const int pass = h * HALF + pp;
                 for (uint32_t k = e0[pp] + sub + 32; k < e1[pp]; k += 16) sum[pp] += pairs[k].cnt & ~kHubFlag;
-                uint32_t v = sum[pp];  // a start vertex emits fewer than 2^32 paths (degree x degree)
+                unsigned long long v = sum[pp];  // (64-bit from here: 16 lanes x 2^32 would not fit -- ADVICE r5; pairs[ne] is the zero sentinel)
                 v += __shfl_xor(v, 8, 16);
                 v += __shfl_xor(v, 4, 16);
                 v += __shfl_xor(v, 2, 16);
