@@ -1449,10 +1449,14 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             GNNPE_REQUIRE(u_hi - u_lo < (1ull << 31), GNNPE_ERR_ARG, "l=3 range covers %llu units; emit in smaller chunks",
                           (unsigned long long)(u_hi - u_lo));
             const uint32_t n_u = (uint32_t)(u_hi - u_lo);
-            if ((rc = c->dsl_first.reserve(((size_t)n_u + 2) * 4))) return rc;
+            // first slice of every unit, then (16-byte aligned, behind them) the units' records for the emitting waves
+            const size_t sf_bytes = (((size_t)n_u + 2) * 4 + 15) & ~(size_t)15;
+            if ((rc = c->dsl_first.reserve(sf_bytes + ((size_t)n_u + 1) * 16))) return rc;
             uint32_t *sfirst = c->dsl_first.as<uint32_t>();
+            uint4 *uinfo = reinterpret_cast<uint4 *>(c->dsl_first.as<char>() + sf_bytes);
             hipLaunchKernelGGL(k_deep_slice_counts, dim3(grid_for(((uint64_t)n_u + 1) * 64)), dim3(kBlock), 0, c->stream, P,
-                               c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, n_u, sfirst);
+                               c->upair.as<uint32_t>(), c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, n_u, sfirst,
+                               c->rank.as<uint32_t>(), uinfo);
             size_t tb = 0;
             GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, sfirst, sfirst, (int64_t)n_u + 1, c->stream));
             if ((rc = c->cub_tmp.reserve(tb))) return rc;
@@ -1462,7 +1466,32 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
             const uint32_t n_sl = *reinterpret_cast<const uint32_t *>(c->h_pinned);
             if (n_sl == 0) return GNNPE_OK;
-            if ((rc = c->dsl_kept.reserve(((size_t)n_sl + 1) * 16))) return rc;
+            if ((rc = c->dsl_kept.reserve(((size_t)n_sl + 1) * 16 + 64))) return rc;
+            // one launch (round 6, k_deep3_slices_fused): the slices' kept rows, their first slots (look-back inside the unit) and
+            // the rows; GNNPE_DEEP_TWO_PASS=1 in a diagnostic build keeps the count kernel + scan + emit kernel of rounds 3-5
+            if (!diag_int("GNNPE_DEEP_TWO_PASS", 0)) {
+                unsigned long long *sstat = c->dsl_kept.as<unsigned long long>();  // status word per slice; behind them the count of
+                uint32_t *sfall = reinterpret_cast<uint32_t *>(sstat + n_sl + 1);   // waves that gave up the look-back (never seen)
+                GNNPE_HIP_TRY(hipMemsetAsync(sstat, 0, ((size_t)n_sl + 2) * 8, c->stream));
+#define GNNPE_L(EE)                                                                                                      \
+    hipLaunchKernelGGL((k_deep3_slices_fused<EE>), dim3((n_sl + 3u) / 4u), dim3(256), 0, c->stream, P, c->upair.as<uint32_t>(), \
+                       c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), uinfo, u_lo, n_u, sfirst, n_sl, sstat, sfall)
+                if (fast_e(e)) {
+                    GNNPE_BY_E(e, GNNPE_L)
+                } else {
+                    GNNPE_L(0);
+                }
+#undef GNNPE_L
+                GNNPE_HIP_TRY(hipGetLastError());
+                if (c->sw.debug) {  // GNNPE_DEBUG=1: how many waves gave up the look-back and counted their unit's earlier slices themselves
+                    uint32_t nf = 0;
+                    GNNPE_HIP_TRY(hipMemcpyAsync(&nf, sfall, 4, hipMemcpyDeviceToHost, c->stream));
+                    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+                    fprintf(stderr, "[deep] k_deep3_slices_fused: %u slices over %u units, %u look-back fallbacks\n", n_sl, n_u, nf);
+                }
+                return GNNPE_OK;
+            }
+#ifdef GNNPE_DIAG
             uint64_t *skept = c->dsl_kept.as<uint64_t>(), *sscan = skept + n_sl + 1;
             const dim3 sgrid(grid_for((uint64_t)n_sl * 64)), sblock(256);
 #define GNNPE_L(EE)                                                                                                      \
@@ -1482,6 +1511,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                 GNNPE_L(0);
             }
 #undef GNNPE_L
+#endif
             GNNPE_HIP_TRY(hipGetLastError());
             return GNNPE_OK;
         }

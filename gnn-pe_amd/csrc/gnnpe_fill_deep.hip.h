@@ -830,9 +830,12 @@ __device__ __forceinline__ uint32_t deep_unit_table(const FillParams &P, uint32_
     return rl32(incl, 63);
 }
 
+// (uinfo, when given: {rank of the start vertex, middle vertex, part of the pair's row, rank of the middle vertex} of every unit, so that
+// the emitting waves find them with one 16-byte load instead of a chain of four dependent ones)
 __global__ __launch_bounds__(256) void k_deep_slice_counts(FillParams P, const uint32_t *__restrict__ upair,
                                                            const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
-                                                           uint64_t u_lo, uint32_t n_u, uint32_t *__restrict__ nsl)
+                                                           uint64_t u_lo, uint32_t n_u, uint32_t *__restrict__ nsl,
+                                                           const uint32_t *__restrict__ rank, uint4 *__restrict__ uinfo)
 {
     const unsigned lane = lane_id();
     const uint64_t nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -842,16 +845,17 @@ __global__ __launch_bounds__(256) void k_deep_slice_counts(FillParams P, const u
             const uint64_t u = u_lo + ui, base = uoff[u], nxt = uoff[u + 1];
             if (nxt != base && base < P.end && nxt > P.begin) {
                 const uint32_t w = upair[u];
-                const uint32_t i = P.erow[w], b = P.pnbr[w];
-                const uint32_t n_cand = deep_unit_table(P, w, (uint32_t)(u - ufirst[w]), P.sorted[P.slab_begin + i], b, lane,
-                                                        nullptr, nullptr, nullptr);
+                const uint32_t i = P.erow[w], b = P.pnbr[w], s = P.sorted[P.slab_begin + i], part = (uint32_t)(u - ufirst[w]);
+                const uint32_t n_cand = deep_unit_table(P, w, part, s, b, lane, nullptr, nullptr, nullptr);
                 out = ((n_cand + 63u) / 64u + kSliceSteps - 1u) / kSliceSteps;
+                if (uinfo && lane == 0) uinfo[ui] = make_uint4(P.slab_begin + i, b, part, rank[b]);
             }
         }
         if (lane == 0) nsl[ui] = out;
     }
 }
 
+#ifdef GNNPE_DIAG  // (the two-pass form of rounds 3-5: kept for the A/B against k_deep3_slices_fused below)
 template <int E, bool EMIT>
 __global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32_t *__restrict__ upair,
                                                       const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
@@ -963,6 +967,186 @@ __global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32
             d = n_d;
             rd = n_rd;
         }
+    }
+}
+
+#endif
+
+// ---- emission by slices in ONE launch (round 6) ---------------------------------------------------------------------------
+// The two-pass form above needs the kept rows of every slice before any row can be written: a kernel that reads every candidate's
+// rank, a scan, then the kernel that reads them again and writes (config 5, a range of 2^26 paths: 0.25-0.52 ms + two scan launches
+// in front of a 4.2-4.6 ms writer; profiles/r06_deep_emit_calls.txt).  Here a wave does both for its slice:
+//   pass A   the slice's 16 steps of 64 candidates: rank only (4 bytes per candidate; "is it b" is a rank comparison -- ranks are a
+//            permutation), the kept lanes of every step as a 64-bit mask in LDS, their number;
+//   offset   first output slot = the unit's (uoff[u], from the count) + the kept rows of the unit's EARLIER slices: decoupled
+//            look-back over the status words of the slices before it (value << 2 | state, as in k_start_scan), which never leaves the
+//            unit -- the unit's first slice publishes an inclusive prefix at once;
+//   pass B   the steps again from the masks: only KEPT lanes fetch their fourth vertex; rows as before (deep_emit_rows).
+// One wave per slice, workgroups in launch order, exit -- NOT a resident grid taking tickets: a wave's first load of its next slice
+// would wait for the acknowledgement of every store of the slice before (one counter for loads and stores, completed in issue
+// order), and that form measured 4-12 % slower than the two passes it replaces (profiles/r06_deep_emit_calls.txt).  The look-back
+// therefore leans on the dispatcher starting workgroups in index order (every slice waited for has a smaller index); it does not
+// DEPEND on it: after kLookbackPolls polls without an answer the wave counts the unit's earlier slices itself (their candidates
+// are behind the table it already holds), so no wave can wait for ever.
+constexpr uint32_t kLookbackPolls = 2048;
+template <int E>
+__global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const uint32_t *__restrict__ upair,
+                                                            const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
+                                                            const uint4 *__restrict__ uinfo, uint64_t u_lo, uint32_t n_u,
+                                                            const uint32_t *__restrict__ sfirst, uint32_t n_slices,
+                                                            unsigned long long *__restrict__ status, uint32_t *__restrict__ fallbacks)
+{
+    __shared__ uint32_t s_off[4][65], s_st[4][64], s_c[4][64];
+    __shared__ uint32_t s_kc[4][64], s_kd[4][64], s_kp[4][64];  // kept rows of one step
+    __shared__ uint64_t s_mask[4][kSliceSteps];                 // kept lanes of every step of the slice
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t *off = s_off[wv], *rst = s_st[wv], *rc = s_c[wv];
+    uint32_t *kc = s_kc[wv], *kd = s_kd[wv], *kp = s_kp[wv];
+    uint64_t *msk = s_mask[wv];
+    const uint64_t sl64 = (uint64_t)blockIdx.x * 4u + wv;
+    if (sl64 >= n_slices) return;  // (no workgroup barrier anywhere in this kernel)
+    const uint32_t sl = (uint32_t)sl64;
+    // the slice's unit: the last one whose first slice is <= sl (units without slices share a value) -- a 64-ary search, one probe
+    // per lane and round: two round trips for up to 4 096 units (a binary search was twelve dependent loads per slice)
+    uint32_t lo_u = 0, len_u = n_u;
+    while (len_u > 1) {
+        const uint32_t stride = (len_u + 63u) / 64u, idx = lo_u + lane * stride;
+        const uint64_t le = __ballot(lane * stride < len_u && sfirst[min(idx, lo_u + len_u - 1u)] <= sl);  // (lane 0 always: the invariant)
+        const uint32_t k = (uint32_t)__popcll(le) - 1u;
+        len_u = min(stride, len_u - k * stride);
+        lo_u += k * stride;
+    }
+    const uint32_t first_sl = sfirst[lo_u], part = sl - first_sl;
+    const uint64_t u = u_lo + lo_u;
+    const uint4 ui4 = uinfo[lo_u];  // {rank[s], b, part of b's row, rank[b]}: k_deep_slice_counts
+    const uint32_t thr = ui4.x, b = ui4.y, rb = ui4.w;
+    const uint32_t s = P.sorted[thr];
+    const uint32_t n_cand = deep_unit_table(P, 0u, ui4.z, s, b, lane, off, rst, rc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto locate = [&](uint32_t q, uint32_t &seg, uint32_t &pos) {
+        uint32_t lo = 0;  // last segment whose first candidate is <= q (skips empty segments)
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (off[lo + step] <= q) lo += step;
+        seg = lo;
+        pos = rst[lo] + (q - off[lo]);
+    };
+    // kept rows of slice `pt` of this unit: ranks only, all the steps' loads before the first ballot; the masks go to LDS for
+    // the wave's own slice
+    auto slice_kept = [&](uint32_t pt, bool keep_masks) -> uint32_t {
+        const uint32_t a_lo = pt * (kSliceSteps * 64u), a_hi = min(n_cand, a_lo + kSliceSteps * 64u);
+        uint32_t rk[kSliceSteps];
+#pragma unroll
+        for (uint32_t st = 0; st < kSliceSteps; st++) {
+            const uint32_t q = a_lo + st * 64u + lane;
+            rk[st] = 0u;  // (rank 0 is never kept: thr >= 0)
+            if (q < a_hi) {
+                uint32_t seg, pos;
+                locate(q, seg, pos);
+                rk[st] = P.nbr_rank[pos];
+            }
+        }
+        uint32_t kept = 0;
+#pragma unroll
+        for (uint32_t st = 0; st < kSliceSteps; st++) {
+            const uint64_t m = __ballot(rk[st] > thr && rk[st] != rb);
+            if (keep_masks && lane == 0) msk[st] = m;
+            kept += (uint32_t)__popcll(m);
+        }
+        return kept;
+    };
+    const uint32_t q_lo = part * (kSliceSteps * 64u), q_hi = min(n_cand, q_lo + kSliceSteps * 64u);
+    const uint32_t mine = slice_kept(part, true);
+    // the slice's first slot: look back over the unit's earlier slices
+    uint64_t prefix = 0;
+    if (lane == 0)
+        __hip_atomic_store(&status[sl], (unsigned long long)(((uint64_t)mine << 2) | (part ? 1ull : 2ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        int64_t top = (int64_t)sl - 1;  // nearest predecessor; never below first_sl
+        uint32_t polls = 0;
+        bool gave_up = false;
+        while (top >= (int64_t)first_sl) {
+            const int64_t idx = top - (int64_t)lane;
+            // (in front of the unit's first slice: an inclusive prefix of zero)
+            const unsigned long long wd = idx >= (int64_t)first_sl ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;
+            const uint64_t inc = __ballot((wd & 3ull) == 2ull), none = __ballot((wd & 3ull) == 0ull);
+            const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+            const uint64_t need = first_inc >= 63u ? ~0ull : ((1ull << (first_inc + 1)) - 1ull);  // lanes up to the first inclusive prefix
+            if (none & need) {  // one of them has not published yet
+                if (++polls > kLookbackPolls) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            uint64_t v = lane <= first_inc ? (uint64_t)(wd >> 2) : 0ull;
+            for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+            prefix += v;
+            if (first_inc < 64u) break;
+            top -= 64;
+        }
+        if (gave_up) {  // (never seen; the dispatcher starts workgroups in index order) -- count the earlier slices here
+            prefix = 0;
+            for (uint32_t pt = 0; pt < part; pt++) prefix += slice_kept(pt, false);
+            if (lane == 0) atomicAdd(fallbacks, 1u);
+        }
+    }
+    if (lane == 0 && part)
+        __hip_atomic_store(&status[sl], (unsigned long long)(((prefix + mine) << 2) | 2ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t piece0 = uoff[u] + prefix;
+    if (mine == 0 || piece0 >= P.end || piece0 + mine <= P.begin) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lane 0's masks are visible to the wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // pass B: the kept lanes' fourth vertices, one step ahead of the rows being written
+    const dbl2 fixed = deep_fixed_piece<E>(P, s, b, lane);
+    uint64_t running = 0;
+    auto fetch = [&](uint32_t st, uint64_t &mask, uint32_t &seg, uint32_t &pos, uint32_t &d) {
+        mask = msk[st];
+        seg = pos = d = 0;
+        if ((mask >> lane) & 1ull) {
+            locate(q_lo + st * 64u + lane, seg, pos);
+            d = P.nbrs[pos];
+        }
+    };
+    const uint32_t n_steps = (q_hi - q_lo + 63u) / 64u;
+    uint64_t mask;
+    uint32_t lo, pos, d;
+    fetch(0, mask, lo, pos, d);
+    for (uint32_t st = 0; st < n_steps; st++) {
+        uint64_t n_mask = 0;
+        uint32_t n_lo = 0, n_pos = 0, n_d = 0;
+        if (st + 1 < n_steps) fetch(st + 1, n_mask, n_lo, n_pos, n_d);
+        const bool keep = (mask >> lane) & 1ull;
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        const uint64_t slot0 = piece0 + running;
+        running += cnt;
+        if (cnt && slot0 < P.end && slot0 + cnt > P.begin) {
+            if (keep) {
+                const uint32_t r = (uint32_t)__popcll(mask & lt);
+                kc[r] = rc[lo];
+                kd[r] = d;
+                kp[r] = pos;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t r_lo = slot0 < P.begin ? (uint32_t)(P.begin - slot0) : 0u;
+            const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
+            const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
+            deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, r_hi - r_lo, o0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        mask = n_mask;
+        lo = n_lo;
+        pos = n_pos;
+        d = n_d;
     }
 }
 
