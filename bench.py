@@ -242,7 +242,7 @@ def config5_leg(torch, stream, local_rank, labels, seed):
     """BASELINE config 5 on ONE GPU (the 8-GPU split of it is in tests/test_gpu_slabs_full.py): power-law 4M / 64M, l = 3
     (4-vertex paths: the reference's rule with the depth fixed, SURVEY D4 -- parity unpinned, the count is checked in the
     tests against the closed form sum_E (du-1)(dv-1) - 3T), e = 8.  The 4.2e13 paths fit nowhere, so the leg times the count
-    (vde + per-row rank sort + k_deep3_count_hist / _coop + scans) and the emission (k_deep3_slices: slice counts, kept rows per slice, emit) on sampled ranges of 2^24 and 2^26 paths."""
+    (vde + per-row rank sort + k_deep3_count_hist / _coop + scans) and the emission (k_deep3_slices_fused, round 6: one wave per slice counts its kept rows, learns its first slot by look-back inside the unit and writes) on sampled ranges of 2^24 and 2^26 paths."""
     L, e = 4, 8
     t0 = time.perf_counter()
     g = synth.powerlaw_graph(4_000_000, 64_000_000, exponent=2.1, max_degree=3000, n_labels=labels, seed=seed)
@@ -294,7 +294,7 @@ def config5_leg(torch, stream, local_rank, labels, seed):
     eng.close()
     deg = np.diff(g["offsets"].astype(np.int64))
     return dict(workload=f"config 5: power-law n=4000000 m=64000000 (max degree {int(deg.max())}), l=3, e=8, one GPU", paths=total,
-                vde_count_s=t_count, vde_ms=min(vms), count_paths_per_s=total / t_count, kernel="k_deep3_slices", bytes_per_path=bpp, emit_samples=samples,
+                vde_count_s=t_count, vde_ms=min(vms), count_paths_per_s=total / t_count, kernel="k_deep3_slices_fused", bytes_per_path=bpp, emit_samples=samples,
                 emit_frac=float(np.mean([x["frac"] for x in samples if x["paths"] >= 1 << 26] or [x["frac"] for x in samples])),
                 emit_frac_note="mean over the 2^26-path ranges (18 GB of output each); the 2^24-path ranges are listed too",
                 host_graph_generation_s=t_gen,

@@ -552,8 +552,11 @@ __device__ __forceinline__ dbl2 deep_fixed_piece(const FillParams &P, uint32_t s
 template <int E>
 __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, uint32_t b, dbl2 fixed, const uint32_t *kc,
                                                const uint32_t *kd, const uint32_t *kp, uint32_t r_lo, uint32_t rows, uint64_t o0,
-                                               unsigned lane)
+                                               unsigned lane, const double *d_table = nullptr)
 {
+    // where the fourth vertex' embedding comes from: the per-entry copy (kp = the entry: consecutive entries of a row are
+    // consecutive lines) or, d_table given, a table indexed by what the caller put into kp (the vertex table by vertex id)
+    const double *const dsrc = d_table ? d_table : P.nbr_vde;
     const uint32_t e = E > 0 ? (uint32_t)E : P.e, D = 4 * e;
     if (rows == 0) return;  // (wave-uniform; the clamped loads below index row rows - 1)
     // Order matters on this hardware (one vmcnt counter for loads AND stores, completed in issue order): a load issued
@@ -585,7 +588,7 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
             constexpr uint32_t H = E / 2, HP = 2 * H, RP = 64 / HP;
             const uint32_t piece = lane % HP, rsub = lane / HP, cp = piece % H;
             const bool is_d = piece >= H;
-            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(P.nbr_vde);
+            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(dsrc);
             dbl2 v[HP];
 #pragma unroll
             for (uint32_t j = 0; j < HP; j++) {
@@ -607,7 +610,7 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
         } else if constexpr (E == 2) {
             // a row is four pieces (s, b, c, d): a lane keeps one column, sixteen rows per pass
             const uint32_t col = lane % 4, rsub = lane / 4;
-            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(P.nbr_vde);
+            const dbl2 *vde2 = reinterpret_cast<const dbl2 *>(P.vde), *nv2 = reinterpret_cast<const dbl2 *>(dsrc);
             dbl2 v[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
@@ -630,7 +633,7 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
                 return which == 0   ? P.vde[(uint64_t)s * e + comp]
                        : which == 1 ? P.vde[(uint64_t)b * e + comp]
                        : which == 2 ? P.vde[(uint64_t)kc[r] * e + comp]
-                                    : P.nbr_vde[(uint64_t)kp[r] * e + comp];
+                                    : dsrc[(uint64_t)kp[r] * e + comp];
             };
             for (uint32_t t2 = lane; t2 < rows * (D / 2); t2 += 64) {
                 dbl2 v;
@@ -798,7 +801,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
 // three table builds per unit).  The library takes slices on graphs with hub rows, units elsewhere (fill_device).
 // (Tried and dropped: collecting kept rows across steps in an LDS ring and writing them 64 at a time -- within 1 % on every
 // range, the sparse ones behind high-ranked starts included: the steps' round trips are not what the slices wait for.)
-constexpr uint32_t kSliceSteps = 16;  // 8 ... 32 time alike on the config-5 graph; 2 and 4 lose to the table rebuilds
+constexpr uint32_t kSliceSteps = 16;  // 8 ... 32 time alike on the config-5 graph; 2 and 4 lose to the table rebuilds (round 6, one-launch
+                                      // kernel: 32 gains 1 % on the sparsest sampled range and loses 1-4 % on the others)
 
 // segment table of unit u for one wave: first candidate, row start and id of each of its 64 third vertices; returns the
 // unit's candidates
@@ -989,6 +993,7 @@ __global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32
 // DEPEND on it: after kLookbackPolls polls without an answer the wave counts the unit's earlier slices itself (their candidates
 // are behind the table it already holds), so no wave can wait for ever.
 constexpr uint32_t kLookbackPolls = 2048;
+constexpr uint32_t kSparseNum = 19, kSparseDen = 20;  // by_vertex below: slices that keep fewer than 0.6 of their candidates
 template <int E>
 __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const uint32_t *__restrict__ upair,
                                                             const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
@@ -1038,23 +1043,31 @@ __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const 
     // the wave's own slice
     auto slice_kept = [&](uint32_t pt, bool keep_masks) -> uint32_t {
         const uint32_t a_lo = pt * (kSliceSteps * 64u), a_hi = min(n_cand, a_lo + kSliceSteps * 64u);
-        uint32_t rk[kSliceSteps];
-#pragma unroll
-        for (uint32_t st = 0; st < kSliceSteps; st++) {
-            const uint32_t q = a_lo + st * 64u + lane;
-            rk[st] = 0u;  // (rank 0 is never kept: thr >= 0)
-            if (q < a_hi) {
-                uint32_t seg, pos;
-                locate(q, seg, pos);
-                rk[st] = P.nbr_rank[pos];
-            }
-        }
+        constexpr uint32_t kChunk = 16;  // steps whose loads are in flight together
         uint32_t kept = 0;
+        for (uint32_t s0 = 0; s0 < kSliceSteps; s0 += kChunk) {
+            if (a_lo + s0 * 64u >= a_hi) {  // (wave-uniform) nothing behind: empty masks
+                if (keep_masks && lane == 0)
+                    for (uint32_t st = s0; st < kSliceSteps; st++) msk[st] = 0ull;
+                break;
+            }
+            uint32_t rk[kChunk];
 #pragma unroll
-        for (uint32_t st = 0; st < kSliceSteps; st++) {
-            const uint64_t m = __ballot(rk[st] > thr && rk[st] != rb);
-            if (keep_masks && lane == 0) msk[st] = m;
-            kept += (uint32_t)__popcll(m);
+            for (uint32_t st = 0; st < kChunk; st++) {
+                const uint32_t q = a_lo + (s0 + st) * 64u + lane;
+                rk[st] = 0u;  // (rank 0 is never kept: thr >= 0)
+                if (q < a_hi) {
+                    uint32_t seg, pos;
+                    locate(q, seg, pos);
+                    rk[st] = P.nbr_rank[pos];
+                }
+            }
+#pragma unroll
+            for (uint32_t st = 0; st < kChunk; st++) {
+                const uint64_t m = __ballot(rk[st] > thr && rk[st] != rb);
+                if (keep_masks && lane == 0) msk[s0 + st] = m;
+                kept += (uint32_t)__popcll(m);
+            }
         }
         return kept;
     };
@@ -1104,6 +1117,9 @@ __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // pass B: the kept lanes' fourth vertices, one step ahead of the rows being written
     const dbl2 fixed = deep_fixed_piece<E>(P, s, b, lane);
+    // a slice that keeps few of its candidates reads the fourth vertices' embeddings from the vertex table (by id: 256 MB at config 5,
+    // mostly answered by the Infinity Cache) instead of the per-entry copy, of whose lines it would use a fraction
+    const bool by_vertex = (uint64_t)mine * kSparseDen < (uint64_t)(q_hi - q_lo) * kSparseNum;
     uint64_t running = 0;
     auto fetch = [&](uint32_t st, uint64_t &mask, uint32_t &seg, uint32_t &pos, uint32_t &d) {
         mask = msk[st];
@@ -1130,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const 
                 const uint32_t r = (uint32_t)__popcll(mask & lt);
                 kc[r] = rc[lo];
                 kd[r] = d;
-                kp[r] = pos;
+                kp[r] = by_vertex ? d : pos;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1138,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const 
             const uint32_t r_lo = slot0 < P.begin ? (uint32_t)(P.begin - slot0) : 0u;
             const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
             const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
-            deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, r_hi - r_lo, o0, lane);
+            deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, r_hi - r_lo, o0, lane, by_vertex ? P.vde : nullptr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
