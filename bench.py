@@ -46,9 +46,10 @@ import gnnpe_amd  # noqa: E402,F401
 from gnnpe_amd import binding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LEAF_TRAFFIC_BYTES = 28.1e9  # index leaf kernel (image alone) at config 3, per launch: profiles/r05_leaf_mem_pmc.txt
+LEAF_TRAFFIC_BYTES = 27.8e9  # index leaf kernel (image alone) at config 3, per launch: 7.0 GB read + 20.8 GB written, profiles/r05_leaf_mem_pmc.txt
+                            # (the leaf kernel is round 5's: no counter pass of it in round 6)
 CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_fill.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_fill.json")
 
 
 def bytes_per_path(L, e):
@@ -634,7 +635,7 @@ def main():
     cms = sorted(pool_rep["candidates_ms"])
     med_ms = float(np.median(cms)) if len(cms) > 1 else None
     roofline = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r05_pmc_fill.json: separate --pmc passes over the same kernel, graph and buffers' size), not this run",
+                    frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source="committed profile (profiles/r06_pmc_fill.json: separate --pmc passes over the same kernel, graph and buffers' size), not this run",
                     traffic_note=traffic_note, bytes_per_path=bpp,
                     paths_per_launch=total, launch_ms=fill_avg_ms,
                     emit_shapes=None if shapes is None else dict(

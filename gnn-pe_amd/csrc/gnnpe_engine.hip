@@ -156,6 +156,8 @@ template <class K> static OccPlan occupancy_plan(K kernel_fn, int want, int devi
 
 }  // namespace gnnpe
 
+// (diagnostic builds read the environment again at every count and fill, so that the A/B scripts under scripts/ can switch shapes
+// and knobs between two launches of one process: GNNPE_DIAG_REREAD below)
 gnnpe::Switches gnnpe::read_switches()
 {
     Switches w;
@@ -1132,6 +1134,9 @@ static int ensure_tile_table(gnnpe_ctx *c, uint64_t rows_hi, uint32_t ts)
 
 static int count_paths_impl(gnnpe_ctx *c, uint32_t l, uint64_t *host_per_start, uint64_t *host_total, bool fetch_total)
 {
+#ifdef GNNPE_DIAG
+    if (c) c->sw = read_switches();  // GNNPE_DIAG_REREAD
+#endif
     GNNPE_REQUIRE(c, GNNPE_ERR_ARG, "null context");
     GNNPE_HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_rank_arrays(c);
@@ -1391,6 +1396,9 @@ int gnnpe_count_total_device(gnnpe_ctx *c, void *dev_u64)
 static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids, void *d_pde, void *d_pdl,
                        void *d_part, bool capped = false)
 {
+#ifdef GNNPE_DIAG
+    if (c) c->sw = read_switches();  // GNNPE_DIAG_REREAD
+#endif
     GNNPE_REQUIRE(c && c->counted, GNNPE_ERR_ARG, "gnnpe_fill_paths: call gnnpe_count_paths first");
     if (capped) {
         GNNPE_REQUIRE(begin == 0 && !d_pdl && !d_part && c->counted_variant == kVarRanked, GNNPE_ERR_UNSUPPORTED,

@@ -4,6 +4,9 @@ scatter / record stores) were temporary and are gone from the library -- DESIGN.
     python scripts/count_ab.py "GNNPE_ROWS_ILP=1" "GNNPE_ROWS_ILP=2" "GNNPE_ROWS_ILP=4,GNNPE_ROWS_GRID=2048" """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _diag  # noqa: F401  (the diagnostic build: this script's knobs live there)
 import numpy as np, torch
 import gnnpe_amd
 from gnnpe_amd import binding, synth

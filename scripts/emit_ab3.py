@@ -3,6 +3,9 @@ compared bit for bit with the start-vertex shape; then every shape timed into K 
 usage: emit_ab3.py [n m] [--bufs K] [--e E] [--tpt 1,2,4,8] [--occ 0,4,3] [--check-only]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _diag  # noqa: F401  (the diagnostic build: this script's knobs live there)
 import numpy as np, torch
 import gnnpe_amd
 from gnnpe_amd import binding, synth

@@ -2,6 +2,9 @@
 a build of the previous commit): both engines count the same graph and emit into the same output buffers, alternately."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _diag  # noqa: F401  (the diagnostic build: this script's knobs live there)
 import numpy as np, torch
 import gnnpe_amd
 from gnnpe_amd import binding, synth

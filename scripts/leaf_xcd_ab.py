@@ -5,6 +5,9 @@ cached pair order, cases interleaved."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, hashlib
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _diag  # noqa: F401  (the diagnostic build: this script's knobs live there)
 import gnnpe_amd
 from gnnpe_amd import binding, synth
 n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1_000_000, 10_000_000)

@@ -3,6 +3,9 @@ rocprofv3 by scripts/rows_probe.sh."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _diag  # noqa: F401  (the diagnostic build: this script's knobs live there)
 import gnnpe_amd
 from gnnpe_amd import binding, synth
 g = synth.gnm_graph(1_000_000, 10_000_000)
