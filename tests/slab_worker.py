@@ -85,6 +85,7 @@ def oracle_l3_check(eng, g, sn, e, n_labels, total):
     out["oracle_count_s"] = round(time.time() - t0, 1)
     got_total, got = eng.count_paths(3, per_start=True)
     out["per_start_equal"] = bool(np.array_equal(got, want)) and int(got_total) == total == int(want.sum(dtype=np.uint64))
+    out["p4_closed_form"] = int(orc.count_p4(g["offsets"], g["nbrs"])[1])  # sum_E (du - 1)(dv - 1) - 3 T
     out["starts_with_paths"] = int((want > 0).sum())
     base = np.zeros(n + 1, np.uint64)
     np.cumsum(want, out=base[1:])

@@ -284,7 +284,9 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
     P, ovde, so, ref, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
     assert total == P and np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
     seen = 0
-    full = set(range(p))  # every partition: 22 GB through the host validator takes under a minute on the GPU box's host
+    # through the host validator: every partition at config 2; at config 3 the first, a middle and the last one (8 GB of the 22 GB:
+    # all eight took 46 s of the suite), the others by header -- entry count, node counts, file size
+    full = set(range(p)) if n < 1_000_000 else {0, p // 2, p - 1}
     for pid in range(p):
         mine = _partition_paths(ref, mem, pid)
         img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)

@@ -138,14 +138,15 @@ def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
     total8 = sum(r["total"] for r in res)
     ranges = [[r["base"], r["base"] + r["emitted"]] for r in res]
     out1 = str(tmp_path / "w1")
-    _run(1, ["--graph", gp, "--out", out1, "-l", "3", "-e", "8", "--ranges", json.dumps(ranges)], timeout=2400)
+    # one rank over the whole graph: the ranks' id ranges again (checksums), and -- in the same process, the graph loaded once -- the
+    # checker that is not the engine (--oracle-l3, below)
+    _run(1, ["--graph", gp, "--out", out1, "-l", "3", "-e", "8", "--ranges", json.dumps(ranges), "--oracle-l3", "1"], timeout=2400)
     one = _results(out1, 1)[0]
     assert one["total"] == total8 == res[0]["global_total"] and total8 > 10 ** 13
     # the independent count: 4-vertex simple paths in closed form, sum_E (du-1)(dv-1) - 3 T, by the oracle's
-    # OpenMP triangle count -- pinned against the fixed-depth DFS on small graphs (tests/test_oracle_golden.py)
-    from oracle import Oracle
-    tri, p4 = Oracle().count_p4(g["offsets"], g["nbrs"])
-    assert total8 == p4, (total8, p4, tri)
+    # OpenMP triangle count -- pinned against the fixed-depth DFS on small graphs (tests/test_oracle_golden.py); computed by the
+    # worker beside the per-start counts (their sum must be the same number)
+    assert total8 == one["oracle_l3"]["p4_closed_form"], (total8, one["oracle_l3"])
     base = 0
     for r, want in zip(res, one["range_checksums"]):
         assert r["base"] == base
@@ -156,9 +157,7 @@ def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
     # highest-degree hub (4 517 neighbours: rows THROUGH the hub row, ids beyond 2^32), the last 2^16 rows (the highest-ranked
     # hub starts) -- against rows the oracle's DFS enumerates for the covering start vertices: ids and all 32 doubles bit for bit.
     # (Parity stays unpinned: no reference runs l = 3)
-    out_o = str(tmp_path / "wo")
-    _run(1, ["--graph", gp, "--out", out_o, "-l", "3", "-e", "8", "--ranges", "[]", "--oracle-l3", "1"], timeout=2400)
-    o3 = _results(out_o, 1)[0]["oracle_l3"]
+    o3 = one["oracle_l3"]
     assert o3["per_start_equal"] and o3["starts_with_paths"] > 3_000_000, o3
     assert o3["hub"]["degree"] > 4000 and len(o3["ranges"]) == 3
     for r in o3["ranges"]:
