@@ -59,6 +59,7 @@ def main(argv=None):
     ap.add_argument("--index", action="store_true", help="also write partition-i/index.dat")
     ap.add_argument("--chunk", type=int, default=16 << 20, help="paths rendered per device pass")
     ap.add_argument("--timing", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="refuse a graph file with a duplicate `e` line (simple graphs only)")
     ap.add_argument("-q", "--query", dest="query", default=None,
                     help="also answer this query graph (filter on every rank's slab, bitmaps OR-ed, refinement on rank 0)")
     args = ap.parse_args(argv)
@@ -85,7 +86,13 @@ def main(argv=None):
     t0 = time.perf_counter()
 
     # R0 / R1 with the library's own loader; every rank reads the (small) text inputs, keeps only its rows
-    g = binding.host_load_graph(args.graph)
+    # (a file with duplicate `e` lines loads as the reference loads it -- graph.cpp:211-218: the repeats count in `degree` and in
+    # gen_vde's neighbour sums, the enumeration sees the de-duplicated rows; --strict refuses it, as rounds 1-5 did)
+    g = binding.host_load_graph(args.graph, strict=args.strict)
+    stored = None  # the rows with their repeats, when the file has any
+    if g.get("simple_offsets") is not None:
+        stored = dict(offsets=g["offsets"], nbrs=g["nbrs"])
+        g = dict(g, offsets=g["simple_offsets"], nbrs=g["simple_nbrs"])  # what every structure below is built on
     n, L, e, p = g["n"], args.l + 1, args.e, args.p
     if rank == 0:
         print(f"|V|: {g['n']}, |E|: {g['m']}, |Σ|: {g['labels_count']}")
@@ -103,10 +110,15 @@ def main(argv=None):
     if world == 1:
         eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
         owned_entries = len(g["nbrs"])
+        if stored is not None:
+            eng.set_multigraph_rows(stored["offsets"].astype(np.uint64), stored["nbrs"])
     else:
         rows, roff, rnbr = owned_rows(g, sn, bounds, rank)
         owned_entries = int(roff[-1])
         eng.load_rows(n, g["labels"], rows, roff, rnbr, nbr_capacity=len(g["nbrs"]) + owned_entries)
+        if stored is not None:  # this rank's rows again, as stored: what gen_vde sums over
+            _, moff, mnbr = owned_rows(stored, sn, bounds, rank)
+            eng.set_multigraph_rows(moff, mnbr)
     eng.set_order(sn, mem, p)
     eng.set_slab(int(bounds[rank]), int(bounds[rank + 1]))
     eng.set_label_table(binding.host_label_table(max(g["labels_count"], 1), e))
@@ -124,7 +136,7 @@ def main(argv=None):
             raise SystemExit("--query needs -l 2")
         plan = binding.host_query_plan(args.query, e)
         if world > 1:
-            eng.set_degrees(np.diff(g["offsets"].astype(np.int64)))  # slab-only engine: degrees of 2-hop vertices
+            eng.set_degrees(np.diff((stored or g)["offsets"].astype(np.int64)))  # slab-only engine: degrees of 2-hop vertices (stored rows' lengths)
         bm = sb.filter(plan)
         if rank == 0:
             print(len(plan["vids"]))

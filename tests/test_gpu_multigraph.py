@@ -148,3 +148,38 @@ def test_twenty_random_multigraphs_through_both_binaries(tmp_path):
         subprocess.check_call([ref_dump_path(), gp, "2", dump])
         ref_b, our_b = open(dump, "rb").read(), open(os.path.join(dirs["ours"], "gnn-pe", "vde.bin"), "rb").read()
         assert our_b == ref_b[: 8 + 3 * n * 2 * 8], i  # header n, e and x, nx, vde: the same bytes
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_python_driver_writes_the_reference_files_for_golden_multigraphs(tmp_path, world):
+    """gnn-pe_amd/offline.py (one process per GPU over torch.distributed; here one or two rank processes sharing device 0 with
+    their collectives staged over gloo): the same two-step load -- simple rows, then the stored rows -- on every rank."""
+    import socket
+    import sys
+    driver = os.path.join(ROOT, "gnn-pe_amd", "offline.py")
+    for ci in (1, 7, 14):  # p = 2, 5, 3
+        c = multigraph_cases()[ci]
+        d = str(tmp_path / f"c{ci}")
+        p = _dataset(d, c)
+        gp = os.path.join(d, "g.graph")
+        synth.write_graph_file(gp, c["g"])
+        args = [driver, "-f", d + "/", "-d", gp, "-p", str(p)]
+        env = dict(os.environ)
+        if world == 1:
+            cmd = [sys.executable] + args
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env["GNNPE_BENCH_SAME_DEVICE"] = "1"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port)] + args
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert open(os.path.join(d, "gnn-pe", "all_paths.txt"), "rb").read() == _all_paths_text(c["paths"]), ci
+        for j in range(p):
+            got = open(os.path.join(d, "gnn-pe", "partitions", f"partition-{j}", "partition_paths.txt"), "rb").read()
+            assert got == _ids_text(c[f"part{j}"]), (ci, j)
+        if world == 1:
+            r = subprocess.run([sys.executable] + args + ["--strict"], capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode != 0 and "duplicate edge" in (r.stderr + r.stdout)
