@@ -846,6 +846,7 @@ int gnnpe_vde_unpack_slab(gnnpe_ctx *c, uint32_t begin, uint32_t end, const void
     c->nbr_vde_valid = false;
     c->ranked_vde_valid = false;
     c->vkey_valid = false;
+    c->vinfo_fused = false;  // (the count kernel's vertex records carried the vde table as it was)
     return GNNPE_OK;
 }
 
@@ -870,6 +871,7 @@ int gnnpe_vde_unpack_all(gnnpe_ctx *c, uint32_t n_ranks, const uint32_t *bounds,
     c->nbr_vde_valid = false;
     c->ranked_vde_valid = false;
     c->vkey_valid = false;
+    c->vinfo_fused = false;  // (the count kernel's vertex records carried the vde table as it was)
     return GNNPE_OK;
 }
 
@@ -965,6 +967,7 @@ static int build_ranked(gnnpe_ctx *c, uint64_t ne)
         // k_vde wrote the per-vertex records when it ran (run_vde) and the slab's pair offsets have not changed since
         const bool vinfo_current = c->vinfo_fused && c->vinfo_gen == c->slab_struct_gen && c->have_vde;
         c->vinfo_fused = false;  // (good for one count: the next gnnpe_vde decides again)
+        if (c->sw.debug) fprintf(stderr, "[count] vertex records: %s\n", vinfo_current ? "written by k_vde" : "k_pack_vinfo");
         // k_start_scan's status words + ticket are zeroed by the row kernel (count_paths passes them through the context)
         uint32_t *clear_words = c->clear_words;
         const uint32_t n_clear = c->n_clear;
@@ -1482,8 +1485,8 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                 uint32_t *sfall = reinterpret_cast<uint32_t *>(sstat + n_sl + 1);   // waves that gave up the look-back (never seen)
                 GNNPE_HIP_TRY(hipMemsetAsync(sstat, 0, ((size_t)n_sl + 2) * 8, c->stream));
 #define GNNPE_L(EE)                                                                                                      \
-    hipLaunchKernelGGL((k_deep3_slices_fused<EE>), dim3((n_sl + 3u) / 4u), dim3(256), 0, c->stream, P, c->upair.as<uint32_t>(), \
-                       c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), uinfo, u_lo, n_u, sfirst, n_sl, sstat, sfall)
+    hipLaunchKernelGGL((k_deep3_slices_fused<EE>), dim3((n_sl + 3u) / 4u), dim3(256), 0, c->stream, P, c->uoff.as<uint64_t>(), uinfo, \
+                       u_lo, n_u, sfirst, n_sl, sstat, sfall)
                 if (fast_e(e)) {
                     GNNPE_BY_E(e, GNNPE_L)
                 } else {

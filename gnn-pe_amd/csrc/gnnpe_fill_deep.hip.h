@@ -995,8 +995,7 @@ __global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32
 constexpr uint32_t kLookbackPolls = 2048;
 constexpr uint32_t kSparseNum = 19, kSparseDen = 20;  // by_vertex below: slices that keep fewer than 0.6 of their candidates
 template <int E>
-__global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const uint32_t *__restrict__ upair,
-                                                            const uint64_t *__restrict__ ufirst, const uint64_t *__restrict__ uoff,
+__global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const uint64_t *__restrict__ uoff,
                                                             const uint4 *__restrict__ uinfo, uint64_t u_lo, uint32_t n_u,
                                                             const uint32_t *__restrict__ sfirst, uint32_t n_slices,
                                                             unsigned long long *__restrict__ status, uint32_t *__restrict__ fallbacks)

@@ -402,8 +402,9 @@ int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
  *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.2-3.3 /
  *        3.3-3.55 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
  *   3    persistent waves that take output tiles in order from ticket counters, three tiles in flight per wave
- *        (k_fill_tickets, e <= 2; other widths: shape 2): 3.9 / 4.1 ms -- measured and never chosen, kept for the A/B
- * The environment variable GNNPE_EMIT=starts|starts_low|tiles|tickets overrides the context's setting (same-process A/B runs). */
+ *        (k_fill_tickets, e <= 2): 3.9 / 4.1 ms -- measured and never chosen.  Since ABI 6 the kernel lives in the diagnostic
+ *        build only (make DIAG=1 diag); the shipped library accepts the value and answers with shape 2
+ * The environment variable GNNPE_EMIT=starts|starts_low|tiles, read when the context is created, overrides the context's setting. */
 int gnnpe_set_emit_shape(gnnpe_ctx *ctx, int shape);
 /* Times the emit shapes 1, 4 and 2 into the caller's output buffers (rows [0, total) of the context's current l=2 count, which
  * must fit rows_cap, the buffers' capacity in rows; three launches each: the buffers are overwritten with the paths) and

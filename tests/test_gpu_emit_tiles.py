@@ -196,3 +196,33 @@ def test_start_vertices_from_ticket_counters(binding, oracle):
     ids, _, _ = eng.fill_paths(pde=False)
     assert np.array_equal(ids, ref)
     eng.close()
+
+
+def test_the_step_is_four_launches_after_the_first():
+    """Round 6: in a steady-state step (vde, count, fill on the same graph / order / slab) k_vde writes the count kernel's per-vertex
+    records itself -- no k_pack_vinfo, no k_x_from_labels launch -- and the clears ride in the neighbouring kernels.  GNNPE_DEBUG=1
+    (read when the context is created) says which path a count took: the first count packs, every later one finds the records."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import numpy as np, torch, gnnpe_amd\n"
+        "from gnnpe_amd import binding, synth\n"
+        "g = synth.gnm_graph(5000, 40000, n_labels=8, seed=4)\n"
+        "eng = binding.Engine(0)\n"
+        "eng.load_csr(g['offsets'], g['nbrs'], g['labels']); eng.set_order(synth.degree_order(g['offsets']), np.zeros(5000, np.uint32), 1)\n"
+        "eng.set_label_table(binding.host_label_table(8, 2))\n"
+        "tot = []\n"
+        "for step in range(3):\n"
+        "    eng.vde(want=False); tot.append(eng.count_paths(2)); ids, pde, _ = eng.fill_paths()\n"
+        "x, nx, vde = eng.vde()\n"
+        "assert len(set(tot)) == 1 and np.array_equal(pde, vde[ids].reshape(len(ids), 6)) and np.array_equal(x, binding.host_label_table(8, 2)[g['labels']])\n"
+        "eng.count_paths(2)\n"
+        "eng.set_slab(100, 4000); eng.vde(want=False); eng.count_paths(2)  # a new slab: the pair offsets are rebuilt, so is the packing\n"
+        "eng.vde(want=False); eng.count_paths(2)\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GNNPE_DEBUG="1"), cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    how = [ln.split(": ")[1] for ln in r.stderr.splitlines() if ln.startswith("[count] vertex records")]
+    # three steps; a count behind the vde that fetched the arrays; the two counts around the new slab
+    assert how == ["k_pack_vinfo", "written by k_vde", "written by k_vde", "written by k_vde", "k_pack_vinfo", "written by k_vde"], how
