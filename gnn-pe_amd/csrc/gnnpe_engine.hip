@@ -1455,6 +1455,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         // slices where hub rows put 10^5 candidates behind one unit; one workgroup per unit (a single kernel) where every
         // unit is a few hundred candidates.  GNNPE_DEEP_EMIT=slices|units overrides (tests run both on the same graphs).
         const bool slices = c->sw.deep_emit == 1 ? true : c->sw.deep_emit == 2 ? false : c->n_hub != 0;
+        const uint32_t sparse_num = (uint32_t)diag_int("GNNPE_DEEP_SPARSE_NUM", kSparseNum);  // (gnnpe_fill_deep.hip.h: kSparseNum)
         if (slices && u_hi > u_lo) {
             // slices (gnnpe_fill_deep.hip.h): units -> slices per unit -> kept rows per slice -> emit, one wave per slice
             GNNPE_REQUIRE(u_hi - u_lo < (1ull << 31), GNNPE_ERR_ARG, "l=3 range covers %llu units; emit in smaller chunks",
@@ -1486,7 +1487,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
                 GNNPE_HIP_TRY(hipMemsetAsync(sstat, 0, ((size_t)n_sl + 2) * 8, c->stream));
 #define GNNPE_L(EE)                                                                                                      \
     hipLaunchKernelGGL((k_deep3_slices_fused<EE>), dim3((n_sl + 3u) / 4u), dim3(256), 0, c->stream, P, c->uoff.as<uint64_t>(), uinfo, \
-                       u_lo, n_u, sfirst, n_sl, sstat, sfall)
+                       u_lo, n_u, sfirst, n_sl, sstat, sfall, sparse_num)
                 if (fast_e(e)) {
                     GNNPE_BY_E(e, GNNPE_L)
                 } else {
@@ -1530,7 +1531,7 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         const unsigned n_blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(u_hi - u_lo, 1u << 20));
 #define GNNPE_LW(EE, WW)                                                                                           \
     hipLaunchKernelGGL((k_deep3<EE, WW>), dim3(n_blocks), dim3(64 * WW), 0, c->stream, P, c->upair.as<uint32_t>(),   \
-                       c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi)
+                       c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), u_lo, u_hi, sparse_num)
 #define GNNPE_L(EE)                                     \
     do {                                                \
         if (c->n_hub) GNNPE_LW(EE, 16); else GNNPE_LW(EE, 4); \

@@ -652,6 +652,11 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
     if (P.out_part && lane < rows) P.out_part[o0 + lane] = P.member[s];
 }
 
+// Where a piece of work rejects candidates (it keeps fewer than kSparseNum / kSparseDen of them) the fourth vertices' embeddings are
+// gathered from the vertex table by id instead of streamed from the per-entry copy (round 6, DESIGN 3.5: 0.62 -> 0.74 of spec on the
+// sparse sampled range of config 5; 0.6 and "always" measured too)
+constexpr uint32_t kSparseNum = 19, kSparseDen = 20;  // (the launches pass the numerator: diagnostic builds sweep it, 0 = never, 21 = always)
+
 // E > 0: compile-time embedding width (divisions by constants); E = 0: runtime P.e
 //
 // One WORKGROUP (WAVES waves) per unit since round 3; round 1 gave a unit to one wave.  On a power-law graph a unit
@@ -667,7 +672,8 @@ __device__ __forceinline__ void deep_emit_rows(const FillParams &P, uint32_t s, 
 template <int E, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32_t *__restrict__ upair,
                                                            const uint64_t *__restrict__ ufirst,
-                                                           const uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end)
+                                                           const uint64_t *__restrict__ uoff, uint64_t u_begin, uint64_t u_end,
+                                                           uint32_t sparse_num)
 {
     // the unit's segment table (first candidate, row start and id of each of its 64 third vertices): built by wave 0, read by
     // every wave; two copies, used alternately, so that wave 0 may build the next unit's table while the others still emit
@@ -741,6 +747,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
         __syncthreads();  // s_piece is rewritten by the next unit
         const uint64_t piece0 = base + running;
         if (mine == 0 || piece0 >= P.end || piece0 + mine <= P.begin) continue;  // (after both barriers: block-uniform control flow above)
+        const bool by_vertex = (uint64_t)mine * kSparseDen < (uint64_t)(q_hi - q_lo) * sparse_num;  // (see kSparseNum)
         running = 0;
         // pass B: flattened candidates of the piece, 64 per step
         for (uint32_t q0 = q_lo; q0 < q_hi; q0 += 64) {
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
                         const uint32_t r = (uint32_t)__popcll(mask & lt);
                         kc[r] = rc[lo];
                         kd[r] = d;
-                        kp[r] = pos;
+                        kp[r] = by_vertex ? d : pos;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_deep3(FillParams P, const uint32
                     const uint32_t r_hi = slot0 + cnt > P.end ? (uint32_t)(P.end - slot0) : cnt;
                     const uint64_t o0 = slot0 + r_lo - P.begin;  // first output row of this step
                     const uint32_t rows = r_hi - r_lo;
-                    deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, rows, o0, lane);
+                    deep_emit_rows<E>(P, s, b, fixed, kc, kd, kp, r_lo, rows, o0, lane, by_vertex ? P.vde : nullptr);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -993,12 +1000,12 @@ __global__ __launch_bounds__(256) void k_deep3_slices(FillParams P, const uint32
 // DEPEND on it: after kLookbackPolls polls without an answer the wave counts the unit's earlier slices itself (their candidates
 // are behind the table it already holds), so no wave can wait for ever.
 constexpr uint32_t kLookbackPolls = 2048;
-constexpr uint32_t kSparseNum = 19, kSparseDen = 20;  // by_vertex below: slices that keep fewer than 0.6 of their candidates
 template <int E>
 __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const uint64_t *__restrict__ uoff,
                                                             const uint4 *__restrict__ uinfo, uint64_t u_lo, uint32_t n_u,
                                                             const uint32_t *__restrict__ sfirst, uint32_t n_slices,
-                                                            unsigned long long *__restrict__ status, uint32_t *__restrict__ fallbacks)
+                                                            unsigned long long *__restrict__ status, uint32_t *__restrict__ fallbacks,
+                                                            uint32_t sparse_num)
 {
     __shared__ uint32_t s_off[4][65], s_st[4][64], s_c[4][64];
     __shared__ uint32_t s_kc[4][64], s_kd[4][64], s_kp[4][64];  // kept rows of one step
@@ -1116,9 +1123,9 @@ __global__ __launch_bounds__(256) void k_deep3_slices_fused(FillParams P, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // pass B: the kept lanes' fourth vertices, one step ahead of the rows being written
     const dbl2 fixed = deep_fixed_piece<E>(P, s, b, lane);
-    // a slice that keeps few of its candidates reads the fourth vertices' embeddings from the vertex table (by id: 256 MB at config 5,
-    // mostly answered by the Infinity Cache) instead of the per-entry copy, of whose lines it would use a fraction
-    const bool by_vertex = (uint64_t)mine * kSparseDen < (uint64_t)(q_hi - q_lo) * kSparseNum;
+    // a slice that rejects candidates reads the fourth vertices' embeddings from the vertex table (by id: 256 MB at config 5, mostly
+    // answered by L2 / Infinity Cache) instead of the per-entry copy, of whose lines it would use a fraction (kSparseNum above)
+    const bool by_vertex = (uint64_t)mine * kSparseDen < (uint64_t)(q_hi - q_lo) * sparse_num;
     uint64_t running = 0;
     auto fetch = [&](uint32_t st, uint64_t &mask, uint32_t &seg, uint32_t &pos, uint32_t &d) {
         mask = msk[st];
