@@ -643,9 +643,9 @@ def main():
                         tiles_ms=round(shapes["tiles_ms"], 3), kept=shapes["kept"],
                         note="gnnpe_emit_calibrate_device: three emit launches timed into the output buffer (host clock around stream "
                              "synchronisations, best of two after a first touch), the fastest kept for it: starts = k_fill_ranked, one "
-                             "wave per start vertex taken in order from ticket counters, resident grid of five workgroups per CU; "
-                             "starts_low = the same at three workgroups per CU; tiles = k_fill_tiles, one wave per 64-row output tile, "
-                             "launch order"),
+                             "wave per start vertex, one-shot in launch order (round 6; rounds 4-5: a resident grid of five workgroups per "
+                             "CU with ticket counters); starts_low = the same kernel as a resident grid of three workgroups per CU, start "
+                             "vertices in order from ticket counters; tiles = k_fill_tiles, one wave per 64-row output tile, launch order"),
                     output_pool=dict(candidates_fill_ms=[round(x, 3) for x in pool_rep["candidates_ms"]], kept=pool_rep["kept"],
                                      probe=pool_rep["probe"],
                                      frac_median_candidate=(peak_bytes / (med_ms / 1e3) / HBM_PEAK_GBS) if med_ms else None,
@@ -665,15 +665,15 @@ def main():
                     step_frac=(global_total * bpp / (ms_per_step / 1e3) / 1e9) / (HBM_PEAK_GBS * world),
                     step_frac_note="the same algorithmic bytes over the whole step (vde + count + scan + fill), per GPU")
 
-    # which kind of allocation the output buffer is: by what the default shape (start-vertex waves, five
-    # workgroups per CU) reaches into it, as a fraction of 8 TB/s -- thresholds from profiles/r05_emit_ab.txt section 7: fast >= 0.80
-    # (2.73-2.83 ms at config 3), between 0.74-0.80 (2.92-3.03), slow below; a slow buffer that takes three workgroups per CU faster
-    # than five is `slow3`, the other kind `slow5`.  Top level so that BENCH records of different boxes compare like with like.
+    # which kind of allocation the output buffer is: by what the default shape (start-vertex waves, one-shot since
+    # round 6) reaches into it, as a fraction of 8 TB/s -- thresholds from profiles/r05_emit_ab.txt section 7 / r06_emit_oneshot.txt: fast
+    # >= 0.80 (2.73-2.83 ms at config 3), between 0.74-0.80 (2.92-3.03), slow below; a slow buffer that takes the resident grid of three
+    # workgroups per CU faster is `slow3`, the other kind `slow5`.  Top level so that BENCH records of different boxes compare like with like.
     emit_class, calibration_ms = None, None
     if shapes is not None and shapes["starts_ms"] > 0:  # (nothing is timed below 2^24 paths or on graphs with hub rows)
         f5 = peak_bytes / (shapes["starts_ms"] / 1e3) / HBM_PEAK_GBS
         emit_class = "fast" if f5 >= 0.80 else "between" if f5 >= 0.74 else ("slow3" if shapes["starts_low_ms"] < shapes["starts_ms"] else "slow5")
-        calibration_ms = dict(starts_5_per_cu=round(shapes["starts_ms"], 3), starts_3_per_cu=round(shapes["starts_low_ms"], 3),
+        calibration_ms = dict(starts_one_shot=round(shapes["starts_ms"], 3), starts_resident_3_per_cu=round(shapes["starts_low_ms"], 3),
                               tiles=round(shapes["tiles_ms"], 3), kept=shapes["kept"])
 
     out = dict(metric="offline paths-embedded/sec + index-build wallclock, 1M-V/10M-E l=2",

@@ -625,9 +625,9 @@ class Engine:
 
     def set_emit_shape(self, shape):
         """0 = whatever gnnpe_emit_calibrate_device measured faster into the buffer (start-vertex waves where nothing was measured),
-        1 = one wave per start vertex (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles), 3 = persistent waves taking
+        1 = one wave per start vertex, one-shot in launch order (k_fill_ranked), 2 = one wave per output tile (k_fill_tiles), 3 = persistent waves taking
         tiles from ticket counters (k_fill_tickets: measured, never chosen -- it lives in diagnostic builds, `make DIAG=1`; the
-        shipped library answers with the tile kernel), 4 = shape 1 held to three workgroups per CU.
+        shipped library answers with the tile kernel), 4 = shape 1's kernel as a resident grid of three workgroups per CU with ticket counters.
         Graphs with hub rows always take the start-vertex kernel."""
         self._ck(self.lib.gnnpe_set_emit_shape(self.ctx, int(shape)))
 
@@ -642,7 +642,7 @@ class Engine:
         return self.lib.gnnpe_emit_kernel_name(self.ctx).decode()
 
     def emit_calibrate_device(self, dev_vids=None, dev_pde=None, rows_cap=None):
-        """Times the emit shapes 1 (start-vertex waves), 4 (the same at three workgroups per CU) and 2 (output tiles) into these
+        """Times the emit shapes 1 (start-vertex waves, one-shot), 4 (the same kernel as a resident grid of three workgroups per CU) and 2 (output tiles) into these
         buffers and keeps the fastest for them: dict(starts_ms, starts_low_ms, tiles_ms, kept, kept_shape).  rows_cap = the
         buffers' capacity in rows (default: the tensors' first dimension)."""
         if rows_cap is None:

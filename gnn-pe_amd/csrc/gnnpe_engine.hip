@@ -1555,7 +1555,14 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
         // 3.65 / 3.59 / 3.51 / 4.40 ms.  So: five (shape 1), or three (shape 4) where gnnpe_emit_calibrate_device measured that
         // faster into the buffer.
         int want_per_cu = e <= 2 ? 5 : 0;
-        // Start vertices from ticket counters, in order (the kernel's comment): 16 heads; GNNPE_RANKED_TICKETS=0 restores the
+        // Round 6, shape 1 is ONE-SHOT: one wave per start vertex, workgroups in launch order, exit -- the launch order keeps the rows
+        // the chip writes at one moment together as the tickets do, without the atomic per start vertex, and a wave that is done does
+        // not wait for the acknowledgement of its stores before it loads again (one counter for loads and stores, completed in issue
+        // order: what made the resident ticket form of the l = 3 emit slower).  Same process, same buffers, eight
+        // allocations (profiles/r06_emit_oneshot.txt): fast class 2.81-2.84 -> 2.73-2.76 ms (0.834-0.842), in between 3.04 -> 2.95,
+        // slow class of the kind that prefers many waves 3.36 -> 3.26; the kind that prefers few keeps the resident grid at three
+        // workgroups per CU (shape 4: 3.17 against 3.29-3.31 either way), so the calibration still times both.
+        // (Shape 4 and diagnostic builds:) start vertices from ticket counters, in order (the kernel's comment): 16 heads; GNNPE_RANKED_TICKETS=0 restores the
         // static assignment w, w + waves, ... for A/B runs.  Same process, same buffers, fast / slow class, five workgroups
         // per CU: 2.77 / 3.46 ms against 2.88 / 3.68; three per CU into the slow class 3.32 against 3.51.
         uint32_t *rk_heads = nullptr;
@@ -1568,12 +1575,17 @@ static int fill_device(gnnpe_ctx *c, uint64_t begin, uint64_t end, void *d_vids,
             plan.pad = (size_t)std::min<long>(48 * 1024, pad_ab);                                                       \
             plan.per_cu = blocks_per_cu_at(reinterpret_cast<const void *>(kern), plan.pad);                             \
         }                                                                                                               \
-        const uint64_t want = ((uint64_t)len + 3) / 4, fit = (uint64_t)plan.per_cu * c->num_cus;                        \
+        /* shape 1 since round 6: ONE-SHOT -- a wave per start vertex, workgroups in launch order, exit; no ticket, no   \
+           occupancy cap (the comment above GNNPE_LK's use).  Shape 4 stays the resident grid at three workgroups per CU.   \
+           GNNPE_FILL_ONESHOT=0 in a diagnostic build restores the resident five-per-CU grid of rounds 4-5 for shape 1 */   \
+        const bool oneshot = want_per_cu != 3 && diag_int("GNNPE_FILL_ONESHOT", 1) != 0;                                \
+        if (oneshot && diag_int("GNNPE_FILL_LDS_PAD", -1) < 0) plan.pad = 0;                                              \
+        const uint64_t want = ((uint64_t)len + 3) / 4, fit = oneshot ? want : (uint64_t)plan.per_cu * c->num_cus;       \
         const dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, fit))), block(kBlock);                           \
-        const uint32_t nh_l = std::min<uint32_t>(rk_nh, grid.x * 4u); /* every head needs a wave that serves it */      \
+        const uint32_t nh_l = oneshot ? 0u : std::min<uint32_t>(rk_nh, grid.x * 4u); /* every head needs a wave that serves it */ \
         if (c->sw.debug)                                                                                                \
-            fprintf(stderr, "[emit] k_fill_ranked: %d workgroups per CU wanted, %d planned, %zu B of dynamic LDS, grid %u, %u ticket heads\n", \
-                    want_per_cu, plan.per_cu, plan.pad, grid.x, nh_l);                                                  \
+            fprintf(stderr, "[emit] k_fill_ranked: %s, %d workgroups per CU wanted, %d planned, %zu B of dynamic LDS, grid %u, %u ticket heads\n", \
+                    oneshot ? "one wave per start vertex in launch order" : "resident grid", want_per_cu, plan.per_cu, plan.pad, grid.x, nh_l); \
         if (nh_l) {                                                                                                     \
             if ((rc = c->tk_ctl.reserve(kStartHeadsBytes + 64))) return rc;                                             \
             if (!c->heads_clean) GNNPE_HIP_TRY(hipMemsetAsync(c->tk_ctl.p, 0, (size_t)nh_l * kStartHeadWords * 4, c->stream)); \

@@ -392,13 +392,14 @@ const char *gnnpe_fill_kernel_name(void);
  *     without a specialised instantiation (e not in {1,2,3,4,8}); selectable as the A/B baseline */
 int gnnpe_set_fill_variant(gnnpe_ctx *ctx, int variant);
 /* Shape of the emit launch of variant 4 (the reference's dfs + gen_pde, custom.h:66-92, 546-572); outputs are identical.
- * Times: BASELINE config 3 into an allocation of the fast / of the slow class, profiles/r05_emit_ab.txt.
+ * Times: BASELINE config 3 into an allocation of the fast / of the slow class, profiles/r05_emit_ab.txt, r06_emit_oneshot.txt.
  *   0    whichever gnnpe_emit_calibrate_device measured fastest into the fill's output buffer; shape 1 for a buffer nobody
  *        calibrated (default)
- *   1    one wave per start vertex, resident grid, five workgroups per CU, start vertices taken in order from ticket
- *        counters, 128 rows staged per flush (k_fill_ranked): 2.73-2.83 / 3.3-3.4 ms
- *   4    the same kernel held to three workgroups per CU: 3.05-3.25 / 3.13-3.6 ms -- the faster one in one kind of slow
- *        allocation (at widths e > 2 there is no occupancy cap: = shape 1)
+ *   1    one wave per start vertex, ONE-SHOT since round 6 -- workgroups in launch order, exit; 128 rows staged per flush
+ *        (k_fill_ranked): 2.73-2.76 / 3.23-3.3 ms (rounds 4-5: a resident grid of five workgroups per CU, start vertices from
+ *        ticket counters: 2.81-2.84 / 3.3-3.4)
+ *   4    the same kernel as a resident grid of three workgroups per CU, start vertices in order from ticket counters:
+ *        3.05-3.25 / 3.13-3.6 ms -- the faster one in one kind of slow allocation (at widths e > 2: natural occupancy)
  *   2    one wave per output tile of 64 rows, workgroups in launch order, one store burst per wave (k_fill_tiles): 3.2-3.3 /
  *        3.3-3.55 ms; graphs with rows longer than 64 still take the start-vertex kernel, which streams such rows
  *   3    persistent waves that take output tiles in order from ticket counters, three tiles in flight per wave
