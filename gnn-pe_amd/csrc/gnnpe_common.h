@@ -155,6 +155,11 @@ struct gnnpe_ctx {
     std::vector<uint64_t> px_bounds, px_points;  // first sorted pair / first point of every partition (p + 1 entries)
     uint64_t count_gen = 0, px_gen = 0;
     bool px_valid = false;  // R6 scratch + the assembled index.dat image
+    // the triple-major order of an l = 3 count (gnnpe_index_deep.hip.h): shares px_recs / px_sorted / px_pref / px_first / px_tmp
+    gnnpe::DevBuf tx_cpre, tx_row_units, tx_toff, tx_padj;
+    std::vector<uint64_t> tx_bounds, tx_points;
+    uint64_t tx_gen = 0, tx_nu = 0;
+    bool tx_valid = false;
     gnnpe::DevBuf px_raux;  // {degree, label} strips beside the row blocks (k_px_raux), valid for one count like the pair order
     bool px_raux_valid = false;
     bool px_raux_compact = false;  // the word rides in the records' id bits (degree | label << px_raux_dbits)

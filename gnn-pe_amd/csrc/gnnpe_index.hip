@@ -911,6 +911,10 @@ __global__ __launch_bounds__(256) void k_px_aux_blocks(uint32_t n_held, const ui
     }
 }
 
+}  // namespace gnnpe
+#include "gnnpe_index_deep.hip.h"
+namespace gnnpe {
+
 // zero the bytes [from, 4096) of every block of the image: the leaf kernel below stores only a leaf's used prefix
 __global__ void k_scrub_tails(char *__restrict__ image, uint64_t n_blocks, uint32_t from)
 {
@@ -2270,6 +2274,194 @@ static int build_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, u
     return GNNPE_OK;
 }
 
+
+// ---- triple-major build (l = 3), host side: gnnpe_index_deep.hip.h ------------------------------------------------------
+// the enumeration state this build reads: the work units and output slots of an l = 3 count, the current vde table
+static bool triple_major_ok(const gnnpe_ctx *c)
+{
+    return c->counted && c->l == 3 && c->counted_variant == 5 && c->have_vde && c->eoff_valid && fast_dim(c->e) &&
+           c->total_paths < (1ull << 40);
+}
+
+// once per count: units sorted by [partition | label(s) | label(b) | label(c) | z(s, b, c)], their records in that order, the
+// prefix of their path counts and every partition's range
+static int build_triple_order(gnnpe_ctx *c)
+{
+    int rc;
+    if ((rc = ensure_vkey(c))) return rc;
+    const uint32_t len = c->slab_end - c->slab_begin, e = c->e, p = c->p, n = c->n;
+    const uint64_t ne = c->n_edges, n_wu = c->n_units;
+    size_t tb = 0;
+    c->tx_valid = false;
+    c->px_valid = false;  // (the buffers below are the pair order's)
+    // 0. pieces of the rows behind every adjacency entry, units of every pair
+    if ((rc = c->tx_cpre.reserve(((size_t)c->nbr_used + 1) * 4)) || (rc = c->tx_row_units.reserve(((size_t)n + 1) * 4)) ||
+        (rc = c->tx_toff.reserve((ne + 2) * 8)))
+        return rc;
+    uint64_t *toff = c->tx_toff.as<uint64_t>();
+    uint64_t nu = 0;
+    if (n)
+        hipLaunchKernelGGL(k_tx_row_pieces, dim3(grid_for((uint64_t)n * 64)), dim3(kBlock), 0, c->stream, n,
+                           c->rows_identity ? (const uint8_t *)nullptr : c->present.as<uint8_t>(), c->adj_start.as<uint32_t>(),
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->tx_cpre.as<uint32_t>(), c->tx_row_units.as<uint32_t>());
+    hipLaunchKernelGGL(k_tx_pair_units, dim3(grid_for(ne + 1)), dim3(kBlock), 0, c->stream, ne, c->pnbr.as<uint32_t>(),
+                       c->tx_row_units.as<uint32_t>(), toff);
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, toff, toff, (int64_t)(ne + 1), c->stream));
+    if ((rc = c->cub_tmp.reserve(tb))) return rc;
+    tb = c->cub_tmp.bytes;
+    GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, toff, toff, (int64_t)(ne + 1), c->stream));
+    GNNPE_HIP_TRY(hipMemcpyAsync(&nu, toff + ne, 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    GNNPE_REQUIRE(nu < (1ull << 31), GNNPE_ERR_RANGE, "%llu sort units exceed the 32-bit unit ids", (unsigned long long)nu);
+    // scratch layout (px_tmp): start sort {part_in, part_out, idx_in, idx_out: u32 x len}, counts / positions / pbase {u64 x (len + 2)},
+    // unit keys {u64 x (nu + 1) x 2}, unit values {u32 x (nu + 1) x 2}, device bounds {u64 x 2 (p + 1)}
+    const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
+                 o_pos = o_cnt + ((size_t)len + 2) * 8, o_pb = o_pos + ((size_t)len + 2) * 8, o_keys = o_pb + ((size_t)len + 2) * 8,
+                 o_vals = o_keys + (nu + 1) * 16, o_bnd = o_vals + (nu + 1) * 8, o_end = o_bnd + ((size_t)p + 2) * 16;
+    if ((rc = c->px_tmp.reserve(o_end + 64)) || (rc = c->px_recs.reserve((nu + 1) * sizeof(TripX))) ||
+        (rc = c->px_sorted.reserve((nu + 1) * sizeof(TripX))) || (rc = c->px_pref.reserve((nu + 2) * 8)) ||
+        (rc = c->tx_padj.reserve(((size_t)len + 1) * 8)))
+        return rc;
+    char *tmp = c->px_tmp.as<char>();
+    uint32_t *part_in = reinterpret_cast<uint32_t *>(tmp + o_part), *part_out = part_in + len + 1;
+    uint32_t *idx_in = reinterpret_cast<uint32_t *>(tmp + o_idx), *idx_out = idx_in + len + 1;
+    uint64_t *cnt = reinterpret_cast<uint64_t *>(tmp + o_cnt), *pos = reinterpret_cast<uint64_t *>(tmp + o_pos);
+    uint64_t *pbase = reinterpret_cast<uint64_t *>(tmp + o_pb);
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(tmp + o_vals), *v_out = v_in + nu + 1;
+    uint64_t *d_bounds = reinterpret_cast<uint64_t *>(tmp + o_bnd);
+    const uint32_t *poffs = c->poffs.as<uint32_t>();
+    const uint64_t *eoff = c->eoff.as<uint64_t>();
+    // 1. partition-local index of every start vertex' first path (minus its first output slot)
+    if (len && p > 1) {
+        hipLaunchKernelGGL(k_tx_start_parts, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, c->slab_begin, c->sorted.as<uint32_t>(),
+                           c->member.as<uint32_t>(), part_in, idx_in);
+        const int pb = (int)std::max(1u, bits_for(p));
+        tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, part_in, part_out, idx_in, idx_out, (int)len, 0, pb, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, part_in, part_out, idx_in, idx_out, (int)len, 0, pb, c->stream));
+        hipLaunchKernelGGL(k_tx_sorted_counts, dim3(grid_for((uint64_t)len + 1)), dim3(kBlock), 0, c->stream, len, poffs, eoff, idx_out, cnt);
+        tb = 0;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, pos, (int64_t)len + 1, c->stream));
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;
+        tb = c->cub_tmp.bytes;
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, cnt, pos, (int64_t)len + 1, c->stream));
+        hipLaunchKernelGGL(k_px_pbase, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, part_out, idx_out, pos, pbase);
+    }
+    if (len)
+        hipLaunchKernelGGL(k_tx_padj, dim3(grid_for(len)), dim3(kBlock), 0, c->stream, len, poffs, eoff,
+                           p > 1 ? pbase : (const uint64_t *)nullptr, c->tx_padj.as<int64_t>());
+    // 2. unit records + keys, sorted, gathered, scanned
+    const uint32_t lb = c->vkey_lb, zbits = c->vkey_zb * 3 * e, shift = 3 * lb + zbits, kbits = bits_for(p) + shift;
+    GNNPE_REQUIRE(kbits <= 64, GNNPE_ERR_UNSUPPORTED, "triple key needs %u bits", kbits);
+    TripX *recs = c->px_recs.as<TripX>(), *sorted = c->px_sorted.as<TripX>();
+    uint64_t *pref = c->px_pref.as<uint64_t>();
+#define GNNPE_TX_SORT(KT)                                                                                                   \
+    do {                                                                                                                    \
+        KT *k_in = reinterpret_cast<KT *>(tmp + o_keys), *k_out = k_in + nu + 1;                                            \
+        hipLaunchKernelGGL((k_tx_fill_empty<KT>), dim3(grid_for(nu)), dim3(kBlock), 0, c->stream, nu, (KT)((uint64_t)p << shift), k_in, v_in); \
+        hipLaunchKernelGGL((k_tx_units<KT>), dim3((unsigned)((n_wu + 3) / 4)), dim3(256), 0, c->stream, n_wu, c->upair.as<uint32_t>(), \
+                           c->ufirst.as<uint64_t>(), c->uoff.as<uint64_t>(), c->erow.as<uint32_t>(), c->pnbr.as<uint32_t>(),  \
+                           c->sorted.as<uint32_t>(), c->slab_begin, c->member.as<uint32_t>(), c->adj_start.as<uint32_t>(),     \
+                           c->adj_deg.as<uint32_t>(), c->nbrs.as<uint32_t>(), c->nbr_rank.as<uint32_t>(), c->rank.as<uint32_t>(), \
+                           c->tx_cpre.as<uint32_t>(), toff, c->tx_padj.as<int64_t>(), c->vkey.as<uint64_t>(), e, lb, zbits, recs, k_in); \
+        tb = 0;                                                                                                             \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                       \
+        tb = c->cub_tmp.bytes;                                                                                              \
+        GNNPE_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(c->cub_tmp.p, tb, k_in, k_out, v_in, v_out, (int)nu, 0, (int)kbits, c->stream)); \
+        hipLaunchKernelGGL((k_tx_gather<KT>), dim3(grid_for(nu + 1)), dim3(kBlock), 0, c->stream, nu, p, shift, k_out, v_out, recs, sorted, pref); \
+        tb = 0;                                                                                                             \
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, pref, pref, (int64_t)(nu + 1), c->stream));             \
+        if ((rc = c->cub_tmp.reserve(tb))) return rc;                                                                       \
+        tb = c->cub_tmp.bytes;                                                                                              \
+        GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, pref, pref, (int64_t)(nu + 1), c->stream));        \
+        hipLaunchKernelGGL((k_px_bounds<KT>), dim3(((p + 1) + 63) / 64), dim3(64), 0, c->stream, nu, p, (const KT *)k_out, shift, pref, d_bounds); \
+    } while (0)
+    GNNPE_REQUIRE(n_wu < (1ull << 33), GNNPE_ERR_RANGE, "too many work units for one launch");
+    if (nu && n_wu) {
+        if (kbits <= 32) GNNPE_TX_SORT(uint32_t); else GNNPE_TX_SORT(uint64_t);
+    } else {
+        GNNPE_HIP_TRY(hipMemsetAsync(pref, 0, 16, c->stream));
+        GNNPE_HIP_TRY(hipMemsetAsync(d_bounds, 0, 2 * ((size_t)p + 1) * 8, c->stream));
+    }
+#undef GNNPE_TX_SORT
+    GNNPE_HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> both(2 * ((size_t)p + 1));
+    GNNPE_HIP_TRY(hipMemcpyAsync(both.data(), d_bounds, both.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tx_bounds.assign(both.begin(), both.begin() + p + 1);
+    c->tx_points.assign(both.begin() + p + 1, both.end());
+    c->tx_nu = nu;
+    c->tx_valid = true;
+    c->tx_gen = c->count_gen;
+    return GNNPE_OK;
+}
+
+static int build_triple_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8])
+{
+    int rc;
+    if (!(c->tx_valid && c->tx_gen == c->count_gen) && (rc = build_triple_order(c))) return rc;
+    const uint64_t r0 = c->tx_bounds[pid], r1 = c->tx_bounds[pid + 1], cnt = c->tx_points[pid + 1] - c->tx_points[pid];
+    GNNPE_REQUIRE(cnt < (1ull << 31), GNNPE_ERR_RANGE, "index over %llu entries exceeds the format's int32 counts", (unsigned long long)cnt);
+    const uint32_t e = c->e, D = 4 * e;
+    const uint32_t F = index_fanout(D);
+    c->img_aux_valid = false;
+    if (cnt == 0) {  // the reference's empty tree
+        LeafSrc S = {nullptr, c->vde.as<double>(), nullptr, 4, e, D};
+        return build_image(c, 0, S, dev_image, nbytes, hdr_out);
+    }
+    std::vector<uint64_t> level_n;
+    const uint64_t n_nodes = plan_levels(cnt, F, level_n);
+    GNNPE_REQUIRE(n_nodes < (1ull << 31), GNNPE_ERR_RANGE, "too many index nodes");
+    const uint64_t image_bytes = (n_nodes + 1) * (uint64_t)kBlockLen;
+    uint64_t max_level = 0;
+    for (uint64_t v : level_n) max_level = std::max(max_level, v);
+    if ((rc = reserve_image(c, image_bytes)) || (rc = c->px_first.reserve((level_n[0] + 1) * 4)) ||
+        (rc = c->idx_mbr.reserve(2 * max_level * 2 * D * 8)))
+        return rc;
+    char *image = c->index_image.as<char>();
+    // the leaf kernel stores a leaf's used prefix only (see build_partition_image)
+    const uint32_t tail_from = (5 + F * (16 * D + 4) + 15) / 16 * 16;
+    if (c->img_scrub_ptr != image || c->img_scrub_bytes != c->index_image.bytes || c->img_scrub_from != tail_from) {
+        if (tail_from < (uint32_t)kBlockLen)
+            hipLaunchKernelGGL(k_scrub_tails, dim3(kMaxGrid), dim3(kBlock), 0, c->stream, image, (uint64_t)(c->index_image.bytes / kBlockLen),
+                               tail_from);
+        c->img_scrub_ptr = image;
+        c->img_scrub_bytes = c->index_image.bytes;
+        c->img_scrub_from = tail_from;
+    }
+    double *mbr_a = c->idx_mbr.as<double>(), *mbr_b = mbr_a + max_level * 2 * D;
+    GNNPE_HIP_TRY(hipMemsetAsync(image, 0, kBlockLen, c->stream));
+    int32_t hdr[8] = {kBlockLen, (int32_t)n_nodes, (int32_t)D, (int32_t)cnt, (int32_t)level_n[0], (int32_t)(n_nodes - level_n[0]), 0,
+                      (int32_t)(n_nodes - 1)};
+    const uint64_t nl = level_n[0];
+    hipLaunchKernelGGL(k_px_leaf_first, dim3(grid_for(r1 - r0)), dim3(kBlock), 0, c->stream, nl, F, r0, r1, c->px_pref.as<uint64_t>(),
+                       c->px_first.as<uint32_t>());
+    GNNPE_REQUIRE((nl + kLeafWaves - 1) / kLeafWaves < (1ull << 31), GNNPE_ERR_UNSUPPORTED, "too many leaves for one launch");
+    const uint32_t g = (uint32_t)((nl + kLeafWaves - 1) / kLeafWaves);
+#define GNNPE_TXL(EE)                                                                                                     \
+    hipLaunchKernelGGL((k_tx_leaves<EE>), dim3(g), dim3(64 * kLeafWaves), 0, c->stream, cnt, nl, r1, c->tx_points[pid],    \
+                       c->px_pref.as<uint64_t>(), c->px_first.as<uint32_t>(), c->px_sorted.as<TripX>(), c->nbrs.as<uint32_t>(), \
+                       c->vde.as<double>(), image, mbr_a)
+    switch (e) {
+    case 1: GNNPE_TXL(1); break;
+    case 2: GNNPE_TXL(2); break;
+    case 3: GNNPE_TXL(3); break;
+    case 4: GNNPE_TXL(4); break;
+    default: GNNPE_TXL(8); break;
+    }
+#undef GNNPE_TXL
+    GNNPE_HIP_TRY(hipGetLastError());
+    if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
+    if ((rc = write_header(c, image, hdr))) return rc;
+    *dev_image = image;
+    *nbytes = image_bytes;
+    if (hdr_out) memcpy(hdr_out, hdr, sizeof(hdr));
+    return GNNPE_OK;
+}
+
 int gnnpe_write_device_file(gnnpe_ctx *c, const void *dev_src, uint64_t nbytes, const char *path)
 {
     GNNPE_REQUIRE(c && path && (dev_src || !nbytes), GNNPE_ERR_ARG, "gnnpe_write_device_file: null argument");
@@ -2341,8 +2533,10 @@ static int build_partition(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_
     c->img_aux_valid = false;
     if (pair_major_ok(c)) {
         rc = build_partition_image(c, pid, dev_image, nbytes, hdr_out, with_aux && fused_aux_ok(c));
+    } else if (triple_major_ok(c)) {
+        rc = build_triple_partition_image(c, pid, dev_image, nbytes, hdr_out);
     } else {
-        // l = 3 or the generic enumeration: the partition's tuples, then the tuple-array build
+        // the generic enumeration (embedding widths without a specialised kernel): the partition's tuples, then the tuple-array build
         DevBuf mine;
         uint64_t cnt = 0;
         rc = collect_partition_tuples(c, pid, mine, &cnt);

@@ -171,6 +171,81 @@ def test_pair_major_partition_images(oracle, e, p):
     eng.close()
 
 
+
+# ---- l = 3: the triple-major build (gnnpe_index_deep.hip.h) --------------------------------------------------------------
+@pytest.mark.parametrize("e,p", [(2, 1), (2, 3), (1, 2), (3, 1), (4, 2), (8, 1), (8, 3)])
+def test_triple_major_partition_images(oracle, e, p):
+    """l = 3 on a hub-free graph: gnnpe_build_index_partition_device sorts the (s, b, c) triples and reads the fourth vertices
+    out of c's adjacency row through the unit's kept mask.  Same contract as the pair-major build one level up: every consumer
+    constraint holds, every 4-vertex path of the partition is a leaf entry exactly once with son = its index inside the
+    partition (custom.h:243) and lo = hi = its pde row (custom.h:244-248), bit for bit; leaves hold capacity - 1 entries."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(1500, 9000, n_labels=5, seed=11 + e)
+    assert np.diff(g["offsets"].astype(np.int64)).max() <= 64
+    rng = np.random.default_rng(100 + e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(3)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(ref) > 100_000
+    D = 4 * e
+    F = min((4096 - 5) // (16 * D + 4) - 1, 64)
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["dim"] == D and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
+        assert d["dnodes"] == -(-len(mine) // F)  # (the tuple-array build fills to capacity - 2: this is the triple-major one)
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), D))
+    # leaves are triple-major: left to right, the labels of (s, b, c) never decrease
+    mine = _partition_paths(ref, mem, 0)
+    d = oracle.index_validate(eng.copy_to_host(*eng.build_index_partition_device(0)[:2]).tobytes())
+    lab = g["labels"].astype(np.int64)[mine[d["leaf_son"]]]
+    assert np.all(np.diff((lab[:, 0] * 5 + lab[:, 1]) * 5 + lab[:, 2]) >= 0)
+    # a second count (another order) rebuilds the unit order: same contract
+    sn2 = rng.permutation(g["n"]).astype(np.uint32)
+    eng.set_order(sn2, mem, p)
+    eng.vde()
+    assert eng.count_paths(3) == total
+    ref2 = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn2, 4)
+    mine = _partition_paths(ref2, mem, p - 1)
+    d = oracle.index_validate(eng.copy_to_host(*eng.build_index_partition_device(p - 1)[:2]).tobytes())
+    order = np.argsort(d["leaf_son"], kind="stable")
+    assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+    assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), D))
+    eng.close()
+
+
+@pytest.mark.parametrize("e,p", [(2, 2), (8, 1)])
+def test_triple_major_power_law_partitions(oracle, e, p):
+    """l = 3 on a power-law graph: third vertices with rows of more than a hundred entries are cut into units of 64 row entries (one
+    kept mask each), units of one triple spread over many leaves, and a work unit of the enumeration mixes hub and ordinary
+    third vertices.  Per partition the leaf entries are exactly its paths."""
+    from gnnpe_amd import binding
+    g = synth.powerlaw_graph(800, 2500, exponent=2.1, max_degree=250, n_labels=4, seed=9)
+    assert np.diff(g["offsets"].astype(np.int64)).max() > 128  # (rows of three pieces)
+    rng = np.random.default_rng(7 + e)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, e)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(3)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(ref) > 100_000
+    for pid in range(p):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert d["num_data"] == len(mine) and np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), 4 * e))
+    eng.close()
+
+
 def test_index_build_is_deterministic_across_builds_and_counts():
     """The image and the auxiliary arrays of a power-law graph (hub units included): a second build is the first, byte for byte,
     and so is the build after a new count (the pair order is sorted again -- to the same order)."""

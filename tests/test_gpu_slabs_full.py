@@ -15,6 +15,7 @@ sharing device 0, each with its own engine context and stream, their collectives
 (dist.ThreadRanks); with >= 2 GPUs visible the RCCL tests at the bottom run the same code over xGMI, one process per GPU.
 """
 import json
+import time
 import os
 import socket
 import subprocess
@@ -129,11 +130,14 @@ def test_config4_work_balanced_slabs(tmp_path):
 
 
 def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
+    t_start = time.time()
     g = synth.powerlaw_graph(4_000_000, 64_000_000, exponent=2.1, max_degree=3000)
     gp = _save(tmp_path, g)
     sample = 1 << 22
     out8 = str(tmp_path / "w8")
+    t_gen = time.time()
     _run(8, ["--graph", gp, "--out", out8, "-l", "3", "-e", "8", "--sample", str(sample)], timeout=2400)
+    t_w8 = time.time()
     res = _results(out8, 8)
     total8 = sum(r["total"] for r in res)
     ranges = [[r["base"], r["base"] + r["emitted"]] for r in res]
@@ -142,6 +146,8 @@ def test_config5_4m_64m_powerlaw_l3_e8(tmp_path):
     # checker that is not the engine (--oracle-l3, below)
     _run(1, ["--graph", gp, "--out", out1, "-l", "3", "-e", "8", "--ranges", json.dumps(ranges), "--oracle-l3", "1"], timeout=2400)
     one = _results(out1, 1)[0]
+    print(f"config 5: graph {t_gen - t_start:.1f} s, eight ranks {t_w8 - t_gen:.1f} s, one rank + oracle {time.time() - t_w8:.1f} s "
+          f"(oracle count {one['oracle_l3']['oracle_count_s']} s, ranges {[r['seconds'] for r in one['oracle_l3']['ranges']]})")
     assert one["total"] == total8 == res[0]["global_total"] and total8 > 10 ** 13
     # the independent count: 4-vertex simple paths in closed form, sum_E (du-1)(dv-1) - 3 T, by the oracle's
     # OpenMP triangle count -- pinned against the fixed-depth DFS on small graphs (tests/test_oracle_golden.py); computed by the
