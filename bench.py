@@ -303,6 +303,40 @@ def config5_leg(torch, stream, local_rank, labels, seed):
                        "computed by the oracle at full size (tests/test_gpu_slabs_full.py::test_config5_4m_64m_powerlaw_l3_e8)")
 
 
+def index_l3_leg(torch, stream, local_rank, labels, l2_ms_per_gb):
+    """R6 at l = 3: the triple-major index build (csrc/gnnpe_index_deep.hip.h) on two graphs whose partition image
+    is the size of config 3's (22-26 GB): e = 2 (29 entries of 132 bytes per leaf) and config 5's e = 8 (six entries of 516 bytes), per
+    byte of image beside the l = 2 pair-major build of the same run."""
+    rows = []
+    for n, m, e in ((70_000, 600_000, 2), (40_000, 220_000, 8)):
+        g = synth.gnm_graph(n, m, n_labels=labels)
+        eng = binding.Engine(local_rank, stream=stream.cuda_stream)
+        eng.load_csr(g["offsets"], g["nbrs"], g["labels"])
+        eng.set_order(synth.degree_order(g["offsets"]), np.zeros(g["n"], np.uint32), 1)
+        eng.set_label_table(binding.host_label_table(labels, e))
+        eng.vde(want=False)
+        full, cached = [], []
+        for _ in range(3):
+            total = eng.count_paths(3)
+            for dst in (full, cached):  # the first build of a count sorts the units, the second reuses their order
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                _, nbytes, hdr = eng.build_index_partition_device(0)
+                ev1.record()
+                torch.cuda.synchronize()
+                dst.append(ev0.elapsed_time(ev1))
+        eng.close()
+        gb = nbytes / 1e9
+        rows.append(dict(workload=f"G({n}, {m}), l=3, e={e}, p=1", points=total, file_bytes=nbytes, leaves=hdr[4],
+                         wallclock_ms=min(full[1:]), next_partition_ms=min(cached[1:]), ms_per_gb=min(full[1:]) / gb,
+                         per_byte_vs_l2=(min(full[1:]) / gb) / l2_ms_per_gb if l2_ms_per_gb else None))
+    return dict(builds=rows, builder="triple-major: units (s, b, c) x 64-entry pieces of c's row sorted by the 3-vertex key, one wave per leaf "
+                                     "(k_tx_units, radix sort, k_tx_gather, k_tx_leaves, k_tx_inner)",
+                note="per_byte_vs_l2 = (wallclock_ms / image GB) over the same ratio of index_build (the l = 2 pair-major build of this run); "
+                     "until round 6 an l = 3 context took the tuple-array build (index_build.tuple_array_build_ms per 22 GB, after emitting the "
+                     "enumeration twice to collect the partition's tuples)")
+
+
 def e2e_leg(g, sn, p, index, label, allow_large=False):
     """Wall-clock of `gnnpe_main -m offline` on text inputs (load + emit + render + file writes [+ index.dat])."""
     free = shutil.disk_usage(tempfile.gettempdir()).free
@@ -778,6 +812,8 @@ def main():
                                                   "process: hipMalloc of 24 GB right after 130 GB of candidates were freed waits for the driver "
                                                   "to reclaim them (38 ms when the pool drew 8, seconds after 12)",
                                   reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
+        if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw and not args.no_config5:
+            out["index_build"]["l3"] = index_l3_leg(torch, stream, local_rank, args.labels, min(ib[1:]) / (nbytes / 1e9))
     # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
     if legs and e == 2:

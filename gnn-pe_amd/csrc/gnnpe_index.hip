@@ -2454,7 +2454,28 @@ static int build_triple_partition_image(gnnpe_ctx *c, uint32_t pid, void **dev_i
     }
 #undef GNNPE_TXL
     GNNPE_HIP_TRY(hipGetLastError());
-    if ((rc = pack_upper_levels(c, level_n, F, D, image, mbr_a, mbr_b))) return rc;
+    // the upper levels: one launch per level, parents packed from consecutive children (k_tx_inner: the entries spread over the lanes)
+    {
+        uint64_t child0 = 0, node0 = level_n[0];
+        for (size_t lv = 1; lv < level_n.size(); lv++) {
+            const uint32_t gi = (uint32_t)((level_n[lv] + kLeafWaves - 1) / kLeafWaves);
+#define GNNPE_TXI(EE)                                                                                                      \
+    hipLaunchKernelGGL((k_tx_inner<EE>), dim3(gi), dim3(64 * kLeafWaves), 0, c->stream, level_n[lv], level_n[lv - 1], child0, node0, (int)lv, \
+                       (const double *)mbr_a, image, mbr_b)
+            switch (e) {
+            case 1: GNNPE_TXI(1); break;
+            case 2: GNNPE_TXI(2); break;
+            case 3: GNNPE_TXI(3); break;
+            case 4: GNNPE_TXI(4); break;
+            default: GNNPE_TXI(8); break;
+            }
+#undef GNNPE_TXI
+            std::swap(mbr_a, mbr_b);
+            child0 = node0;
+            node0 += level_n[lv];
+        }
+        GNNPE_HIP_TRY(hipGetLastError());
+    }
     if ((rc = write_header(c, image, hdr))) return rc;
     *dev_image = image;
     *nbytes = image_bytes;

@@ -409,4 +409,78 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
     }
 }
 
+// Inner node j of a level for the wide entries of l = 3 (D = 4E: at E = 8 a node holds six entries of 516 bytes).  k_pack_inner gives a
+// lane a whole child entry -- six busy lanes of 64 and a DPP reduction per dimension: 3.4 ms for the 0.74 M level-1 nodes of a 22 GB
+// image, three quarters of the leaf kernel's time.  Here the node's ne x D (lo, hi) pairs are spread over all lanes (one 16-byte load and
+// four window dwords each), the node's own box is a column scan of the window like a leaf's, and only the used prefix is stored.
+// One wave per node, workgroups in launch order.
+template <int E>
+__global__ __launch_bounds__(64 * kLeafWaves) void k_tx_inner(uint64_t n_nodes, uint64_t n_child, uint64_t child0, uint64_t node0, int level,
+                                                              const double *__restrict__ child_mbr, char *__restrict__ image,
+                                                              double *__restrict__ node_mbr)
+{
+    constexpr int D = 4 * E, F = (int)index_fanout(D), kEnt = 4 * D + 1;
+    constexpr int kWin = kBlockLen / 4 + 4;
+    constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;
+    constexpr int kRounds = (F * D + 63) / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv;
+    if (j >= n_nodes) return;
+    uint32_t *w = s_win[wv];
+    const uint64_t c0 = j * (uint64_t)F;
+    const uint32_t ne = (uint32_t)min((uint64_t)F, n_child - c0);
+    const uint32_t n_pair = ne * (uint32_t)D;
+    const uint4 *src = reinterpret_cast<const uint4 *>(child_mbr + c0 * 2 * D);  // (lo, hi) pairs of the node's children, consecutive
+    uint4 v[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) v[r] = src[min(lane + 64u * r, n_pair - 1u)];
+    if (lane == 0) {
+        w[0] = (uint32_t)level << 24;  // byte 3 of the window = byte 0 of the block
+        w[1] = ne;
+    }
+    if (lane < ne) w[2 + lane * kEnt + 4 * D] = (uint32_t)(child0 + c0 + lane);  // the child's block id
+    for (uint32_t t = 2u + ne * kEnt + lane; t < (uint32_t)(4 * kStoreU4 + 1); t += 64) w[t] = 0u;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const uint32_t t = lane + 64u * r;
+        if (t < n_pair) {
+            uint32_t *o = w + 2 + (t / (uint32_t)D) * kEnt + 4 * (t % (uint32_t)D);
+            o[0] = v[r].x;
+            o[1] = v[r].y;
+            o[2] = v[r].z;
+            o[3] = v[r].w;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < (unsigned)D) {
+        double lo = 1e300, hi = -1e300;
+        for (uint32_t i = 0; i < ne; i++) {
+            const uint32_t *p = w + 2 + i * kEnt + 4 * lane;
+            lo = fmin(lo, __longlong_as_double((long long)(((uint64_t)p[1] << 32) | p[0])));
+            hi = fmax(hi, __longlong_as_double((long long)(((uint64_t)p[3] << 32) | p[2])));
+        }
+        node_mbr[(j * D + lane) * 2] = lo;
+        node_mbr[(j * D + lane) * 2 + 1] = hi;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(image + (node0 + j + 1) * (uint64_t)kBlockLen);
+#pragma unroll
+    for (int r = 0; r < (kStoreU4 + 63) / 64; r++) {
+        const int cidx = (int)lane + 64 * r;
+        if (cidx < kStoreU4) {
+            const uint4 lo4 = *reinterpret_cast<const uint4 *>(w + 4 * cidx);
+            const uint32_t nx = w[4 * cidx + 4];
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 o;
+            o.x = (lo4.x >> 24) | (lo4.y << 8);
+            o.y = (lo4.y >> 24) | (lo4.z << 8);
+            o.z = (lo4.z >> 24) | (lo4.w << 8);
+            o.w = (lo4.w >> 24) | (nx << 8);
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst + cidx));
+        }
+    }
+}
+
 }  // namespace gnnpe

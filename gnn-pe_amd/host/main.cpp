@@ -438,8 +438,9 @@ int main(int argc, char **argv)
     for (uint32_t i = 0; i < g.n; i++) part_count[membership[sorted_nodes[i]]] += per_start[i];
     if (o.write_index) {  // before anything is written
         const std::string big = index_size_problem(part_count, P, (o.path_length + 1) * o.vde_dim,
-                                                   // the pair-major build exists for l = 2 at the widths with a specialised enumeration; else the tuple-array build
-                                                   (o.path_length == 2 && (o.vde_dim <= 4 || o.vde_dim == 8)) ? 0 : 1);
+                                                   // the pair-major (l = 2) and triple-major (l = 3) builds exist at the widths with a specialised
+                                                   // enumeration; else the tuple-array build
+                                                   (o.vde_dim <= 4 || o.vde_dim == 8) ? 0 : 1);
         if (!big.empty() && !o.allow_large) die(big + " (use --allow-large to write the files anyway)");
         if (!big.empty()) fprintf(stderr, "%s: warning: %s\n", o.tool, big.c_str());
         {

@@ -264,7 +264,9 @@ int gnnpe_build_index_device(gnnpe_ctx *ctx, uint64_t cnt, uint32_t L, const voi
 /* The image of partition `pid` straight from the enumeration state of the context (after gnnpe_vde + gnnpe_count_paths):
  * no tuple array.  For an l = 2 count the tree is built pair-major -- the (s, b) pairs (hub pairs: their 64-entry units)
  * are sorted by [label(s) | label(b) | z-order of vde[s], vde[b]] and the leaves read their points out of the pairs' row
- * blocks -- otherwise (l = 3, generic enumeration kernel) the partition's tuples are collected and handed to
+ * blocks; for an l = 3 count triple-major (round 6, csrc/gnnpe_index_deep.hip.h) -- the (s, b, c) triples x 64-entry pieces of
+ * c's row, each with the mask of its kept fourth vertices, sorted by [label(s) | label(b) | label(c) | z-order of their vde] --
+ * otherwise (embedding widths without a specialised enumeration) the partition's tuples are collected and handed to
  * gnnpe_build_index_device.  Same file format, same
  * consumer constraints; the image stays valid until the next index call on the context. */
 int gnnpe_build_index_partition_device(gnnpe_ctx *ctx, uint32_t pid, void **dev_image, uint64_t *nbytes, int32_t hdr_out[8]);
@@ -416,7 +418,7 @@ int gnnpe_set_emit_shape(gnnpe_ctx *ctx, int shape);
  * gnnpe_output_pool_create calibrates the buffer it keeps unless told not to. */
 int gnnpe_emit_calibrate_device(gnnpe_ctx *ctx, uint64_t rows_cap, void *dev_vids, void *dev_pde, float *ms_by_shape, int *shape_kept);
 /* Bytes of the index.dat a partition of `points` paths of dimension D becomes (header block + one 4 KiB block per node of the
- * bulk-loaded tree; rtnode.cpp:27-28, blk_file.cpp:38-52), by the builder that writes it: 0 = the pair-major build behind
+ * bulk-loaded tree; rtnode.cpp:27-28, blk_file.cpp:38-52), by the builder that writes it: 0 = the pair-major / triple-major build behind
  * gnnpe_build_index / gnnpe_build_index_partition_device (nodes of min(capacity - 1, 64) entries), 1 = the tuple-array build
  * gnnpe_build_index_device (min(capacity - 2, 64): what the multi-GPU path uses).  No GPU, no context: callers check the
  * reference's 2 GiB limit (blk_file.h:32-33) BEFORE anything is built or written.  0 for a dimension no node holds. */

@@ -277,15 +277,28 @@ def test_l3_files_match_the_oracle_writers(tmp_path, oracle, gpus):
     gp = str(tmp_path / "g.graph")
     synth.write_graph_file(gp, g)
     r = subprocess.run([CLI, "-f", d + "/", "-d", gp, "-p", "3", "-l", "3", "--chunk", "5000", "--gpus", str(gpus),
-                        "--same-device"], capture_output=True, text=True)
+                        "--same-device", "--index"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     want = oracle.enumerate_dfs_hash(g["offsets"], g["nbrs"], sn, 4)
     assert open(os.path.join(d, "gnn-pe", "all_paths.txt"), "rb").read() == oracle.format_all_paths(want)
+    from gnnpe_amd import binding
+    vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)[2]  # (-e defaults to 2, main.cpp:30)
+    lib = binding.load()
     for pid in range(3):
         exp = str(tmp_path / f"exp{pid}.txt")
         oracle.write_partition_paths(exp, want, mem, pid)
         got = os.path.join(d, "gnn-pe", "partitions", f"partition-{pid}", "partition_paths.txt")
         assert open(got, "rb").read() == open(exp, "rb").read()
+        # index.dat of the partition (--index; l = 3: the triple-major build): every path once, son = its line in partition_paths.txt,
+        # lo = hi = its pde row; the file is the size the CLI's guard computed before writing
+        mine = want[mem[want[:, 0]] == pid]
+        raw = open(os.path.join(d, "gnn-pe", "partitions", f"partition-{pid}", "index.dat"), "rb").read()
+        # (one context: triple-major, nodes of capacity - 1 entries; --gpus N: the ranks hand tuple arrays to the tuple-array build)
+        assert len(raw) == lib.gnnpe_index_file_bytes(len(mine), 8, 0 if gpus == 1 else 1)
+        dd = oracle.index_validate(raw)
+        order = np.argsort(dd["leaf_son"], kind="stable")
+        assert dd["num_data"] == len(mine) and np.array_equal(dd["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(dd["leaf_pt"][order], vde[mine].reshape(len(mine), 8))
 
 
 @pytest.mark.parametrize("p,method", [(2, "lp"), (5, "lp"), (3, "bfs")])
