@@ -15,15 +15,31 @@ SEED = 2022  # the reference's own seed (gnnpe.py:14)
 
 
 def _csr_from_edges(n, eu, ev):
-    """Undirected simple edge list (u<v) -> CSR with ascending neighbour lists
-    (what graph.cpp:211-233 builds from `e u v` lines)."""
-    # one sort of the combined key src * n + dst (the edges are distinct, so this is the (src, dst) lexicographic order)
-    key = np.concatenate([eu.astype(np.int64) * n + ev, ev.astype(np.int64) * n + eu])
+    """Undirected edge list -> CSR with ascending neighbour lists (what graph.cpp:211-233 builds from `e u v` lines)."""
+    # one sort of the combined key src << 32 | dst = the (src, dst) lexicographic order (shifts: a division of 1.3e8 keys by n costs
+    # more than the sort)
+    eu = np.asarray(eu).astype(np.uint64)
+    ev = np.asarray(ev).astype(np.uint64)
+    key = np.concatenate([(eu << np.uint64(32)) | ev, (ev << np.uint64(32)) | eu])
     key.sort()
-    deg = np.bincount(key // n, minlength=n).astype(np.uint32)
-    offs = np.zeros(n + 1, np.uint32)
-    np.cumsum(deg, out=offs[1:])
-    return offs, (key % n).astype(np.uint32)
+    offs = np.searchsorted(key, np.arange(n + 1, dtype=np.uint64) << np.uint64(32)).astype(np.uint32)  # first key of every source
+    return offs, key.astype(np.uint32)  # (the low 32 bits)
+
+
+def _searchsorted_left(cdf, r):
+    """np.searchsorted(cdf, r) for MANY unsorted r in [0, 1) (6.5e7 needles into 4e6 ascending values: a binary search per needle
+    is 22 cache misses).  A grid of 2^k cells over [0, 1) holds each cell's first candidate -- found with sorted needles, which is
+    fast -- and a needle then walks forward from its cell's candidate (cells hold a couple of values).  r * 2^k and c / 2^k are exact
+    in binary floating point, so the result equals np.searchsorted's bit for bit."""
+    k = int(min(26, max(8, np.ceil(np.log2(max(len(cdf), 2))) + 4)))
+    cells = 1 << k
+    table = np.searchsorted(cdf, np.arange(cells, dtype=np.float64) / cells).astype(np.int64)
+    idx = table[(r * cells).astype(np.int64)]
+    todo = np.flatnonzero(cdf[idx] < r)
+    while len(todo):
+        idx[todo] += 1
+        todo = todo[cdf[idx[todo]] < r[todo]]
+    return idx
 
 
 def gnm_graph(n, m, n_labels=64, seed=SEED):
@@ -52,7 +68,7 @@ def gnm_graph(n, m, n_labels=64, seed=SEED):
     eu = (keys // n).astype(np.uint32)
     ev = (keys % n).astype(np.uint32)
     labels = rng.integers(0, n_labels, size=n, dtype=np.int64).astype(np.uint32)
-    offs, nbrs = _csr_from_edges(n, eu.astype(np.int64), ev.astype(np.int64))
+    offs, nbrs = _csr_from_edges(n, eu, ev)
     return dict(n=n, m=m, offsets=offs, nbrs=nbrs, labels=labels, eu=eu, ev=ev)
 
 
@@ -97,19 +113,19 @@ def powerlaw_graph(n, m, exponent=2.1, max_degree=2000, n_labels=64, seed=SEED):
     cdf = np.cumsum(p)
     cdf[-1] = 1.0
     k = int(m * 1.02)
-    u = np.searchsorted(cdf, rng.random(k)).astype(np.int64)
-    v = np.searchsorted(cdf, rng.random(k)).astype(np.int64)
+    u = _searchsorted_left(cdf, rng.random(k))
+    v = _searchsorted_left(cdf, rng.random(k))
     perm = rng.permutation(n).astype(np.int64)  # decouple id from weight rank
     u = perm[u]
     v = perm[v]
     ok = u != v
-    lo = np.minimum(u, v)[ok]
-    hi = np.maximum(u, v)[ok]
-    keys = np.unique(lo * n + hi)[:m]
-    eu = (keys // n).astype(np.uint32)
-    ev = (keys % n).astype(np.uint32)
+    lo = np.minimum(u, v)[ok].astype(np.uint64)
+    hi = np.maximum(u, v)[ok].astype(np.uint64)
+    keys = np.unique((lo << np.uint64(32)) | hi)[:m]  # (lo, hi) ascending, like lo * n + hi
+    eu = (keys >> np.uint64(32)).astype(np.uint32)
+    ev = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     labels = rng.integers(0, n_labels, size=n, dtype=np.int64).astype(np.uint32)
-    offs, nbrs = _csr_from_edges(n, eu.astype(np.int64), ev.astype(np.int64))
+    offs, nbrs = _csr_from_edges(n, eu, ev)
     return dict(n=n, m=len(keys), offsets=offs, nbrs=nbrs, labels=labels, eu=eu, ev=ev)
 
 
