@@ -832,11 +832,11 @@ int run_offline_slabs(const Options &o, const StaticGraph &g, const std::vector<
         while (done.returned < R) {
             if (!deadline_set && tp.failed()) {
                 deadline_set = true;
-                deadline = Clock::now() + std::chrono::seconds(10);
+                deadline = Clock::now() + std::chrono::seconds(5);
             }
             if (deadline_set) {
                 if (done.cv.wait_until(lk, deadline) == std::cv_status::timeout && done.returned < R) {
-                    fprintf(stderr, "%s: %s (%d of %d ranks did not return within 10 s of the failure: still inside a collective)\n", o.tool,
+                    fprintf(stderr, "%s: %s (%d of %d ranks did not return within 5 s of the failure: still inside a collective)\n", o.tool,
                             tp.first_error().c_str(), R - done.returned, R);
                     fflush(stderr);
                     _exit(1);

@@ -345,7 +345,7 @@ int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *
             if (k > hcap) {
                 free(H);
                 hcap = k * 2;
-                H = (uint64_t *)malloc((size_t)hcap * 2 * sizeof(uint64_t));
+                H = (uint64_t *)malloc(((size_t)hcap * 3 + 1) * sizeof(uint64_t));
                 if (!H) {
                     failed = 1;
                     hcap = 0;
@@ -353,8 +353,10 @@ int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *
                 }
             }
             uint64_t *own = H + hcap; /* own[j] = g of the start vertex itself at its own threshold */
+            int64_t *D = (int64_t *)(H + 2 * (size_t)hcap); /* k + 1 differences (short rows, below) */
             const uint32_t *T = srank + offsets[b]; /* thresholds: the ranks of b's neighbours, ascending */
             for (uint32_t j = 0; j < k; j++) H[j] = 0;
+            for (uint32_t j = 0; j <= k; j++) D[j] = 0;
             for (uint32_t q = offsets[b]; q < offsets[b + 1]; q++) {
                 const uint32_t c = neighbors[q], dc = offsets[c + 1] - offsets[c];
                 const uint32_t *R = srank + offsets[c];
@@ -366,7 +368,23 @@ int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *
                     if (T[m] < rc) a = m + 1; else z = m;
                 }
                 const uint32_t jc = a;
-                if ((uint64_t)k * 8 < dc) { /* few thresholds, long row: search each */
+                if ((uint64_t)dc * 16 < k) { /* many thresholds, short row (a hub b in front of an ordinary c): every entry of the row
+                                               * counts for the thresholds below it -- a difference array over b's thresholds, summed up
+                                               * after the last c (a merge would walk all k thresholds for each of the k rows) */
+                    for (uint32_t t = 0; t < dc; t++) {
+                        uint32_t a2 = 0, z2 = k; /* thresholds T[j] < R[t]: j < a2 */
+                        const uint32_t r = R[t];
+                        while (a2 < z2) {
+                            const uint32_t m = a2 + (z2 - a2) / 2;
+                            if (T[m] < r) a2 = m + 1; else z2 = m;
+                        }
+                        if (a2) {
+                            D[0] += 1;
+                            D[a2] -= 1;
+                        }
+                    }
+                    if (jc < k) own[jc] = row_gt(R, dc, T[jc]);
+                } else if ((uint64_t)k * 8 < dc) { /* few thresholds, long row: search each */
                     for (uint32_t j = 0; j < k; j++) {
                         const uint32_t g = row_gt(R, dc, T[j]);
                         H[j] += g;
@@ -382,7 +400,10 @@ int orc_count_per_start_l3(uint32_t n, const uint32_t *offsets, const uint32_t *
                 }
             }
             const uint32_t rb = rank[b];
+            int64_t run = 0;
             for (uint32_t j = 0; j < k; j++) {
+                run += D[j];
+                H[j] += (uint64_t)run;
                 const uint64_t later = rb > T[j] ? (uint64_t)(k - 1) : 0u;
                 const uint64_t add = H[j] - own[j] - later;
 #pragma omp atomic

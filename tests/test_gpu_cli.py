@@ -51,6 +51,8 @@ def test_test_graph_files_byte_exact_and_online_answer(tmp_path, p):
     if p == 1:
         assert open(os.path.join(tmp, "gnn-pe", "all_paths.txt"), "rb").read() == \
             gzip.open(os.path.join(GOLDEN, "test_graph", "all_paths.txt.gz")).read()
+    if p == 2:  # (the reference's own insertion build of the index takes 16 s of one core: once -- p = 1 -- is enough here; p = 2, 3, 5 go
+        return  # through the reference's online side in test_prep_partition_through_engine_and_reference_online, on index files WE built)
     if not os.path.exists(ref_main_path()):
         pytest.skip("oracle/_ref/ref_main not built: online consumer check skipped")
     # the untouched reference consumes our files (it builds its own index.dat on first run)
@@ -356,7 +358,7 @@ def test_rank_thread_error_is_a_clean_exit(tmp_path):
 def test_injected_rank_fault_ends_every_rank(tmp_path, case):
     """the failure path of `--gpus N` with a fault injected into ONE rank (GNNPE_FAULT_RANK=<rank>:<stage>) while its
     peers sit in barriers / exchanges: the process ends with exit code 1 and that rank's message, well inside the join
-    deadline (a peer stuck in a collective for good is ended by the main thread after 10 s)."""
+    deadline (a peer stuck in a collective for good is ended by the main thread after 5 s)."""
     gpus, transport, fault = case
     g = synth.gnm_graph(3000, 21000, n_labels=9, seed=17)
     sn = synth.degree_order(g["offsets"])

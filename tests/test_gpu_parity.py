@@ -295,8 +295,8 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
     del ids, pde
 
     # The bench's own call pattern -- count_paths_enqueue, then fill_paths_capped_device into ONE full-size 12 GB buffer -- with
-    # every emit kernel a caller can get: the start-vertex shape at five and at three workgroups per CU (k_fill_ranked, start
-    # vertices from ticket counters), the output-tile shape (k_fill_tiles: the kernel BENCH_r04 timed; also what the shipped
+    # every emit kernel a caller can get: the start-vertex shape one-shot and as a resident grid of three workgroups per CU
+    # (k_fill_ranked; the resident form takes its start vertices from ticket counters), the output-tile shape (k_fill_tiles: the kernel BENCH_r04 timed; also what the shipped
     # library answers a request for shape 3 with -- the ticket waves live in diagnostic builds since round 6), and shape 0 after
     # the library's calibration (whichever it measured fastest into THIS buffer).  The oracle's rows live on the device for the comparison (12 GB more).
     t0 = time.perf_counter()
@@ -333,6 +333,43 @@ def test_config3_1m_10m_every_id_and_double_vs_the_oracle(oracle):
         assert same_as_oracle(), (shape, name)
         seen[shape] = name
     print(f"config 3, full-size buffer, shapes {seen}: bit-exact vs the oracle; {time.perf_counter() - t0:.1f} s for this half")
+
+    # The same at the narrowest and the widest embedding with a specialised emit kernel (the calibrated path met
+    # e in {1, 3, 4, 8} on small graphs only).  The ids do not depend on e: they must be the oracle's rows again; vde at that width
+    # is checked against the oracle's gen_vde (custom.h:513-544), and every pde row must be the vde rows of its three ids
+    # (custom.h:546-572), bit for bit, all 2.0e8 of them -- gathered on the device.
+    t0 = time.perf_counter()
+    del pde, o_pde
+    torch.cuda.empty_cache()
+    for e in (8, 1):
+        eng.set_label_table(binding.host_label_table(64, e))
+        vde_e = eng.vde()[2]
+        assert np.array_equal(vde_e.view(np.uint64), oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], e)[2].view(np.uint64))
+        vde_dev = torch.from_numpy(np.ascontiguousarray(vde_e).view(np.int64)).to(dev)
+        pde = torch.empty((total, 3 * e), dtype=torch.float64, device=dev)
+        seen = {}
+        for shape in (1, 4, 2, 0):
+            eng.set_emit_shape(shape)
+            if shape == 0:
+                cal = eng.emit_calibrate_device(ids, pde)
+            ids.zero_()
+            pde.zero_()
+            torch.cuda.synchronize()
+            eng.vde(want=False)
+            eng.count_paths_enqueue(2)
+            eng.fill_paths_capped_device(total, ids, pde)
+            eng.sync()
+            assert eng.count_total() == P
+            seen[shape] = eng.emit_kernel_name()
+            for a in range(0, total, CMP):
+                b = min(total, a + CMP)
+                assert torch.equal(ids[a:b], o_ids[a:b]), (e, shape, a)
+                want = vde_dev[ids[a:b].long().reshape(-1)].reshape(b - a, 3 * e)
+                assert torch.equal(pde[a:b].view(torch.int64), want), (e, shape, a)
+        del pde, vde_dev
+        torch.cuda.empty_cache()
+        print(f"config 3 at e = {e}, full-size buffer, shapes {seen}: ids = the oracle's, pde = vde rows of the ids")
+    print(f"{time.perf_counter() - t0:.1f} s for the e = 8 / e = 1 half")
     eng.close()
 
 
