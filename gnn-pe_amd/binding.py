@@ -81,7 +81,6 @@ SIGNATURES = {
     "gnnpe_rows_checksum_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64, _u64p]),
     "gnnpe_host_query_plan": (C.c_int, [C.c_char_p, C.c_uint32, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_u32p),
                                         C.POINTER(_u32p), C.POINTER(_f64p)]),
-    "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
     "gnnpe_host_load_path_sidecar": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, _u32p, _u32p, _u64p, _u32p, _u32p,
                                                C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_u32p), C.POINTER(_f64p),
                                                C.POINTER(_f64p)]),
@@ -97,7 +96,6 @@ SIGNATURES = {
     "gnnpe_pinned_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
     "gnnpe_pinned_free": (None, [_vp]),
     "gnnpe_set_degrees": (C.c_int, [_vp, _u32p]),
-    "gnnpe_refine": (C.c_int, [_vp, C.c_char_p, _u32p, C.c_uint64, _u64p, _f64p]),
     "gnnpe_filter_candidates": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u32p, _f64p, C.c_uint32, C.c_double, _u32p,
                                           _f64p]),
     "gnnpe_build_index_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.POINTER(_vp), _u64p,
@@ -126,12 +124,39 @@ class GnnpeError(RuntimeError):
     pass
 
 
+# include/gnnpe_online.h (libgnnpe_online.so): the refinement -- out of SURVEY section 8's scope, a library of its own since round 6
+ONLINE_LIB_PATH = os.path.join(_HERE, "libgnnpe_online.so")
+ONLINE_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnpe_online.h")
+ONLINE_SIGNATURES = {
+    "gnnpe_host_refine": (C.c_int, [C.c_uint32, _u32p, _u32p, _u32p, C.c_char_p, _u32p, C.c_uint64, _u64p]),
+    "gnnpe_refine": (C.c_int, [_vp, C.c_char_p, _u32p, C.c_uint64, _u64p, _f64p]),
+}
+_online = None
+
+
+def load_online():
+    """dlopen libgnnpe_online.so (it links against libgnnpe_hip.so, which load() brings in first).  Raises if absent."""
+    global _online
+    if _online is not None:
+        return _online
+    load()
+    if not os.path.exists(ONLINE_LIB_PATH):
+        raise GnnpeError(f"{ONLINE_LIB_PATH} is missing: build it with `make -C gnn-pe_amd`")
+    lib = C.CDLL(ONLINE_LIB_PATH)
+    for name, (res, args) in ONLINE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _online = lib
+    return lib
+
+
 def build(force=False):
     """Compile libgnnpe_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [HEADER_PATH]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "libgnnpe_hip.so"])
+        subprocess.check_call(["make", "-C", _HERE, "libgnnpe_hip.so", "libgnnpe_online.so"])
     return LIB_PATH
 
 
@@ -266,7 +291,7 @@ def host_refine(g, query_path, bitmap, limit=0xFFFFFFFF):
     out = C.c_uint64()
     o, nb, lb = _np(g["offsets"], np.uint32), _np(g["nbrs"], np.uint32), _np(g["labels"], np.uint32)
     bm = _np(bitmap, np.uint32)
-    rc = lib.gnnpe_host_refine(len(o) - 1, _ptr(o, _u32p), _ptr(nb, _u32p), _ptr(lb, _u32p), query_path.encode(),
+    rc = load_online().gnnpe_host_refine(len(o) - 1, _ptr(o, _u32p), _ptr(nb, _u32p), _ptr(lb, _u32p), query_path.encode(),
                                _ptr(bm, _u32p), int(limit), C.byref(out))
     if rc:
         raise GnnpeError(lib.gnnpe_last_error().decode())
@@ -614,7 +639,7 @@ class Engine:
         """Refinement on the device (custom.h:634-932): (answers, device ms) from the filter's candidate bitmap."""
         out, ms = C.c_uint64(), C.c_double()
         bm = _np(bitmap, np.uint32)
-        self._ck(self.lib.gnnpe_refine(self.ctx, query_path.encode(), _ptr(bm, _u32p), int(limit), C.byref(out), C.byref(ms)))
+        self._ck(load_online().gnnpe_refine(self.ctx, query_path.encode(), _ptr(bm, _u32p), int(limit), C.byref(out), C.byref(ms)))
         return out.value, ms.value
 
     def path_partitions_device(self, begin, end, dev_part):

@@ -172,6 +172,18 @@ inline void warn_if_index_too_large_for_reference(const std::string &path)
                         "(blk_file.h:33) -- use a larger -p\n", g_tool, path.c_str(), st.st_size / 1073741824.0);
 }
 
+// directory of the running binary, with the trailing slash ("" when /proc/self/exe cannot be read): where libgnnpe_online.so lives
+inline std::string exe_dir()
+{
+    char buf[4096];
+    const ssize_t k = readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+    if (k <= 0) return "";
+    buf[k] = 0;
+    std::string s(buf);
+    const size_t cut = s.rfind('/');
+    return cut == std::string::npos ? "" : s.substr(0, cut + 1);
+}
+
 // Size of the index.dat a partition of `points` paths becomes, so that the 2 GiB limit above is checked BEFORE anything is
 // written: the library's own figure for the builder that will write the file (gnnpe_index_file_bytes: 0 = the pair-major build
 // of the single-GPU path, 1 = the tuple-array build of --gpus N; their nodes hold different numbers of entries).

@@ -17,6 +17,7 @@
 //     where the reference enumerates 3-vertex paths whatever -l says and prints a garbage 4th column
 //     (SURVEY D4); its online binary cannot read those files.  Other -l values are refused;
 //   - path counts beyond 2^32-1 are refused unless --allow-large (the reference's `ui` overflows).
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -209,7 +210,14 @@ int run_filter(const Options &o)
             limit = lim;
         }
         double refine_ms = 0.0;
-        check(gnnpe_refine(ctx, o.query_graph.c_str(), bitmap.data(), limit, &answers, &refine_ms), "refine");
+        // the refinement lives in libgnnpe_online.so (include/gnnpe_online.h: out of scope, frozen), beside this binary
+        typedef int (*refine_fn)(gnnpe_ctx *, const char *, const uint32_t *, uint64_t, uint64_t *, double *);
+        void *online = dlopen((exe_dir() + "libgnnpe_online.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (!online) online = dlopen("libgnnpe_online.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!online) die(std::string("-m online needs libgnnpe_online.so beside ") + o.tool + ": " + dlerror());
+        refine_fn refine = (refine_fn)dlsym(online, "gnnpe_refine");
+        if (!refine) die("libgnnpe_online.so does not export gnnpe_refine");
+        check(refine(ctx, o.query_graph.c_str(), bitmap.data(), limit, &answers, &refine_ms), "refine");
         gnnpe_destroy(ctx);
         printf("Answer Number: %llu Query Time (ms): %g\n", (unsigned long long)answers, ms + refine_ms);
         if (o.timing)

@@ -42,7 +42,27 @@ def _searchsorted_left(cdf, r):
     return idx
 
 
+_MEMO = {}  # the last few generated graphs of this process (arrays read-only): a test session asks for G(1M, 10M) eight times
+
+
+def _memo(key, make):
+    g = _MEMO.get(key)
+    if g is None:
+        g = make()
+        for v in g.values():
+            if isinstance(v, np.ndarray):
+                v.setflags(write=False)
+        while len(_MEMO) >= 3:
+            _MEMO.pop(next(iter(_MEMO)))
+        _MEMO[key] = g
+    return dict(g)
+
+
 def gnm_graph(n, m, n_labels=64, seed=SEED):
+    return _memo(("gnm", n, m, n_labels, seed), lambda: _gnm_graph(n, m, n_labels, seed))
+
+
+def _gnm_graph(n, m, n_labels, seed):
     """G(n,m): exactly m distinct undirected edges without self-loops, uniform labels.
 
     Returns dict(n, m, offsets u32[n+1], nbrs u32[2m], labels u32[n], eu, ev (u<v, sorted))."""
@@ -100,6 +120,10 @@ def multigraph(n, m, n_dup=0, n_loops=0, n_labels=8, seed=SEED):
 
 
 def powerlaw_graph(n, m, exponent=2.1, max_degree=2000, n_labels=64, seed=SEED):
+    return _memo(("powerlaw", n, m, exponent, max_degree, n_labels, seed), lambda: _powerlaw_graph(n, m, exponent, max_degree, n_labels, seed))
+
+
+def _powerlaw_graph(n, m, exponent, max_degree, n_labels, seed):
     """Chung-Lu style power-law graph with a degree cap (config 5 stress input).
 
     Endpoints are drawn proportionally to weights w_i ~ i^(-1/(exponent-1)) truncated so the

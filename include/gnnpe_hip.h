@@ -330,18 +330,8 @@ int gnnpe_filter_candidates(gnnpe_ctx *ctx, uint32_t n_paths, const uint32_t *q_
                             const uint32_t *q_degrees, const double *q_pde, uint32_t n_query_vertices, double epsilon,
                             uint32_t *host_bitmap, double *device_ms);
 
-/* Refinement half of the reference's online step (custom.h:634-932), host side: the number of embeddings of the
- * query graph in the data graph (injective, labels equal, query degree <= data degree, query edges on data edges)
- * whose START vertex -- fewest candidates, ties to the larger degree, then the smaller id (custom.h:634-654) -- maps
- * into its candidate set, counted up to `limit` (the reference's -n).  candidate_bitmap as written by
- * gnnpe_filter_candidates. */
-int gnnpe_host_refine(uint32_t n, const uint32_t *offsets, const uint32_t *nbrs, const uint32_t *labels,
-                      const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit, uint64_t *answers);
-
-/* The same count on the device: one thread per (start candidate, neighbour slot of its image), depth-first below that.
- * Needs the whole graph on the device (gnnpe_load_csr); query graphs of up to 32 vertices.  device_ms may be NULL. */
-int gnnpe_refine(gnnpe_ctx *ctx, const char *query_graph_path, const uint32_t *candidate_bitmap, uint64_t limit,
-                 uint64_t *answers, double *device_ms);
+/* The refinement half of the reference's online step (custom.h:634-932) is outside SURVEY section 8's scope (frozen since round 1)
+ * and ships in a library of its own since round 6: include/gnnpe_online.h, libgnnpe_online.so (gnnpe_refine, gnnpe_host_refine). */
 
 /* ---- the online side's data load ------------------------------------------------------- */
 /* `gnnpe_main --sidecars` leaves <f>gnn-pe/paths.bin (magic "GNNPEPTH", uint32 version = 1, uint32 L, uint64 P, then the

@@ -260,7 +260,16 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
     if args.ranges is not None:  # single rank: checksum the requested global ranges
         sums = []
         buf = torch.empty((chunk, L), dtype=torch.int32, device=dev)
-        for a, b in json.loads(args.ranges):
+        ranges_json = args.ranges
+        if ranges_json.startswith("@"):  # a file somebody writes while this process is busy with the oracle's count: wait for it
+            import time
+            t_wait = time.time()
+            while not os.path.exists(ranges_json[1:]):
+                if time.time() - t_wait > 600:
+                    raise SystemExit(f"{ranges_json[1:]} did not appear")
+                time.sleep(0.2)
+            ranges_json = open(ranges_json[1:]).read()
+        for a, b in json.loads(ranges_json):
             acc = 0
             for c0 in range(a, b, chunk):
                 c1 = min(c0 + chunk, b)

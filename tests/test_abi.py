@@ -10,8 +10,8 @@ from conftest import GOLDEN, ROOT
 from gnnpe_amd import binding
 
 
-def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "gnnpe_hip.h")).read()
+def _declared_functions(header="gnnpe_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return set(re.findall(r"\b(gnnpe_[a-z0-9_]+)\s*\(", txt))
 
@@ -19,6 +19,8 @@ def _declared_functions():
 def test_header_and_binding_agree():
     decl = _declared_functions()
     assert decl == set(binding.SIGNATURES), (decl ^ set(binding.SIGNATURES))
+    online = _declared_functions("gnnpe_online.h")
+    assert online == set(binding.ONLINE_SIGNATURES) and not (online & decl), (online, online & decl)
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     assert lib.gnnpe_abi_version() == binding.ABI_VERSION
+
+
+def test_refinement_lives_in_a_library_of_its_own():
+    """the refinement (out of SURVEY section 8's scope) is not in libgnnpe_hip.so; libgnnpe_online.so exports what
+    include/gnnpe_online.h declares and finds the rest (contexts, loader, error text) in libgnnpe_hip.so."""
+    binding.build()
+    lib, online = binding.load(), binding.load_online()
+    for name in _declared_functions("gnnpe_online.h"):
+        assert hasattr(online, name), name
+        assert not hasattr(lib, name), f"{name} is still exported by libgnnpe_hip.so"
 
 
 def test_product_does_not_import_the_oracle():
