@@ -46,7 +46,7 @@ import gnnpe_amd  # noqa: E402,F401
 from gnnpe_amd import binding, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LEAF_TRAFFIC_BYTES = 27.8e9  # index leaf kernel (image alone) at config 3, per launch: 7.0 GB read + 20.8 GB written, profiles/r05_leaf_mem_pmc.txt
+LEAF_TRAFFIC_BYTES = 27.7e9  # index leaf kernel (image alone) at config 3, per launch: 7.0 GB read + 20.7 GB written, profiles/r06_leaf_mem_pmc.txt
                             # (the leaf kernel is round 5's: no counter pass of it in round 6)
 CLI = os.path.join(ROOT, "gnn-pe_amd", "gnnpe_main")
 PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_fill.json")
@@ -802,7 +802,7 @@ def main():
                                            if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
                                            note="file_bytes_frac = the image's bytes over wallclock_ms (pair sort included); "
                                                 "leaf_pass_traffic_* = what the leaf kernel moves per launch at config 3 by the counters of the "
-                                                "committed profile (profiles/r05_leaf_mem_pmc.txt: 7.3 GB of 128-byte fabric reads + 20.8 GB of "
+                                                "committed profile (profiles/r06_leaf_mem_pmc.txt: 7.0 GB of 128-byte fabric reads + 20.7 GB of "
                                                 "64-byte writes), over next_partition_ms (leaf kernel + first-pair pass + inner nodes)"),
                                   next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
                                   tuple_array_build_ms=min(ib_tuple),
