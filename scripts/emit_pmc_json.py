@@ -10,7 +10,7 @@ for ln in open(src):
         per.setdefault(f[1], {})[f[0]] = float(f[3])
 out = {"command": "scripts/emit_pmc3.sh (round 5; round 4: emit_pmc.sh) = rocprofv3 --pmc <set> -- python3 scripts/emit_ab3.py --quick (one pass per counter "
                   "set; BASELINE config 3, 2.0e8 paths, the emit kernels into the same buffers in one process; k_fill_ranked with its start "
-                  "vertices from ticket counters, five workgroups per CU)",
+                  "vertices from ticket counters, five workgroups per CU; round 6, r06_pmc_fill.json: the one-shot launch, one wave per start vertex in launch order)",
        "algorithmic_bytes": 200031576 * 92}
 for k, c in per.items():
     rd = c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128 + c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
