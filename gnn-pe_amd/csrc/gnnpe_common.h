@@ -97,7 +97,8 @@ namespace gnnpe {
 //   GNNPE_AUX_WIDE=1                     8-byte {degree, label} words behind the aux records even where they fit the id bits
 //   GNNPE_DEBUG=1                        launch shapes / pool candidates on stderr
 //   GNNPE_TESTING=k=v,...                testing aids: pool_min_probe_bytes (below it the pool takes what comes: 512 MiB),
-//                                        index_keep_bytes (cap on the device copies gnnpe_build_index_files keeps per wave)
+//                                        index_keep_bytes (cap on the device copies gnnpe_build_index_files keeps per wave),
+//                                        index_max_units (sort units the l = 3 index build accepts before it takes the tuple-array build: 2^31)
 // Everything else that rounds 2-5 switched by environment for A/B runs exists in diagnostic builds only (make DIAG=1:
 // gnnpe::diag_int below): the static start-vertex walk, staged rows, LDS pads, the ticket / strip-job emit kernels, tile heights,
 // rows per wave of the count kernel, the leaf kernel's XCD chunks, candidate draws of the image buffer, knock-outs, stamps.
@@ -105,7 +106,7 @@ struct Switches {
     int emit = 0;  // 0 none, else the emit shape to force
     bool deep_merge = false, aux_wide = false, debug = false;
     int deep_emit = 0;  // 1 slices, 2 units
-    uint64_t pool_min_probe_bytes = 512ull << 20, index_keep_bytes = ~0ull;
+    uint64_t pool_min_probe_bytes = 512ull << 20, index_keep_bytes = ~0ull, index_max_units = 1ull << 31;
 };
 Switches read_switches();  // gnnpe_engine.hip
 #ifdef GNNPE_DIAG
@@ -158,7 +159,7 @@ struct gnnpe_ctx {
     // the triple-major order of an l = 3 count (gnnpe_index_deep.hip.h): shares px_recs / px_sorted / px_pref / px_first / px_tmp
     gnnpe::DevBuf tx_cpre, tx_row_units, tx_toff, tx_padj;
     std::vector<uint64_t> tx_bounds, tx_points;
-    uint64_t tx_gen = 0, tx_nu = 0;
+    uint64_t tx_gen = 0, tx_nu = 0, tx_refused_gen = ~0ull;  // tx_refused_gen: the count whose units did not fit (tuple-array build instead)
     bool tx_valid = false;
     gnnpe::DevBuf px_raux;  // {degree, label} strips beside the row blocks (k_px_raux), valid for one count like the pair order
     bool px_raux_valid = false;

@@ -177,6 +177,7 @@ gnnpe::Switches gnnpe::read_switches()
                 const uint64_t v = strtoull(all.c_str() + eq + 1, nullptr, 10);
                 if (k == "pool_min_probe_bytes") w.pool_min_probe_bytes = v;
                 else if (k == "index_keep_bytes") w.index_keep_bytes = v;
+                else if (k == "index_max_units") w.index_max_units = v;
             }
             at = end + 1;
         }

@@ -2312,7 +2312,15 @@ static int build_triple_order(gnnpe_ctx *c)
     GNNPE_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->cub_tmp.p, tb, toff, toff, (int64_t)(ne + 1), c->stream));
     GNNPE_HIP_TRY(hipMemcpyAsync(&nu, toff + ne, 8, hipMemcpyDeviceToHost, c->stream));
     GNNPE_HIP_TRY(hipStreamSynchronize(c->stream));
-    GNNPE_REQUIRE(nu < (1ull << 31), GNNPE_ERR_RANGE, "%llu sort units exceed the 32-bit unit ids", (unsigned long long)nu);
+    // Units are counted with the empty ones (half of them on G(n, m)); a graph whose partitions fit the format's int32 counts can still
+    // have more units than a 32-bit id names, or than memory holds at ~100 bytes each: such a count keeps the tuple-array build
+    size_t free_b = 0, total_b = 0;
+    GNNPE_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t held = c->px_tmp.bytes + c->px_recs.bytes + c->px_sorted.bytes + c->px_pref.bytes;
+    if (nu >= std::min<uint64_t>(1ull << 31, c->sw.index_max_units) || nu * 100 > free_b + held) {
+        c->tx_refused_gen = c->count_gen;
+        return GNNPE_ERR_RANGE;
+    }
     // scratch layout (px_tmp): start sort {part_in, part_out, idx_in, idx_out: u32 x len}, counts / positions / pbase {u64 x (len + 2)},
     // unit keys {u64 x (nu + 1) x 2}, unit values {u32 x (nu + 1) x 2}, device bounds {u64 x 2 (p + 1)}
     const size_t o_part = 0, o_idx = o_part + ((size_t)len + 1) * 8, o_cnt = o_idx + ((size_t)len + 1) * 8,
@@ -2554,8 +2562,9 @@ static int build_partition(gnnpe_ctx *c, uint32_t pid, void **dev_image, uint64_
     c->img_aux_valid = false;
     if (pair_major_ok(c)) {
         rc = build_partition_image(c, pid, dev_image, nbytes, hdr_out, with_aux && fused_aux_ok(c));
-    } else if (triple_major_ok(c)) {
-        rc = build_triple_partition_image(c, pid, dev_image, nbytes, hdr_out);
+    } else if (triple_major_ok(c) && c->tx_refused_gen != c->count_gen &&
+               ((rc = build_triple_partition_image(c, pid, dev_image, nbytes, hdr_out)) == GNNPE_OK || c->tx_refused_gen != c->count_gen)) {
+        // (built, or failed for a reason of its own; a count whose units do not fit falls through to the tuple-array build below)
     } else {
         // the generic enumeration (embedding widths without a specialised kernel): the partition's tuples, then the tuple-array build
         DevBuf mine;

@@ -220,6 +220,32 @@ def test_triple_major_partition_images(oracle, e, p):
     eng.close()
 
 
+
+def test_triple_major_falls_back_to_the_tuple_build_when_its_units_do_not_fit(oracle, monkeypatch):
+    """A count with more sort units than the triple-major build takes (2^31, or what memory holds at ~100 bytes each: the empty units
+    count too) keeps the tuple-array build of rounds 1-5 -- same contract, nodes of capacity - 2 entries.  The limit is lowered through
+    GNNPE_TESTING=index_max_units (a testing aid, read at context creation)."""
+    from gnnpe_amd import binding
+    monkeypatch.setenv("GNNPE_TESTING", "index_max_units=1000")
+    g = synth.gnm_graph(600, 3000, n_labels=4, seed=21)
+    rng = np.random.default_rng(21)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    mem = rng.integers(0, 2, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, 2, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(3)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(ref) > 10_000
+    for pid in range(2):
+        mine = _partition_paths(ref, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        assert d["num_data"] == len(mine) and d["dnodes"] == -(-len(mine) // ((4096 - 5) // (16 * 8 + 4) - 2))  # capacity - 2: the tuple build
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), 8))
+    eng.close()
+
 @pytest.mark.parametrize("e,p", [(2, 2), (8, 1)])
 def test_triple_major_power_law_partitions(oracle, e, p):
     """l = 3 on a power-law graph: third vertices with rows of more than a hundred entries are cut into units of 64 row entries (one
