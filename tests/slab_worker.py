@@ -297,13 +297,17 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
                 ok = int(sb.global_total) == P
                 CH = 1 << 24
 
+                # the oracle's rows of this rank on the device once (six comparisons follow: copying the rank's rows back each time cost
+                # more than the fills)
+                o_ids = torch.from_numpy(np.ascontiguousarray(oids[base:base + emit]).view(np.int32)).to(dev)
+                o_pde = torch.from_numpy(np.ascontiguousarray(opde[base:base + emit]).view(np.int64)).to(dev)
+
                 def rows_equal():
                     good = True
                     for a in range(0, emit, CH):
                         b = min(emit, a + CH)
-                        good = good and np.array_equal(ids[a:b].cpu().numpy().view(np.uint32), oids[base + a:base + b])
-                        good = good and np.array_equal(pde[a:b].cpu().numpy().view(np.uint64), opde[base + a:base + b].view(np.uint64))
-                    return good
+                        good = good and torch.equal(ids[a:b], o_ids[a:b]) and torch.equal(pde[a:b].view(torch.int64), o_pde[a:b])
+                    return bool(good)
                 ok = ok and rows_equal()
                 # every emit shape a caller can get, through the enqueue-only step (count without a read-back, capped fill), then
                 # shape 0 after the library's calibration of THESE buffers
@@ -322,6 +326,7 @@ def run_rank(args, g, rank, world, local_rank, backend, comm):
                     kernels[str(shape)] = eng.emit_kernel_name()
                     ok = ok and eng.count_total() == total and kernels[str(shape)] == eng.EMIT_SHAPE_KERNELS[kept] and rows_equal()
                 eng.set_emit_shape(0)
+                del o_ids, o_pde
                 res["emit_kernels"] = kernels
                 res["oracle_exact"] = bool(ok)
             res["middle_sum"] = int(ids[:emit, 1].to(torch.int64).sum())
