@@ -303,12 +303,13 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
                                                                double *__restrict__ node_mbr)
 {
     constexpr int D = 4 * E, F = (int)index_fanout(D), kEnt = 4 * D + 1;
-    constexpr int kWin = kBlockLen / 4 + 4;
     constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;  // 16-byte pieces of a leaf's used prefix
+    constexpr int kWin = 4 * kStoreU4 + 4;                      // the window ends where the stored prefix ends (+ the dword its last piece shifts in)
     constexpr int kRounds = (F * D + 63) / 64;
+    constexpr int kVid = F * 4 > 64 ? F * 4 : 64;  // the entries' vertex ids; the unit-start flags of the first phase live in the same words
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
-    __shared__ uint32_t s_vid[kLeafWaves][64 * 4];
-    __shared__ uint32_t s_flag[kLeafWaves][64];
+    __shared__ uint32_t s_vid[kLeafWaves][kVid];
+    uint32_t(*s_flag)[kVid] = s_vid;  // (read by the ballot below before any lane writes an id: one wave, LDS in program order)
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t j = blockIdx.x * (uint64_t)kLeafWaves + wv;
     if (j >= n_leaves) return;
@@ -318,6 +319,10 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
     const uint64_t u0 = first[j];
     // where the units from u0 on start, relative to the leaf's first point (u0 itself: <= 0)
     const uint64_t ut = min(u0 + lane, r1);
+    // lane t holds unit u0 + t (record and first point) IN REGISTERS, both loads in flight together; a point lane fetches its unit's
+    // fields from that lane through the crossbar below -- one memory round trip less than loading the record once the unit is known
+    const uint4 *usrc = reinterpret_cast<const uint4 *>(units + min(ut, r1 - 1));
+    const uint4 ua = usrc[0], ub = usrc[1];
     const int64_t rel64 = (int64_t)(pref[ut] - pts0) - (int64_t)q0;
     const int32_t rel = (int32_t)max((int64_t)-0x40000000, min((int64_t)0x40000000, rel64));
     s_flag[wv][lane] = 0u;
@@ -331,9 +336,15 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
     const uint64_t starts = __ballot(s_flag[wv][lane] != 0u);
     const uint32_t ui = (uint32_t)__popcll(starts & ((2ull << lane) - 1ull));
     const int32_t rel_u = __shfl(rel, (int)ui, 64);
+    uint4 a, b;
+    a.x = (uint32_t)__shfl((int)ua.x, (int)ui, 64);
+    a.y = (uint32_t)__shfl((int)ua.y, (int)ui, 64);
+    a.z = (uint32_t)__shfl((int)ua.z, (int)ui, 64);
+    a.w = (uint32_t)__shfl((int)ua.w, (int)ui, 64);
+    b.x = (uint32_t)__shfl((int)ub.x, (int)ui, 64);
+    b.y = (uint32_t)__shfl((int)ub.y, (int)ui, 64);
+    b.z = (uint32_t)__shfl((int)ub.z, (int)ui, 64);
     if (lane < ne) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(units + u0 + ui);
-        const uint4 a = src[0], b = src[1];
         const uint32_t r = (uint32_t)((int32_t)lane - rel_u);
         const uint64_t mask = ((uint64_t)b.y << 32) | b.x;
         const uint32_t d = nbrs[a.w + select_bit(mask, r)];
@@ -420,8 +431,8 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_inner(uint64_t n_nodes, 
                                                               double *__restrict__ node_mbr)
 {
     constexpr int D = 4 * E, F = (int)index_fanout(D), kEnt = 4 * D + 1;
-    constexpr int kWin = kBlockLen / 4 + 4;
     constexpr int kStoreU4 = (5 + F * (16 * D + 4) + 15) / 16;
+    constexpr int kWin = 4 * kStoreU4 + 4;
     constexpr int kRounds = (F * D + 63) / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kLeafWaves][kWin];
     const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;

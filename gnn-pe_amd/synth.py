@@ -77,9 +77,25 @@ def _gnm_graph(n, m, n_labels, seed):
         lo = np.minimum(u, v)[ok]
         hi = np.maximum(u, v)[ok]
         cand = np.concatenate([keys, lo * n + hi])
-        uniq, first = np.unique(cand, return_index=True)
-        # keep draw order so that the first m distinct edges are the ones selected
-        keys = cand[np.sort(first)]
+        # keep draw order so that the first m distinct edges are the ones selected: cand without the later occurrences of a value.
+        # (np.unique(cand, return_index=True) says the same through a stable argsort of everything -- most of a G(1.5M, 60M)'s
+        # generation time; repeats are a few thousand of 6e7 draws, so only THEIR positions are looked up)
+        srt = np.sort(cand)
+        dup = np.unique(srt[1:][srt[1:] == srt[:-1]])
+        del srt
+        if len(dup):
+            at = np.searchsorted(dup, cand)
+            at[at == len(dup)] = 0
+            pos = np.flatnonzero(dup[at] == cand)  # every occurrence of a repeated value, ascending
+            vals = cand[pos]
+            o = np.argsort(vals, kind="stable")
+            later = np.ones(len(o), bool)
+            later[0] = False
+            later[1:] = vals[o][1:] == vals[o][:-1]
+            keep = np.ones(len(cand), bool)
+            keep[pos[o[later]]] = False
+            cand = cand[keep]
+        keys = cand
         if len(keys) >= m:
             keys = keys[:m]
             break
