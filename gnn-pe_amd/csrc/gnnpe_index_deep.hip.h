@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
     const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - q0);
     const uint64_t u0 = first[j];
     // where the units from u0 on start, relative to the leaf's first point (u0 itself: <= 0)
-    const uint64_t ut = min(u0 + lane, r1);
+    const uint64_t ut = min(u0 + min(lane, ne), r1);  // (at most ne units start inside the leaf: the lanes behind re-read the last one)
     // lane t holds unit u0 + t (record and first point) IN REGISTERS, both loads in flight together; a point lane fetches its unit's
     // fields from that lane through the crossbar below -- one memory round trip less than loading the record once the unit is known
     const uint4 *usrc = reinterpret_cast<const uint4 *>(units + min(ut, r1 - 1));
