@@ -316,9 +316,9 @@ __global__ __launch_bounds__(64 * kLeafWaves) void k_tx_leaves(uint64_t n_pts, u
     uint32_t *w = s_win[wv];
     const uint64_t q0 = j * (uint64_t)F;
     const uint32_t ne = (uint32_t)min((uint64_t)F, n_pts - q0);
-    const uint64_t u0 = first[j];
+    const uint64_t u0 = first[j], u_last = j + 1 < n_leaves ? (uint64_t)first[j + 1] : r1;  // the leaf's units: u0 .. u_last
     // where the units from u0 on start, relative to the leaf's first point (u0 itself: <= 0)
-    const uint64_t ut = min(u0 + min(lane, ne), r1);  // (at most ne units start inside the leaf: the lanes behind re-read the last one)
+    const uint64_t ut = min(min(u0 + lane, u_last + 1), r1);  // (the lanes behind the leaf's last unit re-read the one after it: not flagged)
     // lane t holds unit u0 + t (record and first point) IN REGISTERS, both loads in flight together; a point lane fetches its unit's
     // fields from that lane through the crossbar below -- one memory round trip less than loading the record once the unit is known
     const uint4 *usrc = reinterpret_cast<const uint4 *>(units + min(ut, r1 - 1));
