@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256) void k_tx_units(uint64_t n_wu, const uint32_t 
             cst = adj_start[c];
         }
     }
+    // what the records and keys need of s, b and c: asked for here, beside the rows' descriptors, not behind the walk's fences
+    const uint64_t ws = vkey[s], wb = vkey[b], wc = vkey[c];
+    const uint32_t part = member[s];
+    const int64_t padj_i = padj[i];
+    const uint64_t uoff_u = uoff[u], toff_w = toff[w];
+    const uint32_t cpre_q = valid ? cpre[q] : 0u;
     const bool hub = cd > 64u;
     const uint32_t fd = hub ? 0u : cd;
     const uint32_t incl = wave_scan_add(fd), off = incl - fd;
@@ -196,13 +202,12 @@ __global__ __launch_bounds__(256) void k_tx_units(uint64_t n_wu, const uint32_t 
         if ((int)lane == h) cnt = t;
     }
     const uint32_t incl_c = wave_scan_add(cnt);
-    const uint64_t slot = uoff[u] + (incl_c - cnt);
-    const uint32_t son0 = (uint32_t)((int64_t)slot + padj[i]);
-    const uint64_t ubase = toff[w] + (valid ? cpre[q] : 0u);
+    const uint64_t slot = uoff_u + (incl_c - cnt);
+    const uint32_t son0 = (uint32_t)((int64_t)slot + padj_i);
+    const uint64_t ubase = toff_w + cpre_q;
     // key: partition and the words of s and b are the wave's, c is the lane's
     const uint64_t lmask = (1ull << lb) - 1ull;
-    const uint64_t ws = vkey[s], wb = vkey[b], wc = vkey[c];
-    const uint64_t lab = ((((((uint64_t)member[s] << lb) | ((ws >> 32) & lmask)) << lb) | ((wb >> 32) & lmask)) << lb) | ((wc >> 32) & lmask);
+    const uint64_t lab = ((((((uint64_t)part << lb) | ((ws >> 32) & lmask)) << lb) | ((wb >> 32) & lmask)) << lb) | ((wc >> 32) & lmask);
     const uint64_t z = ((ws & 0xffffffffull) << (2u * e)) | ((wb & 0xffffffffull) << e) | (wc & 0xffffffffull);
     const KeyT key = (KeyT)((lab << zbits) | z);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

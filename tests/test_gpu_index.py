@@ -477,10 +477,12 @@ def test_index_size_guard_and_every_partition_through_the_reference(tmp_path):
     assert int(open(os.path.join(d, "gnn-pe", "all_paths.txt")).readline()) == ref["paths"]
     for i in range(4):
         assert 8192 <= os.path.getsize(os.path.join(d, "gnn-pe", "partitions", f"partition-{i}", "index.dat")) < (1 << 31)
-    out = subprocess.run([ref_main_path(), "-f", d + "/", "-d", gp, "-q", query, "-m", "online", "-p", "4"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-300:]
-    assert "This R-Tree contains" not in out.stdout  # it inserted nothing: every partition's tree came from our files
-    assert int(re.search(r"Answer Number: (\d+)", out.stdout).group(1)) == ref["answer_number"] == 2
+    # (the reference re-parses the 1.4e7 text rows: 12 s of one host core -- started here, checked by tests/test_zz_reference_consumers.py
+    # at the end of the session: it must insert nothing -- every partition's tree comes from our files -- and print the golden answer)
+    import conftest
+    if os.path.exists(ref_main_path()):
+        conftest.start_reference_run("g70_p4_online", [ref_main_path(), "-f", d + "/", "-d", gp, "-q", query, "-m", "online", "-p", "4"],
+                                     str(tmp_path))
 
 
 @pytest.mark.parametrize("mode", ["e1_single_gpu", "e2_two_slabs"])
