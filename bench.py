@@ -727,7 +727,7 @@ def main():
                                    "phase (the timed steps run without any)"))
     # what the first hardware SCALE record is to be judged against (per-rank kernels of config 4 emulated on one GPU,
     # scripts/emulate_rank.py, + the 16 MB vde all-gather over xGMI + launch gaps); strong scaling, so ms per step falls with N
-    out["expected_ms_per_step"] = {"1": [3.65, 4.4], "2": [2.5, 2.9], "4": [1.5, 1.8], "8": [1.0, 1.3],
+    out["expected_ms_per_step"] = {"1": [3.55, 4.35], "2": [2.5, 2.9], "4": [1.5, 1.8], "8": [1.0, 1.3],
                                    "source": "PREFLIGHT.md / profiles/r06_emulate_rank.txt: every rank's per-step kernels emulated on one GPU (N = 2: 2.41-2.60 ms, "
                                              "N = 4: 1.40-1.55, N = 8: 0.88-0.94) + the 16 MB vde all-gather + launch gaps; N = 1 = this bench's own spread by "
                                              "allocation class"}
