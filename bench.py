@@ -706,7 +706,7 @@ def main():
     emit_class, calibration_ms = None, None
     if shapes is not None and shapes["starts_ms"] > 0:  # (nothing is timed below 2^24 paths or on graphs with hub rows)
         f5 = peak_bytes / (shapes["starts_ms"] / 1e3) / HBM_PEAK_GBS
-        emit_class = "fast" if f5 >= 0.80 else "between" if f5 >= 0.74 else ("slow3" if shapes["starts_low_ms"] < shapes["starts_ms"] else "slow5")
+        emit_class = "fast" if f5 >= 0.80 else "between" if f5 >= 0.74 else ("slow3" if 0 < shapes["starts_low_ms"] < shapes["starts_ms"] else "slow5")  # (0: not timed -- at e > 2 shape 4 is shape 1)
         calibration_ms = dict(starts_one_shot=round(shapes["starts_ms"], 3), starts_resident_3_per_cu=round(shapes["starts_low_ms"], 3),
                               tiles=round(shapes["tiles_ms"], 3), kept=shapes["kept"])
 

@@ -127,7 +127,7 @@ del ref_ids, ref_pde
 pads = [int(x) for x in opt("--pads", "").split(",") if x]  # k_fill_ranked with other occupancies (GNNPE_FILL_LDS_PAD: dynamic LDS nobody touches)
 rtk = [int(x) for x in opt("--ranked-tickets", "").split(",") if x]  # k_fill_ranked taking its start vertices from this many ticket heads
 oneshot = [int(x) for x in opt("--oneshot", "").split(",") if x]  # one wave per start vertex in launch order (GNNPE_FILL_ONESHOT) at these LDS pads (-1: the default pad)
-variants = ([("starts", None, None), ("starts_low", None, None)] + [("starts", -5, p) for p in oneshot] + ([(sh, -4, r) for r in (64, 256) for sh in ("starts", "starts_low")] if "--rows" in sys.argv else []) + [("starts", -1, p) for p in pads] + [("starts", -2, h) for h in rtk] +
+variants = ([("starts", None, None), ("starts_low", None, None)] + ([("starts", -6, None)] if "--resident" in sys.argv else []) + [("starts", -5, p) for p in oneshot] + ([(sh, -4, r) for r in (64, 256) for sh in ("starts", "starts_low")] if "--rows" in sys.argv else []) + [("starts", -1, p) for p in pads] + [("starts", -2, h) for h in rtk] +
             [("starts", -3, (h, p)) for h in rtk for p in pads] + [("tiles", None, None)]) + [("tickets", t, (o, h)) for t in tpts for o in occs for h in nhs]
 for rnd in range(2):
     for bi, (ids, pde) in enumerate(bufs):
@@ -137,13 +137,15 @@ for rnd in range(2):
             os.environ.pop("GNNPE_RANKED_TICKETS", None)
             os.environ.pop("GNNPE_FILL_ROWS", None)
             os.environ.pop("GNNPE_FILL_ONESHOT", None)
+            if tpt == -6:  # shape 1 as the resident ticket grid of rounds 4-5 (the default is one-shot since round 6)
+                os.environ["GNNPE_FILL_ONESHOT"] = "0"
             if tpt == -5:
                 os.environ["GNNPE_FILL_ONESHOT"] = "1"
                 if occ >= 0:
                     os.environ["GNNPE_FILL_LDS_PAD"] = str(occ)
             if tpt == -4:
                 os.environ["GNNPE_FILL_ROWS"] = str(occ)
-            if tpt in (-4, -5):
+            if tpt in (-4, -5, -6):
                 pass
             elif tpt == -3:
                 os.environ["GNNPE_RANKED_TICKETS"] = str(occ[0]); os.environ["GNNPE_FILL_LDS_PAD"] = str(occ[1])
@@ -160,6 +162,6 @@ for rnd in range(2):
                 e0.record(); eng.fill_paths_device(0, total, ids, pde, None); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             ts.sort()
-            tag = shape if tpt is None else f"starts one-shot pad={occ}" if tpt == -5 else f"{shape} rows{occ}" if tpt == -4 else f"starts lds_pad={occ}" if tpt == -1 else f"starts tickets heads={occ}" if tpt == -2 else f"starts tickets heads={occ[0]} pad={occ[1]}" if tpt == -3 else f"tickets tpt={tpt} occ={occ[0]} heads={occ[1]}"
+            tag = shape if tpt is None else "starts resident grid" if tpt == -6 else f"starts one-shot pad={occ}" if tpt == -5 else f"{shape} rows{occ}" if tpt == -4 else f"starts lds_pad={occ}" if tpt == -1 else f"starts tickets heads={occ}" if tpt == -2 else f"starts tickets heads={occ[0]} pad={occ[1]}" if tpt == -3 else f"tickets tpt={tpt} occ={occ[0]} heads={occ[1]}"
             print(f"round {rnd} buf {bi} {tag:30s}: min {ts[0]:.3f} median {ts[4]:.3f} ms  frac(min) {total * B / ts[0] / 1e-3 / 8e12:.3f}", flush=True)
 eng.close()
