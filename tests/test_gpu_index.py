@@ -221,6 +221,39 @@ def test_triple_major_partition_images(oracle, e, p):
 
 
 
+@pytest.mark.parametrize("l", [2, 3])
+def test_partition_images_of_a_slab_context(oracle, l):
+    """A context that enumerates a SLAB of the processing order (gnnpe_set_slab: what a rank of --gpus N holds) builds its partition
+    images from its own enumeration state too: the entries are the slab's paths of the partition, son = the path's index inside
+    (slab x partition) in emission order -- pair-major at l = 2, triple-major at l = 3."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(1200, 6500, n_labels=5, seed=33)
+    rng = np.random.default_rng(33 + l)
+    sn = rng.permutation(g["n"]).astype(np.uint32)
+    p = 2
+    mem = rng.integers(0, p, size=g["n"]).astype(np.uint32)
+    eng = _engine(binding, g, sn, mem, p, 2)
+    sb, se = 300, 900
+    eng.set_slab(sb, se)
+    x, nx, vde = eng.vde()
+    vde = oracle.gen_vde(g["offsets"], g["nbrs"], g["labels"], 2)[2]  # (a slab context computes the slab's rows of vde)
+    total = eng.count_paths(l)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, l + 1)
+    rank = np.empty(g["n"], np.int64)
+    rank[sn] = np.arange(g["n"])
+    mine_all = ref[(rank[ref[:, 0]] >= sb) & (rank[ref[:, 0]] < se)]
+    assert total == len(mine_all) > 1000
+    D = (l + 1) * 2
+    for pid in range(p):
+        mine = _partition_paths(mine_all, mem, pid)
+        img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
+        d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+        order = np.argsort(d["leaf_son"], kind="stable")
+        assert d["num_data"] == len(mine) and np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
+        assert np.array_equal(d["leaf_pt"][order], vde[mine].reshape(len(mine), D))
+    eng.close()
+
+
 def test_triple_major_falls_back_to_the_tuple_build_when_its_units_do_not_fit(oracle, monkeypatch):
     """A count with more sort units than the triple-major build takes (2^31, or what memory holds at ~100 bytes each: the empty units
     count too) keeps the tuple-array build of rounds 1-5 -- same contract, nodes of capacity - 2 entries.  The limit is lowered through
