@@ -418,9 +418,9 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
     P, ovde, so, ref, _ = oracle.offline_parallel(g["offsets"], g["nbrs"], g["labels"], sn, 2)
     assert total == P and np.array_equal(vde.view(np.uint64), ovde.view(np.uint64))
     seen = 0
-    # through the host validator: every partition at config 2; at config 3 the first, a middle and the last one (8 GB of the 22 GB:
-    # all eight took 46 s of the suite), the others by header -- entry count, node counts, file size
-    full = set(range(p)) if n < 1_000_000 else {0, p // 2, p - 1}
+    # through the host validator: every partition at config 2; at config 3 the first and the last one (5.4 GB of the 22 GB: all eight
+    # took 46 s of the suite), the others by header -- entry count, node counts, file size
+    full = set(range(p)) if n < 1_000_000 else {0, p - 1}
     for pid in range(p):
         mine = _partition_paths(ref, mem, pid)
         img_ptr, nbytes, hdr = eng.build_index_partition_device(pid)
@@ -430,9 +430,9 @@ def test_pair_major_index_at_baseline_sizes(oracle, n, m, p):
             continue
         d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
         assert d["dim"] == 6 and d["num_data"] == len(mine) == hdr[3] and d["root_is_data"] == 0
-        order = np.argsort(d["leaf_son"], kind="stable")
-        assert np.array_equal(d["leaf_son"][order], np.arange(len(mine)))
-        assert np.array_equal(d["leaf_pt"][order].view(np.uint64), ovde[mine].reshape(len(mine), 6).view(np.uint64))
+        # every son once (a permutation of the partition's path indices), and entry k carries the pde row of path son[k]
+        assert np.array_equal(np.bincount(d["leaf_son"], minlength=len(mine)), np.ones(len(mine), np.int64))
+        assert np.array_equal(d["leaf_pt"].view(np.uint64), ovde[mine[d["leaf_son"]]].reshape(len(mine), 6).view(np.uint64))
         seen += len(mine)
     assert seen == total
     eng.close()
