@@ -337,6 +337,23 @@ def index_l3_leg(torch, stream, local_rank, labels, l2_ms_per_gb):
                      "enumeration twice to collect the partition's tuples)")
 
 
+def leg_failed(out, key, ex):
+    """An optional leg raised: the bench line keeps its headline and says what was lost (a leg is outside the timed steps)."""
+    import traceback
+    sys.stderr.write(f"[bench] leg {key} failed:\n{traceback.format_exc()}\n")
+    if isinstance(out.get(key), dict):
+        out[key]["error"] = f"{type(ex).__name__}: {ex}"[:400]
+    else:
+        out[key] = {"error": f"{type(ex).__name__}: {ex}"[:400]}
+
+
+def guarded(out, key, fn, *a, **kw):
+    try:
+        out[key] = fn(*a, **kw)
+    except Exception as ex:
+        leg_failed(out, key, ex)
+
+
 def e2e_leg(g, sn, p, index, label, allow_large=False):
     """Wall-clock of `gnnpe_main -m offline` on text inputs (load + emit + render + file writes [+ index.dat])."""
     free = shutil.disk_usage(tempfile.gettempdir()).free
@@ -740,84 +757,87 @@ def main():
     # index-build wallclock (second half of BASELINE.json's metric), measured outside the timed steps.
     # (a) device image: R*-tree file image of every path (p = 1), bulk-loaded on the device
     if legs:
-        ib, ib_cached = [], []
-        for _ in range(3):
-            eng.count_paths(2)  # untimed: a new count invalidates the cached pair order, so the timed call below rebuilds it
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev2 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
+        try:
+            ib, ib_cached = [], []
+            for _ in range(3):
+                eng.count_paths(2)  # untimed: a new count invalidates the cached pair order, so the timed call below rebuilds it
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev2 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                img, nbytes, hdr = eng.build_index_partition_device(0)
+                ev1.record()
+                eng.build_index_partition_device(0)  # second partition-build of the same count: pair order reused
+                ev2.record()
+                torch.cuda.synchronize()
+                ib.append(ev0.elapsed_time(ev1))
+                ib_cached.append(ev1.elapsed_time(ev2))
+            ib_tuple = []
+            for _ in range(2):  # the tuple-array build (what a caller without the enumeration state uses: distributed ranks)
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                eng.build_index_device(total, L, out_ids)
+                ev1.record()
+                torch.cuda.synchronize()
+                ib_tuple.append(ev0.elapsed_time(ev1))
+            # image AND the tree's auxiliary index (custom.h:268-364; the reference rebuilds it at every online start) in one
+            # build: the leaf kernel computes the leaves' rows while it assembles them, the upper levels are a short pass
+            fused_ms = []
+            for _ in range(3):
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                eng.build_index_partition_aux_device(0)  # pair order cached by the calls above: compare with next_partition_ms
+                ev1.record()
+                torch.cuda.synchronize()
+                fused_ms.append(ev0.elapsed_time(ev1))
+            # the generic pass over a finished image (what a foreign tree or an l = 3 image goes through), for comparison
+            aux_ms = []
             img, nbytes, hdr = eng.build_index_partition_device(0)
-            ev1.record()
-            eng.build_index_partition_device(0)  # second partition-build of the same count: pair order reused
-            ev2.record()
-            torch.cuda.synchronize()
-            ib.append(ev0.elapsed_time(ev1))
-            ib_cached.append(ev1.elapsed_time(ev2))
-        ib_tuple = []
-        for _ in range(2):  # the tuple-array build (what a caller without the enumeration state uses: distributed ranks)
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            eng.build_index_device(total, L, out_ids)
-            ev1.record()
-            torch.cuda.synchronize()
-            ib_tuple.append(ev0.elapsed_time(ev1))
-        # image AND the tree's auxiliary index (custom.h:268-364; the reference rebuilds it at every online start) in one
-        # build: the leaf kernel computes the leaves' rows while it assembles them, the upper levels are a short pass
-        fused_ms = []
-        for _ in range(3):
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            eng.build_index_partition_aux_device(0)  # pair order cached by the calls above: compare with next_partition_ms
-            ev1.record()
-            torch.cuda.synchronize()
-            fused_ms.append(ev0.elapsed_time(ev1))
-        # the generic pass over a finished image (what a foreign tree or an l = 3 image goes through), for comparison
-        aux_ms = []
-        img, nbytes, hdr = eng.build_index_partition_device(0)
-        for _ in range(2):
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            eng.aux_index_device_ptrs(img, nbytes, total, L, out_ids)
-            ev1.record()
-            torch.cuda.synchronize()
-            aux_ms.append(ev0.elapsed_time(ev1))
-        out["index_build"] = dict(wallclock_ms=min(ib[1:]), points=total, file_bytes=nbytes, node_blocks=hdr[1], leaves=hdr[4],
-                                  image_and_aux_index_ms=min(fused_ms),
-                                  aux_index_added_ms=min(fused_ms) - min(ib_cached),
-                                  aux_index_note="Partition::build_auxiliary_index (custom.h:268-364): image_and_aux_index_ms builds the image "
-                                                 "WITH the auxiliary index (leaf rows by the leaf kernel, inner nodes' rows and all keys by the "
-                                                 "inner-node kernel) from the cached pair order -- compare next_partition_ms, the same build without it; "
-                                                 "generic_aux_pass_ms is the stand-alone pass over a finished image (foreign trees, l = 3)",
-                                  generic_aux_pass_ms=min(aux_ms),
-                                  where="device image of index.dat (partition 0 of p = 1), pair-major build from the enumeration "
-                                        "state: pair sort + leaves + upper levels; the files on disk are timed under e2e",
-                                  next_partition_ms=min(ib_cached),
-                                  hbm=dict(file_bytes_frac=nbytes / (min(ib[1:]) / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                           leaf_pass_traffic_bytes=LEAF_TRAFFIC_BYTES if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
-                                           leaf_pass_traffic_frac=(LEAF_TRAFFIC_BYTES / (min(ib_cached) / 1e3) / 1e9 / HBM_PEAK_GBS)
-                                           if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
-                                           note="file_bytes_frac = the image's bytes over wallclock_ms (pair sort included); "
-                                                "leaf_pass_traffic_* = what the leaf kernel moves per launch at config 3 by the counters of the "
-                                                "committed profile (profiles/r06_leaf_mem_pmc.txt: 7.0 GB of 128-byte fabric reads + 20.7 GB of "
-                                                "64-byte writes), over next_partition_ms (leaf kernel + first-pair pass + inner nodes)"),
-                                  next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
-                                  tuple_array_build_ms=min(ib_tuple),
-                                  first_call_ms=ib[0],
-                                  first_call_note="the first call allocates the grow-only buffers (the 22 GB image, pair records) and loads "
-                                                  "the kernels; later calls only enqueue kernels.  It follows the output pool's draw in this "
-                                                  "process: hipMalloc of 24 GB right after 130 GB of candidates were freed waits for the driver "
-                                                  "to reclaim them (38 ms when the pool drew 8, seconds after 12)",
-                                  reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
-        if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw and not args.no_config5:
-            out["index_build"]["l3"] = index_l3_leg(torch, stream, local_rank, args.labels, min(ib[1:]) / (nbytes / 1e9))
+            for _ in range(2):
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                eng.aux_index_device_ptrs(img, nbytes, total, L, out_ids)
+                ev1.record()
+                torch.cuda.synchronize()
+                aux_ms.append(ev0.elapsed_time(ev1))
+            out["index_build"] = dict(wallclock_ms=min(ib[1:]), points=total, file_bytes=nbytes, node_blocks=hdr[1], leaves=hdr[4],
+                                      image_and_aux_index_ms=min(fused_ms),
+                                      aux_index_added_ms=min(fused_ms) - min(ib_cached),
+                                      aux_index_note="Partition::build_auxiliary_index (custom.h:268-364): image_and_aux_index_ms builds the image "
+                                                     "WITH the auxiliary index (leaf rows by the leaf kernel, inner nodes' rows and all keys by the "
+                                                     "inner-node kernel) from the cached pair order -- compare next_partition_ms, the same build without it; "
+                                                     "generic_aux_pass_ms is the stand-alone pass over a finished image (foreign trees, l = 3)",
+                                      generic_aux_pass_ms=min(aux_ms),
+                                      where="device image of index.dat (partition 0 of p = 1), pair-major build from the enumeration "
+                                            "state: pair sort + leaves + upper levels; the files on disk are timed under e2e",
+                                      next_partition_ms=min(ib_cached),
+                                      hbm=dict(file_bytes_frac=nbytes / (min(ib[1:]) / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                               leaf_pass_traffic_bytes=LEAF_TRAFFIC_BYTES if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
+                                               leaf_pass_traffic_frac=(LEAF_TRAFFIC_BYTES / (min(ib_cached) / 1e3) / 1e9 / HBM_PEAK_GBS)
+                                               if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw else None,
+                                               note="file_bytes_frac = the image's bytes over wallclock_ms (pair sort included); "
+                                                    "leaf_pass_traffic_* = what the leaf kernel moves per launch at config 3 by the counters of the "
+                                                    "committed profile (profiles/r06_leaf_mem_pmc.txt: 7.0 GB of 128-byte fabric reads + 20.7 GB of "
+                                                    "64-byte writes), over next_partition_ms (leaf kernel + first-pair pass + inner nodes)"),
+                                      next_partition_note="a further partition of the same count reuses the sorted pairs (p > 1: the order is built once)",
+                                      tuple_array_build_ms=min(ib_tuple),
+                                      first_call_ms=ib[0],
+                                      first_call_note="the first call allocates the grow-only buffers (the 22 GB image, pair records) and loads "
+                                                      "the kernels; later calls only enqueue kernels.  It follows the output pool's draw in this "
+                                                      "process: hipMalloc of 24 GB right after 130 GB of candidates were freed waits for the driver "
+                                                      "to reclaim them (38 ms when the pool drew 8, seconds after 12)",
+                                      reference="~96 us per RTree::insert on the host (BASELINE.md): hours at this size")
+            if (args.n, args.m, e) == (1_000_000, 10_000_000, 2) and not args.powerlaw and not args.no_config5:
+                guarded(out["index_build"], "l3", index_l3_leg, torch, stream, local_rank, args.labels, min(ib[1:]) / (nbytes / 1e9))
+        except Exception as ex:  # (an optional leg must not take the headline line with it)
+            leg_failed(out, "index_build", ex)
     # next row: the online filter over the same paths -- query plan of an 8-vertex query cut out of the
     # data graph, leaf test of Partition::query on every enumerated path; outside the timed steps
     if legs and e == 2:
-        out["online_filter"] = online_filter_leg(eng, g, args.seed)
+        guarded(out, "online_filter", online_filter_leg, eng, g, args.seed)
     del ids_view
     pool.close()
     eng.close()
@@ -825,45 +845,48 @@ def main():
     g2 = None
     if legs and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
         g2 = synth.gnm_graph(100_000, 1_000_000, n_labels=args.labels, seed=args.seed)
-        out["config2"] = device_pass(torch, stream, local_rank, g2, synth.degree_order(g2["offsets"]), args.labels, e, args.steps)
+        guarded(out, "config2", device_pass, torch, stream, local_rank, g2, synth.degree_order(g2["offsets"]), args.labels, e, args.steps)
     if legs and not args.powerlaw and e in (1, 2, 4, 8):
-        out["gnn_pge"] = pge_leg(torch, stream, local_rank, g, args.labels, e, args.steps)
+        guarded(out, "gnn_pge", pge_leg, torch, stream, local_rank, g, args.labels, e, args.steps)
     if legs and not args.no_config5 and not args.powerlaw and (args.n, args.m) == (1_000_000, 10_000_000):
-        out["config5"] = config5_leg(torch, stream, local_rank, args.labels, args.seed)
+        guarded(out, "config5", config5_leg, torch, stream, local_rank, args.labels, args.seed)
     if rank == 0:
         # (b) files on disk + end-to-end wall-clock of the drop-in CLI
         if legs and not args.no_e2e and not args.powerlaw and os.path.exists(CLI):
             big = (args.n, args.m) == (1_000_000, 10_000_000)
             name = "config 3: G(1M, 10M)" if big else f"G({args.n}, {args.m})"
             e2e = {}
-            e2e["text_p1"] = e2e_leg(g, sn, 1, False, name + ", p=1, text files only")
+            guarded(e2e, "text_p1", e2e_leg, g, sn, 1, False, name + ", p=1, text files only")
             # index files the UNTOUCHED reference online binary can read: every index.dat below 2 GiB (its block file seeks with
             # 32-bit arithmetic, blk_file.h:32-33; gnnpe_main --index refuses larger ones unless --allow-large)
             pc = 16 if big else max(1, int(np.ceil(synth.expected_paths_l2(g["offsets"]) * 108 / (1 << 31))))
-            e2e[f"text_index_p{pc}"] = e2e_leg(g, sn, pc, True, name + f", p={pc}, text files + {pc} x index.dat, every file < 2 GiB (consumable)")
+            guarded(e2e, f"text_index_p{pc}", e2e_leg, g, sn, pc, True, name + f", p={pc}, text files + {pc} x index.dat, every file < 2 GiB (consumable)")
             if big:
-                e2e["text_index_p8_allow_large"] = e2e_leg(g, sn, 8, True, name + ", p=8, text files + 8 x index.dat of 2.7 GB (--allow-large: "
-                                                           "not readable by the reference's online binary; kept for comparison with round 3)", allow_large=True)
+                guarded(e2e, "text_index_p8_allow_large", e2e_leg, g, sn, 8, True, name + ", p=8, text files + 8 x index.dat of 2.7 GB (--allow-large: "
+                        "not readable by the reference's online binary; kept for comparison with round 3)", allow_large=True)
             if big and g2 is not None:
-                e2e["config2_text_index_p2"] = e2e_leg(g2, synth.degree_order(g2["offsets"]), 2, True,
-                                                       "config 2: G(100K, 1M), p=2, text files + 2 x index.dat (p=1 would be 2.1 GB)")
+                guarded(e2e, "config2_text_index_p2", e2e_leg, g2, synth.degree_order(g2["offsets"]), 2, True,
+                        "config 2: G(100K, 1M), p=2, text files + 2 x index.dat (p=1 would be 2.1 GB)")
             e2e["reference"] = "BASELINE.md: config 3 offline 1 749 s, config 2 offline 158.8 s (1 thread); its index build is ~96 us per insert"
             out["e2e"] = e2e
             if "index_build" in out:
                 out["index_build"]["files"] = {k: dict(seconds=v.get("index_build_s"), bytes=v.get("index_bytes"))
                                                for k, v in e2e.items() if isinstance(v, dict) and "index_build_s" in v}
         if world == 1 and not args.no_cpu_baseline:
-            sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))
-            small = cpu_baseline(sn_, sm_, args.seed)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(300_000, 3_000_000, e, args.seed)
-            from oracle import ref_main_path
-            age = time.perf_counter() - T_START
-            if os.path.exists(ref_main_path()) and (args.cpu_config2 == "yes" or (args.cpu_config2 == "auto" and age < args.cpu_config2_before)):
-                out["cpu_baseline"] = cpu_baseline(100_000, 1_000_000, args.seed, named="BASELINE config 2")
-                out["cpu_baseline_small_sample"] = small
-            else:
-                out["cpu_baseline"] = small
-                out["cpu_baseline"]["config2_skipped"] = f"the run was {age:.0f} s old (limit {args.cpu_config2_before:.0f} s) or the reference binary is absent"
+            try:
+                sn_, sm_ = (int(x) for x in args.cpu_sample.split(","))
+                small = cpu_baseline(sn_, sm_, args.seed)
+                out["cpu_baseline"] = small  # (replaced below by the config-2 run when there is time for it)
+                guarded(out, "cpu_baseline_all_cores", cpu_baseline_all_cores, 300_000, 3_000_000, e, args.seed)
+                from oracle import ref_main_path
+                age = time.perf_counter() - T_START
+                if os.path.exists(ref_main_path()) and (args.cpu_config2 == "yes" or (args.cpu_config2 == "auto" and age < args.cpu_config2_before)):
+                    out["cpu_baseline"] = cpu_baseline(100_000, 1_000_000, args.seed, named="BASELINE config 2")
+                    out["cpu_baseline_small_sample"] = small
+                else:
+                    out["cpu_baseline"]["config2_skipped"] = f"the run was {age:.0f} s old (limit {args.cpu_config2_before:.0f} s) or the reference binary is absent"
+            except Exception as ex:  # (the line is still worth printing: the GPU numbers above were measured)
+                leg_failed(out, "cpu_baseline", ex)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
