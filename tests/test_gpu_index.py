@@ -221,6 +221,31 @@ def test_triple_major_partition_images(oracle, e, p):
 
 
 
+@pytest.mark.skipif(not os.environ.get("GNNPE_BIG_TESTS"), reason="one-off soak (GNNPE_BIG_TESTS=1): 20 s and 25 GB of host memory")
+def test_triple_major_image_beyond_4_gib(oracle):
+    """l = 3, an image of 7 GB (block offsets and the levels' box arrays past 32 bits, four tree levels, 1.6e6 leaves): every path of the
+    partition once, son = its index, lo = hi = its pde row.  Not part of the default suite (its time budget); run once per round with
+    GNNPE_BIG_TESTS=1 -- round 6: passed (gpurun_out/r06_tx_big.log)."""
+    from gnnpe_amd import binding
+    g = synth.gnm_graph(30_000, 220_000, n_labels=8, seed=4)
+    sn = synth.degree_order(g["offsets"])
+    eng = _engine(binding, g, sn, np.zeros(g["n"], np.uint32), 1, 2)
+    x, nx, vde = eng.vde()
+    total = eng.count_paths(3)
+    ref = oracle.enumerate_closed(g["offsets"], g["nbrs"], sn, 4)
+    assert total == len(ref) > 40_000_000
+    img_ptr, nbytes, hdr = eng.build_index_partition_device(0)
+    assert nbytes > (6 << 30)
+    d = oracle.index_validate(eng.copy_to_host(img_ptr, nbytes).tobytes())
+    assert d["num_data"] == total and d["dnodes"] == -(-total // 29) and d["height"] >= 4
+    assert np.array_equal(np.bincount(d["leaf_son"], minlength=total), np.ones(total, np.int64))
+    CH = 1 << 23
+    for a in range(0, total, CH):
+        son = d["leaf_son"][a:a + CH]
+        assert np.array_equal(d["leaf_pt"][a:a + CH].view(np.uint64), vde[ref[son]].reshape(len(son), 8).view(np.uint64)), a
+    eng.close()
+
+
 @pytest.mark.parametrize("l", [2, 3])
 def test_partition_images_of_a_slab_context(oracle, l):
     """A context that enumerates a SLAB of the processing order (gnnpe_set_slab: what a rank of --gpus N holds) builds its partition
